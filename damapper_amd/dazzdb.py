@@ -1,0 +1,338 @@
+"""DAZZ_DB containers for the damapper hot path: on-disk writer/reader, in-memory block
+builder (the struct layout `Sort_Kmers`/`Match_Filter`/`Reporter` receive) and the
+synthetic genome / PacBio-like read simulator used by tests and bench.
+
+Formats follow the reference's DB.h (cited by line, nothing is copied):
+  * stub text file  <root>.db            DB.h:431-435, parsed DB.c:766-806
+  * index           .<root>.idx          raw DAZZ_DB struct (DB.h:390-420) + DAZZ_READ[] (DB.h:285-295)
+  * bases           .<root>.bps          2 bit/base, first base in the top bits (DB.c:319-363)
+  * in-memory block                      DB.c:1402-1437 (Load_All_Reads): [4] r0 [4] r1 ... [4]
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+DB_BEST = 0x800  # DB.h:279 read flag: survives trimming when all=0
+DB_ALL = 0x1
+
+
+class DAZZ_READ(C.Structure):
+    """DB.h:285-295 (40 bytes on x86-64)."""
+    _fields_ = [
+        ("origin", C.c_int), ("rlen", C.c_int), ("fpulse", C.c_int), ("_pad0", C.c_int),
+        ("boff", C.c_int64), ("coff", C.c_int64), ("flags", C.c_int), ("_pad1", C.c_int),
+    ]
+
+
+class DAZZ_DB(C.Structure):
+    """DB.h:390-420 (112 bytes on x86-64)."""
+    _fields_ = [
+        ("ureads", C.c_int), ("treads", C.c_int), ("cutoff", C.c_int), ("allarr", C.c_int),
+        ("freq", C.c_float * 4),
+        ("maxlen", C.c_int), ("_pad0", C.c_int), ("totlen", C.c_int64),
+        ("nreads", C.c_int), ("trimmed", C.c_int), ("part", C.c_int), ("ufirst", C.c_int),
+        ("tfirst", C.c_int), ("_pad1", C.c_int),
+        ("path", C.c_char_p), ("loaded", C.c_int), ("_pad2", C.c_int),
+        ("bases", C.c_void_p), ("reads", C.c_void_p), ("tracks", C.c_void_p),
+    ]
+
+
+assert C.sizeof(DAZZ_READ) == 40 and C.sizeof(DAZZ_DB) == 112
+
+READ_DTYPE = np.dtype({
+    "names": ["origin", "rlen", "fpulse", "boff", "coff", "flags"],
+    "formats": ["<i4", "<i4", "<i4", "<i8", "<i8", "<i4"],
+    "offsets": [0, 4, 8, 16, 24, 32],
+    "itemsize": 40,
+})
+
+
+# ------------------------------------------------------------------------------------------
+#  Simulator
+# ------------------------------------------------------------------------------------------
+
+def random_genome(rng: np.random.Generator, contig_lens: Sequence[int]) -> List[np.ndarray]:
+    """Uniform random ACGT contigs (values 0..3)."""
+    return [rng.integers(0, 4, size=int(n), dtype=np.uint8) for n in contig_lens]
+
+
+def repeat_rich_genome(rng: np.random.Generator, contig_lens: Sequence[int], family_len: int = 2000,
+                       divergence: float = 0.03, tandem_unit: int = 150, tandem_copies: int = 60
+                       ) -> List[np.ndarray]:
+    """Random contigs seeded with a diverged repeat family on both strands every 1-6 kb and
+    one tandem array per contig (SURVEY.md section 8d generator)."""
+    fam = rng.integers(0, 4, size=family_len, dtype=np.uint8)
+    out = []
+    for n in contig_lens:
+        s = rng.integers(0, 4, size=int(n), dtype=np.uint8)
+        p = int(rng.integers(500, 3000))
+        while p + family_len < n:
+            cp = fam.copy()
+            mut = rng.random(family_len) < divergence
+            cp[mut] = (cp[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+            if rng.random() < 0.5:
+                cp = (3 - cp[::-1]).astype(np.uint8)
+            s[p:p + family_len] = cp
+            p += family_len + int(rng.integers(1000, 6000))
+        tl = tandem_unit * tandem_copies
+        if n > 4 * tl:
+            unit = rng.integers(0, 4, size=tandem_unit, dtype=np.uint8)
+            q = int(rng.integers(0, n - tl))
+            s[q:q + tl] = np.tile(unit, tandem_copies)
+        out.append(s)
+    return out
+
+
+def _mutate(rng: np.random.Generator, seq: np.ndarray, err: float) -> np.ndarray:
+    """i.i.d. per-base errors, ins:del:sub = 60:25:15 (vectorised)."""
+    n = len(seq)
+    r = rng.random(n)
+    is_ins = r < err * 0.60
+    is_del = (r >= err * 0.60) & (r < err * 0.85)
+    is_sub = (r >= err * 0.85) & (r < err)
+    base = seq.copy()
+    nsub = int(is_sub.sum())
+    if nsub:
+        base[is_sub] = (base[is_sub] + rng.integers(1, 4, size=nsub, dtype=np.uint8)) & 3
+    keep = ~is_del
+    counts = keep.astype(np.int64) + is_ins.astype(np.int64)
+    total = int(counts.sum())
+    out = np.empty(total, dtype=np.uint8)
+    ends = np.cumsum(counts)
+    starts = ends - counts
+    # inserted base first, then the (possibly substituted) template base
+    ins_pos = starts[is_ins]
+    out[ins_pos] = rng.integers(0, 4, size=len(ins_pos), dtype=np.uint8)
+    kp = (starts + is_ins.astype(np.int64))[keep]
+    out[kp] = base[keep]
+    return out
+
+
+def simulate_reads(rng: np.random.Generator, contigs: Sequence[np.ndarray], nreads: int,
+                   read_len: int = 10000, err: float = 0.15, dropouts: int = 0
+                   ) -> Tuple[List[np.ndarray], List[Tuple[int, int, int]]]:
+    """Sample (contig, position, strand) uniformly; fixed template length `read_len`.
+    `dropouts` > 0 inserts that many random 200-900 bp junk segments per read (exercises
+    the chain linker). Returns reads and their (contig, pos, strand)."""
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    ok = lens >= read_len
+    w = np.where(ok, lens - read_len + 1, 0).astype(np.float64)
+    w /= w.sum()
+    reads, truth = [], []
+    for _ in range(nreads):
+        ci = int(rng.choice(len(contigs), p=w))
+        pos = int(rng.integers(0, lens[ci] - read_len + 1))
+        strand = int(rng.integers(0, 2))
+        t = contigs[ci][pos:pos + read_len]
+        if strand:
+            t = (3 - t[::-1]).astype(np.uint8)
+        r = _mutate(rng, t, err)
+        for _d in range(dropouts):
+            q = int(rng.integers(500, max(501, len(r) - 500)))
+            junk = rng.integers(0, 4, size=int(rng.integers(200, 900)), dtype=np.uint8)
+            r = np.concatenate([r[:q], junk, r[q:]])
+        reads.append(r)
+        truth.append((ci, pos, strand))
+    return reads, truth
+
+
+# ------------------------------------------------------------------------------------------
+#  On-disk DB
+# ------------------------------------------------------------------------------------------
+
+def _pack_2bit(seq: np.ndarray) -> bytes:
+    n = len(seq)
+    pad = (-n) % 4
+    s = np.concatenate([seq, np.zeros(pad, dtype=np.uint8)]) if pad else seq
+    s = s.reshape(-1, 4).astype(np.uint8)
+    return ((s[:, 0] << 6) | (s[:, 1] << 4) | (s[:, 2] << 2) | s[:, 3]).astype(np.uint8).tobytes()
+
+
+def _unpack_2bit(buf: np.ndarray, n: int) -> np.ndarray:
+    out = np.empty(len(buf) * 4, dtype=np.uint8)
+    out[0::4] = buf >> 6
+    out[1::4] = (buf >> 4) & 3
+    out[2::4] = (buf >> 2) & 3
+    out[3::4] = buf & 3
+    return out[:n]
+
+
+def split_blocks(lens: Sequence[int], block_size: int) -> List[int]:
+    """First-read index of each block plus the end (DBsplit-like: reads are never split;
+    a block closes once its bases reach `block_size`)."""
+    firsts = [0]
+    tot = 0
+    for i, n in enumerate(lens):
+        if tot > 0 and tot + n > block_size:
+            firsts.append(i)
+            tot = 0
+        tot += n
+    firsts.append(len(lens))
+    return firsts
+
+
+def write_db(directory: str, root: str, seqs: Sequence[np.ndarray], block_size: int = 200_000_000,
+             block_firsts: Optional[Sequence[int]] = None) -> List[int]:
+    """Write <root>.db, .<root>.idx, .<root>.bps. Returns the block boundaries."""
+    os.makedirs(directory, exist_ok=True)
+    n = len(seqs)
+    lens = [len(s) for s in seqs]
+    firsts = list(block_firsts) if block_firsts is not None else split_blocks(lens, block_size)
+    nblocks = len(firsts) - 1
+
+    recs = np.zeros(n, dtype=READ_DTYPE)
+    off = 0
+    with open(os.path.join(directory, "." + root + ".bps"), "wb") as f:
+        for i, s in enumerate(seqs):
+            b = _pack_2bit(np.asarray(s, dtype=np.uint8))
+            f.write(b)
+            recs[i] = (i, lens[i], 0, off, 0, DB_BEST)
+            off += len(b)
+
+    allb = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if n else np.zeros(0, np.uint8)
+    cnt = np.bincount(allb, minlength=4).astype(np.float64)
+    freq = cnt / max(1.0, cnt.sum())
+
+    hdr = DAZZ_DB()
+    hdr.ureads = n
+    hdr.treads = n
+    hdr.cutoff = 0
+    hdr.allarr = DB_ALL
+    for j in range(4):
+        hdr.freq[j] = float(freq[j])
+    hdr.maxlen = max(lens) if lens else 0
+    hdr.totlen = int(sum(lens))
+    hdr.nreads = n
+    hdr.trimmed = 1
+    with open(os.path.join(directory, "." + root + ".idx"), "wb") as f:
+        f.write(bytes(hdr))
+        f.write(recs.tobytes())
+
+    with open(os.path.join(directory, root + ".db"), "w") as f:
+        f.write("files = %9d\n" % 1)
+        f.write("  %9d %s %s\n" % (n, root, root))
+        f.write("blocks = %9d\n" % nblocks)
+        f.write("size = %11d cutoff = %9d all = %1d\n" % (block_size, 0, 1))
+        for b in firsts:
+            f.write(" %9d %9d\n" % (b, b))
+    return firsts
+
+
+@dataclass
+class Block:
+    """An in-memory DAZZ_DB block laid out exactly as Load_All_Reads leaves it
+    (DB.c:1402-1437); keeps the numpy buffers alive for the ctypes struct."""
+    db: DAZZ_DB
+    bases: np.ndarray        # uint8, [4] r0 [4] r1 ... [4]; db.bases points at element 1
+    reads: np.ndarray        # READ_DTYPE, nreads+2 records; db.reads points at record 1
+    path: bytes
+
+    @property
+    def nreads(self) -> int:
+        return int(self.db.nreads)
+
+    def ptr(self):
+        return C.byref(self.db)
+
+    def seq(self, i: int) -> np.ndarray:
+        r = self.reads[i + 1]
+        o = int(r["boff"]) + 1
+        return self.bases[o:o + int(r["rlen"])]
+
+    def complement_inplace(self) -> None:
+        """damapper.c:433-469 (complement_DB, inplace): reverse-complement every read and
+        swap the base frequencies."""
+        for i in range(self.nreads):
+            r = self.reads[i + 1]
+            o = int(r["boff"]) + 1
+            n = int(r["rlen"])
+            self.bases[o:o + n] = 3 - self.bases[o:o + n][::-1]
+        f = self.db.freq
+        f[0], f[3] = f[3], f[0]
+        f[1], f[2] = f[2], f[1]
+
+
+def make_block(seqs: Sequence[np.ndarray], tfirst: int = 0, part: int = 0,
+               path: bytes = b"./.mem", freq: Optional[Sequence[float]] = None) -> Block:
+    n = len(seqs)
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    tot = int(lens.sum())
+    bases = np.empty(tot + n + 4, dtype=np.uint8)
+    bases[:] = 4
+    reads = np.zeros(n + 2, dtype=READ_DTYPE)
+    o = 0
+    for i, s in enumerate(seqs):
+        bases[1 + o:1 + o + len(s)] = s
+        reads[i + 1] = (tfirst + i, len(s), 0, o, 0, DB_BEST)
+        o += len(s) + 1
+    reads[n + 1]["boff"] = o
+    db = DAZZ_DB()
+    db.ureads = db.treads = n
+    db.cutoff = 0
+    db.allarr = DB_ALL
+    if freq is None:
+        cnt = np.bincount(bases[bases < 4], minlength=4).astype(np.float64)
+        freq = cnt / max(1.0, cnt.sum())
+    for j in range(4):
+        db.freq[j] = float(freq[j])
+    db.maxlen = int(lens.max()) if n else 0
+    db.totlen = tot
+    db.nreads = n
+    db.trimmed = 1
+    db.part = part
+    db.ufirst = db.tfirst = tfirst
+    db.path = path
+    db.loaded = 1
+    db.bases = bases.ctypes.data + 1
+    db.reads = reads.ctypes.data + 40
+    db.tracks = None
+    # Open_DB's kludge (DB.c:853-854): block read counts in the two ints before reads[0]
+    iv = reads.view(np.int32)
+    iv[9] = n    # ((int *) reads)[-1]
+    iv[8] = n    # ((int *) reads)[-2]
+    return Block(db=db, bases=bases, reads=reads, path=path)
+
+
+def read_stub(path: str) -> Tuple[int, List[Tuple[int, int]]]:
+    """Parse a stub file: returns (nblocks, [(ufirst, tfirst)] * (nblocks+1))."""
+    with open(path) as f:
+        lines = f.read().split("\n")
+    nfiles = int(lines[0].split("=")[1])
+    k = 1 + nfiles
+    nblocks = int(lines[k].split("=")[1])
+    firsts = []
+    for ln in lines[k + 2:k + 2 + nblocks + 1]:
+        a, b = ln.split()
+        firsts.append((int(a), int(b)))
+    return nblocks, firsts
+
+
+def load_db(path: str, part: int = 0) -> Block:
+    """Open + Load_All_Reads equivalent for DBs written by `write_db` (no trimming:
+    cutoff=0, all=1). `path` is 'dir/root.db'; part k > 0 loads block k."""
+    d, base = os.path.split(path)
+    d = d or "."
+    root = base[:-3] if base.endswith(".db") else base
+    nblocks, firsts = read_stub(os.path.join(d, root + ".db"))
+    with open(os.path.join(d, "." + root + ".idx"), "rb") as f:
+        hdr = DAZZ_DB.from_buffer_copy(f.read(112))
+        recs = np.frombuffer(f.read(), dtype=READ_DTYPE)
+    if part > 0:
+        lo, hi = firsts[part - 1][0], firsts[part][0]
+    else:
+        lo, hi = 0, hdr.ureads
+    bps = np.fromfile(os.path.join(d, "." + root + ".bps"), dtype=np.uint8)
+    seqs = []
+    for r in recs[lo:hi]:
+        n = int(r["rlen"])
+        o = int(r["boff"])
+        seqs.append(_unpack_2bit(bps[o:o + (n + 3) // 4], n))
+    blk = make_block(seqs, tfirst=lo, part=part,
+                     path=os.path.join(d, "." + root).encode(),
+                     freq=[hdr.freq[j] for j in range(4)])
+    return blk

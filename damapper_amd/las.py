@@ -1,0 +1,83 @@
+""".las record streams (align.c:3098-3122, map.c:2421-2428): `int64 novl; int32 tspace;` then per
+record 40 bytes {tlen,diffs,abpos,bbpos,aepos,bepos,flags,aread,bread,<4 pad bytes>} followed by
+tlen trace values of 1 byte (tspace <= 125, align.h:21) or 2 bytes each."""
+from __future__ import annotations
+
+import glob
+import os
+import re
+import struct
+from dataclasses import dataclass
+from typing import List, Tuple
+
+TRACE_XOVR = 125
+
+COMP_FLAG = 0x1
+ACOMP_FLAG = 0x2
+START_FLAG = 0x4
+NEXT_FLAG = 0x8
+BEST_FLAG = 0x10
+
+
+@dataclass
+class LasRecord:
+    tlen: int
+    diffs: int
+    abpos: int
+    bbpos: int
+    aepos: int
+    bepos: int
+    flags: int
+    aread: int
+    bread: int
+    trace: bytes
+
+    def key(self) -> Tuple:
+        return (self.aread, self.bread, self.flags, self.abpos, self.aepos, self.bbpos, self.bepos,
+                self.diffs, self.tlen, self.trace)
+
+
+def read_las(path: str) -> Tuple[int, List[LasRecord]]:
+    with open(path, "rb") as f:
+        buf = f.read()
+    novl, tspace = struct.unpack_from("<qi", buf, 0)
+    tbytes = 1 if tspace <= TRACE_XOVR else 2
+    off = 12
+    recs = []
+    for _ in range(novl):
+        tlen, diffs, abpos, bbpos, aepos, bepos, flags, aread, bread = struct.unpack_from("<6iI2i", buf, off)
+        off += 40  # bytes 36..39 are struct padding (uninitialised in the reference)
+        tr = buf[off:off + tlen * tbytes]
+        off += tlen * tbytes
+        recs.append(LasRecord(tlen, diffs, abpos, bbpos, aepos, bepos, flags, aread, bread, tr))
+    if off != len(buf):
+        raise ValueError("%s: %d trailing bytes" % (path, len(buf) - off))
+    return tspace, recs
+
+
+def read_las_set(directory: str, pattern: str) -> Tuple[int, List[LasRecord]]:
+    """Concatenate per-thread files `<dir>/<pattern with @ = 1..T>` in numeric order
+    (the parity artefact of SURVEY.md section 8c)."""
+    pre, post = pattern.split("@")
+    files = glob.glob(os.path.join(directory, pre + "*" + post))
+    rx = re.compile(re.escape(pre) + r"(\d+)" + re.escape(post) + "$")
+    idx = sorted((int(rx.search(os.path.basename(p)).group(1)), p) for p in files
+                 if rx.search(os.path.basename(p)))
+    out: List[LasRecord] = []
+    tspace = -1
+    for _, p in idx:
+        ts, r = read_las(p)
+        tspace = ts
+        out.extend(r)
+    return tspace, out
+
+
+def check_trace_points(rec: LasRecord, tspace: int) -> bool:
+    """Record-level invariants of Check_Trace_Points (align.c:3194-3236)."""
+    tbytes = 1 if tspace <= TRACE_XOVR else 2
+    vals = list(rec.trace) if tbytes == 1 else list(struct.unpack("<%dH" % rec.tlen, rec.trace))
+    if rec.flags & COMP_FLAG:
+        pass
+    if ((rec.aepos - 1) // tspace - rec.abpos // tspace) * 2 != rec.tlen - 2:
+        return False
+    return rec.bbpos + sum(vals[1::2]) == rec.bepos
