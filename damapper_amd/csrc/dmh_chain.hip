@@ -1,0 +1,543 @@
+// dmh_chain.hip -- sparse chain scoring of the sorted seed hits (map.c:1463-1922).
+//
+// The reference keeps the live k-mer hits of one (read, contig) group in a splay tree keyed by
+// (diagonal, apos) and walks the hits sequentially.  Only three things about that tree are
+// observable: which hits are live, the nearest qualifying neighbour on either
+// side in key order, and the order in which chain ends are reported.  Here one wavefront owns a
+// group: the live hits are a window of the sorted list (hits expire in insertion order, the
+// window is [qhead, j)), the two neighbour queries are wavefront min/max reductions over that
+// window, and the scalar chain bookkeeping (cost / from / origin / best end) runs uniformly on
+// all lanes.  Groups are handed out through an atomic ticket so that skewed group sizes do not
+// leave wavefronts idle.
+//
+// The per-read candidate list with its domination rule (map.c:1668-1766) is host code below: it
+// is sequential per read and touches a handful of records per read.
+
+#include "dmh_state.h"
+#include "dmh_chain.h"
+#include <algorithm>
+
+namespace dmh {
+
+constexpr int MAX_GAP   = 1000;   // map.c:36
+constexpr int MIN_PIECE = 300;    // map.c:37
+constexpr int HITMIN    = 3;      // map.c:34
+
+constexpr uint32_t NIL = 0xffffffffu;
+
+constexpr uint32_t ST_LIVE    = 1;   // in the tree
+constexpr uint32_t ST_DEAD    = 0;   // removed (slope rule or expired while not a best end)
+constexpr uint32_t ST_EXPBEST = 2;   // expired while it was the best end of its origin
+
+void gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n);
+
+struct ChainSummary
+{ uint32_t group, rank;
+  int32_t  cost, ab, ae, bb, be;
+  uint32_t end;
+};
+
+struct ChainArgs
+{ const uint64_t *keys;
+  const uint32_t *vals;
+  const uint32_t *gstart;
+  uint32_t        ngroups;
+  uint64_t        pmask;
+  int             K, hithr;
+  int32_t        *cost;
+  uint32_t       *from, *orig, *state, *tmp;
+  unsigned int   *ticket;
+  unsigned int   *out_count;
+  ChainSummary   *out;
+};
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    { uint64_t t = __shfl_xor(v, o);
+      v = (t < v) ? t : v;
+    }
+  return v;
+}
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    { uint64_t t = __shfl_xor(v, o);
+      v = (t > v) ? t : v;
+    }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_chain(ChainArgs A)
+{ const int      lane = threadIdx.x & 63;
+  const uint64_t lt   = (1ull << lane) - 1ull;
+  const int      K    = A.K;
+
+  while (true)
+    { uint32_t g = 0;
+      if (lane == 0) g = atomicAdd(A.ticket, 1u);
+      g = __shfl(g, 0);
+      if (g >= A.ngroups) break;
+
+      const uint32_t g0 = A.gstart[g], g1 = A.gstart[g + 1];
+      uint32_t qhead = g0;
+
+      for (uint32_t j = g0; j < g1; j++)
+        { const int apos = (int) (A.keys[j] & A.pmask) + 1;       // map.c:1784-1785
+          const int bpos = (int) A.vals[j] + 1;
+          const int diag = apos - bpos;
+
+          // ---- expire hits more than MAX_GAP behind in A (map.c:1787-1796)
+          while (qhead < j)
+            { uint32_t x   = qhead + lane;
+              bool     exp = false;
+              if (x < j)
+                exp = ((int) (A.keys[x] & A.pmask) + 1) < apos - MAX_GAP;
+              if (exp && A.state[x] == ST_LIVE)
+                { uint32_t o = A.orig[x];
+                  A.state[x] = (A.orig[o] == x) ? ST_EXPBEST : ST_DEAD;
+                }
+              int cnt = __popcll(__ballot(exp));
+              qhead += cnt;
+              if (cnt < 64) break;
+            }
+
+          // ---- neighbour queries over the live window (predOf/leftmost/succOf, map.c:1262-1318)
+          uint64_t Lbest = ~0ull, Rbest = 0;
+          uint32_t Lidx = NIL, Ridx = NIL;
+          const int thresh = bpos - MAX_GAP;
+          for (uint32_t base = qhead; base < j; base += 64)
+            { uint32_t x  = base + lane;
+              uint64_t lk = ~0ull, rk = 0;
+              if (x < j && A.state[x] == ST_LIVE)
+                { int ax = (int) (A.keys[x] & A.pmask) + 1;
+                  int bx = (int) A.vals[x] + 1;
+                  int dx = ax - bx;
+                  uint64_t db = (uint64_t) ((uint32_t) dx + 0x80000000u);
+                  if (dx > diag)
+                    { if (bx >= thresh) lk = (db << 32) | (uint32_t) (0x7fffffff - ax); }
+                  else
+                    { if (bx <= bpos) rk = (db << 32) | (uint32_t) ax; }
+                }
+              uint64_t lm = wave_min_u64(lk);
+              uint64_t rm = wave_max_u64(rk);
+              if (lm < Lbest)
+                { Lbest = lm;
+                  Lidx  = base + (uint32_t) (__ffsll((long long) __ballot(lk == lm)) - 1);
+                }
+              if (rm > Rbest)
+                { Rbest = rm;
+                  Ridx  = base + (uint32_t) (__ffsll((long long) __ballot(rk == rm)) - 1);
+                }
+            }
+
+          // ---- extend the better neighbour's chain (map.c:1811-1862); uniform on all lanes
+          int lcost = 0, rcost = 0;
+          if (Lidx != NIL)
+            { int la = (int) (A.keys[Lidx] & A.pmask) + 1;
+              int lc = A.cost[Lidx];
+              lcost = (apos >= la + K) ? lc + K : lc + (apos - la);
+            }
+          if (Ridx != NIL)
+            { int rb = (int) A.vals[Ridx] + 1;
+              int rc = A.cost[Ridx];
+              rcost = (bpos >= rb + K) ? rc + K : rc + (bpos - rb);
+            }
+          if (lcost > rcost) rcost = 0; else lcost = 0;
+
+          uint32_t p = NIL;
+          int      c = K;
+          if (lcost > 0)      { p = Lidx; c = lcost; }
+          else if (rcost > 0) { p = Ridx; c = rcost; }
+
+          if (p != NIL)
+            { uint32_t root = (A.from[p] == NIL) ? p : A.orig[p];
+              uint32_t best = A.orig[root];
+              int      bc   = A.cost[best];
+              bool     kill = false;
+              if (c >= bc)
+                { int pa = (int) (A.keys[p] & A.pmask) + 1;
+                  int pd = pa - ((int) A.vals[p] + 1);
+                  int dd = pd - diag;
+                  if (dd < 0) dd = -dd;
+                  kill = ((double) dd <= .2 * (double) (apos - pa));      // map.c:1837,1852
+                }
+              if (lane == 0)
+                { A.from[j]  = p;
+                  A.cost[j]  = c;
+                  A.orig[j]  = root;
+                  A.state[j] = ST_LIVE;
+                  if (c >= bc)
+                    { A.orig[root] = j;
+                      if (kill) A.state[p] = ST_DEAD;
+                    }
+                }
+            }
+          else if (lane == 0)
+            { A.from[j]  = NIL;
+              A.cost[j]  = K;
+              A.orig[j]  = j;
+              A.state[j] = ST_LIVE;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+
+      // ---- report the best end of every origin with cost >= hithr (map.c:1634-1649).  Order:
+      //      live ends by (diag,apos) descending, then expired ends most recent first.
+      uint32_t E = 0;
+      for (uint32_t base = g0; base < g1; base += 64)
+        { uint32_t x = base + lane;
+          bool     f = false;
+          if (x < g1 && A.cost[x] >= A.hithr && A.from[x] != NIL)
+            f = (A.orig[A.orig[x]] == x);
+          uint64_t m = __ballot(f);
+          if (f) A.tmp[g0 + E + __popcll(m & lt)] = x;
+          E += __popcll(m);
+        }
+      if (E == 0) continue;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+      uint32_t obase = 0;
+      if (lane == 0) obase = atomicAdd(A.out_count, E);
+      obase = __shfl(obase, 0);
+
+      for (uint32_t e = lane; e < E; e += 64)
+        { uint32_t x    = A.tmp[g0 + e];
+          bool     live = (A.state[x] == ST_LIVE);
+          int      ax   = (int) (A.keys[x] & A.pmask) + 1;
+          int      bx   = (int) A.vals[x] + 1;
+          int      dx   = ax - bx;
+          uint32_t rank = 0;
+          for (uint32_t f = 0; f < E; f++)
+            { uint32_t y     = A.tmp[g0 + f];
+              bool     ylive = (A.state[y] == ST_LIVE);
+              bool     before;
+              if (ylive != live)
+                before = ylive;
+              else if (live)
+                { int ay = (int) (A.keys[y] & A.pmask) + 1;
+                  int dy = ay - ((int) A.vals[y] + 1);
+                  before = (dy > dx) || (dy == dx && ay > ax);
+                }
+              else
+                before = (y > x);
+              rank += before ? 1u : 0u;
+            }
+          uint32_t     root = A.orig[x];
+          ChainSummary s;
+          s.group = g;
+          s.rank  = rank;
+          s.cost  = A.cost[x];
+          s.ab    = (int) (A.keys[root] & A.pmask) + 1 - K;
+          s.bb    = (int) A.vals[root] + 1 - K;
+          s.ae    = ax;
+          s.be    = bx;
+          s.end   = x;
+          A.out[obase + e] = s;
+        }
+    }
+}
+
+// Compressed Jump displacements of a kept chain (chain_length, map.c:1243-1260, and the encoding
+// loop map.c:1741-1759): links on one diagonal closer than 100 bp to the last kept point are
+// skipped.  One thread per candidate; pass 0 counts, pass 1 writes at joff[c].
+__global__ void k_chain_jumps(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                              uint64_t pmask, const uint32_t *__restrict__ from,
+                              const uint32_t *__restrict__ ends, int n, uint32_t *__restrict__ jlen,
+                              const uint32_t *__restrict__ joff, uint16_t *__restrict__ jout, int write)
+{ int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  uint32_t x  = ends[c];
+  int      ax = (int) (keys[x] & pmask), bx = (int) vals[x];
+  uint32_t y  = from[x];
+  uint32_t cnt = 0;
+  uint16_t *o = write ? jout + 2 * (size_t) joff[c] : nullptr;
+  while (y != NIL)
+    { int ay = (int) (keys[y] & pmask), by = (int) vals[y];
+      int da = ax - ay, db = bx - by;
+      if (da == db && da < 100)
+        y = from[y];
+      else
+        { if (write)
+            { o[2 * cnt]     = (uint16_t) da;
+              o[2 * cnt + 1] = (uint16_t) db;
+            }
+          cnt += 1;
+          x = y; ax = ay; bx = by;
+          y = from[x];
+        }
+    }
+  if (!write) jlen[c] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------
+//  Host: per-read candidate lists
+// ---------------------------------------------------------------------------------------
+
+void chain_reset_reads(const DAZZ_DB *ablock)
+{ State &st = S();
+  st.cur_reads = ablock;
+  st.reads.clear();
+  st.reads.resize(ablock->nreads);
+  st.next_cand_id = 0;
+  st.tfilt = 0;
+  if (PROFILE)
+    for (int i = 0; i < ablock->nreads; i++)
+      st.reads[i].cover.assign((ablock->reads[i].rlen - 1) / SPACING + 2, 0);
+  for (int i = 0; i < ablock->nreads; i++)
+    ablock->reads[i].coff = -1;
+}
+
+int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock, int comp)
+{ State &st = S();
+  const Params &pm = st.params;
+  if (st.cur_reads != ablock || (int) st.reads.size() != ablock->nreads)
+    fatal("Match_Filter: first call for a READS block must have start != 0 (map.c:1574)");
+
+  const int64_t nhits = R.nhits;
+  static DevBuf<int32_t>  cost;
+  static DevBuf<uint32_t> from, orig, state, tmp, ctl;
+  static DevBuf<ChainSummary> out;
+  cost.ensure(nhits, "chain cost");
+  from.ensure(nhits, "chain from");
+  orig.ensure(nhits, "chain orig");
+  state.ensure(nhits, "chain state");
+  tmp.ensure(nhits, "chain scratch");
+  ctl.ensure(4, "chain counters");
+  out.ensure(nhits / HITMIN + 64, "chain summaries");
+  HIP_CHECK(hipMemsetAsync(ctl.p, 0, 4 * sizeof(uint32_t), stream()));
+
+  ChainArgs A;
+  A.keys = R.skeys;
+  A.vals = R.svals;
+  A.gstart = R.gstart.p;
+  A.ngroups = (uint32_t) R.ngroups;
+  A.pmask = ((uint64_t) 1 << R.pbits) - 1;
+  A.K = pm.Kmer;
+  A.hithr = HITMIN * pm.Kmer;
+  A.cost = cost.p;
+  A.from = from.p;
+  A.orig = orig.p;
+  A.state = state.p;
+  A.tmp = tmp.p;
+  A.ticket = ctl.p;
+  A.out_count = ctl.p + 1;
+  A.out = out.p;
+
+  int nblocks = (int) std::min<int64_t>((R.ngroups + 3) / 4, 256 * 8);
+  { StageTimer tm("chain", 16.0 * nhits);
+    hipLaunchKernelGGL(k_chain, dim3(nblocks), dim3(256), 0, stream(), A);
+    HIP_CHECK(hipGetLastError());
+  }
+  uint32_t nsum = 0;
+  HIP_CHECK(hipMemcpyAsync(&nsum, ctl.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+
+  std::vector<ChainSummary> sums(nsum);
+  std::vector<uint32_t>     gfirst;
+  if (nsum > 0)
+    { HIP_CHECK(hipMemcpy(sums.data(), out.p, sizeof(ChainSummary) * nsum, hipMemcpyDeviceToHost));
+      std::sort(sums.begin(), sums.end(), [](const ChainSummary &a, const ChainSummary &b)
+                { return a.group != b.group ? a.group < b.group : a.rank < b.rank; });
+    }
+
+  // group -> (aread, bread): decode from the first hit of each summarised group
+  std::vector<uint32_t> want;
+  for (uint32_t i = 0; i < nsum; i++)
+    if (i == 0 || sums[i].group != sums[i - 1].group) want.push_back(sums[i].end);
+  std::vector<uint64_t> wkeys(want.size());
+  { // gather the keys of those hits (few): one small copy each would be slow, so fetch via a
+    // device gather through the jump kernel's buffers is overkill; copy key by key in batches
+    static DevBuf<uint32_t> d_idx;
+    static DevBuf<uint64_t> d_k;
+    d_idx.ensure(want.size() + 1, "gather idx");
+    d_k.ensure(want.size() + 1, "gather keys");
+    if (!want.empty())
+      { HIP_CHECK(hipMemcpyAsync(d_idx.p, want.data(), sizeof(uint32_t) * want.size(), hipMemcpyHostToDevice, stream()));
+        gather_u64(R.skeys, d_idx.p, d_k.p, (int64_t) want.size());
+        HIP_CHECK(hipMemcpyAsync(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size(), hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+      }
+  }
+
+  const int bshift = R.pbits + R.bbits;
+  const uint64_t bmask = ((uint64_t) 1 << R.bbits) - 1;
+  const int bstart = bblock->tfirst;
+
+  int64_t nfilt = 0;
+  std::vector<Candidate *> fresh;           // candidates added in this call, still alive or not
+  std::vector<uint32_t>    fresh_end;
+  size_t gi = 0;
+  for (uint32_t i = 0; i < nsum; i++)
+    { if (i > 0 && sums[i].group != sums[i - 1].group) gi += 1;
+      const ChainSummary &h = sums[i];
+      int ar = (int) (wkeys[gi] >> bshift);
+      int br = (int) ((wkeys[gi] >> R.pbits) & bmask);
+      ReadState &rs = st.reads[ar];
+      int ab = h.ab, ae = h.ae;
+
+      if (PROFILE)                                                     // map.c:1654-1666
+        { int tb = ab / SPACING, te = (ae - 1) / SPACING + 1;
+          int cb = rs.cover[tb], ce = rs.cover[te];
+          if (cb < 0x7fff && ce > -0xffff)
+            { rs.cover[tb] = (int16_t) (cb + 1);
+              rs.cover[te] = (int16_t) (ce - 1);
+            }
+        }
+
+      // domination scan from the list head (map.c:1668-1713)
+      auto &L = rs.cands;
+      bool dropped = false;
+      size_t d = 0;
+      while (d < L.size())
+        { Candidate &cd = *L[d];
+          bool d_has_c = (cd.afirst < ab + MIN_PIECE && cd.alast > ae - MIN_PIECE);
+          bool c_has_d = (ab < cd.afirst + MIN_PIECE && ae > cd.alast - MIN_PIECE);
+          if (d_has_c && .9 * cd.score >= h.cost)
+            { dropped = true;
+              break;
+            }
+          if (c_has_d && cd.score <= .9 * h.cost)
+            { L.erase(L.begin() + d);
+              nfilt -= 1;
+              continue;
+            }
+          d += 1;
+        }
+      if (dropped) continue;
+
+      std::unique_ptr<Candidate> nc(new Candidate());
+      nc->score  = h.cost;
+      nc->length = 0;
+      nc->bread  = br + bstart;
+      nc->comp   = comp;
+      nc->afirst = ab;
+      nc->alast  = ae;
+      nc->bfirst = h.bb;
+      nc->blast  = h.be;
+      nc->id     = st.next_cand_id++;
+      fresh.push_back(nc.get());
+      fresh_end.push_back(h.end);
+      L.insert(L.begin(), std::move(nc));
+      nfilt += 1;
+    }
+
+  // Jump chains of the candidates added in this call that survived it
+  { std::vector<uint32_t> ends;
+    std::vector<Candidate *> keep;
+    // a fresh candidate may already have been erased again: find survivors by identity
+    std::vector<char> alive(fresh.size(), 0);
+    { std::map<const Candidate *, size_t> pos;
+      for (size_t i = 0; i < fresh.size(); i++) pos[fresh[i]] = i;
+      for (auto &rs : st.reads)
+        for (auto &c : rs.cands)
+          { auto it = pos.find(c.get());
+            if (it != pos.end()) alive[it->second] = 1;
+          }
+    }
+    for (size_t i = 0; i < fresh.size(); i++)
+      if (alive[i])
+        { keep.push_back(fresh[i]);
+          ends.push_back(fresh_end[i]);
+        }
+    int n = (int) ends.size();
+    if (n > 0)
+      { static DevBuf<uint32_t> d_ends, d_len;
+        static DevBuf<uint16_t> d_j;
+        d_ends.ensure(n, "jump ends");
+        d_len.ensure(2 * (size_t) n + 2, "jump lengths");
+        HIP_CHECK(hipMemcpyAsync(d_ends.p, ends.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, stream()));
+        StageTimer tm("chain_jumps", 0.0);
+        hipLaunchKernelGGL(k_chain_jumps, dim3(ceil_div(n, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
+                           (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, (const uint32_t *) d_ends.p, n,
+                           d_len.p, (const uint32_t *) nullptr, (uint16_t *) nullptr, 0);
+        std::vector<uint32_t> len(n), off(n + 1);
+        HIP_CHECK(hipMemcpyAsync(len.data(), d_len.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        off[0] = 0;
+        for (int i = 0; i < n; i++) off[i + 1] = off[i] + len[i];
+        d_j.ensure(2 * (size_t) off[n] + 2, "jump data");
+        HIP_CHECK(hipMemcpyAsync(d_len.p + n, off.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, stream()));
+        hipLaunchKernelGGL(k_chain_jumps, dim3(ceil_div(n, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
+                           (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, (const uint32_t *) d_ends.p, n,
+                           d_len.p, (const uint32_t *) (d_len.p + n), d_j.p, 1);
+        std::vector<uint16_t> jd(2 * (size_t) off[n]);
+        if (off[n] > 0)
+          HIP_CHECK(hipMemcpyAsync(jd.data(), d_j.p, sizeof(uint16_t) * jd.size(), hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        for (int i = 0; i < n; i++)
+          { Candidate *c = keep[i];
+            c->length = (int) len[i];
+            c->adisp.resize(len[i]);
+            c->bdisp.resize(len[i]);
+            for (uint32_t t = 0; t < len[i]; t++)
+              { c->adisp[t] = jd[2 * ((size_t) off[i] + t)];
+                c->bdisp[t] = jd[2 * ((size_t) off[i] + t) + 1];
+              }
+          }
+      }
+  }
+  return nfilt;
+}
+
+__global__ void k_gather_u64(const uint64_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                             uint64_t *__restrict__ dst, int64_t n)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+void gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n)
+{ if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather_u64, dim3(ceil_div(n, 256)), dim3(256), 0, stream(), src, idx, dst, n);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace dmh
+
+using namespace dmh;
+
+extern "C" {
+
+int dmh_read_candidates(DAZZ_DB *ablock, int ar, int *out, int maxc)
+{ State &st = S();
+  if (st.cur_reads != ablock || ar < 0 || ar >= (int) st.reads.size()) return -1;
+  auto &L = st.reads[ar].cands;
+  int n = 0;
+  for (auto &c : L)
+    { if (n < maxc)
+        { int *o = out + 9 * n;
+          o[0] = c->score; o[1] = c->length; o[2] = c->bread; o[3] = c->comp;
+          o[4] = c->afirst; o[5] = c->alast; o[6] = c->bfirst; o[7] = c->blast; o[8] = c->id;
+        }
+      n += 1;
+    }
+  return n;
+}
+
+int dmh_candidate_jumps(DAZZ_DB *ablock, int ar, int k, uint16_t *adisp, uint16_t *bdisp, int maxj)
+{ State &st = S();
+  if (st.cur_reads != ablock || ar < 0 || ar >= (int) st.reads.size()) return -1;
+  auto &L = st.reads[ar].cands;
+  if (k < 0 || k >= (int) L.size()) return -1;
+  Candidate &c = *L[k];
+  int n = (int) c.adisp.size();
+  for (int i = 0; i < n && i < maxj; i++)
+    { adisp[i] = c.adisp[i];
+      bdisp[i] = c.bdisp[i];
+    }
+  return n;
+}
+
+int dmh_read_cover(DAZZ_DB *ablock, int ar, int16_t *out, int maxn)
+{ State &st = S();
+  if (st.cur_reads != ablock || ar < 0 || ar >= (int) st.reads.size()) return -1;
+  auto &cv = st.reads[ar].cover;
+  int n = (int) cv.size();
+  for (int i = 0; i < n && i < maxn; i++) out[i] = cv[i];
+  return n;
+}
+
+}  // extern "C"

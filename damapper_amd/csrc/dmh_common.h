@@ -1,0 +1,79 @@
+// dmh_common.h -- internal helpers shared by the HIP translation units of libdamapper_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/damapper_hip.h"
+
+namespace dmh {
+
+void fatal(const char *fmt, ...) __attribute__((format(printf, 1, 2), noreturn));
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define HIP_CHECK(expr)                                                                  \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      dmh::fatal("HIP error %s at %s:%d: %s", hipGetErrorName(_e), __FILE__, __LINE__,   \
+                 hipGetErrorString(_e));                                                 \
+  } while (0)
+
+hipStream_t stream();
+
+// Device allocation that aborts through Clean_Exit on failure (the reference's behaviour
+// for a failed Malloc, e.g. map.c:689-690).
+void *dev_alloc(size_t bytes, const char *what);
+void  dev_free(void *p);
+
+template <typename T> struct DevBuf
+{ T     *p   = nullptr;
+  size_t cap = 0;      // elements
+  void ensure(size_t n, const char *what)
+  { if (n > cap)
+      { if (p) dev_free(p);
+        cap = n + n / 8 + 256;
+        p   = (T *) dev_alloc(cap * sizeof(T), what);
+      }
+  }
+  void release()
+  { if (p) dev_free(p);
+    p = nullptr; cap = 0;
+  }
+};
+
+// ---- stage timing (HIP events on our stream) -----------------------------------------
+struct StageTimer
+{ StageTimer(const char *name, double bytes = 0.0);
+  ~StageTimer();
+  int    idx;
+  bool   active;
+  hipEvent_t e0, e1;
+};
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int) ((a + b - 1) / b); }
+
+// ---- sort / scan primitives (dmh_sort.hip) ---------------------------------------------
+struct SortScratch
+{ DevBuf<uint32_t> hist;     // 256 x ntiles digit histogram / offsets
+  DevBuf<uint32_t> bsum;     // scan block sums
+  DevBuf<uint64_t> keys_alt;
+  DevBuf<uint32_t> vals_alt;
+};
+
+// Stable LSD radix sort of (key,val) pairs on key bits [lo_bit, lo_bit+nbits).  Uses
+// keys_alt/vals_alt as the ping-pong partner; on return *keys/*vals point at the buffers
+// holding the result (either the originals or the alternates) and *okeys/*ovals at the others.
+void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32_t **ovals,
+                      int64_t n, int lo_bit, int nbits, SortScratch &scr, const char *stage);
+
+// Exclusive scan of n uint32 values in place; returns nothing, total is written to *d_total
+// (device pointer to one uint32) if not null.  n < 2^32, sum < 2^32.
+void exclusive_scan_u32(uint32_t *d_data, int64_t n, DevBuf<uint32_t> &bsum, uint32_t *d_total);
+
+}  // namespace dmh

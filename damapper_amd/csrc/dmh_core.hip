@@ -1,0 +1,511 @@
+// dmh_core.hip -- library state, device memory, stage timing, Set_Filter_Params, Sort_Kmers
+// and the small stage-level helpers of the C-ABI (see include/damapper_hip.h).
+
+#include "dmh_state.h"
+#include "dmh_device.h"
+#include <stdarg.h>
+#include <algorithm>
+
+// ---- globals shared with the driver (damapper.c:58-65; map.h:17-24) ----------------------
+extern "C" {
+int      VERBOSE      = 0;
+int      PROFILE      = 0;
+int      SPACING      = 100;
+double   BEST_TIE     = 1.0;
+char    *SORT_PATH    = (char *) "/tmp";
+uint64_t MEM_LIMIT    = 0;
+uint64_t MEM_PHYSICAL = 0;
+
+__attribute__((weak)) void Clean_Exit(int val) { exit(val); }
+}
+
+namespace dmh {
+
+static char       g_err[1024] = "";
+static hipStream_t g_stream    = nullptr;
+static bool        g_init      = false;
+
+State &S()
+{ static State *s = new State();
+  return *s;
+}
+
+void set_error(const char *fmt, ...)
+{ va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+void fatal(const char *fmt, ...)
+{ va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "damapper_hip: %s\n", g_err);
+  fflush(stderr);
+  Clean_Exit(1);
+  exit(1);
+}
+
+static void init_device()
+{ if (g_init) return;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    fatal("no HIP device available (%s): libdamapper_hip has no CPU fallback",
+          e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  int dev = 0;
+  const char *lr = getenv("LOCAL_RANK");
+  if (lr != nullptr && getenv("DMH_IGNORE_LOCAL_RANK") == nullptr)
+    dev = atoi(lr) % n;
+  const char *dv = getenv("DMH_DEVICE");
+  if (dv != nullptr) dev = atoi(dv) % n;
+  HIP_CHECK(hipSetDevice(dev));
+  HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_init = true;
+}
+
+hipStream_t stream()
+{ init_device();
+  return g_stream;
+}
+
+void *dev_alloc(size_t bytes, const char *what)
+{ init_device();
+  void *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess)
+    fatal("out of device memory allocating %zu bytes (%s): %s", bytes, what, hipGetErrorString(e));
+  return p;
+}
+
+void dev_free(void *p)
+{ if (p != nullptr) HIP_CHECK(hipFree(p)); }
+
+// ---- stage timing -----------------------------------------------------------------------
+
+struct TimerSlot { std::string name; double ms = 0; int64_t launches = 0; double bytes = 0; };
+struct PendingEv { int idx; hipEvent_t e0, e1; };
+static std::vector<TimerSlot> g_slots;
+static std::vector<PendingEv> g_pending;
+static bool g_timing = false;
+
+static int slot_of(const char *name)
+{ for (size_t i = 0; i < g_slots.size(); i++)
+    if (g_slots[i].name == name) return (int) i;
+  g_slots.push_back(TimerSlot());
+  g_slots.back().name = name;
+  return (int) g_slots.size() - 1;
+}
+
+StageTimer::StageTimer(const char *name, double bytes)
+{ active = g_timing;
+  idx = -1;
+  if (!active) return;
+  idx = slot_of(name);
+  g_slots[idx].bytes += bytes;
+  g_slots[idx].launches += 1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventRecord(e0, stream()));
+}
+
+StageTimer::~StageTimer()
+{ if (!active) return;
+  HIP_CHECK(hipEventRecord(e1, stream()));
+  g_pending.push_back({idx, e0, e1});
+}
+
+static void drain_timers()
+{ if (g_pending.empty()) return;
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  for (auto &p : g_pending)
+    { float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, p.e0, p.e1));
+      g_slots[p.idx].ms += ms;
+      HIP_CHECK(hipEventDestroy(p.e0));
+      HIP_CHECK(hipEventDestroy(p.e1));
+    }
+  g_pending.clear();
+}
+
+// ---- block upload -----------------------------------------------------------------------
+
+static uint64_t block_stamp(const DAZZ_DB *b)
+{ const uint8_t *p = (const uint8_t *) b->bases;
+  int64_t L = b->reads[b->nreads].boff;
+  uint64_t h = 1469598103934665603ull ^ (uint64_t) L ^ ((uint64_t) b->nreads << 40);
+  int64_t step = L / 257 + 1;
+  for (int64_t i = 0; i < L; i += step)
+    { int64_t e = std::min<int64_t>(L, i + 16);
+      for (int64_t j = i; j < e; j++) h = (h ^ p[j]) * 1099511628211ull;
+    }
+  return h;
+}
+
+static void free_blockdev(BlockDev &bd)
+{ dev_free(bd.d_raw);
+  dev_free(bd.d_boff);
+  bd.d_raw = nullptr;
+  bd.d_boff = nullptr;
+}
+
+BlockDev &upload_block(const DAZZ_DB *block, bool pin)
+{ State &st = S();
+  uint64_t stamp = block_stamp(block);
+  auto it = st.blocks.find(block);
+  if (it != st.blocks.end())
+    { if (it->second.stamp == stamp && it->second.nreads == block->nreads)
+        { if (pin) it->second.pinned = true;
+          return it->second;
+        }
+      free_blockdev(it->second);
+      st.blocks.erase(it);
+    }
+  BlockDev bd;
+  int n = block->nreads;
+  bd.nreads = n;
+  bd.L = block->reads[n].boff;
+  bd.stamp = stamp;
+  bd.pinned = pin;
+  bd.d_raw = (uint8_t *) dev_alloc((size_t) bd.L + 1, "block bases");
+  // the byte before bases[0] is the leading separator (DB.c:1411)
+  HIP_CHECK(hipMemcpyAsync(bd.d_raw, ((const uint8_t *) block->bases) - 1, (size_t) bd.L + 1,
+                           hipMemcpyHostToDevice, stream()));
+  std::vector<int64_t> off(n + 1);
+  for (int i = 0; i <= n; i++) off[i] = block->reads[i].boff;
+  bd.d_boff = (int64_t *) dev_alloc(sizeof(int64_t) * (n + 1), "block read offsets");
+  HIP_CHECK(hipMemcpyAsync(bd.d_boff, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  st.blocks[block] = bd;
+  return st.blocks[block];
+}
+
+void drop_block(const DAZZ_DB *block)
+{ State &st = S();
+  auto it = st.blocks.find(block);
+  if (it == st.blocks.end()) return;
+  free_blockdev(it->second);
+  st.blocks.erase(it);
+}
+
+// ---- index registry -----------------------------------------------------------------------
+
+static void free_index(IndexDev &ix)
+{ dev_free(ix.keys);
+  dev_free(ix.vals);
+  dev_free(ix.d_boff);
+  dev_free(ix.d_chunk);
+  ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr;
+}
+
+IndexDev *index_of(void *table, const char *who)
+{ if (table == nullptr) return nullptr;
+  IndexStub *stub = (IndexStub *) table;
+  if (stub->magic != INDEX_MAGIC)
+    fatal("%s: table argument is not a handle returned by Sort_Kmers", who);
+  auto it = S().indices.find(stub->id);
+  if (it == S().indices.end())
+    fatal("%s: index %d was already consumed or released", who, stub->id);
+  return &it->second;
+}
+
+__global__ void k_chunk_table(const int64_t *__restrict__ boff, int nreads, int64_t nchunk,
+                              uint32_t *__restrict__ chunk)
+{ int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunk) return;
+  int64_t q = c << CHUNK_SHIFT;
+  int lo = 0, hi = nreads;                 // largest i with boff[i] <= q
+  while (lo < hi)
+    { int m = (lo + hi + 1) >> 1;
+      if (boff[m] > q) hi = m - 1; else lo = m;
+    }
+  chunk[c] = (uint32_t) lo;
+}
+
+// Drop every code that occurs >= TooFrequent times (map.c:590-636, compsize/compress_thread).
+__global__ void k_suppress_flag(const uint64_t *__restrict__ keys, int64_t n, int toofreq,
+                                uint32_t *__restrict__ keep)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t s = run_start(keys, i);
+  int64_t e = run_end(keys, n, i);
+  keep[i] = ((e - s) < toofreq) ? 1u : 0u;
+}
+
+__global__ void k_compact(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                          const uint32_t *__restrict__ keep, const uint32_t *__restrict__ slot, int64_t n,
+                          uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (keep[i])
+    { uint32_t o = slot[i];
+      kout[o] = kin[i];
+      vout[o] = vin[i];
+    }
+}
+
+}  // namespace dmh
+
+using namespace dmh;
+
+// =========================================================================================
+//  C-ABI
+// =========================================================================================
+
+extern "C" {
+
+int dmh_device_count(void)
+{ int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *dmh_last_error(void) { return g_err; }
+
+void dmh_sync(void)
+{ HIP_CHECK(hipStreamSynchronize(stream())); }
+
+void dmh_timing_enable(int on) { g_timing = (on != 0); }
+
+void dmh_timing_reset(void)
+{ drain_timers();
+  g_slots.clear();
+}
+
+int dmh_timing_count(void)
+{ drain_timers();
+  return (int) g_slots.size();
+}
+
+int dmh_timing_get(int idx, char *name, int namelen, double *ms, int64_t *launches, double *bytes)
+{ drain_timers();
+  if (idx < 0 || idx >= (int) g_slots.size()) return -1;
+  snprintf(name, namelen, "%s", g_slots[idx].name.c_str());
+  *ms = g_slots[idx].ms;
+  *launches = g_slots[idx].launches;
+  *bytes = g_slots[idx].bytes;
+  return 0;
+}
+
+void dmh_reset(void)
+{ State &st = S();
+  if (g_init) HIP_CHECK(hipStreamSynchronize(stream()));
+  for (auto &kv : st.indices) free_index(kv.second);
+  st.indices.clear();
+  for (auto &kv : st.blocks) free_blockdev(kv.second);
+  st.blocks.clear();
+  st.reads.clear();
+  st.cur_reads = nullptr;
+  st.tfilt = 0;
+  st.last_seeds.clear();
+  st.sort.hist.release();
+  st.sort.bsum.release();
+  st.sort.keys_alt.release();
+  st.sort.vals_alt.release();
+}
+
+int dmh_preload_block(DAZZ_DB *block)
+{ upload_block(block, true);
+  return 0;
+}
+
+void dmh_release_block(DAZZ_DB *block)
+{ drop_block(block); }
+
+void dmh_retain_ref_index(int on) { S().retain_ref = (on != 0); }
+
+void dmh_free_index(void *table)
+{ if (table == nullptr) return;
+  IndexStub *stub = (IndexStub *) table;
+  if (stub->magic != INDEX_MAGIC) return;
+  auto it = S().indices.find(stub->id);
+  if (it != S().indices.end())
+    { free_index(it->second);
+      S().indices.erase(it);
+    }
+  stub->magic = 0;
+  free(stub);
+}
+
+void dmh_capture_seeds(int on) { S().capture_seeds = (on != 0); }
+
+// ---- map.c:124-150 -------------------------------------------------------------------------
+int Set_Filter_Params(int kmer, int suppress, int nthreads)
+{ if (kmer <= 1) return 1;
+  Params &p = S().params;
+  p.Kmer = kmer;
+  p.Suppress = suppress;
+  p.Kshift = 2 * kmer;
+  p.Kmask = (kmer >= 32) ? ~0ull : ((1ull << p.Kshift) - 1ull);
+  p.TooFrequent = (suppress == 0) ? INT32_MAX : suppress;
+  p.NTHREADS = 1;
+  p.NSHIFT = 0;
+  while (2 * p.NTHREADS <= nthreads)
+    { p.NTHREADS *= 2;
+      p.NSHIFT += 1;
+    }
+  p.set = true;
+  return 0;
+}
+
+// ---- map.c:655-822 -------------------------------------------------------------------------
+void *Sort_Kmers(DAZZ_DB *block, int *len)
+{ State &st = S();
+  Params &pm = st.params;
+  if (!pm.set) fatal("Sort_Kmers called before Set_Filter_Params");
+  int     nreads = block->nreads;
+  int64_t L      = block->reads[nreads].boff;
+  int64_t kmers  = L - (int64_t) pm.Kmer * nreads;        // map.c:676
+  *len = 0;
+  if (kmers <= 0) return nullptr;
+  if (kmers > INT32_MAX) fatal("Sort_Kmers: block has %lld k-mers, limit is 2^31-1 (map.c:663)", (long long) kmers);
+  for (int i = 0; i < nreads; i++)
+    if (block->reads[i].rlen < pm.Kmer - 1)
+      fatal("Sort_Kmers: read %d is shorter than k-1 (%d < %d)", i, block->reads[i].rlen, pm.Kmer - 1);
+
+  if (VERBOSE)
+    { printf("\n   Kmer count = %lld\n", (long long) kmers);
+      printf("   Using %.2fGb of HBM\n", (24. * kmers) / 1073741824.);
+      fflush(stdout);
+    }
+
+  bool       had  = st.blocks.count(block) != 0 && st.blocks[block].pinned;
+  BlockDev  &bd   = upload_block(block, false);
+
+  IndexDev ix;
+  ix.block  = block;
+  ix.nreads = nreads;
+  ix.L      = L;
+  ix.h_boff.resize(nreads + 1);
+  for (int i = 0; i <= nreads; i++) ix.h_boff[i] = block->reads[i].boff;
+
+  uint64_t *keys = (uint64_t *) dev_alloc(sizeof(uint64_t) * kmers, "k-mer codes");
+  uint32_t *vals = (uint32_t *) dev_alloc(sizeof(uint32_t) * kmers, "k-mer positions");
+  st.sort.keys_alt.ensure(kmers, "k-mer sort buffer");
+  st.sort.vals_alt.ensure(kmers, "k-mer sort buffer");
+
+  kmer_emit(bd.d_bases(), L, bd.d_boff, nreads, pm.Kmer, keys, vals, kmers);
+
+  uint64_t *k0 = keys, *k1 = st.sort.keys_alt.p;
+  uint32_t *v0 = vals, *v1 = st.sort.vals_alt.p;
+  radix_sort_pairs(&k0, &v0, &k1, &v1, kmers, 0, pm.Kshift, st.sort, "kmer_sort");
+
+  if (pm.TooFrequent < INT32_MAX)
+    { StageTimer tm("kmer_suppress", 32.0 * kmers);
+      DevBuf<uint32_t> keep, slot;
+      keep.ensure(kmers, "suppress flags");
+      slot.ensure(kmers + 1, "suppress slots");
+      int nb = ceil_div(kmers, 256);
+      hipLaunchKernelGGL(k_suppress_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, kmers,
+                         pm.TooFrequent, keep.p);
+      HIP_CHECK(hipMemcpyAsync(slot.p, keep.p, sizeof(uint32_t) * kmers, hipMemcpyDeviceToDevice, stream()));
+      exclusive_scan_u32(slot.p, kmers, st.sort.bsum, slot.p + kmers);
+      hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0,
+                         (const uint32_t *) v0, (const uint32_t *) keep.p, (const uint32_t *) slot.p, kmers, k1, v1);
+      uint32_t kept = 0;
+      HIP_CHECK(hipMemcpyAsync(&kept, slot.p + kmers, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      std::swap(k0, k1);
+      std::swap(v0, v1);
+      kmers = kept;
+      keep.release();
+      slot.release();
+      if (VERBOSE)
+        printf("   Revised kmer count = %lld\n", (long long) kmers);
+    }
+
+  // the sorted data may sit in the scratch partner: make the index own its buffers
+  if (k0 != keys)
+    { // swap ownership: the scratch takes the originally allocated buffers
+      size_t capk = st.sort.keys_alt.cap, capv = st.sort.vals_alt.cap;
+      (void) capk; (void) capv;
+      // scratch buffers are larger-or-equal; simplest is a device copy into the owned buffers
+      HIP_CHECK(hipMemcpyAsync(keys, k0, sizeof(uint64_t) * kmers, hipMemcpyDeviceToDevice, stream()));
+      HIP_CHECK(hipMemcpyAsync(vals, v0, sizeof(uint32_t) * kmers, hipMemcpyDeviceToDevice, stream()));
+    }
+
+  ix.keys = keys;
+  ix.vals = vals;
+  ix.n    = kmers;
+
+  ix.d_boff = (int64_t *) dev_alloc(sizeof(int64_t) * (nreads + 1), "index read offsets");
+  HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (nreads + 1), hipMemcpyDeviceToDevice, stream()));
+  ix.nchunk = (L >> CHUNK_SHIFT) + 1;
+  ix.d_chunk = (uint32_t *) dev_alloc(sizeof(uint32_t) * ix.nchunk, "index chunk table");
+  hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
+                     (const int64_t *) ix.d_boff, nreads, ix.nchunk, ix.d_chunk);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(stream()));
+
+  if (!had && st.cur_reads != block)
+    { // bases of a REF block are not needed again until Reporter re-uploads the whole REF
+      // (a READS block is kept: Reporter aligns against it)
+    }
+
+  if (VERBOSE)
+    { printf("   Index occupies %.2fGb\n", (12. * kmers) / 1073741824.);
+      fflush(stdout);
+    }
+
+  if (kmers <= 0)
+    { free_index(ix);
+      return nullptr;
+    }
+
+  IndexStub *stub = (IndexStub *) malloc(sizeof(IndexStub));
+  if (stub == nullptr) fatal("out of memory allocating index handle");
+  stub->magic = INDEX_MAGIC;
+  stub->id    = st.next_index_id++;
+  stub->len   = (int32_t) kmers;
+  st.indices[stub->id] = ix;
+  *len = (int) kmers;
+  return stub;
+}
+
+// KmerPos layout of the reference (map.c:78-82, little endian)
+struct KmerPosRec { uint64_t code; int32_t rpos; int32_t read; };
+
+int dmh_index_download(void *table, void *out)
+{ IndexDev *ix = index_of(table, "dmh_index_download");
+  if (ix == nullptr) return 0;
+  std::vector<uint64_t> k(ix->n);
+  std::vector<uint32_t> v(ix->n);
+  HIP_CHECK(hipMemcpyAsync(k.data(), ix->keys, sizeof(uint64_t) * ix->n, hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipMemcpyAsync(v.data(), ix->vals, sizeof(uint32_t) * ix->n, hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  KmerPosRec *o = (KmerPosRec *) out;
+  const std::vector<int64_t> &boff = ix->h_boff;
+  for (int64_t i = 0; i < ix->n; i++)
+    { int64_t q = v[i];
+      int r = (int) (std::upper_bound(boff.begin(), boff.end(), q) - boff.begin()) - 1;
+      o[i].code = k[i];
+      o[i].read = r;
+      o[i].rpos = (int32_t) (q - boff[r]);
+    }
+  return (int) ix->n;
+}
+
+int dmh_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbits)
+{ if (n <= 0) return 0;
+  State &st = S();
+  uint64_t *dk = (uint64_t *) dev_alloc(sizeof(uint64_t) * n, "sort keys");
+  uint32_t *dv = (uint32_t *) dev_alloc(sizeof(uint32_t) * n, "sort vals");
+  st.sort.keys_alt.ensure(n, "sort buffer");
+  st.sort.vals_alt.ensure(n, "sort buffer");
+  HIP_CHECK(hipMemcpyAsync(dk, keys, sizeof(uint64_t) * n, hipMemcpyHostToDevice, stream()));
+  HIP_CHECK(hipMemcpyAsync(dv, vals, sizeof(uint32_t) * n, hipMemcpyHostToDevice, stream()));
+  uint64_t *k0 = dk, *k1 = st.sort.keys_alt.p;
+  uint32_t *v0 = dv, *v1 = st.sort.vals_alt.p;
+  radix_sort_pairs(&k0, &v0, &k1, &v1, n, 0, nbits, st.sort, "sort_pairs");
+  HIP_CHECK(hipMemcpyAsync(keys, k0, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipMemcpyAsync(vals, v0, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  dev_free(dk);
+  dev_free(dv);
+  return 0;
+}
+
+}  // extern "C"

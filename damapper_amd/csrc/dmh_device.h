@@ -1,0 +1,42 @@
+// dmh_device.h -- small device-side helpers shared by several kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmh {
+
+// First index of the run of equal codes containing i (sorted array): gallop + bisect.
+__device__ __forceinline__ int64_t run_start(const uint64_t *__restrict__ k, int64_t i)
+{ const uint64_t c = k[i];
+  int64_t hi = i, lo, step = 1;
+  while (true)
+    { int64_t t = hi - step;
+      if (t < 0) { lo = -1; break; }
+      if (k[t] == c) { hi = t; step <<= 1; }
+      else { lo = t; break; }
+    }
+  while (hi - lo > 1)
+    { int64_t m = (lo + hi) >> 1;
+      if (k[m] == c) hi = m; else lo = m;
+    }
+  return hi;
+}
+
+// One past the last index of the run of equal codes containing i.
+__device__ __forceinline__ int64_t run_end(const uint64_t *__restrict__ k, int64_t n, int64_t i)
+{ const uint64_t c = k[i];
+  int64_t lo = i, hi, step = 1;
+  while (true)
+    { int64_t t = lo + step;
+      if (t >= n) { hi = n; break; }
+      if (k[t] == c) { lo = t; step <<= 1; }
+      else { hi = t; break; }
+    }
+  while (hi - lo > 1)
+    { int64_t m = (lo + hi) >> 1;
+      if (k[m] == c) lo = m; else hi = m;
+    }
+  return hi;
+}
+
+}  // namespace dmh

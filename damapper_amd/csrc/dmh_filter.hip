@@ -1,0 +1,65 @@
+// dmh_filter.hip -- Match_Filter (map.c:2889-3209): merge -> seed sort -> chain scoring ->
+// candidate lists.  Device stages live in dmh_merge.hip / dmh_chain.hip; the per-read
+// candidate bookkeeping (domination rule, Jump storage) is host code in dmh_chain.hip.
+
+#include "dmh_state.h"
+#include "dmh_merge.h"
+#include "dmh_chain.h"
+
+using namespace dmh;
+
+extern "C" {
+
+void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void *btable, int blen,
+                  int comp, int start)
+{ State &st = S();
+  Params &pm = st.params;
+  static MergeResult R;
+
+  if (ablock->tracks != nullptr || bblock->tracks != nullptr)
+    fatal("Match_Filter: mask tracks (-m) are not supported by the HIP filter");
+
+  int64_t nhits = 0, nfilt = 0;
+  if (start)
+    chain_reset_reads(ablock);
+
+  if (alen != 0 && blen != 0 && atable != nullptr && btable != nullptr)
+    { IndexDev *A = index_of(atable, "Match_Filter");
+      IndexDev *B = index_of(btable, "Match_Filter");
+      if (A->n != alen || B->n != blen)
+        fatal("Match_Filter: table lengths (%d,%d) do not match the handles (%lld,%lld)", alen, blen,
+              (long long) A->n, (long long) B->n);
+      merge_and_sort(R, ablock, bblock, *A, *B, pm.Kshift);
+      nhits = R.nhits;
+      if (nhits > 0)
+        nfilt = chain_and_filter(R, ablock, bblock, comp);
+      st.tfilt += nfilt;
+    }
+
+  // the reference consumes the REF table here (map.c:3181-3182)
+  if (btable != nullptr && !st.retain_ref)
+    dmh_free_index(btable);
+
+  if (VERBOSE)
+    { double atot = ablock->totlen, btot = bblock->totlen;
+      printf("\n     %lld %d-mers (%e of matrix)\n     ", (long long) nhits, pm.Kmer, (1. * nhits / atot) / btot);
+      if (nfilt < 0)
+        printf("%lld candidates removed\n     ", (long long) -nfilt);
+      else
+        printf("%lld candidates added\n     ", (long long) nfilt);
+      printf("%lld candidates (%e of matrix)\n", (long long) st.tfilt, (1. * st.tfilt / atot) / btot);
+      fflush(stdout);
+    }
+}
+
+int64_t dmh_last_seed_count(void) { return (int64_t) (S().last_seeds.size() / 4); }
+
+int dmh_last_seeds(void *out)
+{ State &st = S();
+  memcpy(out, st.last_seeds.data(), st.last_seeds.size() * sizeof(int32_t));
+  return (int) (st.last_seeds.size() / 4);
+}
+
+int dmh_last_limit(void) { return S().last_limit; }
+
+}  // extern "C"

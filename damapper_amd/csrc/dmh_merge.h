@@ -1,0 +1,22 @@
+// dmh_merge.h -- result of the seed-hit merge + seed sort of one Match_Filter call.
+#pragma once
+#include "dmh_state.h"
+
+namespace dmh {
+
+struct MergeResult
+{ int64_t nhits   = 0;
+  int64_t limit   = 0;
+  int64_t ngroups = 0;
+  int     pbits = 0, bbits = 0, abits = 0;     // key = aread | bread | apos (high -> low)
+  DevBuf<uint64_t> keys;
+  DevBuf<uint32_t> vals;
+  uint64_t *skeys = nullptr;                   // sorted hits (either keys/vals or the sort partner)
+  uint32_t *svals = nullptr;                   // value = bpos (0-based last base of the REF k-mer)
+  DevBuf<uint32_t> gstart;                     // ngroups+1 first-hit indices of the (aread,bread) groups
+};
+
+void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
+                    IndexDev &A, IndexDev &B, int Kshift);
+
+}  // namespace dmh

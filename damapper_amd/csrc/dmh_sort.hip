@@ -1,0 +1,323 @@
+// dmh_sort.hip -- k-mer emit, stable LSD radix sort of (uint64 key, uint32 value) pairs and the
+// device-wide exclusive scan they share.  gfx950 only: 64-lane wavefronts, 256-thread blocks.
+//
+// Replaces the reference's tuple_thread (map.c:466-579) and lex_sort/lex_thread
+// (map.c:181-444).  The reference moves 16-byte records through 8-bit LSD passes with one
+// pthread per slice; here a k-mer is a (code, base offset) pair of 12 bytes, a pass is
+// histogram -> scan -> scatter, and stability inside a tile comes from wavefront match masks
+// (ballot), so the result is the same total order (code, read, rpos) the reference produces.
+
+#include "dmh_common.h"
+
+namespace dmh {
+
+// ---------------------------------------------------------------------------------------
+//  Device-wide exclusive scan (uint32)
+// ---------------------------------------------------------------------------------------
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS   = 8;
+constexpr int SCAN_CHUNK   = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int lane)
+{
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { uint32_t y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+  return x;
+}
+
+// Exclusive scan across a 256-thread block; *total receives the block sum.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *ws, uint32_t *total)
+{ int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t x = wave_incl_scan(v, lane);
+  if (lane == 63) ws[w] = x;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int i = 0; i < w; i++) wbase += ws[i];
+  *total = ws[0] + ws[1] + ws[2] + ws[3];
+  __syncthreads();
+  return wbase + x - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t *data, int64_t n, uint32_t *bsum)
+{ __shared__ uint32_t ws[4];
+  int64_t base = (int64_t) blockIdx.x * SCAN_CHUNK;
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++)
+    { int64_t i = base + j * SCAN_THREADS + threadIdx.x;
+      if (i < n) s += data[i];
+    }
+  uint32_t tot;
+  block_excl_scan(s, ws, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(uint32_t *bsum, int nb, uint32_t *total)
+{ __shared__ uint32_t ws[4];
+  uint32_t carry = 0;
+  for (int base = 0; base < nb; base += SCAN_THREADS)
+    { int i = base + threadIdx.x;
+      uint32_t v = (i < nb) ? bsum[i] : 0;
+      uint32_t tot;
+      uint32_t e = block_excl_scan(v, ws, &tot);
+      if (i < nb) bsum[i] = carry + e;
+      carry += tot;
+    }
+  if (threadIdx.x == 0 && total != nullptr) *total = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t *data, int64_t n, const uint32_t *bsum)
+{ __shared__ uint32_t ws[4];
+  int64_t base = (int64_t) blockIdx.x * SCAN_CHUNK + (int64_t) threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++)
+    { v[j] = (base + j < n) ? data[base + j] : 0;
+      s += v[j];
+    }
+  uint32_t tot;
+  uint32_t e = block_excl_scan(s, ws, &tot) + bsum[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++)
+    { if (base + j < n) data[base + j] = e;
+      e += v[j];
+    }
+}
+
+void exclusive_scan_u32(uint32_t *d_data, int64_t n, DevBuf<uint32_t> &bsum, uint32_t *d_total)
+{ if (n <= 0)
+    { if (d_total) HIP_CHECK(hipMemsetAsync(d_total, 0, sizeof(uint32_t), stream()));
+      return;
+    }
+  int nb = ceil_div(n, SCAN_CHUNK);
+  bsum.ensure(nb, "scan block sums");
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, stream(), d_data, n, bsum.p);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, stream(), bsum.p, nb, d_total);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, stream(), d_data, n, bsum.p);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------
+//  Radix sort pass: histogram -> scan -> stable scatter
+// ---------------------------------------------------------------------------------------
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS   = 16;
+constexpr int SORT_TILE    = SORT_THREADS * SORT_ITEMS;    // 4096 pairs per workgroup
+constexpr int SORT_WTILE   = 64 * SORT_ITEMS;              // 1024 pairs per wavefront
+
+// Digit histogram of every tile, laid out digit-major (hist[d*ntiles + tile]) so that one
+// exclusive scan over the whole array yields each (digit, tile)'s first output slot.
+__global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__restrict__ keys, int64_t n,
+                                                              int shift, uint32_t mask,
+                                                              uint32_t *__restrict__ hist, int ntiles)
+{ __shared__ uint32_t h[256];
+  int tid = threadIdx.x;
+  h[tid] = 0;
+  __syncthreads();
+  int64_t base = (int64_t) blockIdx.x * SORT_TILE;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++)
+    { int64_t i = base + j * SORT_THREADS + tid;
+      if (i < n)
+        atomicAdd(&h[(uint32_t) (keys[i] >> shift) & mask], 1u);
+    }
+  __syncthreads();
+  hist[(size_t) tid * ntiles + blockIdx.x] = h[tid];
+}
+
+// Stable scatter.  Each wavefront owns 1024 consecutive pairs (item j of lane l is element
+// j*64+l of that run, so loads are coalesced); ranks inside the wavefront come from ballot
+// match masks, ranks across wavefronts from a 4 x 256 LDS table, and the tile's base per digit
+// from the scanned histogram.
+__global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *__restrict__ kin,
+                                                                 const uint32_t *__restrict__ vin,
+                                                                 uint64_t *__restrict__ kout,
+                                                                 uint32_t *__restrict__ vout, int64_t n,
+                                                                 int shift, uint32_t mask,
+                                                                 const uint32_t *__restrict__ offs, int ntiles)
+{ __shared__ uint32_t wh[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int x = tid; x < 1024; x += SORT_THREADS) ((uint32_t *) wh)[x] = 0;
+  __syncthreads();
+
+  const int64_t base = (int64_t) blockIdx.x * SORT_TILE + (int64_t) w * SORT_WTILE + lane;
+  uint64_t key[SORT_ITEMS];
+  uint32_t val[SORT_ITEMS];
+  uint32_t rk[SORT_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++)
+    { int64_t i = base + j * 64;
+      bool ok = i < n;
+      key[j] = ok ? kin[i] : 0;
+      val[j] = ok ? vin[i] : 0;
+    }
+
+  volatile uint32_t *mywh = wh[w];
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++)
+    { bool     ok = (base + j * 64) < n;
+      uint32_t d  = (uint32_t) (key[j] >> shift) & mask;
+      uint64_t peers = __ballot(ok);
+#pragma unroll
+      for (int b = 0; b < 8; b++)
+        { bool     bit = (d >> b) & 1;
+          uint64_t bal = __ballot(bit);
+          peers &= bit ? bal : ~bal;
+        }
+      uint32_t below = __popcll(peers & lt);
+      uint32_t cnt   = __popcll(peers);
+      uint32_t b0    = ok ? mywh[d] : 0;
+      __builtin_amdgcn_wave_barrier();
+      if (ok && below == 0) mywh[d] = b0 + cnt;
+      __builtin_amdgcn_wave_barrier();
+      rk[j] = b0 + below;
+    }
+  __syncthreads();
+
+  { uint32_t g  = offs[(size_t) tid * ntiles + blockIdx.x];
+    uint32_t c0 = wh[0][tid], c1 = wh[1][tid], c2 = wh[2][tid];
+    wh[0][tid] = g;
+    wh[1][tid] = g + c0;
+    wh[2][tid] = g + c0 + c1;
+    wh[3][tid] = g + c0 + c1 + c2;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++)
+    { if ((base + j * 64) < n)
+        { uint32_t d   = (uint32_t) (key[j] >> shift) & mask;
+          uint32_t pos = wh[w][d] + rk[j];
+          kout[pos] = key[j];
+          vout[pos] = val[j];
+        }
+    }
+}
+
+void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32_t **ovals,
+                      int64_t n, int lo_bit, int nbits, SortScratch &scr, const char *stage)
+{ if (n <= 1 || nbits <= 0) return;
+  if (n >= (int64_t) 0xffffffffll) fatal("radix_sort_pairs: %lld pairs exceed the 32-bit slot range", (long long) n);
+  int ntiles = ceil_div(n, SORT_TILE);
+  scr.hist.ensure((size_t) 256 * ntiles, "radix histogram");
+  int npass = (nbits + 7) / 8;
+  // algorithmic traffic of one pass with the reference's 16-byte records: read + write
+  StageTimer tm(stage, (double) npass * 32.0 * (double) n);
+  for (int p = 0; p < npass; p++)
+    { int      shift = lo_bit + 8 * p;
+      int      w     = nbits - 8 * p;
+      uint32_t mask  = (w >= 8) ? 0xffu : ((1u << w) - 1u);
+      hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+                         (const uint64_t *) *keys, n, shift, mask, scr.hist.p, ntiles);
+      exclusive_scan_u32(scr.hist.p, (int64_t) 256 * ntiles, scr.bsum, nullptr);
+      hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+                         (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,
+                         shift, mask, (const uint32_t *) scr.hist.p, ntiles);
+      HIP_CHECK(hipGetLastError());
+      uint64_t *tk = *keys; *keys = *okeys; *okeys = tk;
+      uint32_t *tv = *vals; *vals = *ovals; *ovals = tv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+//  K-mer emit
+// ---------------------------------------------------------------------------------------
+
+constexpr int EMIT_THREADS = 256;
+constexpr int EMIT_ITEMS   = 8;
+constexpr int EMIT_TILE    = EMIT_THREADS * EMIT_ITEMS;   // base positions per workgroup
+
+// One thread walks EMIT_ITEMS consecutive base positions with a rolling 2-bit code
+// (map.c:560-571: first base most significant, rpos = index of the LAST base).  Position q of
+// read i (i = number of separators before q) is the end of a k-mer iff the k bases ending at q
+// are all < 4; its slot in the output is q - i*k - (k-1), i.e. (read, rpos) order, which is the
+// order the reference's tuple_thread generates and the stable sort preserves.
+__global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__restrict__ bases, int64_t L,
+                                                            const int64_t *__restrict__ boff, int nreads,
+                                                            int K, uint64_t kmask,
+                                                            uint64_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ vals, int64_t nk)
+{ __shared__ uint8_t  sb[EMIT_TILE + 32];
+  __shared__ uint64_t scode[EMIT_TILE];
+  __shared__ uint16_t sread[EMIT_TILE];     // read index relative to the tile's first read
+  __shared__ uint8_t  sok[EMIT_TILE];
+  __shared__ uint32_t ws[4];
+  __shared__ int      s_i0;
+
+  const int     tid  = threadIdx.x;
+  const int64_t tile = (int64_t) blockIdx.x * EMIT_TILE;
+  const int     halo = K - 1;
+
+  for (int x = tid; x < EMIT_TILE + halo; x += EMIT_THREADS)
+    { int64_t q = tile - halo + x;
+      sb[x] = (q >= 0 && q < L) ? bases[q] : (uint8_t) 4;
+    }
+  if (tid == 0)
+    { // largest i with boff[i] <= tile  (boff[0] = 0 <= tile always)
+      int lo = 0, hi = nreads;
+      while (lo < hi)
+        { int m = (lo + hi + 1) >> 1;
+          if (boff[m] > tile) hi = m - 1; else lo = m;
+        }
+      s_i0 = lo;
+    }
+  __syncthreads();
+
+  const int x0 = tid * EMIT_ITEMS;
+  uint32_t nsep = 0;
+#pragma unroll
+  for (int j = 0; j < EMIT_ITEMS; j++)
+    nsep += (sb[halo + x0 + j] > 3);
+  uint32_t tot;
+  uint32_t sepb = block_excl_scan(nsep, ws, &tot);   // separators in tile positions [0, x0)
+
+  uint64_t c   = 0;
+  int      run = 0;
+  for (int h = 0; h < halo; h++)
+    { uint32_t b = sb[x0 + h];
+      if (b > 3) { run = 0; c = 0; }
+      else       { run += 1; c = ((c << 2) | b) & kmask; }
+    }
+#pragma unroll
+  for (int j = 0; j < EMIT_ITEMS; j++)
+    { uint32_t b = sb[halo + x0 + j];
+      sread[x0 + j] = (uint16_t) sepb;
+      if (b > 3) { run = 0; c = 0; sepb += 1; }
+      else       { run += 1; c = ((c << 2) | b) & kmask; }
+      scode[x0 + j] = c;
+      sok[x0 + j]   = (run >= K);
+    }
+  __syncthreads();
+
+  const int i0 = s_i0;
+  for (int x = tid; x < EMIT_TILE; x += EMIT_THREADS)
+    if (sok[x])
+      { int64_t q = tile + x;
+        int64_t i = i0 + sread[x];
+        int64_t o = q - i * K - (K - 1);
+        if (o >= 0 && o < nk)
+          { keys[o] = scode[x];
+            vals[o] = (uint32_t) q;
+          }
+      }
+}
+
+void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, int K,
+               uint64_t *d_keys, uint32_t *d_vals, int64_t nk)
+{ if (L <= 0) return;
+  uint64_t kmask = (K >= 32) ? ~0ull : ((1ull << (2 * K)) - 1ull);
+  int nb = ceil_div(L, EMIT_TILE);
+  StageTimer tm("kmer_emit", (double) L + 16.0 * (double) nk);
+  hipLaunchKernelGGL(k_kmer_emit, dim3(nb), dim3(EMIT_THREADS), 0, stream(), d_bases, L, d_boff, nreads,
+                     K, kmask, d_keys, d_vals, nk);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace dmh

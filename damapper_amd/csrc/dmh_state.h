@@ -1,0 +1,98 @@
+// dmh_state.h -- process-wide state of libdamapper_hip (the reference's map.c keeps the
+// equivalent in file statics, map.c:114-122, 2885-2887: one filter per process, not re-entrant).
+#pragma once
+
+#include "dmh_common.h"
+#include <map>
+#include <memory>
+
+namespace dmh {
+
+constexpr uint64_t INDEX_MAGIC = 0x444d48494e444558ull;   // "DMHINDEX"
+
+// What Sort_Kmers hands back to the driver: a malloc()'d stub (the driver free()s it,
+// damapper.c:879); the device storage lives in the registry under `id`.
+struct IndexStub
+{ uint64_t magic;
+  int32_t  id;
+  int32_t  len;
+};
+
+// Device copy of a DAZZ_DB block's bases + read offsets.
+struct BlockDev
+{ uint8_t *d_raw   = nullptr;   // L+1 bytes: leading separator, then the block as in DB.c:1402-1437
+  int64_t  L       = 0;         // reads[nreads].boff
+  int64_t *d_boff  = nullptr;   // nreads+1 offsets
+  int      nreads  = 0;
+  uint64_t stamp   = 0;         // cheap content fingerprint (detects in-place complement)
+  bool     pinned  = false;     // uploaded through dmh_preload_block
+  const uint8_t *d_bases() const { return d_raw + 1; }
+};
+
+struct IndexDev
+{ int64_t   n      = 0;         // k-mers kept
+  uint64_t *keys   = nullptr;   // sorted codes
+  uint32_t *vals   = nullptr;   // base offset q of the k-mer's last base inside the block
+  int64_t  *d_boff = nullptr;   // nreads+1 read offsets (device)
+  uint32_t *d_chunk = nullptr;  // read index of position (c << CHUNK_SHIFT), c = 0..nchunk-1
+  int64_t   nchunk = 0;
+  int       nreads = 0;
+  int64_t   L      = 0;
+  std::vector<int64_t> h_boff;  // host copy
+  DAZZ_DB  *block  = nullptr;
+};
+
+constexpr int CHUNK_SHIFT = 9;
+
+struct Params
+{ int      Kmer = 0, Suppress = 0;
+  int      Kshift = 0;
+  uint64_t Kmask = 0;
+  int      TooFrequent = INT32_MAX;
+  int      NTHREADS = 1, NSHIFT = 0;
+  bool     set = false;
+};
+
+// A candidate chain of one read (map.c:1386-1397) with its Jump displacements (map.c:1380-1384)
+struct Candidate
+{ int score, length, bread, comp;
+  int afirst, alast, bfirst, blast;
+  int id;
+  std::vector<uint16_t> adisp, bdisp;    // end -> start
+};
+
+struct ReadState
+{ std::vector<std::unique_ptr<Candidate>> cands;   // index 0 = list head (newest)
+  std::vector<int16_t> cover;                       // -p deltas
+};
+
+struct State
+{ Params params;
+  std::map<int, IndexDev>          indices;
+  std::map<const DAZZ_DB *, BlockDev> blocks;
+  int  next_index_id = 1;
+  bool retain_ref    = false;
+  bool capture_seeds = false;
+  int  last_limit    = 0;
+  std::vector<int32_t> last_seeds;     // SeedPair records (4 ints each)
+
+  // cross-call filter state (map.c:2885-2887 + DAZZ_READ.coff lists)
+  const DAZZ_DB *cur_reads = nullptr;
+  std::vector<ReadState> reads;
+  int      next_cand_id = 0;
+  int64_t  tfilt = 0;
+
+  SortScratch sort;
+};
+
+State &S();
+
+BlockDev &upload_block(const DAZZ_DB *block, bool pin);
+void      drop_block(const DAZZ_DB *block);
+
+void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, int K,
+               uint64_t *d_keys, uint32_t *d_vals, int64_t nk);
+
+IndexDev *index_of(void *table, const char *who);
+
+}  // namespace dmh

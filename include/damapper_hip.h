@@ -1,0 +1,168 @@
+/* damapper_hip.h -- C-ABI of libdamapper_hip.so (MI355X / gfx950).
+ *
+ * The library is a drop-in for the reference's filter API (map.h) and for the small part of
+ * align.h that damapper.c's main() uses; every entry point below cites the reference
+ * declaration it replaces.  A maintainer links the reference driver against it instead of
+ * map.c + align.c:
+ *
+ *     gcc -O3 damapper.c DB.c QV.c -L. -ldamapper_hip -lpthread -lm -o damapper
+ *
+ * (INTEGRATION.md has the details).  All signatures are plain C: pointers, sizes, scalars.
+ *
+ * Section 1 is the drop-in boundary proper.  Section 2 is the stage-level test/bench surface
+ * (`dmh_*`): the same hot path exposed stage by stage so that the parity tests can compare
+ * each kernel with the oracle, and so that bench.py can read kernel timings.
+ */
+#ifndef DAMAPPER_HIP_H
+#define DAMAPPER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- DAZZ_DB in-memory layout (binary compatible with DB.h:285-295 and DB.h:390-420).  When
+ *      compiling together with the reference's own DB.h define DMH_HAVE_DAZZ_DB first.      */
+#ifndef DMH_HAVE_DAZZ_DB
+typedef struct
+  { int     origin;
+    int     rlen;     /* length of the sequence                                             */
+    int     fpulse;
+    int64_t boff;     /* offset of the read's bases inside DAZZ_DB.bases (in-memory block)  */
+    int64_t coff;     /* scratch: the filter keeps the head of the read's candidate list    */
+                      /*   here between Match_Filter calls (map.c:1578,1875)                */
+    int     flags;
+  } DAZZ_READ;
+
+typedef struct
+  { int        ureads, treads, cutoff, allarr;
+    float      freq[4];
+    int        maxlen;
+    int64_t    totlen;
+    int        nreads, trimmed, part, ufirst, tfirst;
+    char      *path;
+    int        loaded;
+    void      *bases;   /* [4] r0 [4] r1 ... [4], one byte per base 0..3 (DB.c:1402-1437)   */
+    DAZZ_READ *reads;   /* valid for [-1..nreads]                                           */
+    void      *tracks;
+  } DAZZ_DB;
+#endif
+
+typedef void Align_Spec;   /* opaque, align.h:186 */
+
+/* ============================ 1. drop-in boundary ======================================= */
+
+/* Globals the reference driver owns (damapper.c:58-65, declared extern in map.h:17-24).  The
+ * library carries default definitions; when the driver defines them too, ELF symbol
+ * interposition makes both sides share the driver's copy.                                  */
+extern int      VERBOSE;
+extern int      PROFILE;
+extern int      SPACING;
+extern double   BEST_TIE;
+extern char    *SORT_PATH;
+extern uint64_t MEM_LIMIT;
+extern uint64_t MEM_PHYSICAL;
+
+/* map.h:39 / damapper.c:543 -- fatal-error callback.  Weak default: exit(val).              */
+void Clean_Exit(int val);
+
+/* map.h:26 (map.c:124-150).  Returns 1 if kmer <= 1, else 0.  nthreads only decides how many
+ * per-"thread" output files Reporter writes (NTHREADS = 2^floor(log2 nthreads)).            */
+int Set_Filter_Params(int kmer, int suppress, int nthreads);
+
+/* map.h:28 (map.c:655-822).  Builds the sorted k-mer index of `block` in HBM.  The result is
+ * an opaque handle allocated with malloc() -- the driver releases the READS handle with plain
+ * free() (damapper.c:879) -- whose device storage the library tracks.  *len = number of k-mers
+ * kept; NULL and *len = 0 if the block has no k-mers.                                       */
+void *Sort_Kmers(DAZZ_DB *block, int *len);
+
+/* map.h:30 (map.c:2889-3209).  ablock = READS block, bblock = REF block (naming as in map.c).
+ * Consumes btable (as the reference does, map.c:3073-3076,3181-3182).  comp != 0 when bblock
+ * was reverse-complemented in place; start != 0 resets the per-read candidate lists.        */
+void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock,
+                  void *atable, int alen, void *btable, int blen, int comp, int start);
+
+#define FLAG_DOA 0x1   /* map.h:33 */
+#define FLAG_DOB 0x2   /* map.h:34 */
+
+/* map.h:36 (map.c:3227-3319).  Turns the candidate chains into alignments (d-wave kernel),
+ * selects/links them and writes SORT_PATH/<aname>.<bname>.M<i>.las, i = 1..NTHREADS
+ * (and the R files for FLAG_DOB, the .prof track for PROFILE).                              */
+void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock,
+              Align_Spec *asettings, int mflag);
+
+/* align.h:186-199 (align.c:222-287): the subset damapper.c uses.                            */
+Align_Spec *New_Align_Spec(double ave_corr, int trace_space, float *freq, int reach);
+void        Free_Align_Spec(Align_Spec *spec);
+int         Trace_Spacing(Align_Spec *spec);
+double      Average_Correlation(Align_Spec *spec);
+float      *Base_Frequencies(Align_Spec *spec);
+int         Overlap_If_Possible(Align_Spec *spec);
+
+/* ============================ 2. stage-level surface ==================================== */
+
+/* Device / library state */
+int         dmh_device_count(void);
+const char *dmh_last_error(void);
+void        dmh_reset(void);                 /* drop every cached device buffer and all state */
+
+/* Upload `block`'s bases ahead of time so Sort_Kmers / Reporter find them resident in HBM.   */
+int  dmh_preload_block(DAZZ_DB *block);
+void dmh_release_block(DAZZ_DB *block);
+
+/* Keep REF indices after Match_Filter (index replicated per GPU): when set,
+ * Match_Filter does not consume btable; release it with dmh_free_index.                     */
+void dmh_retain_ref_index(int on);
+void dmh_free_index(void *table);
+
+/* Copy an index to the host in the reference's KmerPos layout {uint64 code; int32 rpos;
+ * int32 read} (map.c:78-82), `len` records.                                                 */
+int dmh_index_download(void *table, void *kmerpos_out);
+
+/* Seed hits of the most recent Match_Filter in the reference's SeedPair layout
+ * {int32 diag, apos, bread, aread} (map.c:84-89), sorted (aread,bread,apos,bpos).
+ * Capture must be switched on first (it costs a device->host copy).                         */
+void    dmh_capture_seeds(int on);
+int64_t dmh_last_seed_count(void);
+int     dmh_last_seeds(void *seedpair_out);
+int     dmh_last_limit(void);
+
+/* Candidate lists kept between Match_Filter calls (map.c:1386-1397): per candidate 9 ints
+ * {score,length,bread,comp,afirst,alast,bfirst,blast,id}, list order (newest first).         */
+int dmh_read_candidates(DAZZ_DB *ablock, int aread, int *out, int maxc);
+int dmh_candidate_jumps(DAZZ_DB *ablock, int aread, int k, uint16_t *adisp, uint16_t *bdisp, int maxj);
+/* -p coverage deltas of one read (map.c:1654-1666): (rlen-1)/SPACING+2 int16 values.         */
+int dmh_read_cover(DAZZ_DB *ablock, int aread, int16_t *out, int maxn);
+
+/* Radix sort of (uint64 key, uint32 value) pairs on key bits [0,nbits), stable (the kernel
+ * under Sort_Kmers and the seed sort).  Host buffers in, sorted host buffers out.            */
+int dmh_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbits);
+
+/* Batched Local_Alignment (align.c:1727-1946) on the d-wave kernel.  Sequences are one byte per
+ * base with a 4 on both sides of every sequence (the in-memory DAZZ_DB layout).  For job i:
+ * A = abases[aoff[i] .. +alen[i]), B = bbases[boff[i] .. +blen[i]); comp[i] != 0 aligns the
+ * reverse complement of A with ACOMP_FLAG semantics (map.c:2474-2513); seed diagonal dg[i],
+ * anti-diagonal ad[i] in the (possibly complemented) A frame.  out: per job 8 ints
+ * {abpos,bbpos,aepos,bepos,diffs,tlen, b-view tlen, status}; A-view traces (uint16) are written
+ * at trace_out + i*trace_stride, B-view traces at btrace_out + i*trace_stride (may be NULL). */
+int dmh_local_alignment(Align_Spec *spec,
+                        const uint8_t *abases, int64_t abytes, const uint8_t *bbases, int64_t bbytes,
+                        int njobs, const int64_t *aoff, const int *alen,
+                        const int64_t *boff, const int *blen, const int *comp,
+                        const int *dg, const int *ad,
+                        int *out, uint16_t *trace_out, uint16_t *btrace_out, int trace_stride);
+
+/* Kernel timing (HIP events on the library's stream).  Stages are named; dmh_timing_get
+ * returns accumulated milliseconds and launch count since the last dmh_timing_reset.         */
+void   dmh_timing_enable(int on);
+void   dmh_timing_reset(void);
+int    dmh_timing_count(void);
+int    dmh_timing_get(int idx, char *name, int namelen, double *ms, int64_t *launches, double *bytes);
+/* Blocks until all queued device work is complete.                                          */
+void   dmh_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

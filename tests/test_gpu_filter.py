@@ -1,0 +1,46 @@
+"""GPU parity for Match_Filter: seed hits (merge + seed sort) and the per-read candidate chains
+(chain scoring + domination + Jump encoding) must equal the compiled reference's, bit for bit,
+over every REF block and both orientations."""
+import numpy as np
+import pytest
+
+from util_pipeline import Api, make_dataset, run_filter
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # kind, seed, contigs, nreads, dropouts, K, supp, mem_limit, firsts
+    ("random", 1, [300000, 200000, 250000], 60, 0, 20, 0, 8 << 30, [0, 1, 2, 3]),
+    ("random", 2, [150000, 150000, 100000, 90000], 40, 0, 14, 0, 8 << 30, [0, 2, 4]),
+    ("repeat", 3, [250000, 250000], 40, 2, 20, 0, 8 << 30, [0, 2]),
+    ("repeat", 4, [250000, 200000], 30, 1, 20, 8, 8 << 30, [0, 1, 2]),
+    ("repeat", 5, [300000], 30, 0, 16, 0, 24 << 20, [0, 1]),
+]
+
+
+def _ref_available():
+    import ref_lib
+    return ref_lib.available()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_seeds_and_candidates_match_reference(case):
+    if not _ref_available():
+        pytest.skip("oracle/_ref not built")
+    kind, seed, contigs, nreads, drop, K, supp, mem, firsts = case
+    g, reads = make_dataset(kind, seed, contigs, nreads, dropouts=drop)
+    ref = run_filter(Api("ref"), reads, g, firsts, K=K, supp=supp, mem_limit=mem)
+    hip = run_filter(Api("hip"), reads, g, firsts, K=K, supp=supp, mem_limit=mem)
+    assert len(ref["seeds"]) == len(hip["seeds"])
+    for p, (a, b) in enumerate(zip(ref["seeds"], hip["seeds"])):
+        assert len(a) == len(b), "pass %d: %d vs %d seed hits" % (p, len(a), len(b))
+        for f in ("aread", "bread", "apos", "diag"):
+            assert np.array_equal(a[f], b[f]), "pass %d field %s" % (p, f)
+    nc = 0
+    for ar, ((ca, ja), (cb, jb)) in enumerate(zip(ref["cands"], hip["cands"])):
+        assert ca.shape == cb.shape, "read %d: %d vs %d candidates\n%s\n%s" % (ar, len(ca), len(cb), ca, cb)
+        assert np.array_equal(ca, cb), "read %d candidates differ\n%s\n%s" % (ar, ca, cb)
+        for k, ((a1, b1), (a2, b2)) in enumerate(zip(ja, jb)):
+            assert np.array_equal(a1, a2) and np.array_equal(b1, b2), "read %d cand %d jumps" % (ar, k)
+        nc += len(ca)
+    assert nc > 0
