@@ -149,6 +149,25 @@ def candidate_jumps(reads: Block, ar: int, k: int, maxj: int = 65536) -> Tuple[n
     return a[:max(n, 0)], b[:max(n, 0)]
 
 
+def local_alignment(spec, abuf: np.ndarray, bbuf: np.ndarray, jobs, stride: int = 1024, want_b: bool = True):
+    """jobs: list of (aoff, alen, boff, blen, comp, dg, ad) with offsets into abuf/bbuf (uint8, 4-delimited).
+    Returns (out[n,12], atrace[n,stride], btrace[n,stride])."""
+    n = len(jobs)
+    J = np.asarray(jobs, dtype=np.int64).reshape(n, 7)
+    aoff = np.ascontiguousarray(J[:, 0]); alen = np.ascontiguousarray(J[:, 1].astype(np.int32))
+    boff = np.ascontiguousarray(J[:, 2]); blen = np.ascontiguousarray(J[:, 3].astype(np.int32))
+    comp = np.ascontiguousarray(J[:, 4].astype(np.int32))
+    dg = np.ascontiguousarray(J[:, 5].astype(np.int32)); ad = np.ascontiguousarray(J[:, 6].astype(np.int32))
+    out = np.zeros((n, 16), dtype=np.int32)
+    at = np.zeros((n, stride), dtype=np.uint16)
+    bt = np.zeros((n, stride), dtype=np.uint16)
+    lib().dmh_local_alignment(spec, abuf.ctypes.data, abuf.nbytes, bbuf.ctypes.data, bbuf.nbytes, n,
+                              aoff.ctypes.data, alen.ctypes.data, boff.ctypes.data, blen.ctypes.data,
+                              comp.ctypes.data, dg.ctypes.data, ad.ctypes.data, out.ctypes.data,
+                              at.ctypes.data, bt.ctypes.data if want_b else None, stride)
+    return out, at, bt
+
+
 def sort_pairs(keys: np.ndarray, vals: np.ndarray, nbits: int) -> None:
     assert keys.dtype == np.uint64 and vals.dtype == np.uint32 and len(keys) == len(vals)
     lib().dmh_sort_pairs(keys.ctypes.data, vals.ctypes.data, len(keys), nbits)

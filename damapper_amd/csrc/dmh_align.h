@@ -1,0 +1,847 @@
+// dmh_align.h -- device side of the local alignment (align.c:353-1946) for one wavefront.
+//
+// One wavefront runs one Local_Alignment: lane l of a 64-diagonal chunk owns diagonal base+l of
+// the d-wave, the furthest-reaching state of the band (V, 60-column match vector T, match count
+// M, trace-pebble heads HA/HB, next trace lines NA/NB) lives in a ring in LDS, double buffered so
+// that every diagonal of a wave is computed from the frozen previous wave.  The order-dependent
+// parts of the reference's sequential loop become wavefront scans/ballots:
+//   * best / last / trim point  = record setters of a running max (min for the reverse wave),
+//   * boundary clips            = min/max diagonal that ran into a sequence terminator,
+//   * trace pebbles             = bump-allocated from a per-wavefront arena in global memory.
+// Restricted to damapper's use: one seed diagonal, no diagonal borders (map.c:2513).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmh {
+
+constexpr int      AL_PATH_LEN  = 60;                      // align.c:169
+constexpr uint64_t AL_PATH_TOP  = 0x1000000000000000ull;   // align.c:173
+constexpr uint64_t AL_PATH_INT  = 0x0fffffffffffffffull;   // align.c:174
+constexpr int      AL_TRIM_LEN  = 15;                      // align.c:163
+constexpr int      AL_TRIM_MASK = 0x7fff;
+constexpr int      AL_TRIM_MLAG = 250;                     // align.c:176
+constexpr int      AL_WAVE_LAG  = 30;                      // align.c:177
+constexpr int      AL_DUB_TRIM  = 45;                      // align.c:167
+constexpr int      AL_BIG       = 0x7fffffff;
+
+constexpr int AL_OK           = 0;
+constexpr int AL_ERR_BAND     = 1;    // band wider than the ring
+constexpr int AL_ERR_PEBBLES  = 2;    // pebble arena exhausted
+constexpr int AL_ERR_TRACE    = 3;    // trace buffer exhausted
+constexpr int AL_ERR_LOOP     = 4;    // more waves than the sequences can hold (guards against hangs)
+
+// band ring field indices (ints); two buffers of the path-carried fields, one of NA/NB
+enum { F_V = 0, F_M, F_HA, F_HB, F_HAM, F_HBM, F_TL, F_TH, F_COUNT };
+
+struct AlignSpecDev
+{ int            TS, PATH_AVE, REACH;
+  const int16_t *SCORE, *TABLE;
+};
+
+struct SeqView
+{ const uint8_t *a;      // first base of the A read in the block (forward strand)
+  const uint8_t *b;      // first base of the B contig
+  int            alen, blen;
+  int            comp;   // A is used reverse-complemented (ACOMP_FLAG semantics)
+};
+
+struct PathRes
+{ int abpos, bbpos, aepos, bepos, diffs;
+  int atlen, btlen;      // number of uint16 trace values
+  int aorg, borg;        // offset of the first value relative to the trace buffers' origin
+};
+
+// Per-wavefront working storage
+template <int W> struct WaveWork
+{ int      *band;        // ring: (F_COUNT*2 + 2) * W ints  (LDS or global)
+  int4     *cells;       // pebble arena {ptr, diag, diff, mark}
+  int       cellcap;
+  uint16_t *atrace;      // origin (element 0 of the forward part); room for tcap values either side
+  uint16_t *btrace;
+  int       tcap;
+  int      *mbox;        // 16 ints of LDS: lane 0 hands the trace-back results to the wavefront
+};
+
+__device__ __forceinline__ int aget(const SeqView &S, int i)
+{ if (i < 0 || i >= S.alen) return 4;
+  return S.comp ? 3 - (int) S.a[S.alen - 1 - i] : (int) S.a[i];
+}
+
+__device__ __forceinline__ int bget(const SeqView &S, int i)
+{ if (i < 0 || i >= S.blen) return 4;
+  return (int) S.b[i];
+}
+
+template <int W> struct Ring
+{ int *p;
+  __device__ __forceinline__ int &f(int buf, int field, int k) const
+  { return p[(field * 2 + buf) * W + (k & (W - 1))]; }
+  __device__ __forceinline__ int &na(int k) const { return p[(F_COUNT * 2) * W + (k & (W - 1))]; }
+  __device__ __forceinline__ int &nb(int k) const { return p[(F_COUNT * 2 + 1) * W + (k & (W - 1))]; }
+};
+
+// Lanes of one wavefront hand data to each other through LDS / global memory: make every earlier
+// store of the wavefront complete (s_waitcnt) before any later load is issued.
+__device__ __forceinline__ void wave_sync()
+{ __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int &total)
+{ int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+  total = __shfl(x, 63);
+  return x - v;
+}
+
+// State of one wave pass that survives into the trace back
+struct WaveEnd
+{ int trima, trimy, trimd, trimha, trimhb;
+  int morea, morey, mored, moreha, morehb, morem;
+  int ncell;
+};
+
+// ---------------------------------------------------------------------------------------
+//  One d-wave pass.  DIR = +1 forward (align.c:353-893), -1 reverse (align.c:1015-1550).
+//  Returns AL_OK or an error; on return *plow is the band's low diagonal (unused by callers).
+// ---------------------------------------------------------------------------------------
+template <int W, int DIR>
+__device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const SeqView &S,
+                         int k0, int mida, int aoff, int boff, WaveEnd &E)
+{ const int  lane = threadIdx.x & 63;
+  const int  TS   = sp.TS;
+  Ring<W>    R{wk.band};
+  const int  OUTV = (DIR > 0) ? -1 : AL_BIG;        // value of V outside the band
+  // the reverse wave compares the base BEFORE position (aseq-1 / bseq-1, align.c:1017-1018)
+  const int  soff = (DIR > 0) ? 0 : -1;
+
+  int low = k0, hgh = k0, dif = 0, cur = 0;
+  int more = 1;
+  int aclip = (DIR > 0) ? AL_BIG : -AL_BIG;
+  int bclip = (DIR > 0) ? -AL_BIG : AL_BIG;
+  int besta, besty, trima, trimy, trimd, trimha, trimhb;
+  int morea, morey, mored, moreha, morehb, morem, lasta;
+  int ncell = 0;
+
+  besta = trima = morea = lasta = mida;
+  besty = trimy = morey = (mida - hgh) >> 1;
+  trimd = mored = 0;
+  trimha = moreha = 0;
+  trimhb = morehb = 1;
+  morem = -1;
+
+  // ---- 0-wave on the seed diagonal (align.c:428-547 / 1090-1215); uniform on all lanes
+  { const int k = k0;
+    int y = (mida - k) >> 1;
+    int na, nb, ha, hb, ham, hbm;
+    if (wk.cellcap < 8) return AL_ERR_PEBBLES;
+    if (DIR > 0)
+      { na = (((y + k) + (TS - aoff)) / TS - 1) * TS + aoff;
+        nb = ((y + (TS - boff)) / TS - 1) * TS + boff;
+        if (lane == 0)
+          { wk.cells[0] = make_int4(-1, k, 0, na);
+            wk.cells[1] = make_int4(-1, k, 0, nb);
+          }
+        ham = na; hbm = nb;
+        na += TS; nb += TS;
+      }
+    else
+      { na = (((y + k) + (TS - aoff) - 1) / TS - 1) * TS + aoff;
+        nb = ((y + (TS - boff) - 1) / TS - 1) * TS + boff;
+        if (lane == 0)
+          { wk.cells[0] = make_int4(-1, k, 0, y + k);
+            wk.cells[1] = make_int4(-1, k, 0, y);
+          }
+        ham = y + k; hbm = y;
+      }
+    ha = 0; hb = 1;
+    ncell = 2;
+    while (true)
+      { int cb = bget(S, y + soff);
+        if (cb == 4)
+          { more = 0; bclip = k; break; }
+        int ca = aget(S, k + y + soff);
+        if (cb != ca)
+          { if (ca == 4) { more = 0; aclip = k; }
+            break;
+          }
+        y += DIR;
+      }
+    int c = (y << 1) + k;
+    if (DIR > 0)
+      { while (y + k >= na)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            ha = ncell++; ham = na; na += TS;
+          }
+        while (y >= nb)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(hb, k, 0, nb);
+            hb = ncell++; hbm = nb; nb += TS;
+          }
+        if (c > besta)
+          { besta = trima = lasta = c; besty = trimy = y; trimha = ha; trimhb = hb; }
+      }
+    else
+      { while (y + k <= na)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            ha = ncell++; ham = na; na -= TS;
+          }
+        while (y <= nb)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(hb, k, 0, nb);
+            hb = ncell++; hbm = nb; nb -= TS;
+          }
+        if (c < besta)
+          { besta = trima = lasta = c; besty = trimy = y; trimha = ha; trimhb = hb; }
+      }
+    if (lane == 0)
+      { R.f(cur, F_V, k)   = c;
+        R.f(cur, F_M, k)   = AL_PATH_LEN;
+        R.f(cur, F_TL, k)  = (int) (uint32_t) (AL_PATH_INT & 0xffffffffu);
+        R.f(cur, F_TH, k)  = (int) (uint32_t) (AL_PATH_INT >> 32);
+        R.f(cur, F_HA, k)  = ha;
+        R.f(cur, F_HB, k)  = hb;
+        R.f(cur, F_HAM, k) = ham;
+        R.f(cur, F_HBM, k) = hbm;
+        R.na(k) = na;
+        R.nb(k) = nb;
+      }
+    wave_sync();
+  }
+
+  // boundary handling shared by the 0-wave and every later wave (align.c:549-577, 848-875)
+  auto boundary = [&](bool setd)
+  { if (more != 0) return;
+    if (bget(S, besty + soff) != 4 && aget(S, besta - besty + soff) != 4)
+      more = 1;
+    if (DIR > 0)
+      { if (hgh >= aclip)
+          { hgh = aclip - 1;
+            int m = R.f(cur, F_M, aclip);
+            if (morem <= m)
+              { morem = m; morea = R.f(cur, F_V, aclip); morey = (morea - aclip) / 2;
+                if (setd) mored = dif;
+                moreha = R.f(cur, F_HA, aclip); morehb = R.f(cur, F_HB, aclip);
+              }
+          }
+        if (low <= bclip)
+          { low = bclip + 1;
+            int m = R.f(cur, F_M, bclip);
+            if (morem <= m)
+              { morem = m; morea = R.f(cur, F_V, bclip); morey = (morea - bclip) / 2;
+                if (setd) mored = dif;
+                moreha = R.f(cur, F_HA, bclip); morehb = R.f(cur, F_HB, bclip);
+              }
+          }
+        aclip = AL_BIG;
+        bclip = -AL_BIG;
+      }
+    else
+      { if (low <= aclip)
+          { low = aclip + 1;
+            int m = R.f(cur, F_M, aclip);
+            if (morem <= m)
+              { morem = m; morea = R.f(cur, F_V, aclip); morey = (morea - aclip) / 2;
+                if (setd) mored = dif;
+                moreha = R.f(cur, F_HA, aclip); morehb = R.f(cur, F_HB, aclip);
+              }
+          }
+        if (hgh >= bclip)
+          { hgh = bclip - 1;
+            int m = R.f(cur, F_M, bclip);
+            if (morem <= m)
+              { morem = m; morea = R.f(cur, F_V, bclip); morey = (morea - bclip) / 2;
+                if (setd) mored = dif;
+                moreha = R.f(cur, F_HA, bclip); morehb = R.f(cur, F_HB, bclip);
+              }
+          }
+        aclip = -AL_BIG;
+        bclip = AL_BIG;
+      }
+  };
+
+  boundary(false);
+
+  // ---- successive waves
+  while (more && ((DIR > 0) ? (lasta >= besta - AL_TRIM_MLAG) : (lasta <= besta + AL_TRIM_MLAG)))
+    { low -= 1;
+      hgh += 1;
+      if (hgh - low + 3 > W) return AL_ERR_BAND;
+      if (dif > S.alen + S.blen + 64) return AL_ERR_LOOP;
+      if (lane == 0)
+        { R.na(low) = R.na(low + 1);
+          R.nb(low) = R.nb(low + 1);
+          R.na(hgh) = R.na(hgh - 1);
+          R.nb(hgh) = R.nb(hgh - 1);
+          R.f(cur, F_V, low) = OUTV;
+          R.f(cur, F_V, hgh) = OUTV;
+          R.f(cur, F_V, low - 1) = OUTV;
+          R.f(cur, F_V, hgh + 1) = OUTV;
+        }
+      dif += 1;
+      wave_sync();
+      const int nxt = cur ^ 1;
+
+      // ---- phase 1: every diagonal from the frozen previous wave
+      int hitA = (DIR > 0) ? AL_BIG : -AL_BIG;     // aclip candidate of this wave
+      int hitB = (DIR > 0) ? -AL_BIG : AL_BIG;
+      for (int base = low; base <= hgh; base += 64)
+        { const int  k      = base + lane;
+          const bool active = (k <= hgh);
+          int c = 0, m = 0, ha = 0, hb = 0, ham = 0, hbm = 0, y = 0;
+          uint64_t b = 0;
+          int hita = 0, hitb = 0;
+          int na = 0, nb = 0, cntA = 0, cntB = 0;
+          if (active)
+            { int am = R.f(cur, F_V, k - 1), ac = R.f(cur, F_V, k), ap = R.f(cur, F_V, k + 1);
+              int s;
+              if (DIR > 0)
+                { if (ac < am) s = (am < ap) ? k + 1 : k - 1;
+                  else         s = (ac < ap) ? k + 1 : k;
+                  c = (s == k) ? ac + 2 : ((s > k) ? ap + 1 : am + 1);
+                }
+              else
+                { if (ac > ap) s = (ap > am) ? k - 1 : k + 1;
+                  else         s = (ac > am) ? k - 1 : k;
+                  c = (s == k) ? ac - 2 : ((s > k) ? ap - 1 : am - 1);
+                }
+              m   = R.f(cur, F_M, s);
+              b   = ((uint64_t) (uint32_t) R.f(cur, F_TH, s) << 32) | (uint32_t) R.f(cur, F_TL, s);
+              ha  = R.f(cur, F_HA, s);
+              hb  = R.f(cur, F_HB, s);
+              ham = R.f(cur, F_HAM, s);
+              hbm = R.f(cur, F_HBM, s);
+
+              if ((b & AL_PATH_TOP) != 0) m -= 1;
+              b <<= 1;
+
+              y = (c - k) >> 1;
+              while (true)
+                { int cb = bget(S, y + soff);
+                  if (cb == 4) { hitb = 1; break; }
+                  int ca = aget(S, k + y + soff);
+                  if (cb != ca)
+                    { if (ca == 4) hita = 1;
+                      break;
+                    }
+                  y += DIR;
+                  if ((b & AL_PATH_TOP) == 0) m += 1;
+                  b = (b << 1) | 1;
+                }
+              c = (y << 1) + k;
+
+              // trace lines crossed on this diagonal (align.c:771-817): count the pebbles to drop
+              na = R.na(k);
+              nb = R.nb(k);
+              if (DIR > 0)
+                { int t = na; int h = ham;
+                  while (y + k >= t) { if (h < t) { cntA += 1; h = t; } t += TS; }
+                  t = nb; h = hbm;
+                  while (y >= t) { if (h < t) { cntB += 1; h = t; } t += TS; }
+                }
+              else
+                { int t = na; int h = ham;
+                  while (y + k <= t) { if (h > t) { cntA += 1; h = t; } t -= TS; }
+                  t = nb; h = hbm;
+                  while (y <= t) { if (h > t) { cntB += 1; h = t; } t -= TS; }
+                }
+            }
+          int tot;
+          int off = wave_excl_scan_i(cntA + cntB, lane, tot);
+          if (ncell + tot > wk.cellcap) return AL_ERR_PEBBLES;
+          if (active)
+            { int idx = ncell + off;
+              if (DIR > 0)
+                { while (y + k >= na)
+                    { if (ham < na) { wk.cells[idx] = make_int4(ha, k, dif, na); ha = idx++; ham = na; }
+                      na += TS;
+                    }
+                  while (y >= nb)
+                    { if (hbm < nb) { wk.cells[idx] = make_int4(hb, k, dif, nb); hb = idx++; hbm = nb; }
+                      nb += TS;
+                    }
+                }
+              else
+                { while (y + k <= na)
+                    { if (ham > na) { wk.cells[idx] = make_int4(ha, k, dif, na); ha = idx++; ham = na; }
+                      na -= TS;
+                    }
+                  while (y <= nb)
+                    { if (hbm > nb) { wk.cells[idx] = make_int4(hb, k, dif, nb); hb = idx++; hbm = nb; }
+                      nb -= TS;
+                    }
+                }
+              R.na(k) = na;
+              R.nb(k) = nb;
+              R.f(nxt, F_V, k)   = c;
+              R.f(nxt, F_M, k)   = m;
+              R.f(nxt, F_TL, k)  = (int) (uint32_t) (b & 0xffffffffu);
+              R.f(nxt, F_TH, k)  = (int) (uint32_t) (b >> 32);
+              R.f(nxt, F_HA, k)  = ha;
+              R.f(nxt, F_HB, k)  = hb;
+              R.f(nxt, F_HAM, k) = ham;
+              R.f(nxt, F_HBM, k) = hbm;
+            }
+          ncell += tot;
+
+          // boundary clips: forward aclip = smallest k that hit A's end, bclip = largest k that
+          // hit B's end (align.c:750-762); mirrored for the reverse wave (align.c:1405-1417)
+          uint64_t ma = __ballot(active && hita), mb = __ballot(active && hitb);
+          if (ma)
+            { int lo = base + (__ffsll((long long) ma) - 1), hi = base + (63 - __clzll((long long) ma));
+              if (DIR > 0) { if (lo < hitA) hitA = lo; }
+              else         { if (hi > hitA) hitA = hi; }
+            }
+          if (mb)
+            { int lo = base + (__ffsll((long long) mb) - 1), hi = base + (63 - __clzll((long long) mb));
+              if (DIR > 0) { if (hi > hitB) hitB = hi; }
+              else         { if (lo < hitB) hitB = lo; }
+            }
+        }
+      if (hitA != ((DIR > 0) ? AL_BIG : -AL_BIG)) { more = 0; aclip = hitA; }
+      if (hitB != ((DIR > 0) ? -AL_BIG : AL_BIG)) { more = 0; bclip = hitB; }
+      wave_sync();
+      cur = nxt;
+
+      // ---- phase 2: record setters of the running best, in the reference's loop order
+      //      (descending k forward, align.c:819-833; ascending k reverse, align.c:1471-1485)
+      { const int nch = (hgh - low) / 64 + 1;
+        for (int ci = 0; ci < nch; ci++)
+          { const int  base   = (DIR > 0) ? low + 64 * (nch - 1 - ci) : low + 64 * ci;
+            const int  k      = base + lane;
+            const bool active = (k <= hgh);
+            int c = active ? R.f(cur, F_V, k) : ((DIR > 0) ? -AL_BIG : AL_BIG);
+            // exclusive scan of the best value over the lanes visited before this one
+            int pre = c;
+            if (DIR > 0)
+              { // visited before = higher lanes: suffix max
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                  { int t = __shfl_down(pre, o);
+                    if (lane + o < 64 && t > pre) pre = t;
+                  }
+                int ex = __shfl_down(pre, 1);
+                if (lane == 63) ex = -AL_BIG;
+                if (besta > ex) ex = besta;
+                bool rec = active && (c > ex);
+                int  m   = active ? R.f(cur, F_M, k) : 0;
+                uint64_t b = 0;
+                if (rec) b = ((uint64_t) (uint32_t) R.f(cur, F_TH, k) << 32) | (uint32_t) R.f(cur, F_TL, k);
+                bool lst = rec && (m >= sp.PATH_AVE);
+                bool trm = false;
+                if (lst)
+                  { if (sp.TABLE[b & AL_TRIM_MASK] >= 0)
+                      if (sp.TABLE[(b >> AL_TRIM_LEN) & AL_TRIM_MASK] + sp.SCORE[b & AL_TRIM_MASK] >= 0)
+                        trm = true;
+                  }
+                uint64_t mr = __ballot(rec), ml = __ballot(lst), mt = __ballot(trm);
+                if (mr)
+                  { int l = __ffsll((long long) mr) - 1;          // lowest k = last visited
+                    besta = __shfl(c, l);
+                    besty = (besta - (base + l)) >> 1;
+                  }
+                if (ml)
+                  { int l = __ffsll((long long) ml) - 1;
+                    lasta = __shfl(c, l);
+                  }
+                if (mt)
+                  { int l = __ffsll((long long) mt) - 1;
+                    int hav = active ? R.f(cur, F_HA, k) : 0, hbv = active ? R.f(cur, F_HB, k) : 0;
+                    trima  = __shfl(c, l);
+                    trimy  = (trima - (base + l)) >> 1;
+                    trimd  = dif;
+                    trimha = __shfl(hav, l);
+                    trimhb = __shfl(hbv, l);
+                  }
+              }
+            else
+              { // visited before = lower lanes: prefix min
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                  { int t = __shfl_up(pre, o);
+                    if (lane >= o && t < pre) pre = t;
+                  }
+                int ex = __shfl_up(pre, 1);
+                if (lane == 0) ex = AL_BIG;
+                if (besta < ex) ex = besta;
+                bool rec = active && (c < ex);
+                int  m   = active ? R.f(cur, F_M, k) : 0;
+                uint64_t b = 0;
+                if (rec) b = ((uint64_t) (uint32_t) R.f(cur, F_TH, k) << 32) | (uint32_t) R.f(cur, F_TL, k);
+                bool lst = rec && (m >= sp.PATH_AVE);
+                bool trm = false;
+                if (lst)
+                  { if (sp.TABLE[b & AL_TRIM_MASK] >= 0)
+                      if (sp.TABLE[(b >> AL_TRIM_LEN) & AL_TRIM_MASK] + sp.SCORE[b & AL_TRIM_MASK] >= 0)
+                        trm = true;
+                  }
+                uint64_t mr = __ballot(rec), ml = __ballot(lst), mt = __ballot(trm);
+                if (mr)
+                  { int l = 63 - __clzll((long long) mr);         // highest k = last visited
+                    besta = __shfl(c, l);
+                    besty = (besta - (base + l)) >> 1;
+                  }
+                if (ml)
+                  { int l = 63 - __clzll((long long) ml);
+                    lasta = __shfl(c, l);
+                  }
+                if (mt)
+                  { int l = 63 - __clzll((long long) mt);
+                    int hav = active ? R.f(cur, F_HA, k) : 0, hbv = active ? R.f(cur, F_HB, k) : 0;
+                    trima  = __shfl(c, l);
+                    trimy  = (trima - (base + l)) >> 1;
+                    trimd  = dif;
+                    trimha = __shfl(hav, l);
+                    trimhb = __shfl(hbv, l);
+                  }
+              }
+          }
+      }
+
+      boundary(true);
+
+      // ---- keep the points within WAVE_LAG of the best (align.c:877-885)
+      if (DIR > 0)
+        { int n = besta - AL_WAVE_LAG;
+          while (hgh >= low)
+            if (R.f(cur, F_V, hgh) < n)
+              hgh -= 1;
+            else
+              { while (R.f(cur, F_V, low) < n) low += 1;
+                break;
+              }
+        }
+      else
+        { int n = besta + AL_WAVE_LAG;
+          while (hgh >= low)
+            if (R.f(cur, F_V, hgh) > n)
+              hgh -= 1;
+            else
+              { while (R.f(cur, F_V, low) > n) low += 1;
+                break;
+              }
+        }
+    }
+
+  E.trima = trima; E.trimy = trimy; E.trimd = trimd; E.trimha = trimha; E.trimhb = trimhb;
+  E.morea = morea; E.morey = morey; E.mored = mored; E.moreha = moreha; E.morehb = morehb;
+  E.morem = morem;
+  E.ncell = ncell;
+  return AL_OK;
+}
+
+// Reverse a pebble chain in place and return its first pebble (align.c:900-906)
+__device__ __forceinline__ int reverse_chain(int4 *cells, int head)
+{ int a = -1, h = head;
+  while (h >= 0)
+    { int nx = cells[h].x;
+      cells[h].x = a;
+      a = h;
+      h = nx;
+    }
+  return a;
+}
+
+// Trace back of the forward pass (align.c:895-1006).  Runs on lane 0 only.
+template <int W>
+__device__ int forward_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, const WaveEnd &E, int mida,
+                             PathRes &P, int &klow)
+{ int4 *cells = wk.cells;
+  uint16_t *atrace = wk.atrace + P.aorg, *btrace = wk.btrace + P.borg;
+  int trimx, trimy = E.trimy, trimd = E.trimd, trimha = E.trimha, trimhb = E.trimhb;
+  int atlen = 0, btlen = 0;
+  int a, b, k, h, d, e;
+  const int room_a = wk.tcap - P.aorg - 4, room_b = wk.tcap - P.borg - 4;
+
+  if (E.morem >= 0 && sp.REACH)
+    { trimx = E.morea - E.morey; trimy = E.morey; trimd = E.mored; trimha = E.moreha; trimhb = E.morehb; }
+  else
+    trimx = E.trima - trimy;
+
+  h = reverse_chain(cells, trimha);
+  k = cells[h].y;
+  b = (mida - k) / 2;
+  e = 0;
+  for (h = cells[h].x; h >= 0; h = cells[h].x)
+    { int4 p = cells[h];
+      k = p.y;
+      a = p.w - k;
+      d = p.z;
+      if (atlen >= room_a) return AL_ERR_TRACE;
+      atrace[atlen++] = (uint16_t) (d - e);
+      atrace[atlen++] = (uint16_t) (a - b);
+      b = a; e = d;
+    }
+  if (b + k != trimx)
+    { if (atlen >= room_a) return AL_ERR_TRACE;
+      atrace[atlen++] = (uint16_t) (trimd - e);
+      atrace[atlen++] = (uint16_t) (trimy - b);
+    }
+  else if (b != trimy && atlen > 0)
+    { atrace[atlen - 1] = (uint16_t) (atrace[atlen - 1] + (trimy - b));
+      atrace[atlen - 2] = (uint16_t) (atrace[atlen - 2] + (trimd - e));
+    }
+
+  h = reverse_chain(cells, trimhb);
+  k = cells[h].y;
+  b = (mida + k) / 2;
+  e = 0;
+  klow = k;
+  for (h = cells[h].x; h >= 0; h = cells[h].x)
+    { int4 p = cells[h];
+      k = p.y;
+      a = p.w + k;
+      d = p.z;
+      if (btlen >= room_b) return AL_ERR_TRACE;
+      btrace[btlen++] = (uint16_t) (d - e);
+      btrace[btlen++] = (uint16_t) (a - b);
+      b = a; e = d;
+    }
+  if (b - k != trimy)
+    { if (btlen >= room_b) return AL_ERR_TRACE;
+      btrace[btlen++] = (uint16_t) (trimd - e);
+      btrace[btlen++] = (uint16_t) (trimx - b);
+    }
+  else if (b != trimx && btlen > 0)
+    { btrace[btlen - 1] = (uint16_t) (btrace[btlen - 1] + (trimx - b));
+      btrace[btlen - 2] = (uint16_t) (btrace[btlen - 2] + (trimd - e));
+    }
+
+  P.aepos = trimx;
+  P.bepos = trimy;
+  P.diffs = trimd;
+  P.atlen = atlen;
+  P.btlen = btlen;
+  return AL_OK;
+}
+
+// Trace back of the reverse pass (align.c:1554-1714): prepends to the forward trace.  Lane 0 only.
+template <int W>
+__device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, const WaveEnd &E,
+                             int aoff, int boff, PathRes &P)
+{ int4 *cells = wk.cells;
+  const int TS = sp.TS;
+  uint16_t *atrace = wk.atrace + P.aorg, *btrace = wk.btrace + P.borg;
+  int trimx, trimy = E.trimy, trimd = E.trimd, trimha = E.trimha, trimhb = E.trimhb;
+  int atlen = 0, btlen = 0;
+  int a, b, k, h, d, e;
+  const int room_a = wk.tcap + P.aorg - 4, room_b = wk.tcap + P.borg - 4;
+
+  if (E.morem >= 0 && sp.REACH)
+    { trimx = E.morea - E.morey; trimy = E.morey; trimd = E.mored; trimha = E.moreha; trimhb = E.morehb; }
+  else
+    trimx = E.trima - trimy;
+
+  // A view
+  h = reverse_chain(cells, trimha);
+  k = cells[h].y;
+  b = cells[h].w - k;
+  e = 0;
+  if ((b + k) % TS != aoff)
+    { h = cells[h].x;
+      if (h < 0)
+        { a = trimy; d = trimd; }
+      else
+        { int4 p = cells[h];
+          k = p.y; a = p.w - k; d = p.z;
+        }
+      if (P.atlen == 0)
+        { atrace[--atlen] = (uint16_t) (b - a);
+          atrace[--atlen] = (uint16_t) (d - e);
+        }
+      else
+        { atrace[1] = (uint16_t) (atrace[1] + (b - a));
+          atrace[0] = (uint16_t) (atrace[0] + (d - e));
+        }
+      b = a; e = d;
+    }
+  if (h >= 0)
+    { for (h = cells[h].x; h >= 0; h = cells[h].x)
+        { int4 p = cells[h];
+          k = p.y;
+          a = p.w - k;
+          d = p.z;
+          if (-atlen >= room_a) return AL_ERR_TRACE;
+          atrace[--atlen] = (uint16_t) (b - a);
+          atrace[--atlen] = (uint16_t) (d - e);
+          b = a; e = d;
+        }
+      if (b + k != trimx)
+        { if (-atlen >= room_a) return AL_ERR_TRACE;
+          atrace[--atlen] = (uint16_t) (b - trimy);
+          atrace[--atlen] = (uint16_t) (trimd - e);
+        }
+      else if (b != trimy && (atlen < 0 || P.atlen > 0))
+        { atrace[atlen + 1] = (uint16_t) (atrace[atlen + 1] + (b - trimy));
+          atrace[atlen]     = (uint16_t) (atrace[atlen] + (trimd - e));
+        }
+    }
+
+  // B view
+  h = reverse_chain(cells, trimhb);
+  k = cells[h].y;
+  b = cells[h].w + k;
+  e = 0;
+  if ((b - k) % TS != boff)
+    { h = cells[h].x;
+      if (h < 0)
+        { a = trimx; d = trimd; }
+      else
+        { int4 p = cells[h];
+          k = p.y; a = p.w + k; d = p.z;
+        }
+      if (P.btlen == 0)
+        { btrace[--btlen] = (uint16_t) (b - a);     // sic (align.c:1670-1671): b-a in both slots
+          btrace[--btlen] = (uint16_t) (b - a);
+        }
+      else
+        { btrace[1] = (uint16_t) (btrace[1] + (b - a));
+          btrace[0] = (uint16_t) (btrace[0] + (d - e));
+        }
+      b = a; e = d;
+    }
+  if (h >= 0)
+    { for (h = cells[h].x; h >= 0; h = cells[h].x)
+        { int4 p = cells[h];
+          k = p.y;
+          a = p.w + k;
+          d = p.z;
+          if (-btlen >= room_b) return AL_ERR_TRACE;
+          btrace[--btlen] = (uint16_t) (b - a);
+          btrace[--btlen] = (uint16_t) (d - e);
+          b = a; e = d;
+        }
+      if (b - k != trimy)
+        { if (-btlen >= room_b) return AL_ERR_TRACE;
+          btrace[--btlen] = (uint16_t) (b - trimx);
+          btrace[--btlen] = (uint16_t) (trimd - e);
+        }
+      else if (b != trimx && (btlen < 0 || P.btlen > 0))
+        { btrace[btlen + 1] = (uint16_t) (btrace[btlen + 1] + (b - trimx));
+          btrace[btlen]     = (uint16_t) (btrace[btlen] + (trimd - e));
+        }
+    }
+
+  P.abpos = trimx;
+  P.bbpos = trimy;
+  P.diffs = P.diffs + trimd;
+  P.atlen = P.atlen - atlen;
+  P.aorg  = P.aorg + atlen;
+  P.btlen = P.btlen - btlen;
+  P.borg  = P.borg + btlen;
+  return AL_OK;
+}
+
+// Lane 0 ran the (sequential) trace back; publish its results to the whole wavefront through LDS.
+__device__ __forceinline__ void bcast_path(int *mbox, PathRes &P, int &st, int &klow)
+{ const int lane = threadIdx.x & 63;
+  if (lane == 0)
+    { mbox[0] = P.abpos; mbox[1] = P.bbpos; mbox[2] = P.aepos; mbox[3] = P.bepos; mbox[4] = P.diffs;
+      mbox[5] = P.atlen; mbox[6] = P.btlen; mbox[7] = P.aorg; mbox[8] = P.borg; mbox[9] = st; mbox[10] = klow;
+    }
+  wave_sync();
+  P.abpos = mbox[0]; P.bbpos = mbox[1]; P.aepos = mbox[2]; P.bepos = mbox[3]; P.diffs = mbox[4];
+  P.atlen = mbox[5]; P.btlen = mbox[6]; P.aorg = mbox[7]; P.borg = mbox[8]; st = mbox[9]; klow = mbox[10];
+  wave_sync();
+}
+
+// Local_Alignment (align.c:1727-1946) for one seed (dg, anti); the whole wavefront takes part.
+// On return P holds the A view in the frame the reference reports (flipped back for comp) with
+// the A trace at wk.atrace+P.aorg; B = {babpos,bbbpos,baepos,bbepos} is the B view, its trace
+// at wk.btrace+P.borg (complemented-frame order, as the reference leaves it for ACOMP).
+template <int W>
+__device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, const SeqView &S,
+                               int dg, int anti, PathRes &P, int *B)
+{ const int lane = threadIdx.x & 63;
+  int aoff = S.comp ? (S.alen % sp.TS) : 0, boff = 0;
+  int hgh = dg, low = dg;
+  while (((anti - hgh) >> 1) < 0) hgh -= 1;     // align.c:1774 (never taken for damapper's seeds)
+  low = hgh;
+
+  WaveEnd E;
+  int st, klow = low;
+  P.abpos = P.bbpos = P.aepos = P.bepos = P.diffs = 0;
+  P.atlen = P.btlen = 0;
+  P.aorg = P.borg = 0;
+
+  st = wave_pass<W, +1>(wk, sp, S, low, anti, aoff, boff, E);
+  if (st != AL_OK) return st;
+  wave_sync();
+  if (lane == 0) st = forward_trace<W>(wk, sp, E, anti, P, klow);
+  bcast_path(wk.mbox, P, st, klow);
+  if (st != AL_OK) return st;
+  wave_sync();
+  low = klow;
+  int fshort = ((P.aepos + P.bepos) - anti < AL_DUB_TRIM);
+
+  st = wave_pass<W, -1>(wk, sp, S, low, anti, aoff, boff, E);
+  if (st != AL_OK) return st;
+  wave_sync();
+  if (lane == 0) st = reverse_trace<W>(wk, sp, E, aoff, boff, P);
+  bcast_path(wk.mbox, P, st, klow);
+  if (st != AL_OK) return st;
+  wave_sync();
+  int rshort = (anti - (P.abpos + P.bbpos) < AL_DUB_TRIM);
+
+  if (fshort)
+    { if (rshort)
+        { P.aepos = P.abpos = (P.abpos + P.aepos) / 2;
+          P.bepos = P.bbpos = (P.bbpos + P.bepos) / 2;
+          P.atlen = P.btlen = 0;
+        }
+      else
+        { low  = P.abpos - P.bbpos;
+          anti = P.abpos + P.bbpos;
+          P.atlen = P.btlen = 0;
+          st = wave_pass<W, +1>(wk, sp, S, low, anti, aoff, boff, E);
+          if (st != AL_OK) return st;
+          wave_sync();
+          if (lane == 0) st = forward_trace<W>(wk, sp, E, anti, P, klow);
+          bcast_path(wk.mbox, P, st, klow);
+          if (st != AL_OK) return st;
+          wave_sync();
+        }
+    }
+  else if (rshort)
+    { low  = P.aepos - P.bepos;
+      anti = P.aepos + P.bepos;
+      P.atlen = P.btlen = 0;
+      P.diffs = 0;
+      st = wave_pass<W, -1>(wk, sp, S, low, anti, aoff, boff, E);
+      if (st != AL_OK) return st;
+      wave_sync();
+      if (lane == 0) st = reverse_trace<W>(wk, sp, E, aoff, boff, P);
+      bcast_path(wk.mbox, P, st, klow);
+      if (st != AL_OK) return st;
+      wave_sync();
+    }
+
+  // B view and, for a complemented A, the flip back to the forward frame (align.c:1857-1912)
+  B[0] = P.bbpos; B[1] = P.abpos; B[2] = P.bepos; B[3] = P.aepos;
+  if (S.comp)
+    { int abp = S.alen - B[3], bbp = S.blen - B[2], aep = S.alen - B[1], bep = S.blen - B[0];
+      P.abpos = abp; P.bbpos = bbp; P.aepos = aep; P.bepos = bep;
+      if (lane == 0)
+        { uint16_t *t = wk.atrace + P.aorg;
+          int i = P.atlen - 2, j = 0;
+          while (j < i)
+            { uint16_t p = t[i]; t[i] = t[j]; t[j] = p;
+              p = t[i + 1]; t[i + 1] = t[j + 1]; t[j + 1] = p;
+              i -= 2;
+              j += 2;
+            }
+        }
+      wave_sync();
+    }
+  return AL_OK;
+}
+
+}  // namespace dmh

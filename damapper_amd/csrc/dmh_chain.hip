@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
               A.orig[j]  = j;
               A.state[j] = ST_LIVE;
             }
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
 
       // ---- report the best end of every origin with cost >= hithr (map.c:1634-1649).  Order:
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
           E += __popcll(m);
         }
       if (E == 0) continue;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
       uint32_t obase = 0;
       if (lane == 0) obase = atomicAdd(A.out_count, E);

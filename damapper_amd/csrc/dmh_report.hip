@@ -1,18 +1,897 @@
-// dmh_report.hip -- Reporter (map.c:3227-3319) [under construction]
+// dmh_report.hip -- Reporter (map.c:3227-3319): candidate chains -> local alignments (d-wave
+// kernel, one wavefront per candidate) -> redundancy removal, chain linking and selection on the
+// host (sequential per read, a few records per read) -> per-"thread" .las files and -p track.
+
 #include "dmh_state.h"
 #include "dmh_spec.h"
+#include "dmh_align.h"
+#include <algorithm>
+#include <math.h>
 
 namespace dmh {
-int16_t *spec_device_tables(Spec *sp) { return nullptr; }
-void spec_release_device(Spec *sp) { if (sp->d_tables) dev_free(sp->d_tables); sp->d_tables = nullptr; }
+
+constexpr int LDS_W  = 128;    // ring width of the LDS band
+constexpr int GLB_W  = 8192;   // ring width of the global-memory fallback band
+constexpr int CELLCAP = 16384; // pebbles per wavefront arena
+
+int16_t *spec_device_tables(Spec *sp)
+{ if (sp->d_tables == nullptr)
+    { sp->d_tables = (int16_t *) dev_alloc(sizeof(int16_t) * 65536, "trim tables");
+      HIP_CHECK(hipMemcpyAsync(sp->d_tables, sp->score.data(), sizeof(int16_t) * 32768, hipMemcpyHostToDevice, stream()));
+      HIP_CHECK(hipMemcpyAsync(sp->d_tables + 32768, sp->table.data(), sizeof(int16_t) * 32768, hipMemcpyHostToDevice, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+  return sp->d_tables;
 }
+
+void spec_release_device(Spec *sp)
+{ if (sp->d_tables) dev_free(sp->d_tables);
+  sp->d_tables = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------
+//  Kernels
+// ---------------------------------------------------------------------------------------
+
+struct SeedJob          // one Local_Alignment call (stage-level API)
+{ int64_t aoff, boff;
+  int     alen, blen, comp, dg, ad;
+  int     pad;
+};
+
+struct CandJob          // one candidate chain = a sequence of dependent Local_Alignment calls
+{ int64_t  aoff, boff;  // first base of the read / contig inside the uploaded blocks
+  int      alen, blen, comp;
+  int      alast, blast;     // chain end (map.c:2487-2488)
+  int      npts;
+  uint32_t joff;             // first (adisp,bdisp) pair of the chain
+  int      pad;
+};
+
+struct Scratch
+{ int      *band;       // global band (fallback instantiation only)
+  int4     *cells;
+  uint16_t *traces;     // per wavefront: A buffer then B buffer, each 2*tcap values
+  int       tcap;
+};
+
+template <int W, bool LDSBAND>
+__device__ __forceinline__ WaveWork<W> make_work(const Scratch &sc, int *lds, int *mbox, int wave_global, int wave_local)
+{ WaveWork<W> wk;
+  wk.mbox = mbox + 16 * wave_local;
+  if (LDSBAND)
+    wk.band = lds + (size_t) wave_local * ((F_COUNT * 2 + 2) * W);
+  else
+    wk.band = sc.band + (size_t) wave_global * ((F_COUNT * 2 + 2) * W);
+  wk.cells   = sc.cells + (size_t) wave_global * CELLCAP;
+  wk.cellcap = CELLCAP;
+  wk.tcap    = sc.tcap;
+  wk.atrace  = sc.traces + (size_t) wave_global * (4 * (size_t) sc.tcap) + sc.tcap;
+  wk.btrace  = wk.atrace + 2 * (size_t) sc.tcap;
+  return wk;
+}
+
+template <int W, bool LDSBAND>
+__global__ __launch_bounds__(256) void k_align_seeds(const uint8_t *abases, const uint8_t *bbases,
+                                                      const SeedJob *jobs, int njobs, AlignSpecDev sp,
+                                                      Scratch sc, unsigned int *ticket, int *out,
+                                                      uint16_t *atr_out, uint16_t *btr_out, int stride,
+                                                      const int *only)
+{ __shared__ int lds[LDSBAND ? 4 * (F_COUNT * 2 + 2) * W : 4];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  const int wg = blockIdx.x * 4 + wl;
+  __shared__ int mbox[4 * 16];
+  WaveWork<W> wk = make_work<W, LDSBAND>(sc, lds, mbox, wg, wl);
+  while (true)
+    { unsigned int t = 0;
+      if (lane == 0) t = atomicAdd(ticket, 1u);
+      t = __shfl(t, 0);
+      if (t >= (unsigned int) njobs) break;
+      int j = only ? only[t] : (int) t;
+      SeedJob J = jobs[j];
+      SeqView S{abases + J.aoff, bbases + J.boff, J.alen, J.blen, J.comp};
+      PathRes P;
+      int B[4];
+      int st = local_alignment<W>(wk, sp, S, J.dg, J.ad, P, B);
+      if (lane == 0)
+        { int *o = out + 16 * (size_t) j;
+          o[0] = P.abpos; o[1] = P.bbpos; o[2] = P.aepos; o[3] = P.bepos; o[4] = P.diffs;
+          o[5] = (st == AL_OK) ? P.atlen : 0;
+          o[6] = (st == AL_OK) ? P.btlen : 0;
+          o[7] = st;
+          o[8] = B[0]; o[9] = B[1]; o[10] = B[2]; o[11] = B[3];
+          o[12] = P.aorg; o[13] = P.borg; o[14] = wk.atrace[P.aorg]; o[15] = wk.atrace[0];
+        }
+      if (st == AL_OK)
+        { int na = P.atlen < stride ? P.atlen : stride, nb = P.btlen < stride ? P.btlen : stride;
+          for (int i = lane; i < na; i += 64) atr_out[(size_t) j * stride + i] = wk.atrace[P.aorg + i];
+          if (btr_out != nullptr)
+            for (int i = lane; i < nb; i += 64) btr_out[(size_t) j * stride + i] = wk.btrace[P.borg + i];
+        }
+      wave_sync();
+    }
+}
+
+// Output pool record: 12-int header {cand, seq, abpos, bbpos, aepos, bepos, diffs, atlen, pad...}
+// followed by atlen uint16 trace values (padded to a multiple of 2 values).
+constexpr int REC_HDR = 8;
+
+template <int W, bool LDSBAND>
+__global__ __launch_bounds__(256) void k_align_cands(const uint8_t *abases, const uint8_t *bbases,
+                                                      const CandJob *jobs, int njobs,
+                                                      const uint16_t *jumps, int hithr, AlignSpecDev sp,
+                                                      Scratch sc, unsigned int *ticket, int *status,
+                                                      int *pool, unsigned int *pool_used,
+                                                      unsigned int pool_cap, const int *only)
+{ __shared__ int lds[LDSBAND ? 4 * (F_COUNT * 2 + 2) * W : 4];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  const int wg = blockIdx.x * 4 + wl;
+  __shared__ int mbox[4 * 16];
+  WaveWork<W> wk = make_work<W, LDSBAND>(sc, lds, mbox, wg, wl);
+  while (true)
+    { unsigned int t = 0;
+      if (lane == 0) t = atomicAdd(ticket, 1u);
+      t = __shfl(t, 0);
+      if (t >= (unsigned int) njobs) break;
+      const int j = only ? only[t] : (int) t;
+      const CandJob J = jobs[j];
+      SeqView S{abases + J.aoff, bbases + J.boff, J.alen, J.blen, J.comp};
+
+      // map.c:2487-2579: walk the chain from its end; a point is a seed only if it lies left of
+      // the last accepted alignment's start
+      int apos = J.alast, bpos = J.blast, alast = J.alen + 1;
+      int seq = 0, st = AL_OK;
+      for (int n = 0; n < J.npts; n++)
+        { apos -= (int) jumps[2 * ((size_t) J.joff + n)];
+          bpos -= (int) jumps[2 * ((size_t) J.joff + n) + 1];
+          if (apos >= alast) continue;
+          int dg, ad;
+          if (J.comp)
+            { int ac = J.alen - apos, bc = J.blen - bpos;
+              dg = ac - bc;
+              ad = ac + bc;
+            }
+          else
+            { dg = apos - bpos;
+              ad = apos + bpos;
+            }
+          PathRes P;
+          int B[4];
+          st = local_alignment<W>(wk, sp, S, dg, ad, P, B);
+          if (st != AL_OK) break;
+          if (P.aepos - P.abpos >= hithr)
+            { alast = P.abpos;
+              unsigned int need = REC_HDR + ((unsigned int) P.atlen + 1) / 2;
+              unsigned int at = 0;
+              if (lane == 0) at = atomicAdd(pool_used, need);
+              at = __shfl(at, 0);
+              if (at + need > pool_cap) { st = 100; break; }
+              int *r = pool + at;
+              if (lane == 0)
+                { r[0] = j; r[1] = seq; r[2] = P.abpos; r[3] = P.bbpos; r[4] = P.aepos; r[5] = P.bepos;
+                  r[6] = P.diffs; r[7] = P.atlen;
+                }
+              uint16_t *tr = (uint16_t *) (r + REC_HDR);
+              for (int i = lane; i < P.atlen; i += 64) tr[i] = wk.atrace[P.aorg + i];
+              seq += 1;
+            }
+          wave_sync();
+        }
+      if (lane == 0) status[j] = st;
+      wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+//  Host helpers for launching the alignment kernels
+// ---------------------------------------------------------------------------------------
+
+struct AlignScratch
+{ DevBuf<int4>     cells;
+  DevBuf<uint16_t> traces;
+  DevBuf<int>      band;
+  DevBuf<unsigned int> ctl;
+  int nwaves = 0, tcap = 0;
+};
+
+static AlignScratch &ascr()
+{ static AlignScratch s;
+  return s;
+}
+
+static Scratch prepare_scratch(int nblocks, int tcap, bool global_band)
+{ AlignScratch &a = ascr();
+  int nw = nblocks * 4;
+  a.cells.ensure((size_t) nw * CELLCAP, "pebble arenas");
+  a.traces.ensure((size_t) nw * 4 * tcap, "trace buffers");
+  if (global_band)
+    a.band.ensure((size_t) nw * (F_COUNT * 2 + 2) * GLB_W, "global d-wave bands");
+  a.ctl.ensure(8, "alignment counters");
+  Scratch sc;
+  sc.band = a.band.p;
+  sc.cells = a.cells.p;
+  sc.traces = a.traces.p;
+  sc.tcap = tcap;
+  return sc;
+}
+
+static int trace_cap(int maxalen, int tspace)
+{ // A view: <= alen/s + 2 pairs per direction; B view can be ~1.3x longer.  Two reverse passes
+  // may stack on the low side (retry path), hence the factor 2 and the slack.
+  int pairs = (int) ((int64_t) maxalen * 3 / 2 / tspace) + 16;
+  return 2 * (2 * pairs) + 64;
+}
+
+static AlignSpecDev spec_dev(Spec *sp)
+{ AlignSpecDev d;
+  int16_t *t = spec_device_tables(sp);
+  d.TS = sp->trace_space;
+  d.PATH_AVE = sp->ave_path;
+  d.REACH = sp->reach;
+  d.SCORE = t;
+  d.TABLE = t + 32768;
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------
+//  Host: report/select stage (map.c:1953-2871), sequential per read
+// ---------------------------------------------------------------------------------------
+
+constexpr uint32_t COMP_FLAG  = 0x1;    // align.h:127
+constexpr uint32_t START_FLAG = 0x4;    // align.h:133
+constexpr uint32_t NEXT_FLAG  = 0x8;    // align.h:134
+constexpr uint32_t BEST_FLAG  = 0x10;   // align.h:135
+constexpr int      TRACE_XOVR = 125;    // align.h:21
+
+constexpr double CHAIN_OFF  = 500.;     // map.c:42-49
+constexpr double CHAIN_OVL  = 400.;
+constexpr double CHAIN_PLAY = 1.4;
+constexpr double DIFF_SCORE = 2.3;
+constexpr int    TIE_SCORE  = 50;
+constexpr int    TIE_GAP    = 500;
+
+struct Ovl
+{ int      tlen, diffs, abpos, bbpos, aepos, bepos;
+  uint32_t flags;
+  int      aread, bread;
+  size_t   trace;       // offset into the read's trace buffer
+};
+
+struct Link { int score, link, mark; };
+struct Zone { int beg, end, top; };
+
+// map.c:1953-2058: do the two paths share a trace point?  Returns the minimum |b-offset| at the
+// A trace lines both cross (0 => they meet, *where = that A coordinate), -1 if they share none.
+static int entwine(const Ovl &J, const Ovl &K, const std::vector<uint16_t> &tb, int S, int *where)
+{ const uint16_t *kt = tb.data() + K.trace, *jt = tb.data() + J.trace;
+  int min = 10000, den = 0;
+  int y2 = J.bbpos, j = J.abpos / S;
+  int b2 = K.bbpos, k = K.abpos / S;
+  int ac, i;
+
+  if (J.abpos == K.abpos)
+    { min = abs(y2 - b2);
+      if (min == 0) *where = K.abpos;
+    }
+  if (j < k)
+    { ac = k * S;
+      j = 1 + 2 * (k - j);
+      k = 1;
+      for (i = 1; i < j; i += 2) y2 += jt[i];
+    }
+  else
+    { ac = j * S;
+      k = 1 + 2 * (j - k);
+      j = 1;
+      for (i = 1; i < k; i += 2) b2 += kt[i];
+    }
+  int ae = J.aepos;
+  if (ae > K.aepos) ae = K.aepos;
+  while (true)
+    { ac += S;
+      if (ac >= ae) break;
+      y2 += jt[j];
+      b2 += kt[k];
+      j += 2;
+      k += 2;
+      i = abs(y2 - b2);
+      if (i <= min)
+        { min = i;
+          if (i == 0) *where = ac;
+        }
+      den += 1;
+    }
+  if (J.aepos == K.aepos)
+    { i = abs(J.bepos - K.bepos);
+      if (i <= min)
+        { min = i;
+          if (i == 0) *where = K.aepos;
+        }
+    }
+  return (den == 0) ? -1 : min;
+}
+
+// map.c:2065-2109: P1 := prefix of P1 up to trace line ap, then P2 from there on
+static void fusion(Ovl &P1, int ap, const Ovl &P2, std::vector<uint16_t> &tb, int S)
+{ int k1 = 2 * ((ap / S) - (P1.abpos / S));
+  int k2 = 2 * ((ap / S) - (P2.abpos / S));
+  size_t at = tb.size();
+  int diff = 0;
+  for (int k = 0; k < k1; k += 2)
+    { uint16_t d = tb[P1.trace + k], v = tb[P1.trace + k + 1];
+      tb.push_back(d);
+      tb.push_back(v);
+      diff += d;
+    }
+  for (int k = k2; k < P2.tlen; k += 2)
+    { uint16_t d = tb[P2.trace + k], v = tb[P2.trace + k + 1];
+      tb.push_back(d);
+      tb.push_back(v);
+      diff += d;
+    }
+  P1.aepos = P2.aepos;
+  P1.bepos = P2.bepos;
+  P1.diffs = diff;
+  P1.trace = at;
+  P1.tlen  = (int) (tb.size() - at);
+}
+
+static void copy_path(Ovl &dst, const Ovl &src)
+{ dst.tlen = src.tlen; dst.diffs = src.diffs; dst.trace = src.trace;
+  dst.abpos = src.abpos; dst.bbpos = src.bbpos; dst.aepos = src.aepos; dst.bepos = src.bepos;
+}
+
+// map.c:2116-2268 (A view only)
+static int handle_redundancies(Ovl *am, int novls, std::vector<uint16_t> &tb, int S)
+{ int awhen = 0;
+  for (int j = 1; j < novls; j++)
+    { Ovl &J = am[j];
+      for (int k = j - 1; k >= 0; k--)
+        { Ovl &K = am[k];
+          if (K.abpos < 0) continue;
+          if (J.abpos < K.abpos)
+            { if (K.abpos <= J.aepos && K.bbpos <= J.bepos)
+                { int dist = entwine(J, K, tb, S, &awhen);
+                  if (dist == 0)
+                    { if (K.aepos > J.aepos)
+                        fusion(J, awhen, K, tb, S);
+                      K.abpos = -1;
+                      break;
+                    }
+                }
+            }
+          else
+            { if (J.abpos <= K.aepos && J.bbpos <= K.bepos)
+                { int dist = entwine(K, J, tb, S, &awhen);
+                  if (dist == 0)
+                    { if (K.abpos == J.abpos)
+                        { if (K.aepos > J.aepos) copy_path(J, K); }
+                      else if (J.aepos > K.aepos)
+                        { fusion(K, awhen, J, tb, S);
+                          copy_path(J, K);
+                        }
+                      else
+                        copy_path(J, K);
+                      K.abpos = -1;
+                      break;
+                    }
+                }
+            }
+        }
+    }
+  int no = 0;
+  for (int j = 0; j < novls; j++)
+    if (am[j].abpos >= 0) am[no++] = am[j];
+  return no;
+}
+
+// map.c:2270-2302
+static int special_log(int cover)
+{ static double Spow[51];
+  static bool   first = true;
+  if (first)
+    { first = false;
+      for (int m = 0; m <= 40; m++) Spow[m] = pow(10., m / 10.);
+    }
+  if (cover <= 1) return cover;
+  if (cover >= 10000) return 40;
+  double x = cover;
+  int l = 0, r = 41;
+  while (l < r)
+    { int m = (l + r) >> 1;
+      if (Spow[m] <= x) l = m + 1; else r = m;
+    }
+  return l - 1;
+}
+
+static void write_overlap(FILE *f, const Ovl &o, const uint16_t *trace, bool small)
+{ int32_t rec[10];
+  rec[0] = o.tlen; rec[1] = o.diffs; rec[2] = o.abpos; rec[3] = o.bbpos; rec[4] = o.aepos; rec[5] = o.bepos;
+  rec[6] = (int32_t) o.flags; rec[7] = o.aread; rec[8] = o.bread;
+  rec[9] = 0;                                  // struct padding (uninitialised in the reference)
+  fwrite(rec, 40, 1, f);
+  if (small)
+    { std::vector<uint8_t> t8(o.tlen);
+      for (int j = 0; j < o.tlen; j++)
+        { if (trace[j] > 255)               // align.c:3129-3137
+            { fprintf(stderr, "damapper: Compression of trace to bytes fails, value too big\n");
+              exit(1);
+            }
+          t8[j] = (uint8_t) trace[j];
+        }
+      fwrite(t8.data(), 1, o.tlen, f);
+    }
+  else
+    fwrite(trace, 2, o.tlen, f);
+}
+
+struct AlnRec { int seq, abpos, bbpos, aepos, bepos, diffs, tlen; const uint16_t *trace; };
+
+}  // namespace dmh
+
 using namespace dmh;
+
 extern "C" {
+
 void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_Spec *asettings, int mflag)
-{ fatal("Reporter: not implemented yet"); }
-int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes, const uint8_t *bbases, int64_t bbytes,
-                        int njobs, const int64_t *aoff, const int *alen, const int64_t *boff, const int *blen,
-                        const int *comp, const int *dg, const int *ad, int *out, uint16_t *trace_out,
-                        uint16_t *btrace_out, int trace_stride)
-{ fatal("dmh_local_alignment: not implemented yet"); return -1; }
+{ State &st = S();
+  const Params &pm = st.params;
+  Spec *sp = (Spec *) asettings;
+  if (sp == nullptr || sp->magic != SPEC_MAGIC)
+    fatal("Reporter: the Align_Spec was not created by this library's New_Align_Spec");
+  if (mflag & FLAG_DOB)
+    fatal("Reporter: reference-vs-reads output (-C/-N) is not supported by the HIP filter yet");
+  if (st.cur_reads != ablock || (int) st.reads.size() != ablock->nreads)
+    fatal("Reporter: called for a READS block that has not been through Match_Filter");
+  const int doA = (mflag & FLAG_DOA) != 0;
+  const int S_  = SPACING;
+  const int NT  = pm.NTHREADS;
+  const int hithr = 3 * pm.Kmer;
+  const int nreads = ablock->nreads;
+  const int astart = ablock->tfirst;
+
+  ablock->maxlen += SPACING;                  // map.c:3246
+
+  // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel
+  std::vector<CandJob>   jobs;
+  std::vector<uint16_t>  jumps;
+  std::vector<int>       job_of_first(nreads + 1, 0);   // first job index of each read
+  for (int ar = 0; ar < nreads; ar++)
+    { job_of_first[ar] = (int) jobs.size();
+      for (auto &c : st.reads[ar].cands)
+        { CandJob J;
+          J.aoff  = ablock->reads[ar].boff;
+          J.alen  = ablock->reads[ar].rlen;
+          J.boff  = bblock->reads[c->bread].boff;
+          J.blen  = bblock->reads[c->bread].rlen;
+          J.comp  = c->comp;
+          J.alast = c->alast;
+          J.blast = c->blast;
+          J.npts  = c->length;
+          J.joff  = (uint32_t) (jumps.size() / 2);
+          J.pad   = 0;
+          for (int t = 0; t < c->length; t++)
+            { jumps.push_back(c->adisp[t]);
+              jumps.push_back(c->bdisp[t]);
+            }
+          jobs.push_back(J);
+        }
+    }
+  job_of_first[nreads] = (int) jobs.size();
+  const int njobs = (int) jobs.size();
+
+  std::vector<std::vector<AlnRec>> recs(njobs);
+  std::vector<int> pool;
+  if (njobs > 0)
+    { BlockDev &ad = upload_block(ablock, false);
+      BlockDev &bd = upload_block(bblock, false);
+      AlignSpecDev spd = spec_dev(sp);
+      int maxalen = 0;
+      for (int ar = 0; ar < nreads; ar++) maxalen = std::max(maxalen, ablock->reads[ar].rlen);
+      int tcap = trace_cap(maxalen, S_);
+
+      static DevBuf<CandJob>  d_jobs;
+      static DevBuf<uint16_t> d_jumps;
+      static DevBuf<int>      d_status, d_pool, d_only;
+      d_jobs.ensure(njobs, "candidate jobs");
+      d_jumps.ensure(jumps.size() + 2, "candidate jumps");
+      d_status.ensure(njobs, "candidate status");
+      HIP_CHECK(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(CandJob) * njobs, hipMemcpyHostToDevice, stream()));
+      if (!jumps.empty())
+        HIP_CHECK(hipMemcpyAsync(d_jumps.p, jumps.data(), sizeof(uint16_t) * jumps.size(), hipMemcpyHostToDevice, stream()));
+
+      // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
+      size_t pool_cap = (size_t) njobs * 2 * (REC_HDR + (maxalen / S_ + 8)) + 4096;
+      std::vector<int> status(njobs);
+      std::vector<int> todo;                 // jobs to (re)run; empty = all
+      bool global_band = false;
+      for (int round = 0; round < 6; round++)
+        { if (pool_cap > 0xfffffff0ull / 4) fatal("Reporter: alignment pool too large");
+          d_pool.ensure(pool_cap, "alignment pool");
+          int nrun = todo.empty() ? njobs : (int) todo.size();
+          const int *only = nullptr;
+          if (!todo.empty())
+            { d_only.ensure(todo.size(), "retry list");
+              HIP_CHECK(hipMemcpyAsync(d_only.p, todo.data(), sizeof(int) * todo.size(), hipMemcpyHostToDevice, stream()));
+              only = d_only.p;
+            }
+          int nblocks = std::min((nrun + 3) / 4, 256 * 4);
+          Scratch sc = prepare_scratch(nblocks, tcap, global_band);
+          HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), stream()));
+          HIP_CHECK(hipMemsetAsync(d_pool.p, 0xff, sizeof(int) * pool_cap, stream()));   // cand = -1 ends the parse
+          { StageTimer tm(global_band ? "align_global_band" : "align", 0.0);
+            if (global_band)
+              hipLaunchKernelGGL((k_align_cands<GLB_W, false>), dim3(nblocks), dim3(256), 0, stream(),
+                                 ad.d_bases(), bd.d_bases(), (const CandJob *) d_jobs.p, nrun,
+                                 (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                                 ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+            else
+              hipLaunchKernelGGL((k_align_cands<LDS_W, true>), dim3(nblocks), dim3(256), 0, stream(),
+                                 ad.d_bases(), bd.d_bases(), (const CandJob *) d_jobs.p, nrun,
+                                 (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                                 ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+            HIP_CHECK(hipGetLastError());
+          }
+          unsigned int used = 0;
+          HIP_CHECK(hipMemcpyAsync(&used, ascr().ctl.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+          HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, sizeof(int) * njobs, hipMemcpyDeviceToHost, stream()));
+          HIP_CHECK(hipStreamSynchronize(stream()));
+          size_t got = std::min<size_t>(used, pool_cap);
+          size_t base = pool.size();
+          pool.resize(base + got);
+          if (got > 0)
+            HIP_CHECK(hipMemcpy(pool.data() + base, d_pool.p, sizeof(int) * got, hipMemcpyDeviceToHost));
+
+          // which jobs of this run failed, and why
+          std::vector<int> ran;
+          if (todo.empty()) { ran.resize(njobs); for (int i = 0; i < njobs; i++) ran[i] = i; }
+          else ran = todo;
+          std::vector<int> again;
+          bool need_pool = false, need_global = false;
+          for (int j : ran)
+            if (status[j] != AL_OK)
+              { again.push_back(j);
+                if (status[j] == 100) need_pool = true;
+                else if (status[j] == AL_ERR_BAND && !global_band) need_global = true;
+                else fatal("Reporter: alignment of candidate %d failed (status %d)", j, status[j]);
+              }
+          // parse the records of this run (records of failed jobs are dropped below)
+          std::vector<char> failed(njobs, 0);
+          for (int j : again) failed[j] = 1;
+          size_t p = base;
+          while (p + REC_HDR <= base + got)
+            { int *r = pool.data() + p;
+              int cand = r[0], tlen = r[7];
+              size_t need = REC_HDR + ((size_t) tlen + 1) / 2;
+              if (cand < 0 || cand >= njobs || tlen < 0) break;   // unwritten tail (pool overflow)
+              if (p + need > base + got) break;
+              if (!failed[cand])
+                { AlnRec a;
+                  a.seq = r[1]; a.abpos = r[2]; a.bbpos = r[3]; a.aepos = r[4]; a.bepos = r[5];
+                  a.diffs = r[6]; a.tlen = tlen;
+                  a.trace = nullptr;
+                  recs[cand].push_back(a);
+                  recs[cand].back().trace = (const uint16_t *) (size_t) (p + REC_HDR);   // offset, fixed up later
+                }
+              p += need;
+            }
+          for (int j : again) recs[j].clear();
+          if (again.empty()) break;
+          todo = again;
+          if (need_pool) pool_cap *= 4;
+          if (need_global && !need_pool) global_band = true;
+          if (round == 5) fatal("Reporter: alignment retries exhausted");
+        }
+      // fix up trace pointers now that the host pool no longer moves
+      for (auto &v : recs)
+        { for (auto &a : v)
+            a.trace = (const uint16_t *) (pool.data() + (size_t) a.trace);
+          std::sort(v.begin(), v.end(), [](const AlnRec &x, const AlnRec &y) { return x.seq < y.seq; });
+        }
+    }
+
+  // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
+  const bool small = (S_ <= TRACE_XOVR);
+  std::vector<Ovl>      am;
+  std::vector<uint16_t> tb;
+  std::vector<Link>     linker;
+  std::vector<Link *>   perm;
+  std::vector<Zone>     part;
+  int64_t ncheck = 0;
+  std::vector<std::vector<uint8_t>> prof(PROFILE ? nreads : 0);
+
+  for (int ti = 0; ti < NT; ti++)
+    { int abeg = (int) (((int64_t) ti * nreads) >> pm.NSHIFT);
+      int aend = (ti == NT - 1) ? nreads : (int) (((int64_t) (ti + 1) * nreads) >> pm.NSHIFT);
+      FILE *afile = nullptr;
+      int64_t ahits = 0;
+      if (doA)
+        { std::string fn = std::string(SORT_PATH) + "/" + aname + "." + bname + ".M" + std::to_string(ti + 1) + ".las";
+          afile = fopen(fn.c_str(), "w");
+          if (afile == nullptr)
+            { fprintf(stderr, "damapper: Cannot open %s for 'w'\n", fn.c_str());
+              Clean_Exit(1);
+            }
+          fwrite(&ahits, sizeof(int64_t), 1, afile);
+          fwrite(&SPACING, sizeof(int), 1, afile);
+        }
+
+      for (int ar = abeg; ar < aend; ar++)
+        { const int alen = ablock->reads[ar].rlen;
+          const int atck = (alen - 1) / S_ + 1;
+          am.clear();
+          tb.clear();
+          int lovl = 0;
+          auto &cl = st.reads[ar].cands;
+          int job = job_of_first[ar];
+          for (size_t ci = 0; ci < cl.size(); ci++, job++)
+            { Candidate &c = *cl[ci];
+              for (const AlnRec &a : recs[job])
+                { Ovl o;
+                  o.tlen = a.tlen; o.diffs = a.diffs;
+                  o.abpos = a.abpos; o.bbpos = a.bbpos; o.aepos = a.aepos; o.bepos = a.bepos;
+                  o.flags = c.comp ? COMP_FLAG : 0;
+                  o.aread = ar + astart;
+                  o.bread = c.bread;
+                  o.trace = tb.size();
+                  tb.insert(tb.end(), a.trace, a.trace + a.tlen);
+                  am.push_back(o);
+                }
+              bool last = (ci + 1 == cl.size()) || cl[ci + 1]->bread != c.bread || cl[ci + 1]->comp != c.comp;
+              if (last)
+                { int novl = (int) am.size();
+                  if (novl - lovl > 1)
+                    { novl = lovl + handle_redundancies(am.data() + lovl, novl - lovl, tb, S_);
+                      am.resize(novl);
+                    }
+                  if (novl - lovl > 1)
+                    { // AMATCH_SORT (map.c:2304-2315): abpos descending, ties by descending original
+                      // position (glibc sorts 48-byte records through pointers to the originals)
+                      std::vector<std::pair<Ovl, int>> tmp;
+                      for (int i = lovl; i < novl; i++) tmp.push_back({am[i], i});
+                      std::sort(tmp.begin(), tmp.end(), [](const std::pair<Ovl, int> &x, const std::pair<Ovl, int> &y)
+                                { if (x.first.abpos != y.first.abpos) return x.first.abpos > y.first.abpos;
+                                  return x.second > y.second;
+                                });
+                      for (int i = lovl; i < novl; i++) am[i] = tmp[i - lovl].first;
+                    }
+                  lovl = novl;
+                }
+            }
+
+          const int novl = (int) am.size();
+          linker.assign(std::max(novl, 1), Link{0, -1, 1});
+          perm.assign(std::max(novl, 1), nullptr);
+          part.assign(std::max(novl, 1), Zone{0, 0, 0});
+
+          // LA-chain DP (map.c:2630-2710)
+          if (novl > 0)
+            { lovl = 0;
+              linker[0].link = -1;
+              linker[0].score = (int) ((am[0].aepos - am[0].abpos) - DIFF_SCORE * am[0].diffs);
+              linker[0].mark = 1;
+              perm[0] = &linker[0];
+              int br = am[0].bread;
+              for (int c = 1; c < novl; c++)
+                { const Ovl &cp = am[c];
+                  linker[c].link = -1;
+                  linker[c].score = (int) ((cp.aepos - cp.abpos) - DIFF_SCORE * cp.diffs);
+                  linker[c].mark = 1;
+                  perm[c] = &linker[c];
+                  if (am[c].bread != br)
+                    { br = am[c].bread;
+                      lovl = c;
+                      continue;
+                    }
+                  int cor = (am[c].flags & COMP_FLAG);
+                  for (int d = c - 1; d >= lovl; d--)
+                    { int dor = (am[d].flags & COMP_FLAG);
+                      if (dor != cor) continue;
+                      const Ovl &dp = am[d];
+                      if (dor)
+                        { if (dp.bepos < cp.bepos) continue; }
+                      else
+                        { if (dp.bbpos < cp.bbpos) continue; }
+                      if (dp.abpos <= cp.aepos - CHAIN_OVL || dp.bbpos <= cp.bepos - CHAIN_OVL)
+                        continue;
+                      double rat = ((dp.abpos - cp.aepos + CHAIN_OFF) / (dp.bbpos - cp.bepos + CHAIN_OFF));
+                      if (1. > rat * CHAIN_PLAY || rat > CHAIN_PLAY)
+                        continue;
+                      int scr  = (int) (linker[d].score + (cp.aepos - cp.abpos) - DIFF_SCORE * cp.diffs);
+                      int scr2 = linker[c].score;
+                      if (scr < scr2 - TIE_SCORE)
+                        continue;
+                      if (scr <= scr2 + TIE_SCORE)
+                        { int gap = dp.abpos - cp.aepos, gap2;
+                          if (linker[d].link >= 0)
+                            { // map.c:2689-2690 indexes amatch[] with linker[c].link, which may be -1
+                              // (the reference then reads the record before the array)
+                              int lc = linker[c].link;
+                              gap2 = (lc >= 0 ? am[lc].aepos : 0) - dp.abpos;
+                            }
+                          else
+                            gap2 = 0;
+                          if (gap > gap2 + TIE_GAP)
+                            continue;
+                          if (gap >= gap2 - TIE_GAP)
+                            { if (scr < scr2) continue;
+                              if (scr == scr2)
+                                { if (gap >= gap2) continue; }
+                            }
+                        }
+                      linker[c].link = d;
+                      linker[c].score = scr;
+                      linker[d].mark = 0;
+                    }
+                }
+            }
+
+          // LINK_SORT (map.c:2355-2360): score descending, stable (glibc merge sort on 8-byte items)
+          std::stable_sort(perm.begin(), perm.begin() + novl, [](const Link *x, const Link *y) { return x->score > y->score; });
+
+          int nparts = 0;
+          for (int c = 0; c < novl && perm[c]->score >= 0; c++)
+            if (perm[c]->mark == 1)
+              { int b, e, p, n, best;
+                b = e = (int) (perm[c] - linker.data());
+                for (p = linker[b].link; p >= 0 && linker[p].mark >= 0; p = linker[p].link)
+                  e = p;
+                for (p = 0; p < nparts; p++)
+                  if (am[b].abpos < part[p].end - 100 && am[e].aepos > part[p].beg + 100)
+                    break;
+                if (p >= nparts)
+                  { part[p].beg = am[b].abpos;
+                    part[p].end = am[e].aepos;
+                    part[p].top = linker[b].score;
+                    best = 1;
+                    nparts += 1;
+                  }
+                else
+                  { if (linker[b].score < BEST_TIE * part[p].top)
+                      continue;
+                    best = (linker[b].score == part[p].top);
+                  }
+                for (p = b; true; p = n)
+                  { linker[p].mark = -1;
+                    if (doA)
+                      { if (p == b)
+                          { am[p].flags |= START_FLAG;
+                            if (best) am[p].flags |= BEST_FLAG;
+                          }
+                        else
+                          am[p].flags |= NEXT_FLAG;
+                        write_overlap(afile, am[p], tb.data() + am[p].trace, small);
+                        ahits += 1;
+                      }
+                    n = linker[p].link;
+                    if (p == e) break;
+                  }
+              }
+
+          if (PROFILE)                           // map.c:2835-2845
+            { auto &cv = st.reads[ar].cover;
+              prof[ar].resize(atck + 1);
+              int c = 0;
+              for (int i = 0; i <= atck; i++)
+                { c += cv[i];
+                  prof[ar][i] = (uint8_t) special_log(c);
+                }
+            }
+        }
+
+      if (doA)
+        { rewind(afile);
+          fwrite(&ahits, sizeof(int64_t), 1, afile);
+          fclose(afile);
+        }
+      ncheck += ahits;
+    }
+
+  if (VERBOSE)
+    { printf("      %lld mapped segments\n", (long long) ncheck);
+      fflush(stdout);
+    }
+
+  if (PROFILE)                                   // map.c:3295-3318
+    { std::string an = std::string(".") + aname + ".prof.anno", dn = std::string(".") + aname + ".prof.data";
+      FILE *af = fopen(an.c_str(), "w"), *df = fopen(dn.c_str(), "w");
+      if (af == nullptr || df == nullptr)
+        { fprintf(stderr, "damapper: Cannot open profile track files for %s\n", aname);
+          Clean_Exit(1);
+        }
+      int size = sizeof(int64_t);
+      fwrite(&(ablock->nreads), sizeof(int), 1, af);
+      fwrite(&size, sizeof(int), 1, af);
+      int64_t cnt = 0;
+      for (int a = 0; a < nreads; a++)
+        { fwrite(&cnt, sizeof(int64_t), 1, af);
+          cnt += (ablock->reads[a].rlen - 1) / S_ + 2;
+          fwrite(prof[a].data(), 1, prof[a].size(), df);
+        }
+      fwrite(&cnt, sizeof(int64_t), 1, af);
+      fclose(af);
+      fclose(df);
+    }
+
+  // the READS index and block copies are not needed any more; the driver free()s the stub
+  for (auto it = st.indices.begin(); it != st.indices.end();)
+    { if (it->second.block == ablock && !st.retain_ref)
+        { dev_free(it->second.keys); dev_free(it->second.vals);
+          dev_free(it->second.d_boff); dev_free(it->second.d_chunk);
+          it = st.indices.erase(it);
+        }
+      else
+        ++it;
+    }
+  if (st.blocks.count(ablock) && !st.blocks[ablock].pinned) drop_block(ablock);
+  if (st.blocks.count(bblock) && !st.blocks[bblock].pinned) drop_block(bblock);
 }
+
+int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes, const uint8_t *bbases,
+                        int64_t bbytes, int njobs, const int64_t *aoff, const int *alen, const int64_t *boff,
+                        const int *blen, const int *comp, const int *dg, const int *ad, int *out,
+                        uint16_t *trace_out, uint16_t *btrace_out, int trace_stride)
+{ Spec *sp = (Spec *) spec;
+  if (sp == nullptr || sp->magic != SPEC_MAGIC) fatal("dmh_local_alignment: bad Align_Spec");
+  if (njobs <= 0) return 0;
+  AlignSpecDev spd = spec_dev(sp);
+  uint8_t *da = (uint8_t *) dev_alloc(abytes + 256, "A bases");
+  uint8_t *db = (uint8_t *) dev_alloc(bbytes + 256, "B bases");
+  HIP_CHECK(hipMemcpyAsync(da, abases, abytes, hipMemcpyHostToDevice, stream()));
+  HIP_CHECK(hipMemcpyAsync(db, bbases, bbytes, hipMemcpyHostToDevice, stream()));
+  std::vector<SeedJob> jobs(njobs);
+  int maxalen = 1;
+  for (int i = 0; i < njobs; i++)
+    { jobs[i] = SeedJob{aoff[i], boff[i], alen[i], blen[i], comp[i], dg[i], ad[i], 0};
+      maxalen = std::max(maxalen, alen[i]);
+    }
+  SeedJob *dj = (SeedJob *) dev_alloc(sizeof(SeedJob) * njobs, "seed jobs");
+  HIP_CHECK(hipMemcpyAsync(dj, jobs.data(), sizeof(SeedJob) * njobs, hipMemcpyHostToDevice, stream()));
+  int      *dout = (int *) dev_alloc(sizeof(int) * 16 * njobs, "seed results");
+  uint16_t *dat = (uint16_t *) dev_alloc(sizeof(uint16_t) * (size_t) njobs * trace_stride, "seed traces");
+  uint16_t *dbt = (uint16_t *) dev_alloc(sizeof(uint16_t) * (size_t) njobs * trace_stride, "seed traces");
+  int tcap = trace_cap(maxalen, sp->trace_space);
+
+  std::vector<int> res(16 * (size_t) njobs);
+  std::vector<int> todo;
+  int *d_only = nullptr;
+  for (int pass = 0; pass < 2; pass++)
+    { bool global_band = (pass == 1);
+      int  nrun = global_band ? (int) todo.size() : njobs;
+      if (nrun == 0) break;
+      int nblocks = std::min((nrun + 3) / 4, 256 * 4);
+      Scratch sc = prepare_scratch(nblocks, tcap, global_band);
+      HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), stream()));
+      if (global_band)
+        { d_only = (int *) dev_alloc(sizeof(int) * nrun, "retry list");
+          HIP_CHECK(hipMemcpyAsync(d_only, todo.data(), sizeof(int) * nrun, hipMemcpyHostToDevice, stream()));
+        }
+      { StageTimer tm(global_band ? "align_seeds_global_band" : "align_seeds", 0.0);
+        if (global_band)
+          hipLaunchKernelGGL((k_align_seeds<GLB_W, false>), dim3(nblocks), dim3(256), 0, stream(), da, db,
+                             (const SeedJob *) dj, nrun, spd, sc, ascr().ctl.p, dout, dat, dbt, trace_stride,
+                             (const int *) d_only);
+        else
+          hipLaunchKernelGGL((k_align_seeds<LDS_W, true>), dim3(nblocks), dim3(256), 0, stream(), da, db,
+                             (const SeedJob *) dj, nrun, spd, sc, ascr().ctl.p, dout, dat, dbt, trace_stride,
+                             (const int *) nullptr);
+        HIP_CHECK(hipGetLastError());
+      }
+      HIP_CHECK(hipMemcpyAsync(res.data(), dout, sizeof(int) * 16 * njobs, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      todo.clear();
+      for (int i = 0; i < njobs; i++)
+        if (res[16 * (size_t) i + 7] == AL_ERR_BAND) todo.push_back(i);
+    }
+  for (int i = 0; i < njobs; i++)
+    for (int f = 0; f < 16; f++) out[16 * (size_t) i + f] = res[16 * (size_t) i + f];
+  HIP_CHECK(hipMemcpyAsync(trace_out, dat, sizeof(uint16_t) * (size_t) njobs * trace_stride, hipMemcpyDeviceToHost, stream()));
+  if (btrace_out != nullptr)
+    HIP_CHECK(hipMemcpyAsync(btrace_out, dbt, sizeof(uint16_t) * (size_t) njobs * trace_stride, hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  dev_free(da); dev_free(db); dev_free(dj); dev_free(dout); dev_free(dat); dev_free(dbt);
+  if (d_only) dev_free(d_only);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+"""Host-side mirror of damapper.c's main() block loops (damapper.c:825-880) over the C-ABI:
+for every READS block: index it, run Match_Filter against every REF block in both orientations,
+then Reporter against the whole REF.  Pure plumbing -- all compute is in libdamapper_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .dazzdb import Block, load_db, read_stub
+
+
+class Mapper:
+    def __init__(self, kmer: int = 20, suppress: int = 0, threads: int = 4, ave_corr: float = 0.85,
+                 spacing: int = 100, best_tie: float = 1.0, profile: int = 0, verbose: int = 0,
+                 mem_limit: int = 0, sort_path: str = "/tmp"):
+        self.L = capi.lib()
+        self.kmer, self.suppress, self.threads = kmer, suppress, threads
+        self.ave_corr, self.spacing = ave_corr, spacing
+        self.sort_path = sort_path
+        os.makedirs(sort_path, exist_ok=True)
+        if mem_limit == 0:
+            try:
+                mem_limit = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")   # getMemorySize()
+            except (ValueError, OSError):
+                mem_limit = 64 << 30
+        capi.set_globals(verbose=verbose, profile=profile, spacing=spacing, best_tie=best_tie,
+                         sort_path=sort_path, mem_limit=mem_limit, mem_physical=mem_limit)
+        if self.L.Set_Filter_Params(kmer, suppress, threads):
+            raise ValueError("Illegal combination of filter parameters")
+        self.spec = None
+
+    def make_spec(self, freq: Sequence[float]):
+        f = (C.c_float * 4)(*[float(x) for x in freq])
+        if self.spec:
+            self.L.Free_Align_Spec(self.spec)
+        self.spec = self.L.New_Align_Spec(self.ave_corr, self.spacing, f, 1)    # damapper.c:796
+        return self.spec
+
+    def map_block(self, reads: Block, reads_name: str, ref_blocks: Sequence[Block], ref_whole: Block,
+                  ref_name: str, mflag: int = capi.FLAG_DOA, restore: bool = True) -> Dict[str, float]:
+        """One iteration of main()'s outer loop (damapper.c:825-880)."""
+        t = {}
+        t0 = time.time()
+        if self.spec is None:
+            self.make_spec([ref_whole.db.freq[j] for j in range(4)])
+        rh, rn = capi.sort_kmers(reads)
+        t["index_reads"] = time.time() - t0
+        t1 = time.time()
+        for k, blk in enumerate(ref_blocks):
+            for comp in (0, 1):
+                if comp:
+                    blk.complement_inplace()                                      # damapper.c:853
+                h, n = capi.sort_kmers(blk)
+                capi.match_filter(reads, blk, rh, rn, h, n, comp, 1 if (k == 0 and comp == 0) else 0)
+            if restore:
+                blk.complement_inplace()
+        t["filter"] = time.time() - t1
+        t2 = time.time()
+        self.L.Reporter(reads_name.encode(), reads.ptr(), ref_name.encode(), ref_whole.ptr(), self.spec, mflag)
+        t["report"] = time.time() - t2
+        if rh:
+            self.L.dmh_free_index(rh)      # Reporter released the device side; this frees the stub
+        t["total"] = time.time() - t0
+        return t
+
+
+def map_db(workdir: str, ref_root: str, read_root: str, sort_path: Optional[str] = None, **kw) -> Dict[str, float]:
+    """damapper <ref> <reads> on DBs written by dazzdb.write_db (all blocks of the reads DB)."""
+    sort_path = sort_path or os.path.join(workdir, "las_hip")
+    m = Mapper(sort_path=sort_path, **kw)
+    cwd = os.getcwd()
+    os.chdir(workdir)        # the -p track files go to the current directory (map.c:3301-3302)
+    try:
+        nb, _ = read_stub(ref_root + ".db")
+        ref_blocks = [load_db("./" + ref_root + ".db", part=k + 1) for k in range(nb)]
+        ref_whole = load_db("./" + ref_root + ".db")
+        reads = load_db("./" + read_root + ".db")
+        return m.map_block(reads, read_root, ref_blocks, ref_whole, ref_root)
+    finally:
+        os.chdir(cwd)

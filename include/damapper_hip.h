@@ -143,8 +143,9 @@ int dmh_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbits);
  * base with a 4 on both sides of every sequence (the in-memory DAZZ_DB layout).  For job i:
  * A = abases[aoff[i] .. +alen[i]), B = bbases[boff[i] .. +blen[i]); comp[i] != 0 aligns the
  * reverse complement of A with ACOMP_FLAG semantics (map.c:2474-2513); seed diagonal dg[i],
- * anti-diagonal ad[i] in the (possibly complemented) A frame.  out: per job 8 ints
- * {abpos,bbpos,aepos,bepos,diffs,tlen, b-view tlen, status}; A-view traces (uint16) are written
+ * anti-diagonal ad[i] in the (possibly complemented) A frame.  out: per job 16 ints
+ * {abpos,bbpos,aepos,bepos,diffs,tlen, b-view tlen, status, b-view abpos,bbpos,aepos,bepos, 4 debug words};
+ * A-view traces (uint16) are written
  * at trace_out + i*trace_stride, B-view traces at btrace_out + i*trace_stride (may be NULL). */
 int dmh_local_alignment(Align_Spec *spec,
                         const uint8_t *abases, int64_t abytes, const uint8_t *bbases, int64_t bbytes,

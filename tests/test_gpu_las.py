@@ -1,0 +1,67 @@
+"""GPU end-to-end parity: the per-thread .las record streams (and the -p track) written by the HIP
+pipeline must be identical to the compiled reference's on the same DBs (bytes 36..39 of every
+record are uninitialised struct padding in the reference and are not compared)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from damapper_amd import dazzdb, driver, las
+from util_pipeline import make_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ref():
+    import run_ref
+    if not run_ref.have_ref():
+        pytest.skip("oracle/_ref not built")
+    return run_ref
+
+
+CASES = [
+    # name, kind, seed, contigs, nreads, dropouts, block_size, flags(ref), kwargs(hip)
+    ("plain", "random", 41, [300000, 200000, 250000], 120, 0, 400000, [], {}),
+    ("dropout_n95_p", "repeat", 42, [300000, 250000], 80, 2, 1000000, ["-n.95", "-p"], dict(best_tie=0.95, profile=1)),
+    ("k14_e75", "random", 43, [200000, 150000], 50, 1, 1000000, ["-k14", "-e.75"], dict(kmer=14, ave_corr=0.75)),
+    ("s126_t20", "repeat", 44, [250000], 50, 1, 1000000, ["-s126", "-t20"], dict(spacing=126, suppress=20)),
+    ("T1", "random", 45, [150000, 100000], 30, 3, 120000, ["-T1"], dict(threads=1)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_las_identical_to_reference(case, tmp_path):
+    run_ref = _run_ref()
+    name, kind, seed, contigs, nreads, drop, bsize, flags, kw = case
+    g, reads = make_dataset(kind, seed, contigs, nreads, dropouts=drop)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=bsize)
+    dazzdb.write_db(d, "READS", reads)
+    threads = kw.pop("threads", 4)
+    mem = 8 << 30
+    run_ref.run_reference(d, "REF", ["READS"], flags=list(flags) + ["-M8"], threads=threads)
+    prof_ref = None
+    if "-p" in flags:
+        prof_ref = (open(os.path.join(d, ".READS.prof.anno"), "rb").read(),
+                    open(os.path.join(d, ".READS.prof.data"), "rb").read())
+        os.remove(os.path.join(d, ".READS.prof.anno"))
+        os.remove(os.path.join(d, ".READS.prof.data"))
+    driver.map_db(d, "REF", "READS", threads=threads, mem_limit=mem, **kw)
+    ts_r, rr = las.read_las_set(os.path.join(d, "las_ref"), "READS.REF.M@.las")
+    ts_h, hr = las.read_las_set(os.path.join(d, "las_hip"), "READS.REF.M@.las")
+    assert ts_r == ts_h
+    assert len(rr) == len(hr), "%d vs %d records" % (len(rr), len(hr))
+    assert len(rr) > 0
+    for i, (a, b) in enumerate(zip(rr, hr)):
+        assert a == b, "record %d differs:\n%s\n%s" % (i, a, b)
+    # per-file record counts must match too (same read partition per thread file)
+    for t in range(1, threads + 1):
+        _, fa = las.read_las(os.path.join(d, "las_ref", "READS.REF.M%d.las" % t))
+        _, fb = las.read_las(os.path.join(d, "las_hip", "READS.REF.M%d.las" % t))
+        assert len(fa) == len(fb)
+    if prof_ref is not None:
+        got = (open(os.path.join(d, ".READS.prof.anno"), "rb").read(),
+               open(os.path.join(d, ".READS.prof.data"), "rb").read())
+        assert got[0] == prof_ref[0]
+        assert got[1] == prof_ref[1]
