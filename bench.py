@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbp of reads mapped per second through the HIP hot path.
+
+A "step" maps ONE read block (default 25,000 simulated PacBio reads x 10 kb, 15 % error = 0.25 Gbp,
+a DBsplit-sized block) against the reference in both orientations, exactly as one iteration of
+damapper.c's main loop does: Sort_Kmers(reads) -> for every REF block {Sort_Kmers, Match_Filter,
+complement, Sort_Kmers, Match_Filter} -> Reporter (.las written).  The workload is BASELINE.json's
+config[1]: an E. coli-sized reference (4.6 Mbp; uniform random ACGT with a fixed seed, there is no
+network for the real K-12 FASTA) and 100 k reads = 4 blocks; K steps cycle over the blocks.
+
+Read blocks shard across GPUs (one process per GPU, no collective on the data path; the reference
+index is rebuilt per GPU): rank r maps its own blocks, so per-GPU work is fixed ("weak").
+Inputs (block bases) are resident in HBM before the timed region starts.
+
+The JSON line also carries
+  roofline     -- the dominant HBM-bound kernel (one LSD radix-sort pass, k_radix_scatter): the
+                  reference's algorithmic bytes per pass (32 B per record) over the kernel's mean
+                  duration measured with HIP events on the library's stream;
+  cpu_baseline -- the compiled reference (oracle/_ref/damapper -T<P>) timed on this box's host
+                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from damapper_amd import capi, dazzdb, driver  # noqa: E402
+
+GENOME_LEN = 4_600_000
+READ_LEN = 10_000
+HBM_PEAK_GBS = 8000.0
+
+
+def make_block(genome, nreads, seed, tfirst=0, part=0):
+    return dazzdb.simulate_block(seed, genome[0], nreads, read_len=READ_LEN, err=0.15, tfirst=tfirst, part=part,
+                                 path=b"./.READS")
+
+
+def cpu_baseline(genome, sample_reads, threads):
+    """Reference `damapper -k20 -e.85 -T<threads>` on a bounded sample; wall time of the process
+    (LAsort/LAcat are shims)."""
+    try:
+        import run_ref
+    except Exception:
+        return None
+    if not run_ref.have_ref():
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        dazzdb.write_db(d, "REF", genome, block_size=400_000_000)
+        dazzdb.write_db(d, "READS", sample_reads)
+        dt, _ = run_ref.run_reference(d, "REF", ["READS"], flags=["-k20", "-e.85"], threads=threads)
+    bases = float(sum(len(r) for r in sample_reads))
+    return {"value": bases / dt / 1e9, "unit": "Gbp/s", "cores": threads, "kind": "reference",
+            "sample": "%d reads x 10 kb (%.0f Mbp) vs the same 4.6 Mbp reference, damapper -k20 -e.85 -T%d, %.1f s wall"
+                      % (len(sample_reads), bases / 1e6, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--block-reads", type=int, default=25000)
+    ap.add_argument("--nblocks", type=int, default=4)
+    ap.add_argument("--cpu-sample-reads", type=int, default=60000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--retain-ref", action="store_true",
+                    help="keep the REF indices resident across steps instead of rebuilding them per read block")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local)
+        dist_mod.init_process_group(backend="nccl")
+        dist = dist_mod
+
+    L = capi.lib()
+    if L.dmh_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libdamapper_hip has no CPU fallback")
+
+    # ---- synthetic workload (seeded): reference shared by all ranks, reads per rank
+    g_rng = np.random.default_rng(20)
+    genome = dazzdb.random_genome(g_rng, [GENOME_LEN])
+    nblk = min(args.nblocks, max(1, args.steps + args.warmup))
+    blocks = []
+    for b in range(nblk):
+        blocks.append(make_block(genome, args.block_reads, 1000 + 97 * rank + b, tfirst=b * args.block_reads, part=b + 1))
+    ref_blocks = [dazzdb.make_block(genome, tfirst=0, part=1, path=b"./.REF")]
+    ref_whole = dazzdb.make_block(genome, path=b"./.REF")
+
+    sort_path = tempfile.mkdtemp(prefix="dmh_bench_%d_" % rank)
+    m = driver.Mapper(kmer=20, ave_corr=0.85, spacing=100, threads=4, sort_path=sort_path, mem_limit=64 << 30)
+    m.make_spec([ref_whole.db.freq[j] for j in range(4)])
+
+    # inputs resident in HBM before the clock starts
+    for blk in blocks:
+        L.dmh_preload_block(blk.ptr())
+    L.dmh_preload_block(ref_whole.ptr())
+    pcie_t0 = time.time()
+    L.dmh_sync()
+
+    def step(i):
+        blk = blocks[i % nblk]
+        return m.map_block(blk, "READS.%d" % (i % nblk + 1), ref_blocks, ref_whole, "REF")
+
+    for i in range(args.warmup):
+        step(i)
+
+    L.dmh_timing_enable(1)
+    L.dmh_timing_reset()
+    if dist is not None:
+        import torch
+        dist.barrier()
+        torch.cuda.synchronize()
+    L.dmh_sync()
+    t0 = time.time()
+    bases = 0
+    host = {"index_reads": 0.0, "filter": 0.0, "report": 0.0}
+    for i in range(args.steps):
+        t = step(args.warmup + i)
+        for k in host:
+            host[k] += t[k]
+        bases += int(blocks[(args.warmup + i) % nblk].db.totlen)
+    L.dmh_sync()
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+        dist.barrier()
+    dt = time.time() - t0
+
+    tot_bases = float(bases)
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tb = torch.tensor([tot_bases], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        tot_bases = float(tb.item())
+
+    timings = capi.timings()
+    L.dmh_timing_enable(0)
+
+    if rank == 0:
+        value = tot_bases / dt / 1e9
+        sc = timings.get("k_radix_scatter", None)
+        roof = None
+        if sc and sc["launches"] > 0 and sc["ms"] > 0:
+            achieved = sc["bytes"] / (sc["ms"] * 1e-3) / 1e9          # GB/s, algorithmic bytes
+            roof = {"bound": "hbm", "kernel": "k_radix_scatter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches": int(sc["launches"]), "avg_ms": round(sc["ms"] / sc["launches"], 4),
+                    "alg_bytes_per_launch": sc["bytes"] / sc["launches"]}
+        stages = {k: round(v["ms"], 2) for k, v in sorted(timings.items(), key=lambda kv: -kv[1]["ms"])}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                ncores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncores = os.cpu_count() or 1
+            ncores = min(ncores, 16)        # a 1-GPU box shares its host: 16 cores are ours
+            p = 1
+            while 2 * p <= ncores:
+                p *= 2
+            sample = dazzdb.block_reads(make_block(genome, args.cpu_sample_reads, 4242))
+            cpu = cpu_baseline(genome, sample, p)
+        out = {
+            "metric": "Gbp reads mapped/sec (whole node), -k20 -e.85; .las parity-checked vs CPU reference",
+            "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic",
+            "config": {"workload": "configs[1]: E.coli-sized random reference (4.6 Mbp) + simulated PacBio reads "
+                                   "(10 kb, 15%% err), %d reads per block/step, %d distinct blocks per GPU, "
+                                   "-k20 -e.85 -s100, REF index %s" %
+                                   (args.block_reads, nblk, "retained" if args.retain_ref else "rebuilt per read block"),
+                       "read_bases_per_step": int(blocks[0].db.totlen), "parallelism": "read blocks sharded x%d" % world},
+            "roofline": roof, "cpu_baseline": cpu,
+            "host_seconds": {k: round(v, 3) for k, v in host.items()},
+            "device_stage_ms": stages,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,12 +214,19 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
     { int      shift = lo_bit + 8 * p;
       int      w     = nbits - 8 * p;
       uint32_t mask  = (w >= 8) ? 0xffu : ((1u << w) - 1u);
-      hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
-                         (const uint64_t *) *keys, n, shift, mask, scr.hist.p, ntiles);
-      exclusive_scan_u32(scr.hist.p, (int64_t) 256 * ntiles, scr.bsum, nullptr);
-      hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
-                         (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,
-                         shift, mask, (const uint32_t *) scr.hist.p, ntiles);
+      { StageTimer th("k_radix_hist", 0.0);
+        hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+                           (const uint64_t *) *keys, n, shift, mask, scr.hist.p, ntiles);
+      }
+      { StageTimer ts("radix_scan", 0.0);
+        exclusive_scan_u32(scr.hist.p, (int64_t) 256 * ntiles, scr.bsum, nullptr);
+      }
+      { // one LSD pass over 16-byte records in the reference: read 16 B + write 16 B per record
+        StageTimer tc("k_radix_scatter", 32.0 * (double) n);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+                           (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,
+                           shift, mask, (const uint32_t *) scr.hist.p, ntiles);
+      }
       HIP_CHECK(hipGetLastError());
       uint64_t *tk = *keys; *keys = *okeys; *okeys = tk;
       uint32_t *tv = *vals; *vals = *ovals; *ovals = tv;

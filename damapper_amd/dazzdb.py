@@ -298,6 +298,72 @@ def make_block(seqs: Sequence[np.ndarray], tfirst: int = 0, part: int = 0,
     return Block(db=db, bases=bases, reads=reads, path=path)
 
 
+_sim = None
+
+
+def _sim_lib():
+    global _sim
+    if _sim is None:
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdmh_sim.so")
+        if not os.path.exists(so):
+            raise RuntimeError("libdmh_sim.so is not built (run __graft_entry__.build())")
+        L = C.CDLL(so)
+        L.dmh_sim_lengths.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_void_p]
+        L.dmh_sim_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]
+        _sim = L
+    return _sim
+
+
+def simulate_block(seed: int, contig: np.ndarray, nreads: int, read_len: int = 10000, err: float = 0.15,
+                   tfirst: int = 0, part: int = 0, path: bytes = b"./.mem") -> Block:
+    """Large synthetic read block straight into the in-memory DAZZ_DB layout (native, threaded
+    generator in tools/simulate.c: uniform position and strand on one contig, i.i.d. errors
+    ins:del:sub = 60:25:15; per-read RNG streams, so the block depends on `seed` only)."""
+    L = _sim_lib()
+    g = np.ascontiguousarray(contig, dtype=np.uint8)
+    rlen = np.zeros(nreads, dtype=np.int32)
+    L.dmh_sim_lengths(g.ctypes.data, len(g), nreads, read_len, err, seed, rlen.ctypes.data)
+    boff = np.zeros(nreads + 1, dtype=np.int64)
+    np.cumsum(rlen.astype(np.int64) + 1, out=boff[1:])
+    tot = int(rlen.sum())
+    bases = np.empty(tot + nreads + 4, dtype=np.uint8)
+    bases[-4:] = 4
+    L.dmh_sim_fill(g.ctypes.data, len(g), nreads, read_len, err, seed, boff.ctypes.data, bases.ctypes.data)
+    reads = np.zeros(nreads + 2, dtype=READ_DTYPE)
+    reads["origin"][1:nreads + 1] = tfirst + np.arange(nreads)
+    reads["rlen"][1:nreads + 1] = rlen
+    reads["boff"][1:nreads + 2] = boff
+    reads["flags"][1:nreads + 1] = DB_BEST
+    db = DAZZ_DB()
+    db.ureads = db.treads = nreads
+    db.cutoff = 0
+    db.allarr = DB_ALL
+    cnt = np.bincount(bases[:1 << 24], minlength=5)[:4].astype(np.float64)
+    for j in range(4):
+        db.freq[j] = float(cnt[j] / max(1.0, cnt.sum()))
+    db.maxlen = int(rlen.max())
+    db.totlen = tot
+    db.nreads = nreads
+    db.trimmed = 1
+    db.part = part
+    db.ufirst = db.tfirst = tfirst
+    db.path = path
+    db.loaded = 1
+    db.bases = bases.ctypes.data + 1
+    db.reads = reads.ctypes.data + 40
+    db.tracks = None
+    iv = reads.view(np.int32)
+    iv[9] = nreads
+    iv[8] = nreads
+    return Block(db=db, bases=bases, reads=reads, path=path)
+
+
+def block_reads(blk: Block, lo: int = 0, hi: Optional[int] = None) -> List[np.ndarray]:
+    """Copies of reads [lo, hi) of a block as separate arrays."""
+    hi = blk.nreads if hi is None else hi
+    return [blk.seq(i).copy() for i in range(lo, hi)]
+
+
 def read_stub(path: str) -> Tuple[int, List[Tuple[int, int]]]:
     """Parse a stub file: returns (nblocks, [(ufirst, tfirst)] * (nblocks+1))."""
     with open(path) as f:
