@@ -44,6 +44,11 @@ def make_block(genome, nreads, seed, tfirst=0, part=0):
                                  path=b"./.READS")
 
 
+def shard_blocks(nblocks, rank, world):
+    """Read blocks are independent units: block b goes to rank b mod world."""
+    return [b for b in range(nblocks) if b % world == rank]
+
+
 def cpu_baseline(genome, sample_reads, threads):
     """Reference `damapper -k20 -e.85 -T<threads>` on a bounded sample; wall time of the process
     (LAsort/LAcat are shims)."""

@@ -65,3 +65,24 @@ def test_las_identical_to_reference(case, tmp_path):
                open(os.path.join(d, ".READS.prof.data"), "rb").read())
         assert got[0] == prof_ref[0]
         assert got[1] == prof_ref[1]
+
+
+def test_reference_driver_linked_against_hip_library(tmp_path):
+    """Drop-in proof: the reference's own damapper.c/DB.c/QV.c, linked against libdamapper_hip.so instead
+    of map.c + align.c (oracle/_ref/damapper_hip), writes the same .las files as the all-CPU reference."""
+    run_ref = _run_ref()
+    if not os.path.exists(os.path.join(run_ref.REF_DIR, "damapper_hip")):
+        pytest.skip("oracle/_ref/damapper_hip not built")
+    g, reads = make_dataset("repeat", 46, [200000, 150000, 120000], 60, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=260000)
+    dazzdb.write_db(d, "READS", reads, block_size=350000)      # two read blocks
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    assert nb >= 2
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    run_ref.run_reference(d, "REF", blocks, flags=["-v", "-p"], threads=4, keep="las_ref")
+    run_ref.run_reference(d, "REF", blocks, flags=["-v", "-p"], threads=4, keep="las_drop", binary="damapper_hip")
+    for b in blocks:
+        ts_r, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        ts_h, hr = las.read_las_set(os.path.join(d, "las_drop"), b + ".REF.M@.las")
+        assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
