@@ -36,12 +36,18 @@ enum { F_V = 0, F_M, F_HA, F_HB, F_HAM, F_HBM, F_TL, F_TH, F_COUNT };
 
 struct AlignSpecDev
 { int            TS, PATH_AVE, REACH;
-  const int16_t *SCORE, *TABLE;
+  int            mscore, dscore;     // align.c:253-254
+  const int16_t *SCORE, *TABLE;      // device copies of the full tables (not used by the hot loop)
 };
 
+// Sequences are read through 2-bit packed copies of the blocks (32 bases per 64-bit word, base q of
+// the block in bits 2*(q&31).. of word q>>5; separators pack as 0 and are never compared because
+// every run is bounded by the sequence lengths).  pa points at the packed READS block -- its
+// reverse-complemented twin for a complemented A -- and abase is the block offset of A[0].
 struct SeqView
-{ const uint8_t *a;      // first base of the A read in the block (forward strand)
-  const uint8_t *b;      // first base of the B contig
+{ const uint64_t *pa;
+  const uint64_t *pb;
+  int64_t        abase, bbase;
   int            alen, blen;
   int            comp;   // A is used reverse-complemented (ACOMP_FLAG semantics)
 };
@@ -63,14 +69,55 @@ template <int W> struct WaveWork
   int      *mbox;        // 16 ints of LDS: lane 0 hands the trace-back results to the wavefront
 };
 
-__device__ __forceinline__ int aget(const SeqView &S, int i)
-{ if (i < 0 || i >= S.alen) return 4;
-  return S.comp ? 3 - (int) S.a[S.alen - 1 - i] : (int) S.a[i];
+// 32 bases starting at block position q (q may be as low as -64: the packed arrays carry two pad
+// words in front and two behind)
+__device__ __forceinline__ uint64_t load32(const uint64_t *__restrict__ p, int64_t q)
+{ int64_t  w  = q >> 5;
+  int      sh = (int) (q & 31) << 1;
+  uint64_t lo = p[w];
+  uint64_t hi = p[w + 1];
+  return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
 }
 
-__device__ __forceinline__ int bget(const SeqView &S, int i)
-{ if (i < 0 || i >= S.blen) return 4;
-  return (int) S.b[i];
+// Length of the exact-match run A[x..] == B[y..] (forward snake, align.c:748-768), bounded by the
+// sequence ends; *end is set when the run stopped at a sequence end rather than at a mismatch.
+__device__ __forceinline__ int match_fwd(const SeqView &S, int x, int y, bool &end)
+{ int rem = min(S.alen - x, S.blen - y);
+  int n = 0;
+  end = true;
+  while (n < rem)
+    { uint64_t d = load32(S.pa, S.abase + x + n) ^ load32(S.pb, S.bbase + y + n);
+      int m = d ? (__builtin_ctzll(d) >> 1) : 32;
+      if (m >= rem - n) { n = rem; break; }
+      n += m;
+      if (m < 32) { end = false; break; }
+    }
+  return n;
+}
+
+// Same going down: A[x-1-i] == B[y-1-i] (reverse snake, align.c:1403-1423)
+__device__ __forceinline__ int match_rev(const SeqView &S, int x, int y, bool &end)
+{ int rem = min(x, y);
+  int n = 0;
+  end = true;
+  while (n < rem)
+    { uint64_t d = load32(S.pa, S.abase + x - n - 32) ^ load32(S.pb, S.bbase + y - n - 32);
+      int m = d ? (__builtin_clzll(d) >> 1) : 32;
+      if (m >= rem - n) { n = rem; break; }
+      n += m;
+      if (m < 32) { end = false; break; }
+    }
+  return n;
+}
+
+// n matches appended to the 60-column window b with match count m (align.c:763-767 n times):
+// each step counts a match if the column leaving the window (bit 60) was a difference.
+__device__ __forceinline__ void push_matches(uint64_t &b, int &m, int n)
+{ if (n <= 0) return;
+  int nn = n < 61 ? n : 61;
+  uint64_t leaving = (b >> (61 - nn)) & ((nn >= 64) ? ~0ull : ((1ull << nn) - 1ull));
+  m += nn - __popcll(leaving);
+  b = (n >= 64) ? ~0ull : ((b << n) | ((1ull << n) - 1ull));
 }
 
 template <int W> struct Ring
@@ -87,6 +134,35 @@ __device__ __forceinline__ void wave_sync()
 { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Inside the d-wave loop lanes only exchange data through LDS, which executes a wavefront's
+// accesses in order: a compiler-level ordering point is enough (no wait for the pebble stores).
+__device__ __forceinline__ void wave_lds_sync()
+{ __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// TABLE[x] / SCORE[x] of align.c:207-218 computed on the fly (15 columns, most significant first):
+// cheaper than two dependent global loads for the one or two record-setting lanes of a wave.
+__device__ __forceinline__ void trim_entry(int x, int mscore, int dscore, int &tab, int &sco)
+{ int s = 0, mx = 0;
+#pragma unroll
+  for (int bit = AL_TRIM_LEN - 1; bit >= 0; bit--)
+    { mx = (s > mx) ? s : mx;
+      s += ((x >> bit) & 1) ? mscore : -dscore;
+    }
+  tab = (int) (int16_t) (s - mx);
+  sco = (int) (int16_t) s;
+}
+
+__device__ __forceinline__ bool trim_ok(uint64_t b, int mscore, int dscore)
+{ int t0, s0, t1, s1;
+  trim_entry((int) (b & AL_TRIM_MASK), mscore, dscore, t0, s0);
+  if (t0 < 0) return false;
+  trim_entry((int) ((b >> AL_TRIM_LEN) & AL_TRIM_MASK), mscore, dscore, t1, s1);
+  return (t1 + s0 >= 0);
 }
 
 __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int &total)
@@ -162,17 +238,16 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
       }
     ha = 0; hb = 1;
     ncell = 2;
-    while (true)
-      { int cb = bget(S, y + soff);
-        if (cb == 4)
-          { more = 0; bclip = k; break; }
-        int ca = aget(S, k + y + soff);
-        if (cb != ca)
-          { if (ca == 4) { more = 0; aclip = k; }
-            break;
-          }
-        y += DIR;
-      }
+    { bool end;
+      int  n = (DIR > 0) ? match_fwd(S, k + y, y, end) : match_rev(S, k + y, y, end);
+      y += DIR * n;
+      if (end)
+        { // the next comparison meets a terminator: B's is looked at first (align.c:750-762)
+          bool bend = (DIR > 0) ? (y == S.blen) : (y == 0);
+          more = 0;
+          if (bend) bclip = k; else aclip = k;
+        }
+    }
     int c = (y << 1) + k;
     if (DIR > 0)
       { while (y + k >= na)
@@ -214,14 +289,16 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
         R.na(k) = na;
         R.nb(k) = nb;
       }
-    wave_sync();
+    wave_lds_sync();
   }
 
   // boundary handling shared by the 0-wave and every later wave (align.c:549-577, 848-875)
   auto boundary = [&](bool setd)
   { if (more != 0) return;
-    if (bget(S, besty + soff) != 4 && aget(S, besta - besty + soff) != 4)
-      more = 1;
+    { int bi = besty + soff, ai = besta - besty + soff;
+      if (bi >= 0 && bi < S.blen && ai >= 0 && ai < S.alen)
+        more = 1;
+    }
     if (DIR > 0)
       { if (hgh >= aclip)
           { hgh = aclip - 1;
@@ -287,7 +364,7 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
           R.f(cur, F_V, hgh + 1) = OUTV;
         }
       dif += 1;
-      wave_sync();
+      wave_lds_sync();
       const int nxt = cur ^ 1;
 
       // ---- phase 1: every diagonal from the frozen previous wave
@@ -324,18 +401,15 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
               b <<= 1;
 
               y = (c - k) >> 1;
-              while (true)
-                { int cb = bget(S, y + soff);
-                  if (cb == 4) { hitb = 1; break; }
-                  int ca = aget(S, k + y + soff);
-                  if (cb != ca)
-                    { if (ca == 4) hita = 1;
-                      break;
-                    }
-                  y += DIR;
-                  if ((b & AL_PATH_TOP) == 0) m += 1;
-                  b = (b << 1) | 1;
-                }
+              { bool end;
+                int  n = (DIR > 0) ? match_fwd(S, k + y, y, end) : match_rev(S, k + y, y, end);
+                y += DIR * n;
+                push_matches(b, m, n);
+                if (end)
+                  { bool bend = (DIR > 0) ? (y == S.blen) : (y == 0);
+                    if (bend) hitb = 1; else hita = 1;
+                  }
+              }
               c = (y << 1) + k;
 
               // trace lines crossed on this diagonal (align.c:771-817): count the pebbles to drop
@@ -354,8 +428,18 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
                   while (y <= t) { if (h > t) { cntB += 1; h = t; } t -= TS; }
                 }
             }
-          int tot;
-          int off = wave_excl_scan_i(cntA + cntB, lane, tot);
+          int tot = 0, off = 0;
+          { const int      t1   = cntA + cntB;
+            const uint64_t any  = __ballot(t1 != 0);
+            if (any != 0)
+              { if (__ballot(t1 > 1) == 0)           // common case: at most one pebble per lane
+                  { off = __popcll(any & ((1ull << lane) - 1ull));
+                    tot = __popcll(any);
+                  }
+                else
+                  off = wave_excl_scan_i(t1, lane, tot);
+              }
+          }
           if (ncell + tot > wk.cellcap) return AL_ERR_PEBBLES;
           if (active)
             { int idx = ncell + off;
@@ -408,99 +492,49 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
         }
       if (hitA != ((DIR > 0) ? AL_BIG : -AL_BIG)) { more = 0; aclip = hitA; }
       if (hitB != ((DIR > 0) ? -AL_BIG : AL_BIG)) { more = 0; bclip = hitB; }
-      wave_sync();
+      wave_lds_sync();
       cur = nxt;
 
       // ---- phase 2: record setters of the running best, in the reference's loop order
-      //      (descending k forward, align.c:819-833; ascending k reverse, align.c:1471-1485)
+      //      (descending k forward, align.c:819-833; ascending k reverse, align.c:1471-1485).
+      //      Only lanes that beat the previous best can be record setters; they are visited one by
+      //      one (usually one or two) with scalar lane reads.
       { const int nch = (hgh - low) / 64 + 1;
         for (int ci = 0; ci < nch; ci++)
           { const int  base   = (DIR > 0) ? low + 64 * (nch - 1 - ci) : low + 64 * ci;
             const int  k      = base + lane;
             const bool active = (k <= hgh);
             int c = active ? R.f(cur, F_V, k) : ((DIR > 0) ? -AL_BIG : AL_BIG);
-            // exclusive scan of the best value over the lanes visited before this one
-            int pre = c;
-            if (DIR > 0)
-              { // visited before = higher lanes: suffix max
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                  { int t = __shfl_down(pre, o);
-                    if (lane + o < 64 && t > pre) pre = t;
-                  }
-                int ex = __shfl_down(pre, 1);
-                if (lane == 63) ex = -AL_BIG;
-                if (besta > ex) ex = besta;
-                bool rec = active && (c > ex);
-                int  m   = active ? R.f(cur, F_M, k) : 0;
-                uint64_t b = 0;
-                if (rec) b = ((uint64_t) (uint32_t) R.f(cur, F_TH, k) << 32) | (uint32_t) R.f(cur, F_TL, k);
-                bool lst = rec && (m >= sp.PATH_AVE);
-                bool trm = false;
-                if (lst)
-                  { if (sp.TABLE[b & AL_TRIM_MASK] >= 0)
-                      if (sp.TABLE[(b >> AL_TRIM_LEN) & AL_TRIM_MASK] + sp.SCORE[b & AL_TRIM_MASK] >= 0)
-                        trm = true;
-                  }
-                uint64_t mr = __ballot(rec), ml = __ballot(lst), mt = __ballot(trm);
-                if (mr)
-                  { int l = __ffsll((long long) mr) - 1;          // lowest k = last visited
-                    besta = __shfl(c, l);
-                    besty = (besta - (base + l)) >> 1;
-                  }
-                if (ml)
-                  { int l = __ffsll((long long) ml) - 1;
-                    lasta = __shfl(c, l);
-                  }
-                if (mt)
-                  { int l = __ffsll((long long) mt) - 1;
-                    int hav = active ? R.f(cur, F_HA, k) : 0, hbv = active ? R.f(cur, F_HB, k) : 0;
-                    trima  = __shfl(c, l);
-                    trimy  = (trima - (base + l)) >> 1;
-                    trimd  = dif;
-                    trimha = __shfl(hav, l);
-                    trimhb = __shfl(hbv, l);
-                  }
+            uint64_t better = __ballot(active && ((DIR > 0) ? (c > besta) : (c < besta)));
+            if (better == 0) continue;
+            int m = 0, tl = 0, th = 0, hav = 0, hbv = 0;
+            if ((better >> lane) & 1)
+              { m   = R.f(cur, F_M, k);
+                tl  = R.f(cur, F_TL, k);
+                th  = R.f(cur, F_TH, k);
+                hav = R.f(cur, F_HA, k);
+                hbv = R.f(cur, F_HB, k);
               }
-            else
-              { // visited before = lower lanes: prefix min
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                  { int t = __shfl_up(pre, o);
-                    if (lane >= o && t < pre) pre = t;
-                  }
-                int ex = __shfl_up(pre, 1);
-                if (lane == 0) ex = AL_BIG;
-                if (besta < ex) ex = besta;
-                bool rec = active && (c < ex);
-                int  m   = active ? R.f(cur, F_M, k) : 0;
-                uint64_t b = 0;
-                if (rec) b = ((uint64_t) (uint32_t) R.f(cur, F_TH, k) << 32) | (uint32_t) R.f(cur, F_TL, k);
-                bool lst = rec && (m >= sp.PATH_AVE);
-                bool trm = false;
-                if (lst)
-                  { if (sp.TABLE[b & AL_TRIM_MASK] >= 0)
-                      if (sp.TABLE[(b >> AL_TRIM_LEN) & AL_TRIM_MASK] + sp.SCORE[b & AL_TRIM_MASK] >= 0)
-                        trm = true;
-                  }
-                uint64_t mr = __ballot(rec), ml = __ballot(lst), mt = __ballot(trm);
-                if (mr)
-                  { int l = 63 - __clzll((long long) mr);         // highest k = last visited
-                    besta = __shfl(c, l);
-                    besty = (besta - (base + l)) >> 1;
-                  }
-                if (ml)
-                  { int l = 63 - __clzll((long long) ml);
-                    lasta = __shfl(c, l);
-                  }
-                if (mt)
-                  { int l = 63 - __clzll((long long) mt);
-                    int hav = active ? R.f(cur, F_HA, k) : 0, hbv = active ? R.f(cur, F_HB, k) : 0;
-                    trima  = __shfl(c, l);
-                    trimy  = (trima - (base + l)) >> 1;
-                    trimd  = dif;
-                    trimha = __shfl(hav, l);
-                    trimhb = __shfl(hbv, l);
+            uint64_t rem = better;
+            while (rem)
+              { int l = (DIR > 0) ? (63 - __clzll((long long) rem)) : (__ffsll((long long) rem) - 1);
+                rem &= ~(1ull << l);
+                int cl = __builtin_amdgcn_readlane(c, l);
+                if ((DIR > 0) ? (cl > besta) : (cl < besta))
+                  { besta = cl;
+                    besty = (cl - (base + l)) >> 1;
+                    if (__builtin_amdgcn_readlane(m, l) >= sp.PATH_AVE)
+                      { lasta = cl;
+                        uint64_t bl = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane(th, l) << 32)
+                                      | (uint32_t) __builtin_amdgcn_readlane(tl, l);
+                        if (trim_ok(bl, sp.mscore, sp.dscore))
+                          { trima  = cl;
+                            trimy  = besty;
+                            trimd  = dif;
+                            trimha = __builtin_amdgcn_readlane(hav, l);
+                            trimhb = __builtin_amdgcn_readlane(hbv, l);
+                          }
+                      }
                   }
               }
           }
@@ -508,8 +542,23 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
 
       boundary(true);
 
-      // ---- keep the points within WAVE_LAG of the best (align.c:877-885)
-      if (DIR > 0)
+      // ---- keep the points within WAVE_LAG of the best (align.c:877-885): trim both ends of the
+      //      band up to the outermost diagonals that are still within the lag
+      if (hgh >= low && hgh - low < 64)
+        { const int  k   = low + lane;
+          const bool act = (k <= hgh);
+          const int  n   = (DIR > 0) ? besta - AL_WAVE_LAG : besta + AL_WAVE_LAG;
+          int v = act ? R.f(cur, F_V, k) : 0;
+          uint64_t keep = __ballot(act && ((DIR > 0) ? (v >= n) : (v <= n)));
+          if (keep)
+            { int l0 = __ffsll((long long) keep) - 1, h0 = 63 - __clzll((long long) keep);
+              hgh = low + h0;
+              low = low + l0;
+            }
+          else
+            hgh = low - 1;
+        }
+      else if (DIR > 0)
         { int n = besta - AL_WAVE_LAG;
           while (hgh >= low)
             if (R.f(cur, F_V, hgh) < n)

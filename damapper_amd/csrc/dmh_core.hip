@@ -148,8 +148,85 @@ static uint64_t block_stamp(const DAZZ_DB *b)
 static void free_blockdev(BlockDev &bd)
 { dev_free(bd.d_raw);
   dev_free(bd.d_boff);
+  dev_free(bd.d_pkraw);
+  dev_free(bd.d_rcraw);
   bd.d_raw = nullptr;
   bd.d_boff = nullptr;
+  bd.d_pkraw = nullptr;
+  bd.d_rcraw = nullptr;
+}
+
+// ---- 2-bit packing for the alignment kernel ------------------------------------------------
+
+__global__ void k_pack_fwd(const uint8_t *__restrict__ bases, int64_t L, uint64_t *__restrict__ pk, int64_t nwords)
+{ int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint64_t v = 0;
+  int64_t  q = w << 5;
+#pragma unroll 8
+  for (int t = 0; t < 32; t++)
+    { uint64_t b = (q + t < L) ? bases[q + t] : 0;
+      v |= (b & 3) << (2 * t);
+    }
+  pk[w] = v;
+}
+
+// Packed reverse complement of every read, stored at the read's own offsets:
+// rc[boff[r]+i] = 3 - a[boff[r] + rlen_r - 1 - i]   (map.c:1940-1948 builds the same per read)
+__global__ void k_pack_rc(const uint8_t *__restrict__ bases, int64_t L, const int64_t *__restrict__ boff,
+                          int nreads, uint64_t *__restrict__ pk, int64_t nwords)
+{ int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  int64_t q0 = w << 5;
+  int lo = 0, hi = nreads;                 // largest r with boff[r] <= q0
+  while (lo < hi)
+    { int m = (lo + hi + 1) >> 1;
+      if (boff[m] > q0) hi = m - 1; else lo = m;
+    }
+  int r = lo;
+  uint64_t v = 0;
+  for (int t = 0; t < 32; t++)
+    { int64_t q = q0 + t;
+      if (q >= L) break;
+      while (r < nreads && q >= boff[r + 1]) r += 1;
+      if (r >= nreads) break;
+      int64_t s = boff[r], rl = boff[r + 1] - s - 1;
+      int64_t i = q - s;
+      if (i >= 0 && i < rl)
+        { uint64_t b = 3 - (uint64_t) (bases[s + rl - 1 - i] & 3);
+          v |= b << (2 * t);
+        }
+    }
+  pk[w] = v;
+}
+
+void pack_bases(const uint8_t *d_bases, int64_t L, uint64_t *d_pkraw)
+{ int64_t nwords = (L >> 5) + 1;
+  HIP_CHECK(hipMemsetAsync(d_pkraw, 0, sizeof(uint64_t) * (nwords + 4), stream()));
+  StageTimer tm("pack_bases", (double) L);
+  hipLaunchKernelGGL(k_pack_fwd, dim3(ceil_div(nwords, 256)), dim3(256), 0, stream(), d_bases, L, d_pkraw + 2, nwords);
+  HIP_CHECK(hipGetLastError());
+}
+
+void pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, uint64_t *d_rcraw)
+{ int64_t nwords = (L >> 5) + 1;
+  HIP_CHECK(hipMemsetAsync(d_rcraw, 0, sizeof(uint64_t) * (nwords + 4), stream()));
+  StageTimer tm("pack_revcomp", (double) L);
+  hipLaunchKernelGGL(k_pack_rc, dim3(ceil_div(nwords, 256)), dim3(256), 0, stream(), d_bases, L, d_boff, nreads,
+                     d_rcraw + 2, nwords);
+  HIP_CHECK(hipGetLastError());
+}
+
+void ensure_packed(BlockDev &bd, bool want_rc)
+{ int64_t nwords = (bd.L >> 5) + 1;
+  if (bd.d_pkraw == nullptr)
+    { bd.d_pkraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * (nwords + 4), "packed bases");
+      pack_bases(bd.d_bases(), bd.L, bd.d_pkraw);
+    }
+  if (want_rc && bd.d_rcraw == nullptr)
+    { bd.d_rcraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * (nwords + 4), "packed reverse complements");
+      pack_revcomp(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, bd.d_rcraw);
+    }
 }
 
 BlockDev &upload_block(const DAZZ_DB *block, bool pin)

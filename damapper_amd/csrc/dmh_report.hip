@@ -72,7 +72,7 @@ __device__ __forceinline__ WaveWork<W> make_work(const Scratch &sc, int *lds, in
 }
 
 template <int W, bool LDSBAND>
-__global__ __launch_bounds__(256) void k_align_seeds(const uint8_t *abases, const uint8_t *bbases,
+__global__ __launch_bounds__(256) void k_align_seeds(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
                                                       const SeedJob *jobs, int njobs, AlignSpecDev sp,
                                                       Scratch sc, unsigned int *ticket, int *out,
                                                       uint16_t *atr_out, uint16_t *btr_out, int stride,
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_align_seeds(const uint8_t *abases, cons
       if (t >= (unsigned int) njobs) break;
       int j = only ? only[t] : (int) t;
       SeedJob J = jobs[j];
-      SeqView S{abases + J.aoff, bbases + J.boff, J.alen, J.blen, J.comp};
+      SeqView S{J.comp ? arc : apk, bpk, J.aoff, J.boff, J.alen, J.blen, J.comp};
       PathRes P;
       int B[4];
       int st = local_alignment<W>(wk, sp, S, J.dg, J.ad, P, B);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_align_seeds(const uint8_t *abases, cons
 constexpr int REC_HDR = 8;
 
 template <int W, bool LDSBAND>
-__global__ __launch_bounds__(256) void k_align_cands(const uint8_t *abases, const uint8_t *bbases,
+__global__ __launch_bounds__(256) void k_align_cands(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
                                                       const CandJob *jobs, int njobs,
                                                       const uint16_t *jumps, int hithr, AlignSpecDev sp,
                                                       Scratch sc, unsigned int *ticket, int *status,
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_align_cands(const uint8_t *abases, cons
       if (t >= (unsigned int) njobs) break;
       const int j = only ? only[t] : (int) t;
       const CandJob J = jobs[j];
-      SeqView S{abases + J.aoff, bbases + J.boff, J.alen, J.blen, J.comp};
+      SeqView S{J.comp ? arc : apk, bpk, J.aoff, J.boff, J.alen, J.blen, J.comp};
 
       // map.c:2487-2579: walk the chain from its end; a point is a seed only if it lies left of
       // the last accepted alignment's start
@@ -228,6 +228,8 @@ static AlignSpecDev spec_dev(Spec *sp)
   d.TS = sp->trace_space;
   d.PATH_AVE = sp->ave_path;
   d.REACH = sp->reach;
+  d.mscore = sp->mscore;
+  d.dscore = sp->dscore;
   d.SCORE = t;
   d.TABLE = t + 32768;
   return d;
@@ -485,6 +487,8 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   if (njobs > 0)
     { BlockDev &ad = upload_block(ablock, false);
       BlockDev &bd = upload_block(bblock, false);
+      ensure_packed(ad, true);
+      ensure_packed(bd, false);
       AlignSpecDev spd = spec_dev(sp);
       int maxalen = 0;
       for (int ar = 0; ar < nreads; ar++) maxalen = std::max(maxalen, ablock->reads[ar].rlen);
@@ -522,12 +526,12 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           { StageTimer tm(global_band ? "align_global_band" : "align", 0.0);
             if (global_band)
               hipLaunchKernelGGL((k_align_cands<GLB_W, false>), dim3(nblocks), dim3(256), 0, stream(),
-                                 ad.d_bases(), bd.d_bases(), (const CandJob *) d_jobs.p, nrun,
+                                 ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
                                  (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
                                  ascr().ctl.p + 1, (unsigned int) pool_cap, only);
             else
               hipLaunchKernelGGL((k_align_cands<LDS_W, true>), dim3(nblocks), dim3(256), 0, stream(),
-                                 ad.d_bases(), bd.d_bases(), (const CandJob *) d_jobs.p, nrun,
+                                 ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
                                  (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
                                  ascr().ctl.p + 1, (unsigned int) pool_cap, only);
             HIP_CHECK(hipGetLastError());
@@ -839,6 +843,20 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
   uint8_t *db = (uint8_t *) dev_alloc(bbytes + 256, "B bases");
   HIP_CHECK(hipMemcpyAsync(da, abases, abytes, hipMemcpyHostToDevice, stream()));
   HIP_CHECK(hipMemcpyAsync(db, bbases, bbytes, hipMemcpyHostToDevice, stream()));
+  // 2-bit packed copies; read boundaries of A (for the reverse complements) are its separators
+  std::vector<int64_t> hboff;
+  for (int64_t q = 0; q < abytes; q++)
+    if (abases[q] > 3) hboff.push_back(q + 1);
+  if (hboff.size() < 2) { hboff.clear(); hboff.push_back(0); hboff.push_back(abytes + 1); }
+  int      nar = (int) hboff.size() - 1;
+  int64_t *d_hboff = (int64_t *) dev_alloc(sizeof(int64_t) * hboff.size(), "A boundaries");
+  HIP_CHECK(hipMemcpyAsync(d_hboff, hboff.data(), sizeof(int64_t) * hboff.size(), hipMemcpyHostToDevice, stream()));
+  uint64_t *apkraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * ((abytes >> 5) + 8), "packed A");
+  uint64_t *arcraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * ((abytes >> 5) + 8), "packed A rc");
+  uint64_t *bpkraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * ((bbytes >> 5) + 8), "packed B");
+  pack_bases(da, abytes, apkraw);
+  pack_revcomp(da, abytes, d_hboff, nar, arcraw);
+  pack_bases(db, bbytes, bpkraw);
   std::vector<SeedJob> jobs(njobs);
   int maxalen = 1;
   for (int i = 0; i < njobs; i++)
@@ -868,11 +886,13 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
         }
       { StageTimer tm(global_band ? "align_seeds_global_band" : "align_seeds", 0.0);
         if (global_band)
-          hipLaunchKernelGGL((k_align_seeds<GLB_W, false>), dim3(nblocks), dim3(256), 0, stream(), da, db,
+          hipLaunchKernelGGL((k_align_seeds<GLB_W, false>), dim3(nblocks), dim3(256), 0, stream(),
+                             (const uint64_t *) (apkraw + 2), (const uint64_t *) (arcraw + 2), (const uint64_t *) (bpkraw + 2),
                              (const SeedJob *) dj, nrun, spd, sc, ascr().ctl.p, dout, dat, dbt, trace_stride,
                              (const int *) d_only);
         else
-          hipLaunchKernelGGL((k_align_seeds<LDS_W, true>), dim3(nblocks), dim3(256), 0, stream(), da, db,
+          hipLaunchKernelGGL((k_align_seeds<LDS_W, true>), dim3(nblocks), dim3(256), 0, stream(),
+                             (const uint64_t *) (apkraw + 2), (const uint64_t *) (arcraw + 2), (const uint64_t *) (bpkraw + 2),
                              (const SeedJob *) dj, nrun, spd, sc, ascr().ctl.p, dout, dat, dbt, trace_stride,
                              (const int *) nullptr);
         HIP_CHECK(hipGetLastError());
@@ -890,6 +910,7 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
     HIP_CHECK(hipMemcpyAsync(btrace_out, dbt, sizeof(uint16_t) * (size_t) njobs * trace_stride, hipMemcpyDeviceToHost, stream()));
   HIP_CHECK(hipStreamSynchronize(stream()));
   dev_free(da); dev_free(db); dev_free(dj); dev_free(dout); dev_free(dat); dev_free(dbt);
+  dev_free(d_hboff); dev_free(apkraw); dev_free(arcraw); dev_free(bpkraw);
   if (d_only) dev_free(d_only);
   return 0;
 }

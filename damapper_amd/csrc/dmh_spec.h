@@ -12,6 +12,7 @@ struct Spec
   int      reach;
   float    freq[4];
   int      ave_path;
+  int      mscore, dscore;
   std::vector<int16_t> score, table;   // 32768 entries each (align.c:256-266)
   int16_t *d_tables = nullptr;         // device copy: score[32768] then table[32768]
 };

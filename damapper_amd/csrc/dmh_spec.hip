@@ -38,6 +38,8 @@ Align_Spec *New_Align_Spec(double ave_corr, int trace_space, float *freq, int re
   sp->ave_path = (int) (PATH_LEN * (1. - Bias_Factor[bias] * (1. - ave_corr)));
   int mscore   = (int) (FRACTION * Bias_Factor[bias] * (1. - ave_corr));
   int dscore   = FRACTION - mscore;
+  sp->mscore = mscore;
+  sp->dscore = dscore;
 
   // align.c:207-218: columns are consumed most significant bit first; `max` is the largest
   // prefix score seen BEFORE each column (the final score does not update it).

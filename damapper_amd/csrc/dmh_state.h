@@ -24,9 +24,13 @@ struct BlockDev
   int64_t  L       = 0;         // reads[nreads].boff
   int64_t *d_boff  = nullptr;   // nreads+1 offsets
   int      nreads  = 0;
+  uint64_t *d_pkraw = nullptr;  // 2-bit packed bases (32 per word), two pad words in front
+  uint64_t *d_rcraw = nullptr;  // same for the per-read reverse complement (READS blocks only)
   uint64_t stamp   = 0;         // cheap content fingerprint (detects in-place complement)
   bool     pinned  = false;     // uploaded through dmh_preload_block
   const uint8_t *d_bases() const { return d_raw + 1; }
+  const uint64_t *d_pk() const { return d_pkraw + 2; }
+  const uint64_t *d_rc() const { return d_rcraw + 2; }
 };
 
 struct IndexDev
@@ -88,6 +92,9 @@ struct State
 State &S();
 
 BlockDev &upload_block(const DAZZ_DB *block, bool pin);
+void      ensure_packed(BlockDev &bd, bool want_rc);
+void      pack_bases(const uint8_t *d_bases, int64_t L, uint64_t *d_pkraw);
+void      pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, uint64_t *d_rcraw);
 void      drop_block(const DAZZ_DB *block);
 
 void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, int K,
