@@ -133,20 +133,27 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
 
 // Stable scatter.  Each wavefront owns 1024 consecutive pairs (item j of lane l is element
 // j*64+l of that run, so loads are coalesced); ranks inside the wavefront come from ballot
-// match masks, ranks across wavefronts from a 4 x 256 LDS table, and the tile's base per digit
-// from the scanned histogram.
+// match masks, ranks across wavefronts from a 4 x 256 LDS table.  The tile is then reordered
+// through LDS into digit order, so that consecutive threads write consecutive slots of each
+// digit's output run (coalesced 8-byte / 4-byte stores), the run's global start coming from the
+// scanned histogram.
 __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *__restrict__ kin,
                                                                  const uint32_t *__restrict__ vin,
                                                                  uint64_t *__restrict__ kout,
                                                                  uint32_t *__restrict__ vout, int64_t n,
                                                                  int shift, uint32_t mask,
                                                                  const uint32_t *__restrict__ offs, int ntiles)
-{ __shared__ uint32_t wh[4][256];
+{ __shared__ uint64_t skey[SORT_TILE];
+  __shared__ uint32_t sval[SORT_TILE];
+  __shared__ uint32_t wh[4][256];
+  __shared__ uint32_t gdelta[256];
+  __shared__ uint32_t ws[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int x = tid; x < 1024; x += SORT_THREADS) ((uint32_t *) wh)[x] = 0;
   __syncthreads();
 
-  const int64_t base = (int64_t) blockIdx.x * SORT_TILE + (int64_t) w * SORT_WTILE + lane;
+  const int64_t tile0 = (int64_t) blockIdx.x * SORT_TILE;
+  const int64_t base  = tile0 + (int64_t) w * SORT_WTILE + lane;
   uint64_t key[SORT_ITEMS];
   uint32_t val[SORT_ITEMS];
   uint32_t rk[SORT_ITEMS];
@@ -181,23 +188,36 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
     }
   __syncthreads();
 
-  { uint32_t g  = offs[(size_t) tid * ntiles + blockIdx.x];
-    uint32_t c0 = wh[0][tid], c1 = wh[1][tid], c2 = wh[2][tid];
-    wh[0][tid] = g;
-    wh[1][tid] = g + c0;
-    wh[2][tid] = g + c0 + c1;
-    wh[3][tid] = g + c0 + c1 + c2;
+  // digit tid: counts per wavefront -> tile-local start of the digit's run and per-wavefront bases
+  { uint32_t c0 = wh[0][tid], c1 = wh[1][tid], c2 = wh[2][tid], c3 = wh[3][tid];
+    uint32_t tot;
+    uint32_t ls = block_excl_scan(c0 + c1 + c2 + c3, ws, &tot);
+    wh[0][tid] = ls;
+    wh[1][tid] = ls + c0;
+    wh[2][tid] = ls + c0 + c1;
+    wh[3][tid] = ls + c0 + c1 + c2;
+    gdelta[tid] = offs[(size_t) tid * ntiles + blockIdx.x] - ls;
   }
   __syncthreads();
 
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; j++)
     { if ((base + j * 64) < n)
-        { uint32_t d   = (uint32_t) (key[j] >> shift) & mask;
-          uint32_t pos = wh[w][d] + rk[j];
-          kout[pos] = key[j];
-          vout[pos] = val[j];
+        { uint32_t d = (uint32_t) (key[j] >> shift) & mask;
+          uint32_t p = wh[w][d] + rk[j];
+          skey[p] = key[j];
+          sval[p] = val[j];
         }
+    }
+  __syncthreads();
+
+  const int count = (int) ((n - tile0 < (int64_t) SORT_TILE) ? (n - tile0) : (int64_t) SORT_TILE);
+  for (int i = tid; i < count; i += SORT_THREADS)
+    { uint64_t k = skey[i];
+      uint32_t d = (uint32_t) (k >> shift) & mask;
+      uint32_t o = gdelta[d] + (uint32_t) i;
+      kout[o] = k;
+      vout[o] = sval[i];
     }
 }
 
