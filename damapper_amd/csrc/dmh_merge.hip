@@ -12,6 +12,7 @@
 #include "dmh_state.h"
 #include "dmh_device.h"
 #include "dmh_merge.h"
+#include <algorithm>
 
 namespace dmh {
 
@@ -57,76 +58,100 @@ __device__ __forceinline__ void b_range(const BLookup &B, uint64_t c, uint32_t &
 }
 
 // ---------------------------------------------------------------------------------------
-//  Count: histogram of group products (map.c:881-934)
+//  Match: ONE pass over the READ index.  Every first element of a run of equal READ codes looks
+//  its code up in the REF index; matched runs are appended to a compact entry list
+//  {a_start, m_a, b_lo, m_b} (a few % of the k-mers) and counted into the product histogram
+//  (map.c:881-934).  Entry order is arbitrary: the seed sort below is stable on
+//  (aread, bread, apos) and ties can only come from one entry, whose pairs are expanded in
+//  (a, b) order.
 // ---------------------------------------------------------------------------------------
 
 constexpr int MG_THREADS = 256;
 constexpr int MG_ITEMS   = 8;
 constexpr int MG_TILE    = MG_THREADS * MG_ITEMS;
+constexpr int HREP       = 64;      // replicated histograms / counters to spread atomic traffic
+constexpr int SMALLBIN   = 32;
 
-__global__ __launch_bounds__(MG_THREADS) void k_merge_count(const uint64_t *__restrict__ akeys, int64_t na,
+struct MergeEntry { uint32_t a0, ma, b0, mb; };
+
+__global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__restrict__ akeys, int64_t na,
                                                             BLookup B, unsigned long long *__restrict__ gram,
-                                                            unsigned long long *__restrict__ nhits)
-{ __shared__ uint32_t h[MAXGRAM];
-  for (int x = threadIdx.x; x < MAXGRAM; x += MG_THREADS) h[x] = 0;
+                                                            unsigned long long *__restrict__ nhits,
+                                                            MergeEntry *__restrict__ entries,
+                                                            unsigned int *__restrict__ nentries)
+{ __shared__ MergeEntry stage[MG_TILE];        // matched runs of this tile, flushed with one atomic
+  __shared__ uint32_t h[SMALLBIN];
+  __shared__ unsigned long long s_hits[4];
+  __shared__ uint32_t s_count, s_gbase;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < SMALLBIN) h[tid] = 0;
+  if (tid == 0) s_count = 0;
   __syncthreads();
+
+  const int rep = blockIdx.x & (HREP - 1);
   unsigned long long local = 0;
-  int64_t base = (int64_t) blockIdx.x * MG_TILE;
   for (int j = 0; j < MG_ITEMS; j++)
-    { int64_t i = base + j * MG_THREADS + threadIdx.x;
-      if (i >= na) continue;
-      uint64_t c = akeys[i];
-      if (i > 0 && akeys[i - 1] == c) continue;          // not the first of its run
-      int64_t  e = run_end(akeys, na, i);
-      uint32_t lo, mb;
-      b_range(B, c, lo, mb);
-      if (mb == 0) continue;
-      unsigned long long ct = (unsigned long long) (e - i) * mb;
-      local += ct;
-      if (ct < MAXGRAM) atomicAdd(&h[(int) ct], 1u);
+    { int64_t i = (int64_t) blockIdx.x * MG_TILE + j * MG_THREADS + tid;
+      unsigned long long ct = 0;
+      uint32_t lo = 0, mb = 0;
+      int64_t  e = 0;
+      bool     hit = false;
+      if (i < na)
+        { uint64_t c = akeys[i];
+          if (i == 0 || akeys[i - 1] != c)              // first of its run
+            { b_range(B, c, lo, mb);
+              if (mb != 0)
+                { e   = (i + 1 < na && akeys[i + 1] == c) ? run_end(akeys, na, i) : i + 1;
+                  ct  = (unsigned long long) (e - i) * mb;
+                  hit = true;
+                }
+            }
+        }
+      if (hit)
+        { if (ct < SMALLBIN) atomicAdd(&h[(int) ct], 1u);
+          else if (ct < MAXGRAM) atomicAdd(&gram[(size_t) rep * (MAXGRAM + 1) + ct], 1ull);
+          local += ct;
+        }
+      uint64_t m = __ballot(hit);
+      if (m)
+        { uint32_t base = 0;
+          int leader = __ffsll((long long) m) - 1;
+          if (lane == leader) base = atomicAdd(&s_count, (uint32_t) __popcll(m));
+          base = __shfl(base, leader);
+          if (hit)
+            { MergeEntry en;
+              en.a0 = (uint32_t) i;
+              en.ma = (uint32_t) (e - i);
+              en.b0 = lo;
+              en.mb = mb;
+              stage[base + __popcll(m & ((1ull << lane) - 1ull))] = en;
+            }
+        }
     }
-  // block reduce of local
   for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
-  if ((threadIdx.x & 63) == 0 && local) atomicAdd(nhits, local);
+  if (lane == 0) s_hits[tid >> 6] = local;
   __syncthreads();
-  for (int x = threadIdx.x; x < MAXGRAM; x += MG_THREADS)
-    if (h[x]) atomicAdd(&gram[x], (unsigned long long) h[x]);
-}
-
-// ---------------------------------------------------------------------------------------
-//  Emit (map.c:939-1002): two passes over the READ index, sizes then records
-// ---------------------------------------------------------------------------------------
-
-__device__ __forceinline__ uint32_t hits_of(const uint64_t *__restrict__ akeys, int64_t na, int64_t i,
-                                            const BLookup &B, int64_t limit, uint32_t &lo)
-{ uint64_t c = akeys[i];
-  uint32_t mb;
-  b_range(B, c, lo, mb);
-  if (mb == 0) return 0;
-  int64_t ma;
-  bool ls = (i == 0) || (akeys[i - 1] != c);
-  bool le = (i + 1 >= na) || (akeys[i + 1] != c);
-  if (ls && le) ma = 1;
-  else ma = run_end(akeys, na, i) - run_start(akeys, i);
-  if (ma * (int64_t) mb < limit) return mb;
-  return 0;
-}
-
-__global__ __launch_bounds__(MG_THREADS) void k_merge_sizes(const uint64_t *__restrict__ akeys, int64_t na,
-                                                            BLookup B, int64_t limit,
-                                                            uint32_t *__restrict__ bsum)
-{ __shared__ uint32_t ws[4];
-  int64_t base = (int64_t) blockIdx.x * MG_TILE + (int64_t) threadIdx.x * MG_ITEMS;
-  uint32_t s = 0;
-  for (int j = 0; j < MG_ITEMS; j++)
-    { int64_t i = base + j;
-      uint32_t lo;
-      if (i < na) s += hits_of(akeys, na, i, B, limit, lo);
+  if (tid == 0)
+    { unsigned long long t = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3];
+      if (t) atomicAdd(&nhits[rep], t);
+      s_gbase = s_count ? atomicAdd(nentries, s_count) : 0;
     }
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  if (tid < SMALLBIN && h[tid])
+    atomicAdd(&gram[(size_t) rep * (MAXGRAM + 1) + tid], (unsigned long long) h[tid]);
   __syncthreads();
-  if (threadIdx.x == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+  const uint32_t cnt = s_count, gb = s_gbase;
+  for (uint32_t x = tid; x < cnt; x += MG_THREADS)
+    entries[gb + x] = stage[x];
+}
+
+// hits each entry will produce under the limit (map.c:978-979)
+__global__ void k_entry_sizes(const MergeEntry *__restrict__ entries, uint32_t n, int64_t limit,
+                              uint32_t *__restrict__ sizes)
+{ uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  MergeEntry e = entries[i];
+  unsigned long long ct = (unsigned long long) e.ma * e.mb;
+  sizes[i] = ((int64_t) ct < limit) ? (uint32_t) ct : 0u;
 }
 
 struct PosMap
@@ -141,49 +166,61 @@ __device__ __forceinline__ void locate(const PosMap &M, uint32_t q, uint32_t &re
   rpos = (uint32_t) ((int64_t) q - M.boff[r]);
 }
 
-__global__ __launch_bounds__(MG_THREADS) void k_merge_emit(const uint64_t *__restrict__ akeys,
-                                                           const uint32_t *__restrict__ avals, int64_t na,
-                                                           BLookup B, const uint32_t *__restrict__ bvals,
-                                                           int64_t limit, const uint32_t *__restrict__ bsum,
-                                                           PosMap MA, PosMap MB, int bshift, int pshift,
-                                                           uint64_t *__restrict__ hkeys,
-                                                           uint32_t *__restrict__ hvals)
-{ __shared__ uint32_t ws[4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int64_t base = (int64_t) blockIdx.x * MG_TILE + (int64_t) threadIdx.x * MG_ITEMS;
-  uint32_t cnt[MG_ITEMS], lo[MG_ITEMS];
-  uint32_t s = 0;
-  for (int j = 0; j < MG_ITEMS; j++)
-    { int64_t i = base + j;
-      cnt[j] = 0;
-      lo[j]  = 0;
-      if (i < na) cnt[j] = hits_of(akeys, na, i, B, limit, lo[j]);
-      s += cnt[j];
-    }
-  // exclusive scan of s across the block
-  uint32_t x = s;
-  for (int o = 1; o < 64; o <<= 1)
-    { uint32_t y = __shfl_up(x, o);
-      if (lane >= o) x += y;
-    }
-  if (lane == 63) ws[w] = x;
-  __syncthreads();
-  uint32_t off = bsum[blockIdx.x] + x - s;
-  for (int i = 0; i < w; i++) off += ws[i];
+constexpr uint32_t BIG_ENTRY = 64;
 
-  for (int j = 0; j < MG_ITEMS; j++)
-    { if (cnt[j] == 0) continue;
-      int64_t  i = base + j;
-      uint32_t ar, ap;
-      locate(MA, avals[i], ar, ap);
+// Expand entries into hits (map.c:984-994).  Small entries: one thread each; entries with more
+// than BIG_ENTRY pairs are queued for the wavefront-per-entry kernel below.
+__global__ void k_merge_expand(const MergeEntry *__restrict__ entries, uint32_t n,
+                               const uint32_t *__restrict__ offs, const uint32_t *__restrict__ sizes,
+                               const uint32_t *__restrict__ avals, const uint32_t *__restrict__ bvals,
+                               PosMap MA, PosMap MB, int bshift, int pshift,
+                               uint64_t *__restrict__ hkeys, uint32_t *__restrict__ hvals,
+                               uint32_t *__restrict__ biglist, unsigned int *__restrict__ nbig)
+{ uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sz = sizes[i];
+  if (sz == 0) return;
+  if (sz > BIG_ENTRY)
+    { biglist[atomicAdd(nbig, 1u)] = i;
+      return;
+    }
+  MergeEntry e = entries[i];
+  uint32_t off = offs[i];
+  for (uint32_t a = 0; a < e.ma; a++)
+    { uint32_t ar, ap;
+      locate(MA, avals[e.a0 + a], ar, ap);
       uint64_t kbase = ((uint64_t) ar << bshift) | (uint64_t) ap;
-      for (uint32_t t = 0; t < cnt[j]; t++)
+      for (uint32_t b = 0; b < e.mb; b++)
         { uint32_t br, bp;
-          locate(MB, bvals[lo[j] + t], br, bp);
+          locate(MB, bvals[e.b0 + b], br, bp);
           hkeys[off] = kbase | ((uint64_t) br << pshift);
           hvals[off] = bp;
           off += 1;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__restrict__ entries,
+                                                          const uint32_t *__restrict__ biglist, uint32_t nbig,
+                                                          const uint32_t *__restrict__ offs,
+                                                          const uint32_t *__restrict__ avals,
+                                                          const uint32_t *__restrict__ bvals,
+                                                          PosMap MA, PosMap MB, int bshift, int pshift,
+                                                          uint64_t *__restrict__ hkeys, uint32_t *__restrict__ hvals)
+{ const int lane = threadIdx.x & 63;
+  uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= nbig) return;
+  uint32_t   i = biglist[w];
+  MergeEntry e = entries[i];
+  uint32_t off = offs[i];
+  uint32_t tot = e.ma * e.mb;
+  for (uint32_t t = lane; t < tot; t += 64)
+    { uint32_t a = t / e.mb, b = t - a * e.mb;
+      uint32_t ar, ap, br, bp;
+      locate(MA, avals[e.a0 + a], ar, ap);
+      locate(MB, bvals[e.b0 + b], br, bp);
+      hkeys[off + t] = ((uint64_t) ar << bshift) | ((uint64_t) br << pshift) | (uint64_t) ap;
+      hvals[off + t] = bp;
     }
 }
 
@@ -250,19 +287,32 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   }
   BLookup BL{Bx.keys, bstart.p, shift};
 
-  // --- count (map.c:2984-2988)
+  // --- match + count (map.c:2984-2988)
   static DevBuf<unsigned long long> gram;
-  gram.ensure(MAXGRAM + 1, "hit histogram");
-  HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (MAXGRAM + 1), stream()));
-  int nblk = ceil_div(A.n, MG_TILE);
-  { StageTimer tm("merge_count", 16.0 * (A.n + Bx.n));
-    hipLaunchKernelGGL(k_merge_count, dim3(nblk), dim3(MG_THREADS), 0, stream(), (const uint64_t *) A.keys, A.n,
-                       BL, gram.p, gram.p + MAXGRAM);
+  static DevBuf<MergeEntry> entries;
+  static DevBuf<unsigned int> mctl;
+  const size_t GR = (size_t) HREP * (MAXGRAM + 1);
+  gram.ensure(GR + HREP, "hit histogram");
+  mctl.ensure(4, "merge counters");
+  int64_t ecap = std::min<int64_t>(A.n, Bx.n) + 64;
+  entries.ensure(ecap, "matched runs");
+  HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (GR + HREP), stream()));
+  HIP_CHECK(hipMemsetAsync(mctl.p, 0, 4 * sizeof(unsigned int), stream()));
+  { StageTimer tm("merge_match", 16.0 * (A.n + Bx.n));
+    hipLaunchKernelGGL(k_merge_match, dim3(ceil_div(A.n, MG_TILE)), dim3(MG_THREADS), 0, stream(),
+                       (const uint64_t *) A.keys, A.n, BL, gram.p, gram.p + GR, entries.p, mctl.p);
+    HIP_CHECK(hipGetLastError());
   }
-  std::vector<unsigned long long> histo(MAXGRAM + 1);
-  HIP_CHECK(hipMemcpyAsync(histo.data(), gram.p, sizeof(unsigned long long) * (MAXGRAM + 1),
-                           hipMemcpyDeviceToHost, stream()));
+  std::vector<unsigned long long> hrep(GR + HREP);
+  unsigned int nent = 0;
+  HIP_CHECK(hipMemcpyAsync(hrep.data(), gram.p, sizeof(unsigned long long) * (GR + HREP), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipMemcpyAsync(&nent, mctl.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
   HIP_CHECK(hipStreamSynchronize(stream()));
+  std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
+  for (int r = 0; r < HREP; r++)
+    { for (int j = 0; j < MAXGRAM; j++) histo[j] += hrep[(size_t) r * (MAXGRAM + 1) + j];
+      histo[MAXGRAM] += hrep[GR + r];
+    }
 
   // --- limit (map.c:2992-3055)
   int64_t limit, nhits;
@@ -316,26 +366,35 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   R.nhits = nhits;
   if (nhits == 0) return;
 
-  // --- emit (map.c:3095-3099)
+  // --- expand the entries under the limit into hits (map.c:3095-3099)
   R.keys.ensure(nhits, "seed keys");
   R.vals.ensure(nhits, "seed positions");
   st.sort.keys_alt.ensure(nhits, "seed sort buffer");
   st.sort.vals_alt.ensure(nhits, "seed sort buffer");
-  static DevBuf<uint32_t> msum;
-  msum.ensure(nblk + 1, "merge block sums");
-  { StageTimer tm("merge_emit", 16.0 * (A.n + Bx.n) + 16.0 * nhits);
-    hipLaunchKernelGGL(k_merge_sizes, dim3(nblk), dim3(MG_THREADS), 0, stream(), (const uint64_t *) A.keys, A.n,
-                       BL, limit, msum.p);
-    exclusive_scan_u32(msum.p, nblk, st.sort.bsum, msum.p + nblk);
+  static DevBuf<uint32_t> esz, eoff, ebig;
+  esz.ensure((size_t) nent + 1, "entry sizes");
+  eoff.ensure((size_t) nent + 2, "entry offsets");
+  ebig.ensure((size_t) nent + 1, "big entries");
+  uint32_t total = 0, nbig = 0;
+  { StageTimer tm("merge_emit", 16.0 * nhits);
+    int nb = ceil_div(nent, 256);
+    hipLaunchKernelGGL(k_entry_sizes, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent, limit, esz.p);
+    HIP_CHECK(hipMemcpyAsync(eoff.p, esz.p, sizeof(uint32_t) * nent, hipMemcpyDeviceToDevice, stream()));
+    exclusive_scan_u32(eoff.p, nent, st.sort.bsum, eoff.p + nent);
     PosMap MA{A.d_boff, A.d_chunk}, MB{Bx.d_boff, Bx.d_chunk};
-    hipLaunchKernelGGL(k_merge_emit, dim3(nblk), dim3(MG_THREADS), 0, stream(), (const uint64_t *) A.keys,
-                       (const uint32_t *) A.vals, A.n, BL, (const uint32_t *) Bx.vals, limit,
-                       (const uint32_t *) msum.p, MA, MB, bshift, pshift, R.keys.p, R.vals.p);
+    hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
+                       (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
+                       (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.keys.p, R.vals.p, ebig.p, mctl.p + 1);
+    HIP_CHECK(hipMemcpyAsync(&total, eoff.p + nent, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipMemcpyAsync(&nbig, mctl.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    if (nbig > 0)
+      hipLaunchKernelGGL(k_merge_expand_big, dim3(ceil_div((int64_t) nbig * 64, 256)), dim3(256), 0, stream(),
+                         (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, nbig, (const uint32_t *) eoff.p,
+                         (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift,
+                         R.keys.p, R.vals.p);
     HIP_CHECK(hipGetLastError());
   }
-  uint32_t total = 0;
-  HIP_CHECK(hipMemcpyAsync(&total, msum.p + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
-  HIP_CHECK(hipStreamSynchronize(stream()));
   if ((int64_t) total != nhits)
     fatal("Match_Filter: emitted %u hits but the histogram promised %lld", total, (long long) nhits);
 
