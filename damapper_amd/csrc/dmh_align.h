@@ -67,6 +67,7 @@ template <int W> struct WaveWork
   uint16_t *btrace;
   int       tcap;
   int      *mbox;        // 16 ints of LDS: lane 0 hands the trace-back results to the wavefront
+  const int2 *trimtab;   // 32 x {sum, max proper-prefix sum} of 5-column chunks (LDS, per workgroup)
 };
 
 // 32 bases starting at block position q (q may be as low as -64: the packed arrays carry two pad
@@ -587,6 +588,413 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
   return AL_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+//  Register-resident d-wave pass for bands of at most REG_BAND diagonals (the common case:
+//  average width 6-12).  Diagonal k lives in lane k & 63 for the whole pass (a ring, so nothing
+//  moves when the band slides); a lane reads its neighbours' previous-wave state with DPP
+//  wavefront rotations, no LDS.  Same arithmetic and the same ordered reductions as wave_pass;
+//  returns AL_ERR_BAND when the band outgrows the ring and the caller re-runs the pass with the
+//  LDS ring.
+// ---------------------------------------------------------------------------------------
+constexpr int REG_BAND = 62;
+
+__device__ __forceinline__ int dpp_from_left(int v)      // lane i <- lane i-1 (wraps)
+{ return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_from_right(int v)     // lane i <- lane i+1 (wraps)
+{ return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
+
+__device__ __forceinline__ uint64_t rot_right64(uint64_t m, int r)
+{ r &= 63;
+  return r ? ((m >> r) | (m << (64 - r))) : m;
+}
+
+// TABLE/SCORE entries from three 5-column chunk lookups {sum, max proper-prefix sum} in LDS
+__device__ __forceinline__ void trim_entry_tab(const int2 *tab, int x, int &t, int &sc)
+{ int2 c0 = tab[(x >> 10) & 31], c1 = tab[(x >> 5) & 31], c2 = tab[x & 31];
+  int sum = c0.x + c1.x + c2.x;
+  int mx = c0.y;
+  int v = c0.x + c1.y;
+  mx = v > mx ? v : mx;
+  v = c0.x + c1.x + c2.y;
+  mx = v > mx ? v : mx;
+  t  = (int) (int16_t) (sum - mx);
+  sc = (int) (int16_t) sum;
+}
+
+__device__ __forceinline__ bool trim_ok_tab(const int2 *tab, uint64_t b)
+{ int t0, s0, t1, s1;
+  trim_entry_tab(tab, (int) (b & AL_TRIM_MASK), t0, s0);
+  if (t0 < 0) return false;
+  trim_entry_tab(tab, (int) ((b >> AL_TRIM_LEN) & AL_TRIM_MASK), t1, s1);
+  return (t1 + s0 >= 0);
+}
+
+// fills the 32-entry chunk table (call with one wavefront, then synchronise)
+__device__ __forceinline__ void build_trim_tab(int2 *tab, int mscore, int dscore)
+{ int lane = threadIdx.x & 63;
+  if (lane < 32)
+    { int s = 0, mx = 0;
+      for (int bit = 4; bit >= 0; bit--)
+        { mx = (s > mx) ? s : mx;
+          s += ((lane >> bit) & 1) ? mscore : -dscore;
+        }
+      tab[lane] = make_int2(s, mx);
+    }
+}
+
+template <int DIR, bool WANT_B, typename WK>
+__device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView &S,
+                             int k0, int mida, int aoff, int boff, WaveEnd &E)
+{ const int  lane = threadIdx.x & 63;
+  const int  TS   = sp.TS;
+  const int  OUTV = (DIR > 0) ? -1 : AL_BIG;
+  const int  soff = (DIR > 0) ? 0 : -1;
+
+  int low = k0, hgh = k0, dif = 0;
+  int more = 1;
+  int aclip = (DIR > 0) ? AL_BIG : -AL_BIG;
+  int bclip = (DIR > 0) ? -AL_BIG : AL_BIG;
+  int besta, besty, trima, trimy, trimd, trimha, trimhb;
+  int morea, morey, mored, moreha, morehb, morem, lasta;
+  int ncell = 0;
+
+  // per-lane state of "my" diagonal
+  int      V = OUTV, M = 0, HA = 0, HB = 0, HAM = 0, HBM = 0, NA = 0, NB = 0;
+  uint32_t TL = 0, TH = 0;
+
+  besta = trima = morea = lasta = mida;
+  besty = trimy = morey = (mida - hgh) >> 1;
+  trimd = mored = 0;
+  trimha = moreha = 0;
+  trimhb = morehb = 1;
+  morem = -1;
+
+  // ---- 0-wave on the seed diagonal (uniform on all lanes)
+  { const int k = k0;
+    int y = (mida - k) >> 1;
+    int na, nb, ha, hb, ham, hbm;
+    if (wk.cellcap < 8) return AL_ERR_PEBBLES;
+    if (DIR > 0)
+      { na = (((y + k) + (TS - aoff)) / TS - 1) * TS + aoff;
+        nb = ((y + (TS - boff)) / TS - 1) * TS + boff;
+        if (lane == 0)
+          { wk.cells[0] = make_int4(-1, k, 0, na);
+            if (WANT_B) wk.cells[1] = make_int4(-1, k, 0, nb);
+          }
+        ham = na; hbm = nb;
+        na += TS; nb += TS;
+      }
+    else
+      { na = (((y + k) + (TS - aoff) - 1) / TS - 1) * TS + aoff;
+        nb = ((y + (TS - boff) - 1) / TS - 1) * TS + boff;
+        if (lane == 0)
+          { wk.cells[0] = make_int4(-1, k, 0, y + k);
+            if (WANT_B) wk.cells[1] = make_int4(-1, k, 0, y);
+          }
+        ham = y + k; hbm = y;
+      }
+    ha = 0; hb = 1;
+    ncell = 2;
+    { bool end;
+      int  n = (DIR > 0) ? match_fwd(S, k + y, y, end) : match_rev(S, k + y, y, end);
+      y += DIR * n;
+      if (end)
+        { bool bend = (DIR > 0) ? (y == S.blen) : (y == 0);
+          more = 0;
+          if (bend) bclip = k; else aclip = k;
+        }
+    }
+    int c = (y << 1) + k;
+    if (DIR > 0)
+      { while (y + k >= na)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            ha = ncell++; ham = na; na += TS;
+          }
+        while (WANT_B && y >= nb)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(hb, k, 0, nb);
+            hb = ncell++; hbm = nb; nb += TS;
+          }
+        if (c > besta)
+          { besta = trima = lasta = c; besty = trimy = y; trimha = ha; trimhb = hb; }
+      }
+    else
+      { while (y + k <= na)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            ha = ncell++; ham = na; na -= TS;
+          }
+        while (WANT_B && y <= nb)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(hb, k, 0, nb);
+            hb = ncell++; hbm = nb; nb -= TS;
+          }
+        if (c < besta)
+          { besta = trima = lasta = c; besty = trimy = y; trimha = ha; trimhb = hb; }
+      }
+    if (lane == (k & 63))
+      { V = c; M = AL_PATH_LEN;
+        TL = (uint32_t) (AL_PATH_INT & 0xffffffffu);
+        TH = (uint32_t) (AL_PATH_INT >> 32);
+        HA = ha; HB = hb; HAM = ham; HBM = hbm; NA = na; NB = nb;
+      }
+  }
+
+  auto boundary = [&](bool setd)
+  { if (more != 0) return;
+    { int bi = besty + soff, ai = besta - besty + soff;
+      if (bi >= 0 && bi < S.blen && ai >= 0 && ai < S.alen)
+        more = 1;
+    }
+    const int  ka = (DIR > 0) ? aclip : bclip;     // clip that lowers hgh forward / raises low reverse...
+    (void) ka;
+    if (DIR > 0)
+      { if (hgh >= aclip)
+          { hgh = aclip - 1;
+            int l = aclip & 63;
+            int m = __builtin_amdgcn_readlane(M, l);
+            if (morem <= m)
+              { morem = m; morea = __builtin_amdgcn_readlane(V, l); morey = (morea - aclip) / 2;
+                if (setd) mored = dif;
+                moreha = __builtin_amdgcn_readlane(HA, l); morehb = __builtin_amdgcn_readlane(HB, l);
+              }
+          }
+        if (low <= bclip)
+          { low = bclip + 1;
+            int l = bclip & 63;
+            int m = __builtin_amdgcn_readlane(M, l);
+            if (morem <= m)
+              { morem = m; morea = __builtin_amdgcn_readlane(V, l); morey = (morea - bclip) / 2;
+                if (setd) mored = dif;
+                moreha = __builtin_amdgcn_readlane(HA, l); morehb = __builtin_amdgcn_readlane(HB, l);
+              }
+          }
+        aclip = AL_BIG;
+        bclip = -AL_BIG;
+      }
+    else
+      { if (low <= aclip)
+          { low = aclip + 1;
+            int l = aclip & 63;
+            int m = __builtin_amdgcn_readlane(M, l);
+            if (morem <= m)
+              { morem = m; morea = __builtin_amdgcn_readlane(V, l); morey = (morea - aclip) / 2;
+                if (setd) mored = dif;
+                moreha = __builtin_amdgcn_readlane(HA, l); morehb = __builtin_amdgcn_readlane(HB, l);
+              }
+          }
+        if (hgh >= bclip)
+          { hgh = bclip - 1;
+            int l = bclip & 63;
+            int m = __builtin_amdgcn_readlane(M, l);
+            if (morem <= m)
+              { morem = m; morea = __builtin_amdgcn_readlane(V, l); morey = (morea - bclip) / 2;
+                if (setd) mored = dif;
+                moreha = __builtin_amdgcn_readlane(HA, l); morehb = __builtin_amdgcn_readlane(HB, l);
+              }
+          }
+        aclip = -AL_BIG;
+        bclip = AL_BIG;
+      }
+  };
+
+  boundary(false);
+
+  while (more && ((DIR > 0) ? (lasta >= besta - AL_TRIM_MLAG) : (lasta <= besta + AL_TRIM_MLAG)))
+    { // an empty band cannot be represented here (its stale edge state matters to the reference)
+      if (hgh < low) return AL_ERR_BAND;
+      low -= 1;
+      hgh += 1;
+      if (hgh - low + 1 > REG_BAND) return AL_ERR_BAND;
+      if (dif > S.alen + S.blen + 64) return AL_ERR_LOOP;
+      dif += 1;
+
+      const int  k      = low + ((lane - low) & 63);     // the diagonal of this lane in the new band
+      const bool active = (k <= hgh);
+      const bool inold  = active && (k > low) && (k < hgh);
+      const int  vold   = inold ? V : OUTV;
+
+      // neighbours' previous-wave state (all lanes take part in the rotations)
+      const int am = dpp_from_left(vold), ap = dpp_from_right(vold), ac = vold;
+      const int nal = dpp_from_left(NA),  nar = dpp_from_right(NA);
+      const int nbl = dpp_from_left(NB),  nbr = dpp_from_right(NB);
+      const int Ml = dpp_from_left(M),    Mr = dpp_from_right(M);
+      const int TLl = dpp_from_left((int) TL), TLr = dpp_from_right((int) TL);
+      const int THl = dpp_from_left((int) TH), THr = dpp_from_right((int) TH);
+      const int HAl = dpp_from_left(HA),  HAr = dpp_from_right(HA);
+      const int HBl = dpp_from_left(HB),  HBr = dpp_from_right(HB);
+      const int HAMl = dpp_from_left(HAM), HAMr = dpp_from_right(HAM);
+      const int HBMl = dpp_from_left(HBM), HBMr = dpp_from_right(HBM);
+
+      int na = NA, nb = NB;
+      if (active && k == low && k != hgh) { na = nar; nb = nbr; }    // align.c:678-681
+      else if (active && k == hgh && k != low) { na = nal; nb = nbl; }
+
+      int c = 0, m = 0, ha = 0, hb = 0, ham = 0, hbm = 0, y = 0;
+      uint64_t b = 0;
+      int hita = 0, hitb = 0, cntA = 0, cntB = 0;
+      if (active)
+        { int s;      // -1: from k-1, 0: stay, +1: from k+1
+          if (DIR > 0)
+            { if (ac < am) s = (am < ap) ? 1 : -1;
+              else         s = (ac < ap) ? 1 : 0;
+              c = (s == 0) ? ac + 2 : ((s > 0) ? ap + 1 : am + 1);
+            }
+          else
+            { if (ac > ap) s = (ap > am) ? -1 : 1;
+              else         s = (ac > am) ? -1 : 0;
+              c = (s == 0) ? ac - 2 : ((s > 0) ? ap - 1 : am - 1);
+            }
+          uint32_t tl, th;
+          if (s == 0)     { m = M;  tl = TL;             th = TH;             ha = HA;  hb = HB;  ham = HAM;  hbm = HBM; }
+          else if (s < 0) { m = Ml; tl = (uint32_t) TLl; th = (uint32_t) THl; ha = HAl; hb = HBl; ham = HAMl; hbm = HBMl; }
+          else            { m = Mr; tl = (uint32_t) TLr; th = (uint32_t) THr; ha = HAr; hb = HBr; ham = HAMr; hbm = HBMr; }
+          b = ((uint64_t) th << 32) | tl;
+
+          if ((b & AL_PATH_TOP) != 0) m -= 1;
+          b <<= 1;
+
+          y = (c - k) >> 1;
+          { bool end;
+            int  n = (DIR > 0) ? match_fwd(S, k + y, y, end) : match_rev(S, k + y, y, end);
+            y += DIR * n;
+            push_matches(b, m, n);
+            if (end)
+              { bool bend = (DIR > 0) ? (y == S.blen) : (y == 0);
+                if (bend) hitb = 1; else hita = 1;
+              }
+          }
+          c = (y << 1) + k;
+
+          if (DIR > 0)
+            { int t = na; int h = ham;
+              while (y + k >= t) { if (h < t) { cntA += 1; h = t; } t += TS; }
+              t = nb; h = hbm;
+              while (WANT_B && y >= t) { if (h < t) { cntB += 1; h = t; } t += TS; }
+            }
+          else
+            { int t = na; int h = ham;
+              while (y + k <= t) { if (h > t) { cntA += 1; h = t; } t -= TS; }
+              t = nb; h = hbm;
+              while (WANT_B && y <= t) { if (h > t) { cntB += 1; h = t; } t -= TS; }
+            }
+        }
+
+      int tot = 0, off = 0;
+      { const int      t1  = cntA + cntB;
+        const uint64_t any = __ballot(t1 != 0);
+        if (any != 0)
+          { if (__ballot(t1 > 1) == 0)
+              { off = __popcll(any & ((1ull << lane) - 1ull));
+                tot = __popcll(any);
+              }
+            else
+              off = wave_excl_scan_i(t1, lane, tot);
+          }
+      }
+      if (ncell + tot > wk.cellcap) return AL_ERR_PEBBLES;
+      if (active)
+        { int idx = ncell + off;
+          if (DIR > 0)
+            { while (y + k >= na)
+                { if (ham < na) { wk.cells[idx] = make_int4(ha, k, dif, na); ha = idx++; ham = na; }
+                  na += TS;
+                }
+              while (WANT_B && y >= nb)
+                { if (hbm < nb) { wk.cells[idx] = make_int4(hb, k, dif, nb); hb = idx++; hbm = nb; }
+                  nb += TS;
+                }
+            }
+          else
+            { while (y + k <= na)
+                { if (ham > na) { wk.cells[idx] = make_int4(ha, k, dif, na); ha = idx++; ham = na; }
+                  na -= TS;
+                }
+              while (WANT_B && y <= nb)
+                { if (hbm > nb) { wk.cells[idx] = make_int4(hb, k, dif, nb); hb = idx++; hbm = nb; }
+                  nb -= TS;
+                }
+            }
+          V = c; M = m; TL = (uint32_t) (b & 0xffffffffu); TH = (uint32_t) (b >> 32);
+          HA = ha; HB = hb; HAM = ham; HBM = hbm; NA = na; NB = nb;
+        }
+      ncell += tot;
+
+      // boundary clips (bit j of a rotated mask <-> diagonal low + j)
+      const int rl = low & 63;
+      { uint64_t ma = rot_right64(__ballot(active && hita), rl), mb = rot_right64(__ballot(active && hitb), rl);
+        if (ma)
+          { more = 0;
+            aclip = (DIR > 0) ? low + (__ffsll((long long) ma) - 1) : low + (63 - __clzll((long long) ma));
+          }
+        if (mb)
+          { more = 0;
+            bclip = (DIR > 0) ? low + (63 - __clzll((long long) mb)) : low + (__ffsll((long long) mb) - 1);
+          }
+      }
+
+      // record setters of the running best, visited in the reference's loop order
+      { const bool beats = active && ((DIR > 0) ? (c > besta) : (c < besta));
+        uint64_t better = __ballot(beats);
+        if (better)
+          { bool lflag = false, tflag = false;
+            if (beats)
+              { lflag = (m >= sp.PATH_AVE);
+                if (lflag) tflag = trim_ok_tab(wk.trimtab, b);
+              }
+            uint64_t rb = rot_right64(better, rl);
+            uint64_t rL = rot_right64(__ballot(lflag), rl);
+            uint64_t rT = rot_right64(__ballot(tflag), rl);
+            while (rb)
+              { int j = (DIR > 0) ? (63 - __clzll((long long) rb)) : (__ffsll((long long) rb) - 1);
+                rb &= ~(1ull << j);
+                int kk = low + j, l = kk & 63;
+                int cl = __builtin_amdgcn_readlane(c, l);
+                if ((DIR > 0) ? (cl > besta) : (cl < besta))
+                  { besta = cl;
+                    besty = (cl - kk) >> 1;
+                    if ((rL >> j) & 1)
+                      { lasta = cl;
+                        if ((rT >> j) & 1)
+                          { trima  = cl;
+                            trimy  = besty;
+                            trimd  = dif;
+                            trimha = __builtin_amdgcn_readlane(ha, l);
+                            trimhb = __builtin_amdgcn_readlane(hb, l);
+                          }
+                      }
+                  }
+              }
+          }
+      }
+
+      boundary(true);
+
+      // keep the points within WAVE_LAG of the best (align.c:877-885)
+      if (hgh >= low)
+        { const int  kk  = low + ((lane - low) & 63);
+          const bool act = (kk <= hgh);
+          const int  n   = (DIR > 0) ? besta - AL_WAVE_LAG : besta + AL_WAVE_LAG;
+          uint64_t keep = rot_right64(__ballot(act && ((DIR > 0) ? (V >= n) : (V <= n))), low & 63);
+          if (keep)
+            { int l0 = __ffsll((long long) keep) - 1, h0 = 63 - __clzll((long long) keep);
+              hgh = low + h0;
+              low = low + l0;
+            }
+          else
+            hgh = low - 1;
+        }
+    }
+
+  E.trima = trima; E.trimy = trimy; E.trimd = trimd; E.trimha = trimha; E.trimhb = trimhb;
+  E.morea = morea; E.morey = morey; E.mored = mored; E.moreha = moreha; E.morehb = morehb;
+  E.morem = morem;
+  E.ncell = ncell;
+  return AL_OK;
+}
+
 // Reverse a pebble chain in place and return its first pebble (align.c:900-906)
 __device__ __forceinline__ int reverse_chain(int4 *cells, int head)
 { int a = -1, h = head;
@@ -600,7 +1008,7 @@ __device__ __forceinline__ int reverse_chain(int4 *cells, int head)
 }
 
 // Trace back of the forward pass (align.c:895-1006).  Runs on lane 0 only.
-template <int W>
+template <int W, bool WANT_B>
 __device__ int forward_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, const WaveEnd &E, int mida,
                              PathRes &P, int &klow)
 { int4 *cells = wk.cells;
@@ -639,6 +1047,10 @@ __device__ int forward_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
       atrace[atlen - 2] = (uint16_t) (atrace[atlen - 2] + (trimd - e));
     }
 
+  if (!WANT_B)
+    { P.aepos = trimx; P.bepos = trimy; P.diffs = trimd; P.atlen = atlen; P.btlen = 0;
+      return AL_OK;
+    }
   h = reverse_chain(cells, trimhb);
   k = cells[h].y;
   b = (mida + k) / 2;
@@ -673,7 +1085,7 @@ __device__ int forward_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
 }
 
 // Trace back of the reverse pass (align.c:1554-1714): prepends to the forward trace.  Lane 0 only.
-template <int W>
+template <int W, bool WANT_B>
 __device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, const WaveEnd &E,
                              int aoff, int boff, PathRes &P)
 { int4 *cells = wk.cells;
@@ -735,6 +1147,11 @@ __device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
     }
 
   // B view
+  if (!WANT_B)
+    { P.abpos = trimx; P.bbpos = trimy; P.diffs = P.diffs + trimd;
+      P.atlen = P.atlen - atlen; P.aorg = P.aorg + atlen;
+      return AL_OK;
+    }
   h = reverse_chain(cells, trimhb);
   k = cells[h].y;
   b = cells[h].w + k;
@@ -806,7 +1223,49 @@ __device__ __forceinline__ void bcast_path(int *mbox, PathRes &P, int &st, int &
 // On return P holds the A view in the frame the reference reports (flipped back for comp) with
 // the A trace at wk.atrace+P.aorg; B = {babpos,bbbpos,baepos,bbepos} is the B view, its trace
 // at wk.btrace+P.borg (complemented-frame order, as the reference leaves it for ACOMP).
-template <int W>
+// One pass (wave + trace back).  Fast path: register-resident band; when the B view is not
+// wanted its pebbles live in the (otherwise idle) LDS ring, so the trace back chases pointers in
+// LDS.  Falls back to the LDS-ring pass with pebbles in global memory when the band or the pebble
+// count outgrows the fast path.
+template <int W, bool WANT_B, int DIR>
+__device__ int run_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const SeqView &S,
+                        int k0, int mida, int aoff, int boff, PathRes &P, int &klow)
+{ const int lane = threadIdx.x & 63;
+  WaveEnd E;
+  int st;
+  WaveWork<W> wf = wk;
+  if (!WANT_B)
+    { wf.cells   = (int4 *) wk.band;
+      wf.cellcap = ((F_COUNT * 2 + 2) * W) / 4;
+    }
+  st = wave_pass_reg<DIR, WANT_B>(wf, sp, S, k0, mida, aoff, boff, E);
+  if (st == AL_ERR_BAND || st == AL_ERR_PEBBLES)
+    { wf = wk;
+      st = wave_pass<W, DIR>(wf, sp, S, k0, mida, aoff, boff, E);
+      if (st != AL_OK) return st;
+      wave_sync();
+      if (lane == 0)
+        st = (DIR > 0) ? forward_trace<W, WANT_B>(wf, sp, E, mida, P, klow)
+                       : reverse_trace<W, WANT_B>(wf, sp, E, aoff, boff, P);
+    }
+  else
+    { if (st != AL_OK) return st;
+      wave_sync();
+      if (lane == 0)
+        st = (DIR > 0) ? forward_trace<W, WANT_B>(wf, sp, E, mida, P, klow)
+                       : reverse_trace<W, WANT_B>(wf, sp, E, aoff, boff, P);
+    }
+  bcast_path(wk.mbox, P, st, klow);
+  if (st != AL_OK) return st;
+  wave_sync();
+  return AL_OK;
+}
+
+// Local_Alignment (align.c:1727-1946) for one seed (dg, anti); the whole wavefront takes part.
+// On return P holds the A view in the frame the reference reports (flipped back for comp) with
+// the A trace at wk.atrace+P.aorg; B = {babpos,bbbpos,baepos,bbepos} is the B view, its trace
+// (WANT_B only) at wk.btrace+P.borg (complemented-frame order, as the reference leaves it).
+template <int W, bool WANT_B>
 __device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, const SeqView &S,
                                int dg, int anti, PathRes &P, int *B)
 { const int lane = threadIdx.x & 63;
@@ -815,29 +1274,17 @@ __device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, co
   while (((anti - hgh) >> 1) < 0) hgh -= 1;     // align.c:1774 (never taken for damapper's seeds)
   low = hgh;
 
-  WaveEnd E;
   int st, klow = low;
   P.abpos = P.bbpos = P.aepos = P.bepos = P.diffs = 0;
   P.atlen = P.btlen = 0;
   P.aorg = P.borg = 0;
 
-  st = wave_pass<W, +1>(wk, sp, S, low, anti, aoff, boff, E);
+  st = run_pass<W, WANT_B, +1>(wk, sp, S, low, anti, aoff, boff, P, klow);
   if (st != AL_OK) return st;
-  wave_sync();
-  if (lane == 0) st = forward_trace<W>(wk, sp, E, anti, P, klow);
-  bcast_path(wk.mbox, P, st, klow);
-  if (st != AL_OK) return st;
-  wave_sync();
-  low = klow;
   int fshort = ((P.aepos + P.bepos) - anti < AL_DUB_TRIM);
 
-  st = wave_pass<W, -1>(wk, sp, S, low, anti, aoff, boff, E);
+  st = run_pass<W, WANT_B, -1>(wk, sp, S, low, anti, aoff, boff, P, klow);
   if (st != AL_OK) return st;
-  wave_sync();
-  if (lane == 0) st = reverse_trace<W>(wk, sp, E, aoff, boff, P);
-  bcast_path(wk.mbox, P, st, klow);
-  if (st != AL_OK) return st;
-  wave_sync();
   int rshort = (anti - (P.abpos + P.bbpos) < AL_DUB_TRIM);
 
   if (fshort)
@@ -850,13 +1297,8 @@ __device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, co
         { low  = P.abpos - P.bbpos;
           anti = P.abpos + P.bbpos;
           P.atlen = P.btlen = 0;
-          st = wave_pass<W, +1>(wk, sp, S, low, anti, aoff, boff, E);
+          st = run_pass<W, WANT_B, +1>(wk, sp, S, low, anti, aoff, boff, P, klow);
           if (st != AL_OK) return st;
-          wave_sync();
-          if (lane == 0) st = forward_trace<W>(wk, sp, E, anti, P, klow);
-          bcast_path(wk.mbox, P, st, klow);
-          if (st != AL_OK) return st;
-          wave_sync();
         }
     }
   else if (rshort)
@@ -864,13 +1306,8 @@ __device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, co
       anti = P.aepos + P.bepos;
       P.atlen = P.btlen = 0;
       P.diffs = 0;
-      st = wave_pass<W, -1>(wk, sp, S, low, anti, aoff, boff, E);
+      st = run_pass<W, WANT_B, -1>(wk, sp, S, low, anti, aoff, boff, P, klow);
       if (st != AL_OK) return st;
-      wave_sync();
-      if (lane == 0) st = reverse_trace<W>(wk, sp, E, aoff, boff, P);
-      bcast_path(wk.mbox, P, st, klow);
-      if (st != AL_OK) return st;
-      wave_sync();
     }
 
   // B view and, for a complemented A, the flip back to the forward frame (align.c:1857-1912)

@@ -333,8 +333,11 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     HIP_CHECK(hipGetLastError());
   }
   uint32_t nsum = 0;
-  HIP_CHECK(hipMemcpyAsync(&nsum, ctl.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
-  HIP_CHECK(hipStreamSynchronize(stream()));
+  { HostTimer ht("chain_wait");
+    HIP_CHECK(hipMemcpyAsync(&nsum, ctl.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipStreamSynchronize(stream()));
+  }
+  HostTimer ht_all("chain_host");
 
   std::vector<ChainSummary> sums(nsum);
   std::vector<uint32_t>     gfirst;

@@ -56,6 +56,15 @@ struct StageTimer
   hipEvent_t e0, e1;
 };
 
+// wall-clock time of a host section, reported next to the device stages as "host:<name>"
+struct HostTimer
+{ HostTimer(const char *name);
+  ~HostTimer();
+  int    idx;
+  bool   active;
+  double t0;
+};
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int) ((a + b - 1) / b); }
 
 // ---- sort / scan primitives (dmh_sort.hip) ---------------------------------------------

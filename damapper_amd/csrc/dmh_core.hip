@@ -4,7 +4,9 @@
 #include "dmh_state.h"
 #include "dmh_device.h"
 #include <stdarg.h>
+#include <time.h>
 #include <algorithm>
+#include <map>
 
 // ---- globals shared with the driver (damapper.c:58-65; map.h:17-24) ----------------------
 extern "C" {
@@ -71,18 +73,67 @@ hipStream_t stream()
   return g_stream;
 }
 
+// Device memory comes from a small caching pool: hipMalloc/hipFree of multi-GB buffers cost
+// milliseconds each and the block loops allocate the same sizes over and over.
+struct PoolBlock { void *p; size_t cap; };
+static std::vector<PoolBlock>    g_free;
+static std::map<void *, size_t>  g_live;
+static size_t                    g_pooled = 0;
+static const size_t              POOL_MAX = (size_t) 96 << 30;
+
 void *dev_alloc(size_t bytes, const char *what)
 { init_device();
-  void *p = nullptr;
   if (bytes == 0) bytes = 16;
+  bytes = (bytes + 255) & ~(size_t) 255;
+  int best = -1;
+  for (size_t i = 0; i < g_free.size(); i++)
+    if (g_free[i].cap >= bytes && g_free[i].cap <= 2 * bytes + (1 << 20))
+      if (best < 0 || g_free[i].cap < g_free[best].cap) best = (int) i;
+  if (best >= 0)
+    { PoolBlock b = g_free[best];
+      g_free.erase(g_free.begin() + best);
+      g_pooled -= b.cap;
+      g_live[b.p] = b.cap;
+      return b.p;
+    }
+  void *p = nullptr;
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess)
+    { // give the pool back and retry once
+      for (auto &b : g_free) (void) hipFree(b.p);
+      g_free.clear();
+      g_pooled = 0;
+      e = hipMalloc(&p, bytes);
+    }
+  if (e != hipSuccess)
     fatal("out of device memory allocating %zu bytes (%s): %s", bytes, what, hipGetErrorString(e));
+  g_live[p] = bytes;
   return p;
 }
 
 void dev_free(void *p)
-{ if (p != nullptr) HIP_CHECK(hipFree(p)); }
+{ if (p == nullptr) return;
+  auto it = g_live.find(p);
+  if (it == g_live.end())
+    { HIP_CHECK(hipFree(p));
+      return;
+    }
+  size_t cap = it->second;
+  g_live.erase(it);
+  if (g_pooled + cap > POOL_MAX)
+    { HIP_CHECK(hipStreamSynchronize(stream()));
+      HIP_CHECK(hipFree(p));
+      return;
+    }
+  g_free.push_back({p, cap});
+  g_pooled += cap;
+}
+
+static void pool_release()
+{ for (auto &b : g_free) (void) hipFree(b.p);
+  g_free.clear();
+  g_pooled = 0;
+}
 
 // ---- stage timing -----------------------------------------------------------------------
 
@@ -116,6 +167,27 @@ StageTimer::~StageTimer()
 { if (!active) return;
   HIP_CHECK(hipEventRecord(e1, stream()));
   g_pending.push_back({idx, e0, e1});
+}
+
+static double now_ms()
+{ struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+HostTimer::HostTimer(const char *name)
+{ active = g_timing;
+  idx = -1;
+  t0 = 0;
+  if (!active) return;
+  idx = slot_of((std::string("host:") + name).c_str());
+  g_slots[idx].launches += 1;
+  t0 = now_ms();
+}
+
+HostTimer::~HostTimer()
+{ if (!active) return;
+  g_slots[idx].ms += now_ms() - t0;
 }
 
 static void drain_timers()
@@ -382,6 +454,7 @@ void dmh_reset(void)
   st.sort.bsum.release();
   st.sort.keys_alt.release();
   st.sort.vals_alt.release();
+  pool_release();
 }
 
 int dmh_preload_block(DAZZ_DB *block)
@@ -433,6 +506,7 @@ void *Sort_Kmers(DAZZ_DB *block, int *len)
 { State &st = S();
   Params &pm = st.params;
   if (!pm.set) fatal("Sort_Kmers called before Set_Filter_Params");
+  HostTimer ht("Sort_Kmers");
   int     nreads = block->nreads;
   int64_t L      = block->reads[nreads].boff;
   int64_t kmers  = L - (int64_t) pm.Kmer * nreads;        // map.c:676

@@ -261,6 +261,7 @@ static int64_t sizeof_db(const DAZZ_DB *db)
 void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
                     IndexDev &A, IndexDev &Bx, int Kshift)
 { State &st = S();
+  HostTimer ht("merge_and_sort");
   R.nhits = 0;
   R.ngroups = 0;
 

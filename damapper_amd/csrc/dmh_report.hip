@@ -77,11 +77,15 @@ __global__ __launch_bounds__(256) void k_align_seeds(const uint64_t *apk, const 
                                                       Scratch sc, unsigned int *ticket, int *out,
                                                       uint16_t *atr_out, uint16_t *btr_out, int stride,
                                                       const int *only)
-{ __shared__ int lds[LDSBAND ? 4 * (F_COUNT * 2 + 2) * W : 4];
+{ __shared__ __attribute__((aligned(16))) int lds[LDSBAND ? 4 * (F_COUNT * 2 + 2) * W : 4];
   const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
   const int wg = blockIdx.x * 4 + wl;
-  __shared__ int mbox[4 * 16];
+  __shared__ int  mbox[4 * 16];
+  __shared__ int2 trimtab[32];
+  if (wl == 0) build_trim_tab(trimtab, sp.mscore, sp.dscore);
+  __syncthreads();
   WaveWork<W> wk = make_work<W, LDSBAND>(sc, lds, mbox, wg, wl);
+  wk.trimtab = trimtab;
   while (true)
     { unsigned int t = 0;
       if (lane == 0) t = atomicAdd(ticket, 1u);
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void k_align_seeds(const uint64_t *apk, const 
       SeqView S{J.comp ? arc : apk, bpk, J.aoff, J.boff, J.alen, J.blen, J.comp};
       PathRes P;
       int B[4];
-      int st = local_alignment<W>(wk, sp, S, J.dg, J.ad, P, B);
+      int st = local_alignment<W, true>(wk, sp, S, J.dg, J.ad, P, B);
       if (lane == 0)
         { int *o = out + 16 * (size_t) j;
           o[0] = P.abpos; o[1] = P.bbpos; o[2] = P.aepos; o[3] = P.bepos; o[4] = P.diffs;
@@ -123,11 +127,15 @@ __global__ __launch_bounds__(256) void k_align_cands(const uint64_t *apk, const 
                                                       Scratch sc, unsigned int *ticket, int *status,
                                                       int *pool, unsigned int *pool_used,
                                                       unsigned int pool_cap, const int *only)
-{ __shared__ int lds[LDSBAND ? 4 * (F_COUNT * 2 + 2) * W : 4];
+{ __shared__ __attribute__((aligned(16))) int lds[LDSBAND ? 4 * (F_COUNT * 2 + 2) * W : 4];
   const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
   const int wg = blockIdx.x * 4 + wl;
-  __shared__ int mbox[4 * 16];
+  __shared__ int  mbox[4 * 16];
+  __shared__ int2 trimtab[32];
+  if (wl == 0) build_trim_tab(trimtab, sp.mscore, sp.dscore);
+  __syncthreads();
   WaveWork<W> wk = make_work<W, LDSBAND>(sc, lds, mbox, wg, wl);
+  wk.trimtab = trimtab;
   while (true)
     { unsigned int t = 0;
       if (lane == 0) t = atomicAdd(ticket, 1u);
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void k_align_cands(const uint64_t *apk, const 
             }
           PathRes P;
           int B[4];
-          st = local_alignment<W>(wk, sp, S, dg, ad, P, B);
+          st = local_alignment<W, false>(wk, sp, S, dg, ad, P, B);
           if (st != AL_OK) break;
           if (P.aepos - P.abpos >= hithr)
             { alast = P.abpos;
@@ -455,6 +463,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   ablock->maxlen += SPACING;                  // map.c:3246
 
   // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel
+  HostTimer *ht1 = new HostTimer("report_align");
   std::vector<CandJob>   jobs;
   std::vector<uint16_t>  jumps;
   std::vector<int>       job_of_first(nreads + 1, 0);   // first job index of each read
@@ -594,6 +603,8 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
         }
     }
 
+  delete ht1;
+  HostTimer ht2("report_select_write");
   // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
   const bool small = (S_ <= TRACE_XOVR);
   std::vector<Ovl>      am;

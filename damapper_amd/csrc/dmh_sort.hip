@@ -131,6 +131,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
   hist[(size_t) tid * ntiles + blockIdx.x] = h[tid];
 }
 
+__device__ __forceinline__ int xcd_tile(int b, int ntiles)
+{ const int per = ntiles >> 3;                 // tiles per XCD (the remainder keeps its own index)
+  if (b >= (per << 3)) return b;
+  return (b & 7) * per + (b >> 3);
+}
+
 // Stable scatter.  Each wavefront owns 1024 consecutive pairs (item j of lane l is element
 // j*64+l of that run, so loads are coalesced); ranks inside the wavefront come from ballot
 // match masks, ranks across wavefronts from a 4 x 256 LDS table.  The tile is then reordered
@@ -152,7 +158,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
   for (int x = tid; x < 1024; x += SORT_THREADS) ((uint32_t *) wh)[x] = 0;
   __syncthreads();
 
-  const int64_t tile0 = (int64_t) blockIdx.x * SORT_TILE;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
+  // L2), so give every XCD one contiguous range of tiles.  Neighbouring tiles write neighbouring
+  // pieces of each digit's output run; processed back to back on one XCD they merge into whole
+  // cache lines in that L2 before being written back.
+  const int tile  = xcd_tile(blockIdx.x, ntiles);
+  const int64_t tile0 = (int64_t) tile * SORT_TILE;
   const int64_t base  = tile0 + (int64_t) w * SORT_WTILE + lane;
   uint64_t key[SORT_ITEMS];
   uint32_t val[SORT_ITEMS];
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
     wh[1][tid] = ls + c0;
     wh[2][tid] = ls + c0 + c1;
     wh[3][tid] = ls + c0 + c1 + c2;
-    gdelta[tid] = offs[(size_t) tid * ntiles + blockIdx.x] - ls;
+    gdelta[tid] = offs[(size_t) tid * ntiles + tile] - ls;
   }
   __syncthreads();
 
