@@ -373,6 +373,8 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   int64_t nfilt = 0;
   std::vector<Candidate *> fresh;           // candidates added in this call, still alive or not
   std::vector<uint32_t>    fresh_end;
+  std::vector<char>        fresh_dead;
+  const int                id0 = st.next_cand_id;
   size_t gi = 0;
   for (uint32_t i = 0; i < nsum; i++)
     { if (i > 0 && sums[i].group != sums[i - 1].group) gi += 1;
@@ -404,7 +406,8 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
               break;
             }
           if (c_has_d && cd.score <= .9 * h.cost)
-            { L.erase(L.begin() + d);
+            { if (cd.id >= id0) fresh_dead[cd.id - id0] = 1;
+              L.erase(L.begin() + d);
               nfilt -= 1;
               continue;
             }
@@ -424,6 +427,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
       nc->id     = st.next_cand_id++;
       fresh.push_back(nc.get());
       fresh_end.push_back(h.end);
+      fresh_dead.push_back(0);
       L.insert(L.begin(), std::move(nc));
       nfilt += 1;
     }
@@ -431,18 +435,9 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   // Jump chains of the candidates added in this call that survived it
   { std::vector<uint32_t> ends;
     std::vector<Candidate *> keep;
-    // a fresh candidate may already have been erased again: find survivors by identity
-    std::vector<char> alive(fresh.size(), 0);
-    { std::map<const Candidate *, size_t> pos;
-      for (size_t i = 0; i < fresh.size(); i++) pos[fresh[i]] = i;
-      for (auto &rs : st.reads)
-        for (auto &c : rs.cands)
-          { auto it = pos.find(c.get());
-            if (it != pos.end()) alive[it->second] = 1;
-          }
-    }
+    // a fresh candidate may already have been erased again by a later chain of this call
     for (size_t i = 0; i < fresh.size(); i++)
-      if (alive[i])
+      if (!fresh_dead[i])
         { keep.push_back(fresh[i]);
           ends.push_back(fresh_end[i]);
         }

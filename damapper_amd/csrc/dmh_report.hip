@@ -414,14 +414,14 @@ static int special_log(int cover)
   return l - 1;
 }
 
-static void write_overlap(FILE *f, const Ovl &o, const uint16_t *trace, bool small)
-{ int32_t rec[10];
+static void write_overlap(FILE *f, const Ovl &o, const uint16_t *trace, bool small, std::vector<uint8_t> &buf)
+{ buf.resize(40 + 2 * (size_t) o.tlen);
+  int32_t *rec = (int32_t *) buf.data();
   rec[0] = o.tlen; rec[1] = o.diffs; rec[2] = o.abpos; rec[3] = o.bbpos; rec[4] = o.aepos; rec[5] = o.bepos;
   rec[6] = (int32_t) o.flags; rec[7] = o.aread; rec[8] = o.bread;
   rec[9] = 0;                                  // struct padding (uninitialised in the reference)
-  fwrite(rec, 40, 1, f);
   if (small)
-    { std::vector<uint8_t> t8(o.tlen);
+    { uint8_t *t8 = buf.data() + 40;
       for (int j = 0; j < o.tlen; j++)
         { if (trace[j] > 255)               // align.c:3129-3137
             { fprintf(stderr, "damapper: Compression of trace to bytes fails, value too big\n");
@@ -429,10 +429,12 @@ static void write_overlap(FILE *f, const Ovl &o, const uint16_t *trace, bool sma
             }
           t8[j] = (uint8_t) trace[j];
         }
-      fwrite(t8.data(), 1, o.tlen, f);
+      fwrite(buf.data(), 1, 40 + (size_t) o.tlen, f);
     }
   else
-    fwrite(trace, 2, o.tlen, f);
+    { memcpy(buf.data() + 40, trace, 2 * (size_t) o.tlen);
+      fwrite(buf.data(), 1, 40 + 2 * (size_t) o.tlen, f);
+    }
 }
 
 struct AlnRec { int seq, abpos, bbpos, aepos, bepos, diffs, tlen; const uint16_t *trace; };
@@ -493,6 +495,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   std::vector<std::vector<AlnRec>> recs(njobs);
   std::vector<int> pool;
+  { HostTimer hj("report_jobs_built"); }
   if (njobs > 0)
     { BlockDev &ad = upload_block(ablock, false);
       BlockDev &bd = upload_block(bblock, false);
@@ -546,9 +549,12 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
             HIP_CHECK(hipGetLastError());
           }
           unsigned int used = 0;
-          HIP_CHECK(hipMemcpyAsync(&used, ascr().ctl.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
-          HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, sizeof(int) * njobs, hipMemcpyDeviceToHost, stream()));
-          HIP_CHECK(hipStreamSynchronize(stream()));
+          { HostTimer hw("report_kernel_wait");
+            HIP_CHECK(hipMemcpyAsync(&used, ascr().ctl.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+            HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, sizeof(int) * njobs, hipMemcpyDeviceToHost, stream()));
+            HIP_CHECK(hipStreamSynchronize(stream()));
+          }
+          HostTimer hp("report_pool_parse");
           size_t got = std::min<size_t>(used, pool_cap);
           size_t base = pool.size();
           pool.resize(base + got);
@@ -612,6 +618,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   std::vector<Link>     linker;
   std::vector<Link *>   perm;
   std::vector<Zone>     part;
+  std::vector<uint8_t>  wbuf;
   int64_t ncheck = 0;
   std::vector<std::vector<uint8_t>> prof(PROFILE ? nreads : 0);
 
@@ -627,6 +634,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
             { fprintf(stderr, "damapper: Cannot open %s for 'w'\n", fn.c_str());
               Clean_Exit(1);
             }
+          setvbuf(afile, nullptr, _IOFBF, 1 << 20);
           fwrite(&ahits, sizeof(int64_t), 1, afile);
           fwrite(&SPACING, sizeof(int), 1, afile);
         }
@@ -775,7 +783,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
                           }
                         else
                           am[p].flags |= NEXT_FLAG;
-                        write_overlap(afile, am[p], tb.data() + am[p].trace, small);
+                        write_overlap(afile, am[p], tb.data() + am[p].trace, small, wbuf);
                         ahits += 1;
                       }
                     n = linker[p].link;

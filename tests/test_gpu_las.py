@@ -43,6 +43,12 @@ def test_las_identical_to_reference(case, tmp_path):
     run_ref.run_reference(d, "REF", ["READS"], flags=list(flags) + ["-M8"], threads=threads)
     prof_ref = None
     if "-p" in flags:
+        # The reference's special_log() fills a static table lazily without a lock (map.c:2270-2283):
+        # with more than one report thread a second thread can read the half-filled table and emit
+        # bogus 40s.  The track itself is -T invariant, so take it from a single-threaded run.
+        os.remove(os.path.join(d, ".READS.prof.anno"))
+        os.remove(os.path.join(d, ".READS.prof.data"))
+        run_ref.run_reference(d, "REF", ["READS"], flags=list(flags) + ["-M8"], threads=1, keep="las_ref_T1")
         prof_ref = (open(os.path.join(d, ".READS.prof.anno"), "rb").read(),
                     open(os.path.join(d, ".READS.prof.data"), "rb").read())
         os.remove(os.path.join(d, ".READS.prof.anno"))
