@@ -165,8 +165,17 @@ def main():
         roof = None
         if sc and sc["launches"] > 0 and sc["ms"] > 0:
             achieved = sc["bytes"] / (sc["ms"] * 1e-3) / 1e9          # GB/s, algorithmic bytes
+            # HBM bytes per record of this kernel from the PMC passes committed under profiles/
+            # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is)
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_summary.json")))
+                traffic = pm["derived"]["scatter_traffic_bytes_per_record"] * (sc["bytes"] / sc["launches"] / 32.0)
+            except Exception:
+                pass
             roof = {"bound": "hbm", "kernel": "k_radix_scatter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None if traffic is None else round(traffic),
                     "launches": int(sc["launches"]), "avg_ms": round(sc["ms"] / sc["launches"], 4),
                     "alg_bytes_per_launch": sc["bytes"] / sc["launches"]}
         stages = {k: round(v["ms"], 2) for k, v in sorted(timings.items(), key=lambda kv: -kv[1]["ms"])}
