@@ -83,56 +83,67 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
       if (g >= A.ngroups) break;
 
       const uint32_t g0 = A.gstart[g], g1 = A.gstart[g + 1];
-      uint32_t qhead = g0;
+      // The live set (hits in the tree) is kept as an unordered index list in this group's slice of
+      // A.tmp: one scan per hit drops expired / removed entries (compacting in place) and answers
+      // both neighbour queries, so a hit costs O(live/64) even when thousands of dead hits share
+      // its 1000-bp window (tandem repeats).
+      uint32_t *live  = A.tmp + g0;
+      uint32_t  nlive = 0;
 
       for (uint32_t j = g0; j < g1; j++)
         { const int apos = (int) (A.keys[j] & A.pmask) + 1;       // map.c:1784-1785
           const int bpos = (int) A.vals[j] + 1;
           const int diag = apos - bpos;
 
-          // ---- expire hits more than MAX_GAP behind in A (map.c:1787-1796)
-          while (qhead < j)
-            { uint32_t x   = qhead + lane;
-              bool     exp = false;
-              if (x < j)
-                exp = ((int) (A.keys[x] & A.pmask) + 1) < apos - MAX_GAP;
-              if (exp && A.state[x] == ST_LIVE)
-                { uint32_t o = A.orig[x];
-                  A.state[x] = (A.orig[o] == x) ? ST_EXPBEST : ST_DEAD;
-                }
-              int cnt = __popcll(__ballot(exp));
-              qhead += cnt;
-              if (cnt < 64) break;
-            }
-
-          // ---- neighbour queries over the live window (predOf/leftmost/succOf, map.c:1262-1318)
+          // ---- expiry (map.c:1787-1796) + neighbour queries (predOf/leftmost/succOf, map.c:1262-1318)
           uint64_t Lbest = ~0ull, Rbest = 0;
           uint32_t Lidx = NIL, Ridx = NIL;
           const int thresh = bpos - MAX_GAP;
-          for (uint32_t base = qhead; base < j; base += 64)
-            { uint32_t x  = base + lane;
+          uint32_t  wr = 0;
+          for (uint32_t base = 0; base < nlive; base += 64)
+            { uint32_t i  = base + lane;
+              uint32_t x  = NIL;
+              bool     keep = false;
               uint64_t lk = ~0ull, rk = 0;
-              if (x < j && A.state[x] == ST_LIVE)
-                { int ax = (int) (A.keys[x] & A.pmask) + 1;
-                  int bx = (int) A.vals[x] + 1;
-                  int dx = ax - bx;
-                  uint64_t db = (uint64_t) ((uint32_t) dx + 0x80000000u);
-                  if (dx > diag)
-                    { if (bx >= thresh) lk = (db << 32) | (uint32_t) (0x7fffffff - ax); }
-                  else
-                    { if (bx <= bpos) rk = (db << 32) | (uint32_t) ax; }
+              if (i < nlive)
+                { x = live[i];
+                  if (A.state[x] == ST_LIVE)
+                    { int ax = (int) (A.keys[x] & A.pmask) + 1;
+                      if (ax < apos - MAX_GAP)
+                        { uint32_t o = A.orig[x];
+                          A.state[x] = (A.orig[o] == x) ? ST_EXPBEST : ST_DEAD;
+                        }
+                      else
+                        { int bx = (int) A.vals[x] + 1;
+                          int dx = ax - bx;
+                          uint64_t db = (uint64_t) ((uint32_t) dx + 0x80000000u);
+                          keep = true;
+                          if (dx > diag)
+                            { if (bx >= thresh) lk = (db << 32) | (uint32_t) (0x7fffffff - ax); }
+                          else
+                            { if (bx <= bpos) rk = (db << 32) | (uint32_t) ax; }
+                        }
+                    }
                 }
+              uint64_t km = __ballot(keep);
               uint64_t lm = wave_min_u64(lk);
               uint64_t rm = wave_max_u64(rk);
               if (lm < Lbest)
                 { Lbest = lm;
-                  Lidx  = base + (uint32_t) (__ffsll((long long) __ballot(lk == lm)) - 1);
+                  Lidx  = __shfl(x, __ffsll((long long) __ballot(lk == lm)) - 1);
                 }
               if (rm > Rbest)
                 { Rbest = rm;
-                  Ridx  = base + (uint32_t) (__ffsll((long long) __ballot(rk == rm)) - 1);
+                  Ridx  = __shfl(x, __ffsll((long long) __ballot(rk == rm)) - 1);
                 }
+              // in-place compaction: the write index never passes this chunk's first read index, and
+              // the stored value is the loaded one, so the stores cannot overtake the loads
+              if (keep) live[wr + __popcll(km & lt)] = x;
+              wr += __popcll(km);
             }
+          nlive = wr;
+          if (lane == 0) live[nlive] = j;
+          nlive += 1;
 
           // ---- extend the better neighbour's chain (map.c:1811-1862); uniform on all lanes
           int lcost = 0, rcost = 0;
