@@ -44,8 +44,14 @@ struct ChainArgs
   uint32_t        ngroups;
   uint64_t        pmask;
   int             K, hithr;
-  int32_t        *cost;
-  uint32_t       *from, *orig, *state, *tmp;
+  int32_t        *cost;        // per hit: chain score ending here
+  uint32_t       *from;        //          predecessor (NIL for an origin)
+  uint32_t       *rootof;      //          origin of the hit's chain tree (itself for an origin)
+  uint32_t       *best;        // per origin: current best end of its tree (map.c: orig->orig)
+  int32_t        *bestcost;    //             and that end's score
+  uint32_t       *state;       // ST_*
+  uint32_t       *tmp;         // reporting scratch
+  uint4          *live;        // live-set entries {hit, apos, bpos, cost}
   unsigned int   *ticket;
   unsigned int   *out_count;
   ChainSummary   *out;
@@ -83,12 +89,12 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
       if (g >= A.ngroups) break;
 
       const uint32_t g0 = A.gstart[g], g1 = A.gstart[g + 1];
-      // The live set (hits in the tree) is kept as an unordered index list in this group's slice of
-      // A.tmp: one scan per hit drops expired / removed entries (compacting in place) and answers
-      // both neighbour queries, so a hit costs O(live/64) even when thousands of dead hits share
-      // its 1000-bp window (tandem repeats).
-      uint32_t *live  = A.tmp + g0;
-      uint32_t  nlive = 0;
+      // The live set (hits in the reference's tree) is an unordered list of self-contained entries
+      // {hit, apos, bpos, cost} in this group's slice of A.live.  One coalesced scan per hit drops
+      // expired / removed entries (compacting in place) and answers both neighbour queries, so a
+      // hit costs O(live/64) even when thousands of dead hits share its 1000-bp window.
+      uint4   *live  = A.live + g0;
+      uint32_t nlive = 0;
 
       for (uint32_t j = g0; j < g1; j++)
         { const int apos = (int) (A.keys[j] & A.pmask) + 1;       // map.c:1784-1785
@@ -97,24 +103,23 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
 
           // ---- expiry (map.c:1787-1796) + neighbour queries (predOf/leftmost/succOf, map.c:1262-1318)
           uint64_t Lbest = ~0ull, Rbest = 0;
-          uint32_t Lidx = NIL, Ridx = NIL;
+          uint4    Le = make_uint4(NIL, 0, 0, 0), Re = make_uint4(NIL, 0, 0, 0);
+          uint32_t Lpos = 0, Rpos = 0;
           const int thresh = bpos - MAX_GAP;
           uint32_t  wr = 0;
           for (uint32_t base = 0; base < nlive; base += 64)
             { uint32_t i  = base + lane;
-              uint32_t x  = NIL;
+              uint4    en = make_uint4(NIL, 0, 0, 0);
               bool     keep = false;
               uint64_t lk = ~0ull, rk = 0;
               if (i < nlive)
-                { x = live[i];
-                  if (A.state[x] == ST_LIVE)
-                    { int ax = (int) (A.keys[x] & A.pmask) + 1;
+                { en = live[i];
+                  if (en.x != NIL)                       // NIL = removed by the slope rule
+                    { int ax = (int) en.y;
                       if (ax < apos - MAX_GAP)
-                        { uint32_t o = A.orig[x];
-                          A.state[x] = (A.orig[o] == x) ? ST_EXPBEST : ST_DEAD;
-                        }
+                        A.state[en.x] = (A.best[A.rootof[en.x]] == en.x) ? ST_EXPBEST : ST_DEAD;
                       else
-                        { int bx = (int) A.vals[x] + 1;
+                        { int bx = (int) en.z;
                           int dx = ax - bx;
                           uint64_t db = (uint64_t) ((uint32_t) dx + 0x80000000u);
                           keep = true;
@@ -125,74 +130,79 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
                         }
                     }
                 }
-              uint64_t km = __ballot(keep);
+              uint64_t km  = __ballot(keep);
+              uint32_t dst = wr + (uint32_t) __popcll(km & lt);
               uint64_t lm = wave_min_u64(lk);
               uint64_t rm = wave_max_u64(rk);
               if (lm < Lbest)
-                { Lbest = lm;
-                  Lidx  = __shfl(x, __ffsll((long long) __ballot(lk == lm)) - 1);
+                { int sl = __ffsll((long long) __ballot(lk == lm)) - 1;
+                  Lbest = lm;
+                  Le.x = __shfl(en.x, sl); Le.y = __shfl(en.y, sl); Le.z = __shfl(en.z, sl); Le.w = __shfl(en.w, sl);
+                  Lpos = __shfl(dst, sl);
                 }
               if (rm > Rbest)
-                { Rbest = rm;
-                  Ridx  = __shfl(x, __ffsll((long long) __ballot(rk == rm)) - 1);
+                { int sl = __ffsll((long long) __ballot(rk == rm)) - 1;
+                  Rbest = rm;
+                  Re.x = __shfl(en.x, sl); Re.y = __shfl(en.y, sl); Re.z = __shfl(en.z, sl); Re.w = __shfl(en.w, sl);
+                  Rpos = __shfl(dst, sl);
                 }
               // in-place compaction: the write index never passes this chunk's first read index, and
               // the stored value is the loaded one, so the stores cannot overtake the loads
-              if (keep) live[wr + __popcll(km & lt)] = x;
-              wr += __popcll(km);
+              if (keep) live[dst] = en;
+              wr += (uint32_t) __popcll(km);
             }
           nlive = wr;
-          if (lane == 0) live[nlive] = j;
-          nlive += 1;
 
           // ---- extend the better neighbour's chain (map.c:1811-1862); uniform on all lanes
           int lcost = 0, rcost = 0;
-          if (Lidx != NIL)
-            { int la = (int) (A.keys[Lidx] & A.pmask) + 1;
-              int lc = A.cost[Lidx];
-              lcost = (apos >= la + K) ? lc + K : lc + (apos - la);
-            }
-          if (Ridx != NIL)
-            { int rb = (int) A.vals[Ridx] + 1;
-              int rc = A.cost[Ridx];
-              rcost = (bpos >= rb + K) ? rc + K : rc + (bpos - rb);
-            }
+          if (Le.x != NIL)
+            lcost = (apos >= (int) Le.y + K) ? (int) Le.w + K : (int) Le.w + (apos - (int) Le.y);
+          if (Re.x != NIL)
+            rcost = (bpos >= (int) Re.z + K) ? (int) Re.w + K : (int) Re.w + (bpos - (int) Re.z);
           if (lcost > rcost) rcost = 0; else lcost = 0;
 
-          uint32_t p = NIL;
+          uint4    pe = make_uint4(NIL, 0, 0, 0);
+          uint32_t ppos = 0;
           int      c = K;
-          if (lcost > 0)      { p = Lidx; c = lcost; }
-          else if (rcost > 0) { p = Ridx; c = rcost; }
+          if (lcost > 0)      { pe = Le; ppos = Lpos; c = lcost; }
+          else if (rcost > 0) { pe = Re; ppos = Rpos; c = rcost; }
 
-          if (p != NIL)
-            { uint32_t root = (A.from[p] == NIL) ? p : A.orig[p];
-              uint32_t best = A.orig[root];
-              int      bc   = A.cost[best];
+          if (pe.x != NIL)
+            { uint32_t root = A.rootof[pe.x];
+              int      bc   = A.bestcost[root];
               bool     kill = false;
               if (c >= bc)
-                { int pa = (int) (A.keys[p] & A.pmask) + 1;
-                  int pd = pa - ((int) A.vals[p] + 1);
+                { int pa = (int) pe.y;
+                  int pd = pa - (int) pe.z;
                   int dd = pd - diag;
                   if (dd < 0) dd = -dd;
                   kill = ((double) dd <= .2 * (double) (apos - pa));      // map.c:1837,1852
                 }
               if (lane == 0)
-                { A.from[j]  = p;
-                  A.cost[j]  = c;
-                  A.orig[j]  = root;
-                  A.state[j] = ST_LIVE;
+                { A.from[j]   = pe.x;
+                  A.cost[j]   = c;
+                  A.rootof[j] = root;
+                  A.state[j]  = ST_LIVE;
                   if (c >= bc)
-                    { A.orig[root] = j;
-                      if (kill) A.state[p] = ST_DEAD;
+                    { A.best[root]     = j;
+                      A.bestcost[root] = c;
+                      if (kill)
+                        { A.state[pe.x] = ST_DEAD;
+                          live[ppos].x  = NIL;
+                        }
                     }
                 }
             }
           else if (lane == 0)
-            { A.from[j]  = NIL;
-              A.cost[j]  = K;
-              A.orig[j]  = j;
-              A.state[j] = ST_LIVE;
+            { A.from[j]     = NIL;
+              A.cost[j]     = K;
+              A.rootof[j]   = j;
+              A.best[j]     = j;
+              A.bestcost[j] = K;
+              A.state[j]    = ST_LIVE;
             }
+          if (lane == 0) live[nlive] = make_uint4(j, (uint32_t) apos, (uint32_t) bpos, (uint32_t) c);
+          nlive += 1;
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
 
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
         { uint32_t x = base + lane;
           bool     f = false;
           if (x < g1 && A.cost[x] >= A.hithr && A.from[x] != NIL)
-            f = (A.orig[A.orig[x]] == x);
+            f = (A.best[A.rootof[x]] == x);
           uint64_t m = __ballot(f);
           if (f) A.tmp[g0 + E + __popcll(m & lt)] = x;
           E += __popcll(m);
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
 
       for (uint32_t e = lane; e < E; e += 64)
         { uint32_t x    = A.tmp[g0 + e];
-          bool     live = (A.state[x] == ST_LIVE);
+          bool     live_x = (A.state[x] == ST_LIVE);
           int      ax   = (int) (A.keys[x] & A.pmask) + 1;
           int      bx   = (int) A.vals[x] + 1;
           int      dx   = ax - bx;
@@ -226,9 +236,9 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
             { uint32_t y     = A.tmp[g0 + f];
               bool     ylive = (A.state[y] == ST_LIVE);
               bool     before;
-              if (ylive != live)
+              if (ylive != live_x)
                 before = ylive;
-              else if (live)
+              else if (live_x)
                 { int ay = (int) (A.keys[y] & A.pmask) + 1;
                   int dy = ay - ((int) A.vals[y] + 1);
                   before = (dy > dx) || (dy == dx && ay > ax);
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
                 before = (y > x);
               rank += before ? 1u : 0u;
             }
-          uint32_t     root = A.orig[x];
+          uint32_t     root = A.rootof[x];
           ChainSummary s;
           s.group = g;
           s.rank  = rank;
@@ -309,12 +319,16 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     fatal("Match_Filter: first call for a READS block must have start != 0 (map.c:1574)");
 
   const int64_t nhits = R.nhits;
-  static DevBuf<int32_t>  cost;
-  static DevBuf<uint32_t> from, orig, state, tmp, ctl;
+  static DevBuf<int32_t>  cost, bestcost;
+  static DevBuf<uint32_t> from, rootof, best, state, tmp, ctl;
+  static DevBuf<uint4>    livebuf;
   static DevBuf<ChainSummary> out;
   cost.ensure(nhits, "chain cost");
   from.ensure(nhits, "chain from");
-  orig.ensure(nhits, "chain orig");
+  rootof.ensure(nhits, "chain origin");
+  best.ensure(nhits, "chain best end");
+  bestcost.ensure(nhits, "chain best score");
+  livebuf.ensure(nhits + 1, "chain live set");
   state.ensure(nhits, "chain state");
   tmp.ensure(nhits, "chain scratch");
   ctl.ensure(4, "chain counters");
@@ -331,7 +345,10 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.hithr = HITMIN * pm.Kmer;
   A.cost = cost.p;
   A.from = from.p;
-  A.orig = orig.p;
+  A.rootof = rootof.p;
+  A.best = best.p;
+  A.bestcost = bestcost.p;
+  A.live = livebuf.p;
   A.state = state.p;
   A.tmp = tmp.p;
   A.ticket = ctl.p;
