@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--nblocks", type=int, default=4)
     ap.add_argument("--cpu-sample-reads", type=int, default=60000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-report", action="store_true", help="write the .las files inside Reporter (drop-in behaviour)")
     ap.add_argument("--retain-ref", action="store_true",
                     help="keep the REF indices resident across steps instead of rebuilding them per read block")
     args = ap.parse_args()
@@ -124,6 +125,7 @@ def main():
     for i in range(args.warmup):
         step(i)
 
+    L.dmh_async_report(0 if args.sync_report else 1)      # .las selection/writing of block i overlaps the filtering of block i+1
     L.dmh_timing_enable(1)
     L.dmh_timing_reset()
     if dist is not None:
@@ -139,6 +141,7 @@ def main():
         for k in host:
             host[k] += t[k]
         bases += int(blocks[(args.warmup + i) % nblk].db.totlen)
+    L.dmh_report_wait()
     L.dmh_sync()
     if dist is not None:
         import torch

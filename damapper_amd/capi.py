@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.dmh_local_alignment.restype = C.c_int
     L.dmh_timing_enable.argtypes = [C.c_int]
+    L.dmh_async_report.argtypes = [C.c_int]
     L.dmh_timing_count.restype = C.c_int
     L.dmh_timing_get.argtypes = [C.c_int, C.c_char_p, C.c_int, P(C.c_double), P(C.c_int64), P(C.c_double)]
     L.dmh_timing_get.restype = C.c_int
@@ -89,7 +90,8 @@ def exported_symbols() -> List[str]:
             "dmh_retain_ref_index", "dmh_free_index", "dmh_index_download", "dmh_capture_seeds",
             "dmh_last_seed_count", "dmh_last_seeds", "dmh_last_limit", "dmh_read_candidates",
             "dmh_candidate_jumps", "dmh_read_cover", "dmh_sort_pairs", "dmh_local_alignment",
-            "dmh_timing_enable", "dmh_timing_reset", "dmh_timing_count", "dmh_timing_get", "dmh_sync"]
+            "dmh_timing_enable", "dmh_timing_reset", "dmh_timing_count", "dmh_timing_get", "dmh_sync",
+            "dmh_async_report", "dmh_report_wait"]
 
 
 def set_globals(verbose: int = 0, profile: int = 0, spacing: int = 100, best_tie: float = 1.0,

@@ -7,6 +7,7 @@
 #include <time.h>
 #include <algorithm>
 #include <map>
+#include <mutex>
 
 // ---- globals shared with the driver (damapper.c:58-65; map.h:17-24) ----------------------
 extern "C" {
@@ -139,6 +140,7 @@ static void pool_release()
 
 struct TimerSlot { std::string name; double ms = 0; int64_t launches = 0; double bytes = 0; };
 struct PendingEv { int idx; hipEvent_t e0, e1; };
+static std::mutex g_tmu;                 // timers are also used from the report worker thread
 static std::vector<TimerSlot> g_slots;
 static std::vector<PendingEv> g_pending;
 static bool g_timing = false;
@@ -155,9 +157,11 @@ StageTimer::StageTimer(const char *name, double bytes)
 { active = g_timing;
   idx = -1;
   if (!active) return;
-  idx = slot_of(name);
-  g_slots[idx].bytes += bytes;
-  g_slots[idx].launches += 1;
+  { std::lock_guard<std::mutex> lk(g_tmu);
+    idx = slot_of(name);
+    g_slots[idx].bytes += bytes;
+    g_slots[idx].launches += 1;
+  }
   HIP_CHECK(hipEventCreate(&e0));
   HIP_CHECK(hipEventCreate(&e1));
   HIP_CHECK(hipEventRecord(e0, stream()));
@@ -166,6 +170,7 @@ StageTimer::StageTimer(const char *name, double bytes)
 StageTimer::~StageTimer()
 { if (!active) return;
   HIP_CHECK(hipEventRecord(e1, stream()));
+  std::lock_guard<std::mutex> lk(g_tmu);
   g_pending.push_back({idx, e0, e1});
 }
 
@@ -193,6 +198,7 @@ HostTimer::~HostTimer()
 static void drain_timers()
 { if (g_pending.empty()) return;
   HIP_CHECK(hipStreamSynchronize(stream()));
+  std::lock_guard<std::mutex> lk(g_tmu);
   for (auto &p : g_pending)
     { float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, p.e0, p.e1));

@@ -7,6 +7,10 @@
 #include "dmh_align.h"
 #include <algorithm>
 #include <math.h>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
 
 namespace dmh {
 
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void k_align_seeds(const uint64_t *apk, const 
 constexpr int REC_HDR = 8;
 
 template <int W, bool LDSBAND>
-__global__ __launch_bounds__(256) void k_align_cands(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
+__global__ __launch_bounds__(256, 4) void k_align_cands(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
                                                       const CandJob *jobs, int njobs,
                                                       const uint16_t *jumps, int hithr, AlignSpecDev sp,
                                                       Scratch sc, unsigned int *ticket, int *status,
@@ -439,6 +443,295 @@ static void write_overlap(FILE *f, const Ovl &o, const uint16_t *trace, bool sma
 
 struct AlnRec { int seq, abpos, bbpos, aepos, bepos, diffs, tlen; const uint16_t *trace; };
 
+
+// Everything the per-read select/write stage needs, detached from the library state so that it
+// can run on the report worker thread while the next read block is already being filtered.
+struct ReportCtx
+{ int S_, NT, nshift, nreads, astart, doA, spacing, profile, verbose;
+  double best_tie;
+  std::string aname, bname, sort_path;
+  std::vector<int> rlen;
+  std::vector<ReadState> reads;
+  std::vector<int> job_of_first;
+  std::vector<std::vector<AlnRec>> recs;
+  std::vector<int> pool;
+};
+
+static void select_and_write(ReportCtx &C)
+{ const int S_ = C.S_, NT = C.NT, nreads = C.nreads, astart = C.astart, doA = C.doA;
+  HostTimer ht2("report_select_write");
+  // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
+  const bool small = (S_ <= TRACE_XOVR);
+  std::vector<Ovl>      am;
+  std::vector<uint16_t> tb;
+  std::vector<Link>     linker;
+  std::vector<Link *>   perm;
+  std::vector<Zone>     part;
+  std::vector<uint8_t>  wbuf;
+  int64_t ncheck = 0;
+  std::vector<std::vector<uint8_t>> prof(C.profile ? nreads : 0);
+
+  for (int ti = 0; ti < NT; ti++)
+    { int abeg = (int) (((int64_t) ti * nreads) >> C.nshift);
+      int aend = (ti == NT - 1) ? nreads : (int) (((int64_t) (ti + 1) * nreads) >> C.nshift);
+      FILE *afile = nullptr;
+      int64_t ahits = 0;
+      if (doA)
+        { std::string fn = C.sort_path + "/" + C.aname + "." + C.bname + ".M" + std::to_string(ti + 1) + ".las";
+          afile = fopen(fn.c_str(), "w");
+          if (afile == nullptr)
+            { fprintf(stderr, "damapper: Cannot open %s for 'w'\n", fn.c_str());
+              Clean_Exit(1);
+            }
+          setvbuf(afile, nullptr, _IOFBF, 1 << 20);
+          fwrite(&ahits, sizeof(int64_t), 1, afile);
+          fwrite(&C.spacing, sizeof(int), 1, afile);
+        }
+
+      for (int ar = abeg; ar < aend; ar++)
+        { const int alen = C.rlen[ar];
+          const int atck = (alen - 1) / S_ + 1;
+          am.clear();
+          tb.clear();
+          int lovl = 0;
+          auto &cl = C.reads[ar].cands;
+          int job = C.job_of_first[ar];
+          for (size_t ci = 0; ci < cl.size(); ci++, job++)
+            { Candidate &c = *cl[ci];
+              for (const AlnRec &a : C.recs[job])
+                { Ovl o;
+                  o.tlen = a.tlen; o.diffs = a.diffs;
+                  o.abpos = a.abpos; o.bbpos = a.bbpos; o.aepos = a.aepos; o.bepos = a.bepos;
+                  o.flags = c.comp ? COMP_FLAG : 0;
+                  o.aread = ar + astart;
+                  o.bread = c.bread;
+                  o.trace = tb.size();
+                  tb.insert(tb.end(), a.trace, a.trace + a.tlen);
+                  am.push_back(o);
+                }
+              bool last = (ci + 1 == cl.size()) || cl[ci + 1]->bread != c.bread || cl[ci + 1]->comp != c.comp;
+              if (last)
+                { int novl = (int) am.size();
+                  if (novl - lovl > 1)
+                    { novl = lovl + handle_redundancies(am.data() + lovl, novl - lovl, tb, S_);
+                      am.resize(novl);
+                    }
+                  if (novl - lovl > 1)
+                    { // AMATCH_SORT (map.c:2304-2315): abpos descending, ties by descending original
+                      // position (glibc sorts 48-byte records through pointers to the originals)
+                      std::vector<std::pair<Ovl, int>> tmp;
+                      for (int i = lovl; i < novl; i++) tmp.push_back({am[i], i});
+                      std::sort(tmp.begin(), tmp.end(), [](const std::pair<Ovl, int> &x, const std::pair<Ovl, int> &y)
+                                { if (x.first.abpos != y.first.abpos) return x.first.abpos > y.first.abpos;
+                                  return x.second > y.second;
+                                });
+                      for (int i = lovl; i < novl; i++) am[i] = tmp[i - lovl].first;
+                    }
+                  lovl = novl;
+                }
+            }
+
+          const int novl = (int) am.size();
+          linker.assign(std::max(novl, 1), Link{0, -1, 1});
+          perm.assign(std::max(novl, 1), nullptr);
+          part.assign(std::max(novl, 1), Zone{0, 0, 0});
+
+          // LA-chain DP (map.c:2630-2710)
+          if (novl > 0)
+            { lovl = 0;
+              linker[0].link = -1;
+              linker[0].score = (int) ((am[0].aepos - am[0].abpos) - DIFF_SCORE * am[0].diffs);
+              linker[0].mark = 1;
+              perm[0] = &linker[0];
+              int br = am[0].bread;
+              for (int c = 1; c < novl; c++)
+                { const Ovl &cp = am[c];
+                  linker[c].link = -1;
+                  linker[c].score = (int) ((cp.aepos - cp.abpos) - DIFF_SCORE * cp.diffs);
+                  linker[c].mark = 1;
+                  perm[c] = &linker[c];
+                  if (am[c].bread != br)
+                    { br = am[c].bread;
+                      lovl = c;
+                      continue;
+                    }
+                  int cor = (am[c].flags & COMP_FLAG);
+                  for (int d = c - 1; d >= lovl; d--)
+                    { int dor = (am[d].flags & COMP_FLAG);
+                      if (dor != cor) continue;
+                      const Ovl &dp = am[d];
+                      if (dor)
+                        { if (dp.bepos < cp.bepos) continue; }
+                      else
+                        { if (dp.bbpos < cp.bbpos) continue; }
+                      if (dp.abpos <= cp.aepos - CHAIN_OVL || dp.bbpos <= cp.bepos - CHAIN_OVL)
+                        continue;
+                      double rat = ((dp.abpos - cp.aepos + CHAIN_OFF) / (dp.bbpos - cp.bepos + CHAIN_OFF));
+                      if (1. > rat * CHAIN_PLAY || rat > CHAIN_PLAY)
+                        continue;
+                      int scr  = (int) (linker[d].score + (cp.aepos - cp.abpos) - DIFF_SCORE * cp.diffs);
+                      int scr2 = linker[c].score;
+                      if (scr < scr2 - TIE_SCORE)
+                        continue;
+                      if (scr <= scr2 + TIE_SCORE)
+                        { int gap = dp.abpos - cp.aepos, gap2;
+                          if (linker[d].link >= 0)
+                            { // map.c:2689-2690 indexes amatch[] with linker[c].link, which may be -1
+                              // (the reference then reads the record before the array)
+                              int lc = linker[c].link;
+                              gap2 = (lc >= 0 ? am[lc].aepos : 0) - dp.abpos;
+                            }
+                          else
+                            gap2 = 0;
+                          if (gap > gap2 + TIE_GAP)
+                            continue;
+                          if (gap >= gap2 - TIE_GAP)
+                            { if (scr < scr2) continue;
+                              if (scr == scr2)
+                                { if (gap >= gap2) continue; }
+                            }
+                        }
+                      linker[c].link = d;
+                      linker[c].score = scr;
+                      linker[d].mark = 0;
+                    }
+                }
+            }
+
+          // LINK_SORT (map.c:2355-2360): score descending, stable (glibc merge sort on 8-byte items)
+          std::stable_sort(perm.begin(), perm.begin() + novl, [](const Link *x, const Link *y) { return x->score > y->score; });
+
+          int nparts = 0;
+          for (int c = 0; c < novl && perm[c]->score >= 0; c++)
+            if (perm[c]->mark == 1)
+              { int b, e, p, n, best;
+                b = e = (int) (perm[c] - linker.data());
+                for (p = linker[b].link; p >= 0 && linker[p].mark >= 0; p = linker[p].link)
+                  e = p;
+                for (p = 0; p < nparts; p++)
+                  if (am[b].abpos < part[p].end - 100 && am[e].aepos > part[p].beg + 100)
+                    break;
+                if (p >= nparts)
+                  { part[p].beg = am[b].abpos;
+                    part[p].end = am[e].aepos;
+                    part[p].top = linker[b].score;
+                    best = 1;
+                    nparts += 1;
+                  }
+                else
+                  { if (linker[b].score < C.best_tie * part[p].top)
+                      continue;
+                    best = (linker[b].score == part[p].top);
+                  }
+                for (p = b; true; p = n)
+                  { linker[p].mark = -1;
+                    if (doA)
+                      { if (p == b)
+                          { am[p].flags |= START_FLAG;
+                            if (best) am[p].flags |= BEST_FLAG;
+                          }
+                        else
+                          am[p].flags |= NEXT_FLAG;
+                        write_overlap(afile, am[p], tb.data() + am[p].trace, small, wbuf);
+                        ahits += 1;
+                      }
+                    n = linker[p].link;
+                    if (p == e) break;
+                  }
+              }
+
+          if (C.profile)                           // map.c:2835-2845
+            { auto &cv = C.reads[ar].cover;
+              prof[ar].resize(atck + 1);
+              int c = 0;
+              for (int i = 0; i <= atck; i++)
+                { c += cv[i];
+                  prof[ar][i] = (uint8_t) special_log(c);
+                }
+            }
+        }
+
+      if (doA)
+        { rewind(afile);
+          fwrite(&ahits, sizeof(int64_t), 1, afile);
+          fclose(afile);
+        }
+      ncheck += ahits;
+    }
+
+  if (C.verbose)
+    { printf("      %lld mapped segments\n", (long long) ncheck);
+      fflush(stdout);
+    }
+
+  if (C.profile)                                   // map.c:3295-3318
+    { std::string an = std::string(".") + C.aname + ".prof.anno", dn = std::string(".") + C.aname + ".prof.data";
+      FILE *af = fopen(an.c_str(), "w"), *df = fopen(dn.c_str(), "w");
+      if (af == nullptr || df == nullptr)
+        { fprintf(stderr, "damapper: Cannot open profile track files for %s\n", C.aname.c_str());
+          Clean_Exit(1);
+        }
+      int size = sizeof(int64_t);
+      fwrite(&C.nreads, sizeof(int), 1, af);
+      fwrite(&size, sizeof(int), 1, af);
+      int64_t cnt = 0;
+      for (int a = 0; a < nreads; a++)
+        { fwrite(&cnt, sizeof(int64_t), 1, af);
+          cnt += (C.rlen[a] - 1) / S_ + 2;
+          fwrite(prof[a].data(), 1, prof[a].size(), df);
+        }
+      fwrite(&cnt, sizeof(int64_t), 1, af);
+      fclose(af);
+      fclose(df);
+    }
+
+}
+
+
+// ---- report worker: one thread, FIFO; synchronous unless dmh_async_report(1) ---------------
+static std::thread              *g_worker = nullptr;
+static std::mutex                g_rmu;
+static std::condition_variable   g_rcv;
+static std::deque<ReportCtx *>   g_rqueue;
+static int                       g_rbusy = 0;
+static bool                      g_async = false;
+
+static void worker_main()
+{ while (true)
+    { ReportCtx *C;
+      { std::unique_lock<std::mutex> lk(g_rmu);
+        g_rcv.wait(lk, [] { return !g_rqueue.empty(); });
+        C = g_rqueue.front();
+        g_rqueue.pop_front();
+      }
+      select_and_write(*C);
+      delete C;
+      { std::unique_lock<std::mutex> lk(g_rmu);
+        g_rbusy -= 1;
+      }
+      g_rcv.notify_all();
+    }
+}
+
+void report_wait()
+{ std::unique_lock<std::mutex> lk(g_rmu);
+  g_rcv.wait(lk, [] { return g_rbusy == 0; });
+}
+
+static void report_submit(ReportCtx *C)
+{ if (!g_async)
+    { select_and_write(*C);
+      delete C;
+      return;
+    }
+  { std::unique_lock<std::mutex> lk(g_rmu);
+    if (g_worker == nullptr) g_worker = new std::thread(worker_main);
+    g_rqueue.push_back(C);
+    g_rbusy += 1;
+  }
+  g_rcv.notify_all();
+}
+
 }  // namespace dmh
 
 using namespace dmh;
@@ -610,231 +903,20 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     }
 
   delete ht1;
-  HostTimer ht2("report_select_write");
-  // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
-  const bool small = (S_ <= TRACE_XOVR);
-  std::vector<Ovl>      am;
-  std::vector<uint16_t> tb;
-  std::vector<Link>     linker;
-  std::vector<Link *>   perm;
-  std::vector<Zone>     part;
-  std::vector<uint8_t>  wbuf;
-  int64_t ncheck = 0;
-  std::vector<std::vector<uint8_t>> prof(PROFILE ? nreads : 0);
-
-  for (int ti = 0; ti < NT; ti++)
-    { int abeg = (int) (((int64_t) ti * nreads) >> pm.NSHIFT);
-      int aend = (ti == NT - 1) ? nreads : (int) (((int64_t) (ti + 1) * nreads) >> pm.NSHIFT);
-      FILE *afile = nullptr;
-      int64_t ahits = 0;
-      if (doA)
-        { std::string fn = std::string(SORT_PATH) + "/" + aname + "." + bname + ".M" + std::to_string(ti + 1) + ".las";
-          afile = fopen(fn.c_str(), "w");
-          if (afile == nullptr)
-            { fprintf(stderr, "damapper: Cannot open %s for 'w'\n", fn.c_str());
-              Clean_Exit(1);
-            }
-          setvbuf(afile, nullptr, _IOFBF, 1 << 20);
-          fwrite(&ahits, sizeof(int64_t), 1, afile);
-          fwrite(&SPACING, sizeof(int), 1, afile);
-        }
-
-      for (int ar = abeg; ar < aend; ar++)
-        { const int alen = ablock->reads[ar].rlen;
-          const int atck = (alen - 1) / S_ + 1;
-          am.clear();
-          tb.clear();
-          int lovl = 0;
-          auto &cl = st.reads[ar].cands;
-          int job = job_of_first[ar];
-          for (size_t ci = 0; ci < cl.size(); ci++, job++)
-            { Candidate &c = *cl[ci];
-              for (const AlnRec &a : recs[job])
-                { Ovl o;
-                  o.tlen = a.tlen; o.diffs = a.diffs;
-                  o.abpos = a.abpos; o.bbpos = a.bbpos; o.aepos = a.aepos; o.bepos = a.bepos;
-                  o.flags = c.comp ? COMP_FLAG : 0;
-                  o.aread = ar + astart;
-                  o.bread = c.bread;
-                  o.trace = tb.size();
-                  tb.insert(tb.end(), a.trace, a.trace + a.tlen);
-                  am.push_back(o);
-                }
-              bool last = (ci + 1 == cl.size()) || cl[ci + 1]->bread != c.bread || cl[ci + 1]->comp != c.comp;
-              if (last)
-                { int novl = (int) am.size();
-                  if (novl - lovl > 1)
-                    { novl = lovl + handle_redundancies(am.data() + lovl, novl - lovl, tb, S_);
-                      am.resize(novl);
-                    }
-                  if (novl - lovl > 1)
-                    { // AMATCH_SORT (map.c:2304-2315): abpos descending, ties by descending original
-                      // position (glibc sorts 48-byte records through pointers to the originals)
-                      std::vector<std::pair<Ovl, int>> tmp;
-                      for (int i = lovl; i < novl; i++) tmp.push_back({am[i], i});
-                      std::sort(tmp.begin(), tmp.end(), [](const std::pair<Ovl, int> &x, const std::pair<Ovl, int> &y)
-                                { if (x.first.abpos != y.first.abpos) return x.first.abpos > y.first.abpos;
-                                  return x.second > y.second;
-                                });
-                      for (int i = lovl; i < novl; i++) am[i] = tmp[i - lovl].first;
-                    }
-                  lovl = novl;
-                }
-            }
-
-          const int novl = (int) am.size();
-          linker.assign(std::max(novl, 1), Link{0, -1, 1});
-          perm.assign(std::max(novl, 1), nullptr);
-          part.assign(std::max(novl, 1), Zone{0, 0, 0});
-
-          // LA-chain DP (map.c:2630-2710)
-          if (novl > 0)
-            { lovl = 0;
-              linker[0].link = -1;
-              linker[0].score = (int) ((am[0].aepos - am[0].abpos) - DIFF_SCORE * am[0].diffs);
-              linker[0].mark = 1;
-              perm[0] = &linker[0];
-              int br = am[0].bread;
-              for (int c = 1; c < novl; c++)
-                { const Ovl &cp = am[c];
-                  linker[c].link = -1;
-                  linker[c].score = (int) ((cp.aepos - cp.abpos) - DIFF_SCORE * cp.diffs);
-                  linker[c].mark = 1;
-                  perm[c] = &linker[c];
-                  if (am[c].bread != br)
-                    { br = am[c].bread;
-                      lovl = c;
-                      continue;
-                    }
-                  int cor = (am[c].flags & COMP_FLAG);
-                  for (int d = c - 1; d >= lovl; d--)
-                    { int dor = (am[d].flags & COMP_FLAG);
-                      if (dor != cor) continue;
-                      const Ovl &dp = am[d];
-                      if (dor)
-                        { if (dp.bepos < cp.bepos) continue; }
-                      else
-                        { if (dp.bbpos < cp.bbpos) continue; }
-                      if (dp.abpos <= cp.aepos - CHAIN_OVL || dp.bbpos <= cp.bepos - CHAIN_OVL)
-                        continue;
-                      double rat = ((dp.abpos - cp.aepos + CHAIN_OFF) / (dp.bbpos - cp.bepos + CHAIN_OFF));
-                      if (1. > rat * CHAIN_PLAY || rat > CHAIN_PLAY)
-                        continue;
-                      int scr  = (int) (linker[d].score + (cp.aepos - cp.abpos) - DIFF_SCORE * cp.diffs);
-                      int scr2 = linker[c].score;
-                      if (scr < scr2 - TIE_SCORE)
-                        continue;
-                      if (scr <= scr2 + TIE_SCORE)
-                        { int gap = dp.abpos - cp.aepos, gap2;
-                          if (linker[d].link >= 0)
-                            { // map.c:2689-2690 indexes amatch[] with linker[c].link, which may be -1
-                              // (the reference then reads the record before the array)
-                              int lc = linker[c].link;
-                              gap2 = (lc >= 0 ? am[lc].aepos : 0) - dp.abpos;
-                            }
-                          else
-                            gap2 = 0;
-                          if (gap > gap2 + TIE_GAP)
-                            continue;
-                          if (gap >= gap2 - TIE_GAP)
-                            { if (scr < scr2) continue;
-                              if (scr == scr2)
-                                { if (gap >= gap2) continue; }
-                            }
-                        }
-                      linker[c].link = d;
-                      linker[c].score = scr;
-                      linker[d].mark = 0;
-                    }
-                }
-            }
-
-          // LINK_SORT (map.c:2355-2360): score descending, stable (glibc merge sort on 8-byte items)
-          std::stable_sort(perm.begin(), perm.begin() + novl, [](const Link *x, const Link *y) { return x->score > y->score; });
-
-          int nparts = 0;
-          for (int c = 0; c < novl && perm[c]->score >= 0; c++)
-            if (perm[c]->mark == 1)
-              { int b, e, p, n, best;
-                b = e = (int) (perm[c] - linker.data());
-                for (p = linker[b].link; p >= 0 && linker[p].mark >= 0; p = linker[p].link)
-                  e = p;
-                for (p = 0; p < nparts; p++)
-                  if (am[b].abpos < part[p].end - 100 && am[e].aepos > part[p].beg + 100)
-                    break;
-                if (p >= nparts)
-                  { part[p].beg = am[b].abpos;
-                    part[p].end = am[e].aepos;
-                    part[p].top = linker[b].score;
-                    best = 1;
-                    nparts += 1;
-                  }
-                else
-                  { if (linker[b].score < BEST_TIE * part[p].top)
-                      continue;
-                    best = (linker[b].score == part[p].top);
-                  }
-                for (p = b; true; p = n)
-                  { linker[p].mark = -1;
-                    if (doA)
-                      { if (p == b)
-                          { am[p].flags |= START_FLAG;
-                            if (best) am[p].flags |= BEST_FLAG;
-                          }
-                        else
-                          am[p].flags |= NEXT_FLAG;
-                        write_overlap(afile, am[p], tb.data() + am[p].trace, small, wbuf);
-                        ahits += 1;
-                      }
-                    n = linker[p].link;
-                    if (p == e) break;
-                  }
-              }
-
-          if (PROFILE)                           // map.c:2835-2845
-            { auto &cv = st.reads[ar].cover;
-              prof[ar].resize(atck + 1);
-              int c = 0;
-              for (int i = 0; i <= atck; i++)
-                { c += cv[i];
-                  prof[ar][i] = (uint8_t) special_log(c);
-                }
-            }
-        }
-
-      if (doA)
-        { rewind(afile);
-          fwrite(&ahits, sizeof(int64_t), 1, afile);
-          fclose(afile);
-        }
-      ncheck += ahits;
-    }
-
-  if (VERBOSE)
-    { printf("      %lld mapped segments\n", (long long) ncheck);
-      fflush(stdout);
-    }
-
-  if (PROFILE)                                   // map.c:3295-3318
-    { std::string an = std::string(".") + aname + ".prof.anno", dn = std::string(".") + aname + ".prof.data";
-      FILE *af = fopen(an.c_str(), "w"), *df = fopen(dn.c_str(), "w");
-      if (af == nullptr || df == nullptr)
-        { fprintf(stderr, "damapper: Cannot open profile track files for %s\n", aname);
-          Clean_Exit(1);
-        }
-      int size = sizeof(int64_t);
-      fwrite(&(ablock->nreads), sizeof(int), 1, af);
-      fwrite(&size, sizeof(int), 1, af);
-      int64_t cnt = 0;
-      for (int a = 0; a < nreads; a++)
-        { fwrite(&cnt, sizeof(int64_t), 1, af);
-          cnt += (ablock->reads[a].rlen - 1) / S_ + 2;
-          fwrite(prof[a].data(), 1, prof[a].size(), df);
-        }
-      fwrite(&cnt, sizeof(int64_t), 1, af);
-      fclose(af);
-      fclose(df);
-    }
+  { ReportCtx *C = new ReportCtx();
+    C->S_ = S_; C->NT = NT; C->nshift = pm.NSHIFT; C->nreads = nreads; C->astart = astart; C->doA = doA;
+    C->spacing = SPACING; C->profile = PROFILE; C->verbose = VERBOSE; C->best_tie = BEST_TIE;
+    C->aname = aname; C->bname = bname; C->sort_path = SORT_PATH;
+    C->rlen.resize(nreads);
+    for (int i = 0; i < nreads; i++) C->rlen[i] = ablock->reads[i].rlen;
+    C->reads = std::move(st.reads);
+    st.reads.clear();
+    st.cur_reads = nullptr;
+    C->job_of_first = std::move(job_of_first);
+    C->recs = std::move(recs);
+    C->pool = std::move(pool);
+    report_submit(C);
+  }
 
   // the READS index and block copies are not needed any more; the driver free()s the stub
   for (auto it = st.indices.begin(); it != st.indices.end();)
@@ -849,6 +931,13 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   if (st.blocks.count(ablock) && !st.blocks[ablock].pinned) drop_block(ablock);
   if (st.blocks.count(bblock) && !st.blocks[bblock].pinned) drop_block(bblock);
 }
+
+void dmh_async_report(int on)
+{ report_wait();
+  g_async = (on != 0);
+}
+
+void dmh_report_wait(void) { report_wait(); }
 
 int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes, const uint8_t *bbases,
                         int64_t bbytes, int njobs, const int64_t *aoff, const int *alen, const int64_t *boff,

@@ -247,11 +247,16 @@ class Block:
     def complement_inplace(self) -> None:
         """damapper.c:433-469 (complement_DB, inplace): reverse-complement every read and
         swap the base frequencies."""
-        for i in range(self.nreads):
-            r = self.reads[i + 1]
-            o = int(r["boff"]) + 1
-            n = int(r["rlen"])
-            self.bases[o:o + n] = 3 - self.bases[o:o + n][::-1]
+        try:
+            L = _sim_lib()
+            boff = np.ascontiguousarray(self.reads["boff"][1:self.nreads + 2])
+            L.dmh_host_complement(self.bases.ctypes.data + 1, boff.ctypes.data, self.nreads)
+        except (RuntimeError, AttributeError, OSError):
+            for i in range(self.nreads):
+                r = self.reads[i + 1]
+                o = int(r["boff"]) + 1
+                n = int(r["rlen"])
+                self.bases[o:o + n] = 3 - self.bases[o:o + n][::-1]
         f = self.db.freq
         f[0], f[3] = f[3], f[0]
         f[1], f[2] = f[2], f[1]
@@ -310,6 +315,7 @@ def _sim_lib():
         L = C.CDLL(so)
         L.dmh_sim_lengths.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_void_p]
         L.dmh_sim_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.dmh_host_complement.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _sim = L
     return _sim
 

@@ -68,3 +68,24 @@ void dmh_sim_fill(const uint8_t *g, int64_t glen, int nreads, int rl, double err
       bases[1 + boff[i] + n] = 4;
     }
 }
+
+/* In-place reverse complement of every read of an in-memory block (damapper.c:417-469,
+ * complement_DB with inplace != 0): bases points at the block's first base, boff[i] are the read
+ * offsets, boff[nreads] the total. */
+#include <string.h>
+
+static void comp_one(uint8_t *s, int64_t len)
+{ uint8_t *restrict t = (uint8_t *) malloc(len > 0 ? len : 1);
+  const uint8_t *restrict r = s;
+  int64_t i;
+  for (i = 0; i < len; i++)
+    t[i] = (uint8_t) (3 - r[len-1-i]);
+  memcpy(s, t, len);
+  free(t);
+}
+
+void dmh_host_complement(uint8_t *bases, const int64_t *boff, int nreads)
+{ int i;
+  for (i = 0; i < nreads; i++)
+    comp_one(bases + boff[i], boff[i+1] - boff[i] - 1);
+}

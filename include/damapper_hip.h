@@ -154,6 +154,13 @@ int dmh_local_alignment(Align_Spec *spec,
                         const int *dg, const int *ad,
                         int *out, uint16_t *trace_out, uint16_t *btrace_out, int trace_stride);
 
+/* Reporter's last stage (per-read selection + .las writing, host only) can run on a worker
+ * thread so that the driver may start filtering the next read block at once.  Off by default
+ * (the reference driver reads the files right after Reporter returns); dmh_report_wait()
+ * blocks until every queued report has been written.                                        */
+void dmh_async_report(int on);
+void dmh_report_wait(void);
+
 /* Kernel timing (HIP events on the library's stream).  Stages are named; dmh_timing_get
  * returns accumulated milliseconds and launch count since the last dmh_timing_reset.         */
 void   dmh_timing_enable(int on);
