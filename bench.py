@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--nblocks", type=int, default=4)
     ap.add_argument("--cpu-sample-reads", type=int, default=60000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true", help="do not record HIP events around the kernels")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not queue the next block's index before Reporter")
     ap.add_argument("--sync-report", action="store_true", help="write the .las files inside Reporter (drop-in behaviour)")
     ap.add_argument("--retain-ref", action="store_true",
                     help="keep the REF indices resident across steps instead of rebuilding them per read block")
@@ -118,15 +120,18 @@ def main():
     pcie_t0 = time.time()
     L.dmh_sync()
 
+    last = args.warmup + args.steps - 1
+
     def step(i):
         blk = blocks[i % nblk]
-        return m.map_block(blk, "READS.%d" % (i % nblk + 1), ref_blocks, ref_whole, "REF")
+        nxt = blocks[(i + 1) % nblk] if (i < last and not args.no_prefetch and nblk > 1) else None
+        return m.map_block(blk, "READS.%d" % (i % nblk + 1), ref_blocks, ref_whole, "REF", next_reads=nxt)
 
     for i in range(args.warmup):
         step(i)
 
     L.dmh_async_report(0 if args.sync_report else 1)      # .las selection/writing of block i overlaps the filtering of block i+1
-    L.dmh_timing_enable(1)
+    L.dmh_timing_enable(0 if args.no_stage_timing else 1)
     L.dmh_timing_reset()
     if dist is not None:
         import torch

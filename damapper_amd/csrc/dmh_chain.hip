@@ -497,12 +497,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
         for (int i = 0; i < n; i++)
           { Candidate *c = keep[i];
             c->length = (int) len[i];
-            c->adisp.resize(len[i]);
-            c->bdisp.resize(len[i]);
-            for (uint32_t t = 0; t < len[i]; t++)
-              { c->adisp[t] = jd[2 * ((size_t) off[i] + t)];
-                c->bdisp[t] = jd[2 * ((size_t) off[i] + t) + 1];
-              }
+            c->jumps.assign(jd.begin() + 2 * (size_t) off[i], jd.begin() + 2 * ((size_t) off[i] + len[i]));
           }
       }
   }
@@ -549,10 +544,10 @@ int dmh_candidate_jumps(DAZZ_DB *ablock, int ar, int k, uint16_t *adisp, uint16_
   auto &L = st.reads[ar].cands;
   if (k < 0 || k >= (int) L.size()) return -1;
   Candidate &c = *L[k];
-  int n = (int) c.adisp.size();
+  int n = (int) (c.jumps.size() / 2);
   for (int i = 0; i < n && i < maxj; i++)
-    { adisp[i] = c.adisp[i];
-      bdisp[i] = c.bdisp[i];
+    { adisp[i] = c.jumps[2 * i];
+      bdisp[i] = c.jumps[2 * i + 1];
     }
   return n;
 }

@@ -65,6 +65,7 @@ static void init_device()
   const char *dv = getenv("DMH_DEVICE");
   if (dv != nullptr) dev = atoi(dv) % n;
   HIP_CHECK(hipSetDevice(dev));
+  if (getenv("DMH_SPIN") != nullptr) (void) hipSetDeviceFlags(hipDeviceScheduleSpin);
   HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   g_init = true;
 }
@@ -85,7 +86,15 @@ static const size_t              POOL_MAX = (size_t) 96 << 30;
 void *dev_alloc(size_t bytes, const char *what)
 { init_device();
   if (bytes == 0) bytes = 16;
-  bytes = (bytes + 255) & ~(size_t) 255;
+  // quantise sizes (8 steps per octave above 1 MB) so that near-equal requests -- read blocks
+  // differ by a fraction of a percent -- land in the same pool bucket instead of in hipMalloc
+  { size_t g = 256;
+    if (bytes > ((size_t) 1 << 20))
+      { size_t p2 = (size_t) 1 << (63 - __builtin_clzll((unsigned long long) bytes));
+        g = p2 >> 3;
+      }
+    bytes = (bytes + g - 1) / g * g;
+  }
   int best = -1;
   for (size_t i = 0; i < g_free.size(); i++)
     if (g_free[i].cap >= bytes && g_free[i].cap <= 2 * bytes + (1 << 20))
@@ -530,7 +539,10 @@ void *Sort_Kmers(DAZZ_DB *block, int *len)
     }
 
   bool       had  = st.blocks.count(block) != 0 && st.blocks[block].pinned;
+  HostTimer *hu = new HostTimer("sk_upload");
   BlockDev  &bd   = upload_block(block, false);
+  delete hu;
+  HostTimer *ha = new HostTimer("sk_alloc");
 
   IndexDev ix;
   ix.block  = block;
@@ -539,12 +551,20 @@ void *Sort_Kmers(DAZZ_DB *block, int *len)
   ix.h_boff.resize(nreads + 1);
   for (int i = 0; i <= nreads; i++) ix.h_boff[i] = block->reads[i].boff;
 
-  uint64_t *keys = (uint64_t *) dev_alloc(sizeof(uint64_t) * kmers, "k-mer codes");
-  uint32_t *vals = (uint32_t *) dev_alloc(sizeof(uint32_t) * kmers, "k-mer positions");
+  // same slack as the sort scratch: the two buffer pairs may swap roles below
+  const int64_t kmers0 = kmers + kmers / 8 + 256;
+  uint64_t *keys = (uint64_t *) dev_alloc(sizeof(uint64_t) * kmers0, "k-mer codes");
+  uint32_t *vals = (uint32_t *) dev_alloc(sizeof(uint32_t) * kmers0, "k-mer positions");
   st.sort.keys_alt.ensure(kmers, "k-mer sort buffer");
   st.sort.vals_alt.ensure(kmers, "k-mer sort buffer");
 
+  delete ha;
+  HostTimer *he = new HostTimer("sk_enqueue");
   kmer_emit(bd.d_bases(), L, bd.d_boff, nreads, pm.Kmer, keys, vals, kmers);
+  if (getenv("DMH_DEBUG_SYNC") != nullptr)
+    { HostTimer hs("sk_emit_sync");
+      HIP_CHECK(hipStreamSynchronize(stream()));
+    }
 
   uint64_t *k0 = keys, *k1 = st.sort.keys_alt.p;
   uint32_t *v0 = vals, *v1 = st.sort.vals_alt.p;
@@ -574,14 +594,17 @@ void *Sort_Kmers(DAZZ_DB *block, int *len)
         printf("   Revised kmer count = %lld\n", (long long) kmers);
     }
 
-  // the sorted data may sit in the scratch partner: make the index own its buffers
+  delete he;
+  HostTimer hf("sk_finish");
+  // the sorted data may sit in the scratch partner: the index then takes over the partner's
+  // buffers and the sort scratch keeps the ones allocated above (no device copy)
   if (k0 != keys)
-    { // swap ownership: the scratch takes the originally allocated buffers
-      size_t capk = st.sort.keys_alt.cap, capv = st.sort.vals_alt.cap;
-      (void) capk; (void) capv;
-      // scratch buffers are larger-or-equal; simplest is a device copy into the owned buffers
-      HIP_CHECK(hipMemcpyAsync(keys, k0, sizeof(uint64_t) * kmers, hipMemcpyDeviceToDevice, stream()));
-      HIP_CHECK(hipMemcpyAsync(vals, v0, sizeof(uint32_t) * kmers, hipMemcpyDeviceToDevice, stream()));
+    { st.sort.keys_alt.p   = keys;
+      st.sort.keys_alt.cap = (size_t) kmers0;
+      st.sort.vals_alt.p   = vals;
+      st.sort.vals_alt.cap = (size_t) kmers0;
+      keys = k0;
+      vals = v0;
     }
 
   ix.keys = keys;
@@ -595,7 +618,8 @@ void *Sort_Kmers(DAZZ_DB *block, int *len)
   hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
                      (const int64_t *) ix.d_boff, nreads, ix.nchunk, ix.d_chunk);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipStreamSynchronize(stream()));
+  // no synchronisation here: every later use of the index is ordered on the same stream, and a
+  // driver may queue more work (e.g. the next block's Reporter) behind the sort right away
 
   if (!had && st.cur_reads != block)
     { // bases of a REF block are not needed again until Reporter re-uploads the whole REF

@@ -455,10 +455,46 @@ struct ReportCtx
   std::vector<int> job_of_first;
   std::vector<std::vector<AlnRec>> recs;
   std::vector<int> pool;
+  size_t deferred_got = 0;       // > 0: pool[0..deferred_got) still has to be parsed into recs
 };
+
+// Records of the alignment pool: {cand, seq, abpos, bbpos, aepos, bepos, diffs, tlen} + trace
+static void parse_pool(std::vector<int> &pool, size_t base, size_t got, int njobs, const std::vector<char> &failed,
+                       std::vector<std::vector<AlnRec>> &recs)
+{ size_t p = base;
+  while (p + REC_HDR <= base + got)
+    { int *r = pool.data() + p;
+      int cand = r[0], tlen = r[7];
+      size_t need = REC_HDR + ((size_t) tlen + 1) / 2;
+      if (cand < 0 || cand >= njobs || tlen < 0) break;   // unwritten tail (pool overflow)
+      if (p + need > base + got) break;
+      if (failed.empty() || !failed[cand])
+        { AlnRec a;
+          a.seq = r[1]; a.abpos = r[2]; a.bbpos = r[3]; a.aepos = r[4]; a.bepos = r[5];
+          a.diffs = r[6]; a.tlen = tlen;
+          a.trace = (const uint16_t *) (size_t) (p + REC_HDR);      // offset, fixed up later
+          recs[cand].push_back(a);
+        }
+      p += need;
+    }
+}
+
+// turn the trace offsets into pointers once the host pool no longer moves; order by sequence no.
+static void fixup_recs(std::vector<int> &pool, std::vector<std::vector<AlnRec>> &recs)
+{ for (auto &v : recs)
+    { for (auto &a : v)
+        a.trace = (const uint16_t *) (pool.data() + (size_t) a.trace);
+      if (v.size() > 1)
+        std::sort(v.begin(), v.end(), [](const AlnRec &x, const AlnRec &y) { return x.seq < y.seq; });
+    }
+}
 
 static void select_and_write(ReportCtx &C)
 { const int S_ = C.S_, NT = C.NT, nreads = C.nreads, astart = C.astart, doA = C.doA;
+  if (C.deferred_got > 0)
+    { parse_pool(C.pool, 0, C.deferred_got, (int) C.recs.size(), std::vector<char>(), C.recs);
+      fixup_recs(C.pool, C.recs);
+    }
   HostTimer ht2("report_select_write");
   // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
   const bool small = (S_ <= TRACE_XOVR);
@@ -776,10 +812,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           J.npts  = c->length;
           J.joff  = (uint32_t) (jumps.size() / 2);
           J.pad   = 0;
-          for (int t = 0; t < c->length; t++)
-            { jumps.push_back(c->adisp[t]);
-              jumps.push_back(c->bdisp[t]);
-            }
+          jumps.insert(jumps.end(), c->jumps.begin(), c->jumps.end());
           jobs.push_back(J);
         }
     }
@@ -788,6 +821,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   std::vector<std::vector<AlnRec>> recs(njobs);
   std::vector<int> pool;
+  size_t deferred_got = 0;
   { HostTimer hj("report_jobs_built"); }
   if (njobs > 0)
     { BlockDev &ad = upload_block(ablock, false);
@@ -852,7 +886,19 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           size_t base = pool.size();
           pool.resize(base + got);
           if (got > 0)
-            HIP_CHECK(hipMemcpy(pool.data() + base, d_pool.p, sizeof(int) * got, hipMemcpyDeviceToHost));
+            { // through a persistent pinned staging buffer: a direct copy into pageable memory makes
+              // the runtime pin and unpin the destination pages around the transfer
+              static int   *h_stage = nullptr;
+              static size_t h_cap = 0;
+              if (got > h_cap)
+                { if (h_stage) (void) hipHostFree(h_stage);
+                  h_cap = got + got / 4 + 4096;
+                  HIP_CHECK(hipHostMalloc((void **) &h_stage, sizeof(int) * h_cap, hipHostMallocDefault));
+                }
+              HIP_CHECK(hipMemcpyAsync(h_stage, d_pool.p, sizeof(int) * got, hipMemcpyDeviceToHost, stream()));
+              HIP_CHECK(hipStreamSynchronize(stream()));
+              memcpy(pool.data() + base, h_stage, sizeof(int) * got);
+            }
 
           // which jobs of this run failed, and why
           std::vector<int> ran;
@@ -867,26 +913,15 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
                 else if (status[j] == AL_ERR_BAND && !global_band) need_global = true;
                 else fatal("Reporter: alignment of candidate %d failed (status %d)", j, status[j]);
               }
-          // parse the records of this run (records of failed jobs are dropped below)
+          // parse the records of this run (records of failed jobs are dropped below); when the whole
+          // batch succeeded at once the parse is left to the report stage (worker thread)
+          if (again.empty() && round == 0)
+            { deferred_got = got;
+              break;
+            }
           std::vector<char> failed(njobs, 0);
           for (int j : again) failed[j] = 1;
-          size_t p = base;
-          while (p + REC_HDR <= base + got)
-            { int *r = pool.data() + p;
-              int cand = r[0], tlen = r[7];
-              size_t need = REC_HDR + ((size_t) tlen + 1) / 2;
-              if (cand < 0 || cand >= njobs || tlen < 0) break;   // unwritten tail (pool overflow)
-              if (p + need > base + got) break;
-              if (!failed[cand])
-                { AlnRec a;
-                  a.seq = r[1]; a.abpos = r[2]; a.bbpos = r[3]; a.aepos = r[4]; a.bepos = r[5];
-                  a.diffs = r[6]; a.tlen = tlen;
-                  a.trace = nullptr;
-                  recs[cand].push_back(a);
-                  recs[cand].back().trace = (const uint16_t *) (size_t) (p + REC_HDR);   // offset, fixed up later
-                }
-              p += need;
-            }
+          parse_pool(pool, base, got, njobs, failed, recs);
           for (int j : again) recs[j].clear();
           if (again.empty()) break;
           todo = again;
@@ -894,12 +929,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           if (need_global && !need_pool) global_band = true;
           if (round == 5) fatal("Reporter: alignment retries exhausted");
         }
-      // fix up trace pointers now that the host pool no longer moves
-      for (auto &v : recs)
-        { for (auto &a : v)
-            a.trace = (const uint16_t *) (pool.data() + (size_t) a.trace);
-          std::sort(v.begin(), v.end(), [](const AlnRec &x, const AlnRec &y) { return x.seq < y.seq; });
-        }
+      if (deferred_got == 0) fixup_recs(pool, recs);
     }
 
   delete ht1;
@@ -915,6 +945,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     C->job_of_first = std::move(job_of_first);
     C->recs = std::move(recs);
     C->pool = std::move(pool);
+    C->deferred_got = deferred_got;
     report_submit(C);
   }
 

@@ -62,7 +62,7 @@ struct Candidate
 { int score, length, bread, comp;
   int afirst, alast, bfirst, blast;
   int id;
-  std::vector<uint16_t> adisp, bdisp;    // end -> start
+  std::vector<uint16_t> jumps;           // (adisp, bdisp) pairs, end -> start (map.c:1380-1384)
 };
 
 struct ReadState

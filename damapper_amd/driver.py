@@ -42,13 +42,22 @@ class Mapper:
         return self.spec
 
     def map_block(self, reads: Block, reads_name: str, ref_blocks: Sequence[Block], ref_whole: Block,
-                  ref_name: str, mflag: int = capi.FLAG_DOA, restore: bool = True) -> Dict[str, float]:
-        """One iteration of main()'s outer loop (damapper.c:825-880)."""
+                  ref_name: str, mflag: int = capi.FLAG_DOA, restore: bool = True,
+                  next_reads: Optional[Block] = None) -> Dict[str, float]:
+        """One iteration of main()'s outer loop (damapper.c:825-880).  With `next_reads` the index of
+        the following read block is queued on the GPU before this block's Reporter, so the device
+        never idles while the host selects and writes alignments (software pipelining of the block
+        loop; results are unchanged)."""
         t = {}
         t0 = time.time()
         if self.spec is None:
             self.make_spec([ref_whole.db.freq[j] for j in range(4)])
-        rh, rn = capi.sort_kmers(reads)
+        pre = getattr(self, "_prefetched", None)
+        if pre is not None and pre[0] is reads:
+            rh, rn = pre[1], pre[2]
+        else:
+            rh, rn = capi.sort_kmers(reads)
+        self._prefetched = None
         t["index_reads"] = time.time() - t0
         t1 = time.time()
         for k, blk in enumerate(ref_blocks):
@@ -61,6 +70,9 @@ class Mapper:
                 blk.complement_inplace()
         t["filter"] = time.time() - t1
         t2 = time.time()
+        if next_reads is not None:
+            h2, n2 = capi.sort_kmers(next_reads)
+            self._prefetched = (next_reads, h2, n2)
         self.L.Reporter(reads_name.encode(), reads.ptr(), ref_name.encode(), ref_whole.ptr(), self.spec, mflag)
         t["report"] = time.time() - t2
         if rh:
