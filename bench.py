@@ -91,7 +91,7 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist_mod
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist_mod.init_process_group(backend="nccl")
         dist = dist_mod
 

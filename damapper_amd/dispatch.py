@@ -1,0 +1,83 @@
+"""Read-block dispatcher for one node (the MI355X counterpart of HPC.damapper's job lists,
+HPC.damapper.c:369-442): every read block of a DAZZ_DB is an independent unit, block b goes to GPU
+b mod N, the reference index is rebuilt on each GPU, and a block whose output files already exist
+is skipped (resume granularity = read block, as HPC.damapper.c:329-354).
+
+    python -m damapper_amd.dispatch REF.db READS.db --gpus 8 [-k20 -e.85 -s100 -T4 -p]
+
+One worker process per GPU (DMH_DEVICE selects it); no communication between workers."""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+from .dazzdb import load_db, read_stub
+
+
+def _worker(args) -> None:
+    from . import capi, driver
+    d, ref_root = os.path.split(args.ref)
+    d = d or "."
+    ref_root = ref_root[:-3] if ref_root.endswith(".db") else ref_root
+    rd, read_root = os.path.split(args.reads)
+    read_root = read_root[:-3] if read_root.endswith(".db") else read_root
+    nrb, _ = read_stub(os.path.join(rd or ".", read_root + ".db"))
+    mine = [b for b in range(1, nrb + 1) if (b - 1) % args.gpus == args.rank]
+    out = args.out or os.path.join(d, "las_hip")
+    m = driver.Mapper(kmer=args.k, suppress=args.t, threads=args.T, ave_corr=args.e, spacing=args.s,
+                      best_tie=args.n, profile=int(args.p), verbose=int(args.v), sort_path=out)
+    nb, _ = read_stub(os.path.join(d, ref_root + ".db"))
+    ref_blocks = [load_db(os.path.join(d, ref_root + ".db"), part=k + 1) for k in range(nb)]
+    ref_whole = load_db(os.path.join(d, ref_root + ".db"))
+    for b in mine:
+        name = "%s.%d" % (read_root, b)
+        done = all(os.path.exists(os.path.join(out, "%s.%s.M%d.las" % (name, ref_root, i + 1))) for i in range(m.threads_pow2()))
+        if done and not args.force:
+            print("[gpu %d] %s: output present, skipped" % (args.rank, name), flush=True)
+            continue
+        reads = load_db(os.path.join(rd or ".", read_root + ".db"), part=b)
+        t0 = time.time()
+        m.map_block(reads, name, ref_blocks, ref_whole, ref_root)
+        dt = time.time() - t0
+        print("[gpu %d] %s: %d reads, %.1f Mbp in %.2f s (%.3f Gbp/s)" %
+              (args.rank, name, reads.nreads, reads.db.totlen / 1e6, dt, reads.db.totlen / dt / 1e9), flush=True)
+    capi.lib().dmh_report_wait()
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="damapper_amd.dispatch")
+    ap.add_argument("ref")
+    ap.add_argument("reads")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-k", type=int, default=20)
+    ap.add_argument("-t", type=int, default=0)
+    ap.add_argument("-e", type=float, default=0.85)
+    ap.add_argument("-s", type=int, default=100)
+    ap.add_argument("-n", type=float, default=1.0)
+    ap.add_argument("-T", type=int, default=4)
+    ap.add_argument("-p", action="store_true")
+    ap.add_argument("-v", action="store_true")
+    args = ap.parse_args(argv)
+    if args.rank >= 0:
+        _worker(args)
+        return 0
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env["DMH_DEVICE"] = str(r)
+        cmd = [sys.executable, "-m", "damapper_amd.dispatch"] + (argv if argv is not None else sys.argv[1:]) + ["--rank", str(r)]
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    for p in procs:
+        rc |= p.wait()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

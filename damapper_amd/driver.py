@@ -34,6 +34,13 @@ class Mapper:
             raise ValueError("Illegal combination of filter parameters")
         self.spec = None
 
+    def threads_pow2(self) -> int:
+        """NTHREADS of map.c:142-147: the number of per-"thread" output files."""
+        n = 1
+        while 2 * n <= self.threads:
+            n *= 2
+        return n
+
     def make_spec(self, freq: Sequence[float]):
         f = (C.c_float * 4)(*[float(x) for x in freq])
         if self.spec:

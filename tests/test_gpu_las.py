@@ -100,3 +100,31 @@ def test_reference_driver_linked_against_hip_library(tmp_path):
         ts_r, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
         ts_h, hr = las.read_las_set(os.path.join(d, "las_drop"), b + ".REF.M@.las")
         assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
+
+
+def test_dispatcher_maps_every_read_block(tmp_path):
+    """damapper_amd.dispatch (read blocks -> GPUs, resume by output file) against the reference run on
+    the same blocks."""
+    import subprocess
+    import sys
+    run_ref = _run_ref()
+    g, reads = make_dataset("random", 47, [180000, 160000], 50, dropouts=0)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=200000)
+    dazzdb.write_db(d, "READS", reads, block_size=270000)
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    assert nb >= 2
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    run_ref.run_reference(d, "REF", blocks, flags=["-M8"], threads=4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "damapper_amd.dispatch", os.path.join(d, "REF.db"), os.path.join(d, "READS.db"),
+           "--gpus", "1", "--out", os.path.join(d, "las_disp")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    for b in blocks:
+        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        _, hr = las.read_las_set(os.path.join(d, "las_disp"), b + ".REF.M@.las")
+        assert len(rr) > 0 and rr == hr, b
+    p2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0 and p2.stdout.count("skipped") == nb
