@@ -362,7 +362,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   }
   uint32_t nsum = 0;
   { HostTimer ht("chain_wait");
-    HIP_CHECK(hipMemcpyAsync(&nsum, ctl.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+    copy_d2h(&nsum, ctl.p + 1, sizeof(uint32_t));
     HIP_CHECK(hipStreamSynchronize(stream()));
   }
   HostTimer ht_all("chain_host");
@@ -370,7 +370,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   std::vector<ChainSummary> sums(nsum);
   std::vector<uint32_t>     gfirst;
   if (nsum > 0)
-    { HIP_CHECK(hipMemcpy(sums.data(), out.p, sizeof(ChainSummary) * nsum, hipMemcpyDeviceToHost));
+    { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum);
       std::sort(sums.begin(), sums.end(), [](const ChainSummary &a, const ChainSummary &b)
                 { return a.group != b.group ? a.group < b.group : a.rank < b.rank; });
     }
@@ -387,9 +387,9 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     d_idx.ensure(want.size() + 1, "gather idx");
     d_k.ensure(want.size() + 1, "gather keys");
     if (!want.empty())
-      { HIP_CHECK(hipMemcpyAsync(d_idx.p, want.data(), sizeof(uint32_t) * want.size(), hipMemcpyHostToDevice, stream()));
+      { copy_h2d(d_idx.p, want.data(), sizeof(uint32_t) * want.size());
         gather_u64(R.skeys, d_idx.p, d_k.p, (int64_t) want.size());
-        HIP_CHECK(hipMemcpyAsync(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size(), hipMemcpyDeviceToHost, stream()));
+        copy_d2h(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size());
         HIP_CHECK(hipStreamSynchronize(stream()));
       }
   }
@@ -475,24 +475,24 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
         static DevBuf<uint16_t> d_j;
         d_ends.ensure(n, "jump ends");
         d_len.ensure(2 * (size_t) n + 2, "jump lengths");
-        HIP_CHECK(hipMemcpyAsync(d_ends.p, ends.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, stream()));
+        copy_h2d(d_ends.p, ends.data(), sizeof(uint32_t) * n);
         StageTimer tm("chain_jumps", 0.0);
         hipLaunchKernelGGL(k_chain_jumps, dim3(ceil_div(n, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
                            (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, (const uint32_t *) d_ends.p, n,
                            d_len.p, (const uint32_t *) nullptr, (uint16_t *) nullptr, 0);
         std::vector<uint32_t> len(n), off(n + 1);
-        HIP_CHECK(hipMemcpyAsync(len.data(), d_len.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream()));
+        copy_d2h(len.data(), d_len.p, sizeof(uint32_t) * n);
         HIP_CHECK(hipStreamSynchronize(stream()));
         off[0] = 0;
         for (int i = 0; i < n; i++) off[i + 1] = off[i] + len[i];
         d_j.ensure(2 * (size_t) off[n] + 2, "jump data");
-        HIP_CHECK(hipMemcpyAsync(d_len.p + n, off.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, stream()));
+        copy_h2d(d_len.p + n, off.data(), sizeof(uint32_t) * n);
         hipLaunchKernelGGL(k_chain_jumps, dim3(ceil_div(n, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
                            (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, (const uint32_t *) d_ends.p, n,
                            d_len.p, (const uint32_t *) (d_len.p + n), d_j.p, 1);
         std::vector<uint16_t> jd(2 * (size_t) off[n]);
         if (off[n] > 0)
-          HIP_CHECK(hipMemcpyAsync(jd.data(), d_j.p, sizeof(uint16_t) * jd.size(), hipMemcpyDeviceToHost, stream()));
+          copy_d2h(jd.data(), d_j.p, sizeof(uint16_t) * jd.size());
         HIP_CHECK(hipStreamSynchronize(stream()));
         for (int i = 0; i < n; i++)
           { Candidate *c = keep[i];

@@ -31,6 +31,12 @@ hipStream_t stream();
 void *dev_alloc(size_t bytes, const char *what);
 void  dev_free(void *p);
 
+// Host <-> device transfers go through one persistent pinned staging buffer: handing pageable host
+// memory to hipMemcpyAsync makes the runtime pin and unpin those pages around the copy, and the
+// unpin was observed to delay the next kernel dispatch by ~10 ms.  Both calls are synchronous.
+void copy_d2h(void *host, const void *dev, size_t bytes);
+void copy_h2d(void *dev, const void *host, size_t bytes);
+
 template <typename T> struct DevBuf
 { T     *p   = nullptr;
   size_t cap = 0;      // elements

@@ -145,6 +145,40 @@ static void pool_release()
   g_pooled = 0;
 }
 
+static uint8_t *g_pin = nullptr;
+static const size_t PIN_CHUNK = (size_t) 32 << 20;
+
+static void pin_init()
+{ if (g_pin == nullptr)
+    HIP_CHECK(hipHostMalloc((void **) &g_pin, PIN_CHUNK, hipHostMallocDefault));
+}
+
+void copy_d2h(void *host, const void *dev, size_t bytes)
+{ pin_init();
+  size_t off = 0;
+  do
+    { size_t c = std::min(PIN_CHUNK, bytes - off);
+      if (c > 0)
+        HIP_CHECK(hipMemcpyAsync(g_pin, (const uint8_t *) dev + off, c, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      if (c > 0) memcpy((uint8_t *) host + off, g_pin, c);
+      off += c;
+    }
+  while (off < bytes);
+}
+
+void copy_h2d(void *dev, const void *host, size_t bytes)
+{ pin_init();
+  size_t off = 0;
+  while (off < bytes)
+    { size_t c = std::min(PIN_CHUNK, bytes - off);
+      memcpy(g_pin, (const uint8_t *) host + off, c);
+      HIP_CHECK(hipMemcpyAsync((uint8_t *) dev + off, g_pin, c, hipMemcpyHostToDevice, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      off += c;
+    }
+}
+
 // ---- stage timing -----------------------------------------------------------------------
 
 struct TimerSlot { std::string name; double ms = 0; int64_t launches = 0; double bytes = 0; };
@@ -336,12 +370,11 @@ BlockDev &upload_block(const DAZZ_DB *block, bool pin)
   bd.pinned = pin;
   bd.d_raw = (uint8_t *) dev_alloc((size_t) bd.L + 1, "block bases");
   // the byte before bases[0] is the leading separator (DB.c:1411)
-  HIP_CHECK(hipMemcpyAsync(bd.d_raw, ((const uint8_t *) block->bases) - 1, (size_t) bd.L + 1,
-                           hipMemcpyHostToDevice, stream()));
+  copy_h2d(bd.d_raw, ((const uint8_t *) block->bases) - 1, (size_t) bd.L + 1);
   std::vector<int64_t> off(n + 1);
   for (int i = 0; i <= n; i++) off[i] = block->reads[i].boff;
   bd.d_boff = (int64_t *) dev_alloc(sizeof(int64_t) * (n + 1), "block read offsets");
-  HIP_CHECK(hipMemcpyAsync(bd.d_boff, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, stream()));
+  copy_h2d(bd.d_boff, off.data(), sizeof(int64_t) * (n + 1));
   HIP_CHECK(hipStreamSynchronize(stream()));
   st.blocks[block] = bd;
   return st.blocks[block];
@@ -583,7 +616,7 @@ void *Sort_Kmers(DAZZ_DB *block, int *len)
       hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0,
                          (const uint32_t *) v0, (const uint32_t *) keep.p, (const uint32_t *) slot.p, kmers, k1, v1);
       uint32_t kept = 0;
-      HIP_CHECK(hipMemcpyAsync(&kept, slot.p + kmers, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+      copy_d2h(&kept, slot.p + kmers, sizeof(uint32_t));
       HIP_CHECK(hipStreamSynchronize(stream()));
       std::swap(k0, k1);
       std::swap(v0, v1);
@@ -654,8 +687,8 @@ int dmh_index_download(void *table, void *out)
   if (ix == nullptr) return 0;
   std::vector<uint64_t> k(ix->n);
   std::vector<uint32_t> v(ix->n);
-  HIP_CHECK(hipMemcpyAsync(k.data(), ix->keys, sizeof(uint64_t) * ix->n, hipMemcpyDeviceToHost, stream()));
-  HIP_CHECK(hipMemcpyAsync(v.data(), ix->vals, sizeof(uint32_t) * ix->n, hipMemcpyDeviceToHost, stream()));
+  copy_d2h(k.data(), ix->keys, sizeof(uint64_t) * ix->n);
+  copy_d2h(v.data(), ix->vals, sizeof(uint32_t) * ix->n);
   HIP_CHECK(hipStreamSynchronize(stream()));
   KmerPosRec *o = (KmerPosRec *) out;
   const std::vector<int64_t> &boff = ix->h_boff;
@@ -676,13 +709,13 @@ int dmh_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbits)
   uint32_t *dv = (uint32_t *) dev_alloc(sizeof(uint32_t) * n, "sort vals");
   st.sort.keys_alt.ensure(n, "sort buffer");
   st.sort.vals_alt.ensure(n, "sort buffer");
-  HIP_CHECK(hipMemcpyAsync(dk, keys, sizeof(uint64_t) * n, hipMemcpyHostToDevice, stream()));
-  HIP_CHECK(hipMemcpyAsync(dv, vals, sizeof(uint32_t) * n, hipMemcpyHostToDevice, stream()));
+  copy_h2d(dk, keys, sizeof(uint64_t) * n);
+  copy_h2d(dv, vals, sizeof(uint32_t) * n);
   uint64_t *k0 = dk, *k1 = st.sort.keys_alt.p;
   uint32_t *v0 = dv, *v1 = st.sort.vals_alt.p;
   radix_sort_pairs(&k0, &v0, &k1, &v1, n, 0, nbits, st.sort, "sort_pairs");
-  HIP_CHECK(hipMemcpyAsync(keys, k0, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, stream()));
-  HIP_CHECK(hipMemcpyAsync(vals, v0, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream()));
+  copy_d2h(keys, k0, sizeof(uint64_t) * n);
+  copy_d2h(vals, v0, sizeof(uint32_t) * n);
   HIP_CHECK(hipStreamSynchronize(stream()));
   dev_free(dk);
   dev_free(dv);

@@ -306,8 +306,8 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   }
   std::vector<unsigned long long> hrep(GR + HREP);
   unsigned int nent = 0;
-  HIP_CHECK(hipMemcpyAsync(hrep.data(), gram.p, sizeof(unsigned long long) * (GR + HREP), hipMemcpyDeviceToHost, stream()));
-  HIP_CHECK(hipMemcpyAsync(&nent, mctl.p, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+  copy_d2h(hrep.data(), gram.p, sizeof(unsigned long long) * (GR + HREP));
+  copy_d2h(&nent, mctl.p, sizeof(unsigned int));
   HIP_CHECK(hipStreamSynchronize(stream()));
   std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
   for (int r = 0; r < HREP; r++)
@@ -386,8 +386,8 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                        (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
                        (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.keys.p, R.vals.p, ebig.p, mctl.p + 1);
-    HIP_CHECK(hipMemcpyAsync(&total, eoff.p + nent, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
-    HIP_CHECK(hipMemcpyAsync(&nbig, mctl.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
+    copy_d2h(&total, eoff.p + nent, sizeof(uint32_t));
+    copy_d2h(&nbig, mctl.p + 1, sizeof(unsigned int));
     HIP_CHECK(hipStreamSynchronize(stream()));
     if (nbig > 0)
       hipLaunchKernelGGL(k_merge_expand_big, dim3(ceil_div((int64_t) nbig * 64, 256)), dim3(256), 0, stream(),
@@ -414,22 +414,22 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     hipLaunchKernelGGL(k_group_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.skeys, nhits, pshift, flag.p);
     exclusive_scan_u32(flag.p, nhits, st.sort.bsum, flag.p + nhits);
     uint32_t ng = 0;
-    HIP_CHECK(hipMemcpyAsync(&ng, flag.p + nhits, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+    copy_d2h(&ng, flag.p + nhits, sizeof(uint32_t));
     HIP_CHECK(hipStreamSynchronize(stream()));
     R.ngroups = ng;
     R.gstart.ensure((size_t) ng + 1, "group starts");
     hipLaunchKernelGGL(k_group_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.skeys, nhits, pshift,
                        (const uint32_t *) flag.p, R.gstart.p);
     uint32_t endv = (uint32_t) nhits;
-    HIP_CHECK(hipMemcpyAsync(R.gstart.p + ng, &endv, sizeof(uint32_t), hipMemcpyHostToDevice, stream()));
+    copy_h2d(R.gstart.p + ng, &endv, sizeof(uint32_t));
     HIP_CHECK(hipStreamSynchronize(stream()));
   }
 
   if (st.capture_seeds)
     { std::vector<uint64_t> hk(nhits);
       std::vector<uint32_t> hv(nhits);
-      HIP_CHECK(hipMemcpy(hk.data(), R.skeys, sizeof(uint64_t) * nhits, hipMemcpyDeviceToHost));
-      HIP_CHECK(hipMemcpy(hv.data(), R.svals, sizeof(uint32_t) * nhits, hipMemcpyDeviceToHost));
+      copy_d2h(hk.data(), R.skeys, sizeof(uint64_t) * nhits);
+      copy_d2h(hv.data(), R.svals, sizeof(uint32_t) * nhits);
       st.last_seeds.resize((size_t) nhits * 4);
       uint64_t pm = ((uint64_t) 1 << R.pbits) - 1, bm = ((uint64_t) 1 << R.bbits) - 1;
       for (int64_t i = 0; i < nhits; i++)

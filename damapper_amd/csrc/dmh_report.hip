@@ -21,8 +21,8 @@ constexpr int CELLCAP = 16384; // pebbles per wavefront arena
 int16_t *spec_device_tables(Spec *sp)
 { if (sp->d_tables == nullptr)
     { sp->d_tables = (int16_t *) dev_alloc(sizeof(int16_t) * 65536, "trim tables");
-      HIP_CHECK(hipMemcpyAsync(sp->d_tables, sp->score.data(), sizeof(int16_t) * 32768, hipMemcpyHostToDevice, stream()));
-      HIP_CHECK(hipMemcpyAsync(sp->d_tables + 32768, sp->table.data(), sizeof(int16_t) * 32768, hipMemcpyHostToDevice, stream()));
+      copy_h2d(sp->d_tables, sp->score.data(), sizeof(int16_t) * 32768);
+      copy_h2d(sp->d_tables + 32768, sp->table.data(), sizeof(int16_t) * 32768);
       HIP_CHECK(hipStreamSynchronize(stream()));
     }
   return sp->d_tables;
@@ -731,18 +731,31 @@ static std::condition_variable   g_rcv;
 static std::deque<ReportCtx *>   g_rqueue;
 static int                       g_rbusy = 0;
 static bool                      g_async = false;
+static bool                      g_stop  = false;
+static std::vector<ReportCtx *>  g_rdone;
+
+static void dispose_done()
+{ std::vector<ReportCtx *> d;
+  { std::unique_lock<std::mutex> lk(g_rmu);
+    d.swap(g_rdone);
+  }
+  for (auto *c : d) delete c;
+}
 
 static void worker_main()
 { while (true)
     { ReportCtx *C;
       { std::unique_lock<std::mutex> lk(g_rmu);
-        g_rcv.wait(lk, [] { return !g_rqueue.empty(); });
+        g_rcv.wait(lk, [] { return !g_rqueue.empty() || g_stop; });
+        if (g_rqueue.empty()) return;
         C = g_rqueue.front();
         g_rqueue.pop_front();
       }
       select_and_write(*C);
-      delete C;
-      { std::unique_lock<std::mutex> lk(g_rmu);
+      { // the context was allocated piece by piece on the main thread: hand it back for disposal
+        // there (freeing it here would fight the main thread for its malloc arena)
+        std::unique_lock<std::mutex> lk(g_rmu);
+        g_rdone.push_back(C);
         g_rbusy -= 1;
       }
       g_rcv.notify_all();
@@ -750,8 +763,10 @@ static void worker_main()
 }
 
 void report_wait()
-{ std::unique_lock<std::mutex> lk(g_rmu);
-  g_rcv.wait(lk, [] { return g_rbusy == 0; });
+{ { std::unique_lock<std::mutex> lk(g_rmu);
+    g_rcv.wait(lk, [] { return g_rbusy == 0; });
+  }
+  dispose_done();
 }
 
 static void report_submit(ReportCtx *C)
@@ -761,7 +776,13 @@ static void report_submit(ReportCtx *C)
       return;
     }
   { std::unique_lock<std::mutex> lk(g_rmu);
-    if (g_worker == nullptr) g_worker = new std::thread(worker_main);
+    if (g_worker == nullptr)
+      { g_worker = new std::thread(worker_main);
+        atexit([] { { std::unique_lock<std::mutex> lk2(g_rmu); g_stop = true; }
+                    g_rcv.notify_all();
+                    if (g_worker && g_worker->joinable()) g_worker->join();
+                  });
+      }
     g_rqueue.push_back(C);
     g_rbusy += 1;
   }
@@ -839,9 +860,9 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
       d_jobs.ensure(njobs, "candidate jobs");
       d_jumps.ensure(jumps.size() + 2, "candidate jumps");
       d_status.ensure(njobs, "candidate status");
-      HIP_CHECK(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(CandJob) * njobs, hipMemcpyHostToDevice, stream()));
+      copy_h2d(d_jobs.p, jobs.data(), sizeof(CandJob) * njobs);
       if (!jumps.empty())
-        HIP_CHECK(hipMemcpyAsync(d_jumps.p, jumps.data(), sizeof(uint16_t) * jumps.size(), hipMemcpyHostToDevice, stream()));
+        copy_h2d(d_jumps.p, jumps.data(), sizeof(uint16_t) * jumps.size());
 
       // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
       size_t pool_cap = (size_t) njobs * 2 * (REC_HDR + (maxalen / S_ + 8)) + 4096;
@@ -855,7 +876,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           const int *only = nullptr;
           if (!todo.empty())
             { d_only.ensure(todo.size(), "retry list");
-              HIP_CHECK(hipMemcpyAsync(d_only.p, todo.data(), sizeof(int) * todo.size(), hipMemcpyHostToDevice, stream()));
+              copy_h2d(d_only.p, todo.data(), sizeof(int) * todo.size());
               only = d_only.p;
             }
           int nblocks = std::min((nrun + 3) / 4, 256 * 4);
@@ -875,10 +896,11 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
                                  ascr().ctl.p + 1, (unsigned int) pool_cap, only);
             HIP_CHECK(hipGetLastError());
           }
+          dispose_done();        // free finished report contexts while the kernel runs
           unsigned int used = 0;
           { HostTimer hw("report_kernel_wait");
-            HIP_CHECK(hipMemcpyAsync(&used, ascr().ctl.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream()));
-            HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, sizeof(int) * njobs, hipMemcpyDeviceToHost, stream()));
+            copy_d2h(&used, ascr().ctl.p + 1, sizeof(unsigned int));
+            copy_d2h(status.data(), d_status.p, sizeof(int) * njobs);
             HIP_CHECK(hipStreamSynchronize(stream()));
           }
           HostTimer hp("report_pool_parse");
@@ -980,8 +1002,8 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
   AlignSpecDev spd = spec_dev(sp);
   uint8_t *da = (uint8_t *) dev_alloc(abytes + 256, "A bases");
   uint8_t *db = (uint8_t *) dev_alloc(bbytes + 256, "B bases");
-  HIP_CHECK(hipMemcpyAsync(da, abases, abytes, hipMemcpyHostToDevice, stream()));
-  HIP_CHECK(hipMemcpyAsync(db, bbases, bbytes, hipMemcpyHostToDevice, stream()));
+  copy_h2d(da, abases, abytes);
+  copy_h2d(db, bbases, bbytes);
   // 2-bit packed copies; read boundaries of A (for the reverse complements) are its separators
   std::vector<int64_t> hboff;
   for (int64_t q = 0; q < abytes; q++)
@@ -989,7 +1011,7 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
   if (hboff.size() < 2) { hboff.clear(); hboff.push_back(0); hboff.push_back(abytes + 1); }
   int      nar = (int) hboff.size() - 1;
   int64_t *d_hboff = (int64_t *) dev_alloc(sizeof(int64_t) * hboff.size(), "A boundaries");
-  HIP_CHECK(hipMemcpyAsync(d_hboff, hboff.data(), sizeof(int64_t) * hboff.size(), hipMemcpyHostToDevice, stream()));
+  copy_h2d(d_hboff, hboff.data(), sizeof(int64_t) * hboff.size());
   uint64_t *apkraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * ((abytes >> 5) + 8), "packed A");
   uint64_t *arcraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * ((abytes >> 5) + 8), "packed A rc");
   uint64_t *bpkraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * ((bbytes >> 5) + 8), "packed B");
@@ -1003,7 +1025,7 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
       maxalen = std::max(maxalen, alen[i]);
     }
   SeedJob *dj = (SeedJob *) dev_alloc(sizeof(SeedJob) * njobs, "seed jobs");
-  HIP_CHECK(hipMemcpyAsync(dj, jobs.data(), sizeof(SeedJob) * njobs, hipMemcpyHostToDevice, stream()));
+  copy_h2d(dj, jobs.data(), sizeof(SeedJob) * njobs);
   int      *dout = (int *) dev_alloc(sizeof(int) * 16 * njobs, "seed results");
   uint16_t *dat = (uint16_t *) dev_alloc(sizeof(uint16_t) * (size_t) njobs * trace_stride, "seed traces");
   uint16_t *dbt = (uint16_t *) dev_alloc(sizeof(uint16_t) * (size_t) njobs * trace_stride, "seed traces");
@@ -1021,7 +1043,7 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
       HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), stream()));
       if (global_band)
         { d_only = (int *) dev_alloc(sizeof(int) * nrun, "retry list");
-          HIP_CHECK(hipMemcpyAsync(d_only, todo.data(), sizeof(int) * nrun, hipMemcpyHostToDevice, stream()));
+          copy_h2d(d_only, todo.data(), sizeof(int) * nrun);
         }
       { StageTimer tm(global_band ? "align_seeds_global_band" : "align_seeds", 0.0);
         if (global_band)
@@ -1036,7 +1058,7 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
                              (const int *) nullptr);
         HIP_CHECK(hipGetLastError());
       }
-      HIP_CHECK(hipMemcpyAsync(res.data(), dout, sizeof(int) * 16 * njobs, hipMemcpyDeviceToHost, stream()));
+      copy_d2h(res.data(), dout, sizeof(int) * 16 * njobs);
       HIP_CHECK(hipStreamSynchronize(stream()));
       todo.clear();
       for (int i = 0; i < njobs; i++)
@@ -1044,9 +1066,9 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
     }
   for (int i = 0; i < njobs; i++)
     for (int f = 0; f < 16; f++) out[16 * (size_t) i + f] = res[16 * (size_t) i + f];
-  HIP_CHECK(hipMemcpyAsync(trace_out, dat, sizeof(uint16_t) * (size_t) njobs * trace_stride, hipMemcpyDeviceToHost, stream()));
+  copy_d2h(trace_out, dat, sizeof(uint16_t) * (size_t) njobs * trace_stride);
   if (btrace_out != nullptr)
-    HIP_CHECK(hipMemcpyAsync(btrace_out, dbt, sizeof(uint16_t) * (size_t) njobs * trace_stride, hipMemcpyDeviceToHost, stream()));
+    copy_d2h(btrace_out, dbt, sizeof(uint16_t) * (size_t) njobs * trace_stride);
   HIP_CHECK(hipStreamSynchronize(stream()));
   dev_free(da); dev_free(db); dev_free(dj); dev_free(dout); dev_free(dat); dev_free(dbt);
   dev_free(d_hboff); dev_free(apkraw); dev_free(arcraw); dev_free(bpkraw);

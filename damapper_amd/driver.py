@@ -17,7 +17,7 @@ from .dazzdb import Block, load_db, read_stub
 class Mapper:
     def __init__(self, kmer: int = 20, suppress: int = 0, threads: int = 4, ave_corr: float = 0.85,
                  spacing: int = 100, best_tie: float = 1.0, profile: int = 0, verbose: int = 0,
-                 mem_limit: int = 0, sort_path: str = "/tmp"):
+                 mem_limit: int = 0, sort_path: str = "/tmp", retain_ref: bool = False):
         self.L = capi.lib()
         self.kmer, self.suppress, self.threads = kmer, suppress, threads
         self.ave_corr, self.spacing = ave_corr, spacing
@@ -33,6 +33,32 @@ class Mapper:
         if self.L.Set_Filter_Params(kmer, suppress, threads):
             raise ValueError("Illegal combination of filter parameters")
         self.spec = None
+        # north_star: "reference k-mer index replicated per GPU": build both orientations of every REF
+        # block once and keep them in HBM for all read blocks (Match_Filter then does not consume them)
+        self.retain_ref = retain_ref
+        self._ref_cache = None
+        self.L.dmh_retain_ref_index(1 if retain_ref else 0)
+
+    def release_ref(self) -> None:
+        if self._ref_cache:
+            for (h, n, comp, k) in self._ref_cache:
+                if h:
+                    self.L.dmh_free_index(h)
+        self._ref_cache = None
+
+    def _ref_indices(self, ref_blocks):
+        if self._ref_cache is None:
+            cache = []
+            for k, blk in enumerate(ref_blocks):
+                h0, n0 = capi.sort_kmers(blk)
+                blk.complement_inplace()
+                h1, n1 = capi.sort_kmers(blk)
+                blk.complement_inplace()
+                self.L.dmh_sync()
+                cache.append((h0, n0, 0, k))
+                cache.append((h1, n1, 1, k))
+            self._ref_cache = cache
+        return self._ref_cache
 
     def threads_pow2(self) -> int:
         """NTHREADS of map.c:142-147: the number of per-"thread" output files."""
@@ -67,14 +93,18 @@ class Mapper:
         self._prefetched = None
         t["index_reads"] = time.time() - t0
         t1 = time.time()
-        for k, blk in enumerate(ref_blocks):
-            for comp in (0, 1):
-                if comp:
-                    blk.complement_inplace()                                      # damapper.c:853
-                h, n = capi.sort_kmers(blk)
-                capi.match_filter(reads, blk, rh, rn, h, n, comp, 1 if (k == 0 and comp == 0) else 0)
-            if restore:
-                blk.complement_inplace()
+        if self.retain_ref:
+            for (h, n, comp, k) in self._ref_indices(ref_blocks):
+                capi.match_filter(reads, ref_blocks[k], rh, rn, h, n, comp, 1 if (k == 0 and comp == 0) else 0)
+        else:
+            for k, blk in enumerate(ref_blocks):
+                for comp in (0, 1):
+                    if comp:
+                        blk.complement_inplace()                                      # damapper.c:853
+                    h, n = capi.sort_kmers(blk)
+                    capi.match_filter(reads, blk, rh, rn, h, n, comp, 1 if (k == 0 and comp == 0) else 0)
+                if restore:
+                    blk.complement_inplace()
         t["filter"] = time.time() - t1
         t2 = time.time()
         if next_reads is not None:

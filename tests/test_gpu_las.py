@@ -128,3 +128,44 @@ def test_dispatcher_maps_every_read_block(tmp_path):
         assert len(rr) > 0 and rr == hr, b
     p2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p2.returncode == 0 and p2.stdout.count("skipped") == nb
+
+
+def test_retained_ref_index_and_pipelining_give_identical_files(tmp_path):
+    """The opt-in throughput modes of the driver (REF indices built once and kept resident, next block's
+    index queued before Reporter, .las written by the worker thread) must not change a byte."""
+    from damapper_amd import capi
+    g, reads = make_dataset("repeat", 48, [200000, 150000, 100000], 90, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=260000)
+    dazzdb.write_db(d, "READS", reads, block_size=320000)
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    nrb, _ = dazzdb.read_stub(os.path.join(d, "REF.db"))
+    assert nb >= 3
+
+    def run(out, fast):
+        cwd = os.getcwd()
+        os.chdir(d)
+        try:
+            m = driver.Mapper(threads=4, mem_limit=8 << 30, sort_path=os.path.join(d, out), retain_ref=fast)
+            ref_blocks = [dazzdb.load_db("./REF.db", part=k + 1) for k in range(nrb)]
+            ref_whole = dazzdb.load_db("./REF.db")
+            blocks = [dazzdb.load_db("./READS.db", part=b + 1) for b in range(nb)]
+            capi.lib().dmh_async_report(1 if fast else 0)
+            for b, blk in enumerate(blocks):
+                nxt = blocks[b + 1] if (fast and b + 1 < nb) else None
+                m.map_block(blk, "READS.%d" % (b + 1), ref_blocks, ref_whole, "REF", next_reads=nxt)
+            capi.lib().dmh_report_wait()
+            capi.lib().dmh_async_report(0)
+            m.release_ref()
+            capi.lib().dmh_retain_ref_index(0)
+        finally:
+            os.chdir(cwd)
+
+    run("las_plain", False)
+    run("las_fast", True)
+    for b in range(nb):
+        for t in range(1, 5):
+            fn = "READS.%d.REF.M%d.las" % (b + 1, t)
+            a = open(os.path.join(d, "las_plain", fn), "rb").read()
+            c = open(os.path.join(d, "las_fast", fn), "rb").read()
+            assert a == c and len(a) > 12, fn
