@@ -120,11 +120,12 @@ __global__ __launch_bounds__(256) void k_align_seeds(const uint64_t *apk, const 
     }
 }
 
-// Output pool record: 12-int header {cand, seq, abpos, bbpos, aepos, bepos, diffs, atlen, pad...}
-// followed by atlen uint16 trace values (padded to a multiple of 2 values).
-constexpr int REC_HDR = 8;
+// Output pool record: 16-int header {cand, seq, abpos, bbpos, aepos, bepos, diffs, atlen,
+// B view: abpos, bbpos, aepos, bepos, btlen, 0, 0, 0} followed by atlen uint16 A-trace values (padded
+// to an even count) and, for -C, btlen B-trace values (padded likewise).
+constexpr int REC_HDR = 16;
 
-template <int W, bool LDSBAND>
+template <int W, bool LDSBAND, bool WANT_B>
 __global__ __launch_bounds__(256, 4) void k_align_cands(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
                                                       const CandJob *jobs, int njobs,
                                                       const uint16_t *jumps, int hithr, AlignSpecDev sp,
@@ -169,11 +170,12 @@ __global__ __launch_bounds__(256, 4) void k_align_cands(const uint64_t *apk, con
             }
           PathRes P;
           int B[4];
-          st = local_alignment<W, false>(wk, sp, S, dg, ad, P, B);
+          st = local_alignment<W, WANT_B>(wk, sp, S, dg, ad, P, B);
           if (st != AL_OK) break;
           if (P.aepos - P.abpos >= hithr)
             { alast = P.abpos;
-              unsigned int need = REC_HDR + ((unsigned int) P.atlen + 1) / 2;
+              const int    btl  = WANT_B ? P.btlen : 0;
+              unsigned int need = REC_HDR + ((unsigned int) P.atlen + 1) / 2 + ((unsigned int) btl + 1) / 2;
               unsigned int at = 0;
               if (lane == 0) at = atomicAdd(pool_used, need);
               at = __shfl(at, 0);
@@ -182,9 +184,15 @@ __global__ __launch_bounds__(256, 4) void k_align_cands(const uint64_t *apk, con
               if (lane == 0)
                 { r[0] = j; r[1] = seq; r[2] = P.abpos; r[3] = P.bbpos; r[4] = P.aepos; r[5] = P.bepos;
                   r[6] = P.diffs; r[7] = P.atlen;
+                  r[8] = B[0]; r[9] = B[1]; r[10] = B[2]; r[11] = B[3]; r[12] = btl;
+                  r[13] = 0; r[14] = 0; r[15] = 0;
                 }
               uint16_t *tr = (uint16_t *) (r + REC_HDR);
               for (int i = lane; i < P.atlen; i += 64) tr[i] = wk.atrace[P.aorg + i];
+              if (WANT_B)
+                { uint16_t *tb2 = (uint16_t *) (r + REC_HDR + (P.atlen + 1) / 2);
+                  for (int i = lane; i < btl; i += 64) tb2[i] = wk.btrace[P.borg + i];
+                }
               seq += 1;
             }
           wave_sync();
@@ -355,9 +363,11 @@ static void copy_path(Ovl &dst, const Ovl &src)
   dst.abpos = src.abpos; dst.bbpos = src.bbpos; dst.aepos = src.aepos; dst.bepos = src.bepos;
 }
 
-// map.c:2116-2268 (A view only)
-static int handle_redundancies(Ovl *am, int novls, std::vector<uint16_t> &tb, int S)
-{ int awhen = 0;
+// map.c:2116-2268.  bm (may be null) is the parallel array of B views (-C): a pair is fused only if
+// the B views meet at a trace point as well (Entwine's argument order depends on the orientation).
+static int handle_redundancies(Ovl *am, int novls, Ovl *bm, std::vector<uint16_t> &tb, int S, int cm)
+{ int awhen = 0, bwhen = 0;
+  const bool hasB = (bm != nullptr);
   for (int j = 1; j < novls; j++)
     { Ovl &J = am[j];
       for (int k = j - 1; k >= 0; k--)
@@ -368,7 +378,25 @@ static int handle_redundancies(Ovl *am, int novls, std::vector<uint16_t> &tb, in
                 { int dist = entwine(J, K, tb, S, &awhen);
                   if (dist == 0)
                     { if (K.aepos > J.aepos)
-                        fusion(J, awhen, K, tb, S);
+                        { if (hasB)
+                            { Ovl &JB = bm[j], &KB = bm[k];
+                              if (cm)
+                                { dist = entwine(KB, JB, tb, S, &bwhen);
+                                  if (dist != 0) continue;
+                                  fusion(J, awhen, K, tb, S);
+                                  fusion(KB, bwhen, JB, tb, S);
+                                  copy_path(JB, KB);
+                                }
+                              else
+                                { dist = entwine(JB, KB, tb, S, &bwhen);
+                                  if (dist != 0) continue;
+                                  fusion(J, awhen, K, tb, S);
+                                  fusion(JB, bwhen, KB, tb, S);
+                                }
+                            }
+                          else
+                            fusion(J, awhen, K, tb, S);
+                        }
                       K.abpos = -1;
                       break;
                     }
@@ -379,13 +407,39 @@ static int handle_redundancies(Ovl *am, int novls, std::vector<uint16_t> &tb, in
                 { int dist = entwine(K, J, tb, S, &awhen);
                   if (dist == 0)
                     { if (K.abpos == J.abpos)
-                        { if (K.aepos > J.aepos) copy_path(J, K); }
+                        { if (K.aepos > J.aepos)
+                            { copy_path(J, K);
+                              if (hasB) copy_path(bm[j], bm[k]);
+                            }
+                        }
                       else if (J.aepos > K.aepos)
-                        { fusion(K, awhen, J, tb, S);
-                          copy_path(J, K);
+                        { if (hasB)
+                            { Ovl &JB = bm[j], &KB = bm[k];
+                              if (cm)
+                                { dist = entwine(JB, KB, tb, S, &bwhen);
+                                  if (dist != 0) continue;
+                                  fusion(K, awhen, J, tb, S);
+                                  copy_path(J, K);
+                                  fusion(JB, bwhen, KB, tb, S);
+                                }
+                              else
+                                { dist = entwine(KB, JB, tb, S, &bwhen);
+                                  if (dist != 0) continue;
+                                  fusion(K, awhen, J, tb, S);
+                                  copy_path(J, K);
+                                  fusion(KB, bwhen, JB, tb, S);
+                                  copy_path(JB, KB);
+                                }
+                            }
+                          else
+                            { fusion(K, awhen, J, tb, S);
+                              copy_path(J, K);
+                            }
                         }
                       else
-                        copy_path(J, K);
+                        { copy_path(J, K);
+                          if (hasB) copy_path(bm[j], bm[k]);
+                        }
                       K.abpos = -1;
                       break;
                     }
@@ -395,7 +449,10 @@ static int handle_redundancies(Ovl *am, int novls, std::vector<uint16_t> &tb, in
     }
   int no = 0;
   for (int j = 0; j < novls; j++)
-    if (am[j].abpos >= 0) am[no++] = am[j];
+    if (am[j].abpos >= 0)
+      { if (hasB) bm[no] = bm[j];
+        am[no++] = am[j];
+      }
   return no;
 }
 
@@ -441,13 +498,17 @@ static void write_overlap(FILE *f, const Ovl &o, const uint16_t *trace, bool sma
     }
 }
 
-struct AlnRec { int seq, abpos, bbpos, aepos, bepos, diffs, tlen; const uint16_t *trace; };
+struct AlnRec
+{ int seq, abpos, bbpos, aepos, bepos, diffs, tlen;
+  int babpos, bbbpos, baepos, bbepos, btlen;        // B view (-C)
+  const uint16_t *trace, *btrace;
+};
 
 
 // Everything the per-read select/write stage needs, detached from the library state so that it
 // can run on the report worker thread while the next read block is already being filtered.
 struct ReportCtx
-{ int S_, NT, nshift, nreads, astart, doA, spacing, profile, verbose;
+{ int S_, NT, nshift, nreads, astart, doA, doB, spacing, profile, verbose;
   double best_tie;
   std::string aname, bname, sort_path;
   std::vector<int> rlen;
@@ -465,14 +526,17 @@ static void parse_pool(std::vector<int> &pool, size_t base, size_t got, int njob
   while (p + REC_HDR <= base + got)
     { int *r = pool.data() + p;
       int cand = r[0], tlen = r[7];
-      size_t need = REC_HDR + ((size_t) tlen + 1) / 2;
-      if (cand < 0 || cand >= njobs || tlen < 0) break;   // unwritten tail (pool overflow)
+      int btl = r[12];
+      if (cand < 0 || cand >= njobs || tlen < 0 || btl < 0) break;   // unwritten tail (pool overflow)
+      size_t need = REC_HDR + ((size_t) tlen + 1) / 2 + ((size_t) btl + 1) / 2;
       if (p + need > base + got) break;
       if (failed.empty() || !failed[cand])
         { AlnRec a;
           a.seq = r[1]; a.abpos = r[2]; a.bbpos = r[3]; a.aepos = r[4]; a.bepos = r[5];
           a.diffs = r[6]; a.tlen = tlen;
-          a.trace = (const uint16_t *) (size_t) (p + REC_HDR);      // offset, fixed up later
+          a.babpos = r[8]; a.bbbpos = r[9]; a.baepos = r[10]; a.bbepos = r[11]; a.btlen = btl;
+          a.trace  = (const uint16_t *) (size_t) (p + REC_HDR);      // offsets, fixed up later
+          a.btrace = (const uint16_t *) (size_t) (p + REC_HDR + ((size_t) tlen + 1) / 2);
           recs[cand].push_back(a);
         }
       p += need;
@@ -483,14 +547,16 @@ static void parse_pool(std::vector<int> &pool, size_t base, size_t got, int njob
 static void fixup_recs(std::vector<int> &pool, std::vector<std::vector<AlnRec>> &recs)
 { for (auto &v : recs)
     { for (auto &a : v)
-        a.trace = (const uint16_t *) (pool.data() + (size_t) a.trace);
+        { a.trace  = (const uint16_t *) (pool.data() + (size_t) a.trace);
+          a.btrace = (const uint16_t *) (pool.data() + (size_t) a.btrace);
+        }
       if (v.size() > 1)
         std::sort(v.begin(), v.end(), [](const AlnRec &x, const AlnRec &y) { return x.seq < y.seq; });
     }
 }
 
 static void select_and_write(ReportCtx &C)
-{ const int S_ = C.S_, NT = C.NT, nreads = C.nreads, astart = C.astart, doA = C.doA;
+{ const int S_ = C.S_, NT = C.NT, nreads = C.nreads, astart = C.astart, doA = C.doA, doB = C.doB;
   if (C.deferred_got > 0)
     { parse_pool(C.pool, 0, C.deferred_got, (int) C.recs.size(), std::vector<char>(), C.recs);
       fixup_recs(C.pool, C.recs);
@@ -498,7 +564,7 @@ static void select_and_write(ReportCtx &C)
   HostTimer ht2("report_select_write");
   // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
   const bool small = (S_ <= TRACE_XOVR);
-  std::vector<Ovl>      am;
+  std::vector<Ovl>      am, bm;
   std::vector<uint16_t> tb;
   std::vector<Link>     linker;
   std::vector<Link *>   perm;
@@ -511,7 +577,19 @@ static void select_and_write(ReportCtx &C)
     { int abeg = (int) (((int64_t) ti * nreads) >> C.nshift);
       int aend = (ti == NT - 1) ? nreads : (int) (((int64_t) (ti + 1) * nreads) >> C.nshift);
       FILE *afile = nullptr;
-      int64_t ahits = 0;
+      FILE *bfile = nullptr;
+      int64_t ahits = 0, bhits = 0;
+      if (doB)                                  // map.c:3256-3261
+        { std::string fn = C.sort_path + "/" + C.bname + "." + C.aname + ".R" + std::to_string(ti + 1) + ".las";
+          bfile = fopen(fn.c_str(), "w");
+          if (bfile == nullptr)
+            { fprintf(stderr, "damapper: Cannot open %s for 'w'\n", fn.c_str());
+              Clean_Exit(1);
+            }
+          setvbuf(bfile, nullptr, _IOFBF, 1 << 20);
+          fwrite(&bhits, sizeof(int64_t), 1, bfile);
+          fwrite(&C.spacing, sizeof(int), 1, bfile);
+        }
       if (doA)
         { std::string fn = C.sort_path + "/" + C.aname + "." + C.bname + ".M" + std::to_string(ti + 1) + ".las";
           afile = fopen(fn.c_str(), "w");
@@ -528,6 +606,7 @@ static void select_and_write(ReportCtx &C)
         { const int alen = C.rlen[ar];
           const int atck = (alen - 1) / S_ + 1;
           am.clear();
+          bm.clear();
           tb.clear();
           int lovl = 0;
           auto &cl = C.reads[ar].cands;
@@ -544,13 +623,26 @@ static void select_and_write(ReportCtx &C)
                   o.trace = tb.size();
                   tb.insert(tb.end(), a.trace, a.trace + a.tlen);
                   am.push_back(o);
+                  if (doB)                       // map.c:2556-2572
+                    { Ovl b;
+                      b.tlen = a.btlen; b.diffs = a.diffs;
+                      b.abpos = a.babpos; b.bbpos = a.bbbpos; b.aepos = a.baepos; b.bepos = a.bbepos;
+                      b.flags = o.flags;
+                      b.aread = c.bread;
+                      b.bread = ar + astart;
+                      b.trace = tb.size();
+                      tb.insert(tb.end(), a.btrace, a.btrace + a.btlen);
+                      bm.push_back(b);
+                    }
                 }
               bool last = (ci + 1 == cl.size()) || cl[ci + 1]->bread != c.bread || cl[ci + 1]->comp != c.comp;
               if (last)
                 { int novl = (int) am.size();
                   if (novl - lovl > 1)
-                    { novl = lovl + handle_redundancies(am.data() + lovl, novl - lovl, tb, S_);
+                    { novl = lovl + handle_redundancies(am.data() + lovl, novl - lovl,
+                                                        doB ? bm.data() + lovl : nullptr, tb, S_, c.comp);
                       am.resize(novl);
+                      if (doB) bm.resize(novl);
                     }
                   if (novl - lovl > 1)
                     { // AMATCH_SORT (map.c:2304-2315): abpos descending, ties by descending original
@@ -562,6 +654,23 @@ static void select_and_write(ReportCtx &C)
                                   return x.second > y.second;
                                 });
                       for (int i = lovl; i < novl; i++) am[i] = tmp[i - lovl].first;
+                      if (doB)
+                        { // BC_MATCH_SORT / BN_MATCH_SORT (map.c:2317-2341): the B views are sorted on
+                          // their own keys -- bepos ascending (comp) or bbpos descending (normal)
+                          tmp.clear();
+                          for (int i = lovl; i < novl; i++) tmp.push_back({bm[i], i});
+                          if (c.comp)
+                            std::sort(tmp.begin(), tmp.end(), [](const std::pair<Ovl, int> &x, const std::pair<Ovl, int> &y)
+                                      { if (x.first.bepos != y.first.bepos) return x.first.bepos < y.first.bepos;
+                                        return x.second > y.second;
+                                      });
+                          else
+                            std::sort(tmp.begin(), tmp.end(), [](const std::pair<Ovl, int> &x, const std::pair<Ovl, int> &y)
+                                      { if (x.first.bbpos != y.first.bbpos) return x.first.bbpos > y.first.bbpos;
+                                        return x.second > y.second;
+                                      });
+                          for (int i = lovl; i < novl; i++) bm[i] = tmp[i - lovl].first;
+                        }
                     }
                   lovl = novl;
                 }
@@ -659,6 +768,7 @@ static void select_and_write(ReportCtx &C)
                       continue;
                     best = (linker[b].score == part[p].top);
                   }
+                int q = -1;
                 for (p = b; true; p = n)
                   { linker[p].mark = -1;
                     if (doA)
@@ -672,7 +782,38 @@ static void select_and_write(ReportCtx &C)
                         ahits += 1;
                       }
                     n = linker[p].link;
+                    if (doB)                     // map.c:2758-2777
+                      { if (bm[p].flags & COMP_FLAG)
+                          { linker[p].link = q;  // complemented chains run the other way in B: stack them
+                            q = p;
+                          }
+                        else
+                          { if (p == b)
+                              { bm[p].flags |= START_FLAG;
+                                if (best) bm[p].flags |= BEST_FLAG;
+                              }
+                            else
+                              bm[p].flags |= NEXT_FLAG;
+                            write_overlap(bfile, bm[p], tb.data() + bm[p].trace, small, wbuf);
+                            bhits += 1;
+                          }
+                      }
                     if (p == e) break;
+                  }
+                if (doB && (bm[b].flags & COMP_FLAG))      // map.c:2796-2815
+                  { e = b;
+                    b = q;
+                    for (p = b; true; p = linker[p].link)
+                      { if (p == b)
+                          { bm[p].flags |= START_FLAG;
+                            if (best) bm[p].flags |= BEST_FLAG;
+                          }
+                        else
+                          bm[p].flags |= NEXT_FLAG;
+                        write_overlap(bfile, bm[p], tb.data() + bm[p].trace, small, wbuf);
+                        bhits += 1;
+                        if (p == e) break;
+                      }
                   }
               }
 
@@ -692,7 +833,12 @@ static void select_and_write(ReportCtx &C)
           fwrite(&ahits, sizeof(int64_t), 1, afile);
           fclose(afile);
         }
-      ncheck += ahits;
+      if (doB)
+        { rewind(bfile);
+          fwrite(&bhits, sizeof(int64_t), 1, bfile);
+          fclose(bfile);
+        }
+      ncheck += doA ? ahits : bhits;
     }
 
   if (C.verbose)
@@ -801,11 +947,10 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   Spec *sp = (Spec *) asettings;
   if (sp == nullptr || sp->magic != SPEC_MAGIC)
     fatal("Reporter: the Align_Spec was not created by this library's New_Align_Spec");
-  if (mflag & FLAG_DOB)
-    fatal("Reporter: reference-vs-reads output (-C/-N) is not supported by the HIP filter yet");
   if (st.cur_reads != ablock || (int) st.reads.size() != ablock->nreads)
     fatal("Reporter: called for a READS block that has not been through Match_Filter");
   const int doA = (mflag & FLAG_DOA) != 0;
+  const int doB = (mflag & FLAG_DOB) != 0;
   const int S_  = SPACING;
   const int NT  = pm.NTHREADS;
   const int hithr = 3 * pm.Kmer;
@@ -865,7 +1010,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
         copy_h2d(d_jumps.p, jumps.data(), sizeof(uint16_t) * jumps.size());
 
       // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
-      size_t pool_cap = (size_t) njobs * 2 * (REC_HDR + (maxalen / S_ + 8)) + 4096;
+      size_t pool_cap = (size_t) njobs * 2 * (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8)) + 4096;
       std::vector<int> status(njobs);
       std::vector<int> todo;                 // jobs to (re)run; empty = all
       bool global_band = false;
@@ -885,15 +1030,29 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           HIP_CHECK(hipMemsetAsync(d_pool.p, 0xff, sizeof(int) * pool_cap, stream()));   // cand = -1 ends the parse
           { StageTimer tm(global_band ? "align_global_band" : "align", 0.0);
             if (global_band)
-              hipLaunchKernelGGL((k_align_cands<GLB_W, false>), dim3(nblocks), dim3(256), 0, stream(),
-                                 ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
-                                 (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
-                                 ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+              { if (doB)
+                  hipLaunchKernelGGL((k_align_cands<GLB_W, false, true>), dim3(nblocks), dim3(256), 0, stream(),
+                                     ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
+                                     (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                                     ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+                else
+                  hipLaunchKernelGGL((k_align_cands<GLB_W, false, false>), dim3(nblocks), dim3(256), 0, stream(),
+                                     ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
+                                     (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                                     ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+              }
             else
-              hipLaunchKernelGGL((k_align_cands<LDS_W, true>), dim3(nblocks), dim3(256), 0, stream(),
-                                 ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
-                                 (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
-                                 ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+              { if (doB)
+                  hipLaunchKernelGGL((k_align_cands<LDS_W, true, true>), dim3(nblocks), dim3(256), 0, stream(),
+                                     ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
+                                     (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                                     ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+                else
+                  hipLaunchKernelGGL((k_align_cands<LDS_W, true, false>), dim3(nblocks), dim3(256), 0, stream(),
+                                     ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
+                                     (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                                     ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+              }
             HIP_CHECK(hipGetLastError());
           }
           dispose_done();        // free finished report contexts while the kernel runs
@@ -956,7 +1115,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   delete ht1;
   { ReportCtx *C = new ReportCtx();
-    C->S_ = S_; C->NT = NT; C->nshift = pm.NSHIFT; C->nreads = nreads; C->astart = astart; C->doA = doA;
+    C->S_ = S_; C->NT = NT; C->nshift = pm.NSHIFT; C->nreads = nreads; C->astart = astart; C->doA = doA; C->doB = doB;
     C->spacing = SPACING; C->profile = PROFILE; C->verbose = VERBOSE; C->best_tie = BEST_TIE;
     C->aname = aname; C->bname = bname; C->sort_path = SORT_PATH;
     C->rlen.resize(nreads);

@@ -118,8 +118,10 @@ class Mapper:
         return t
 
 
-def map_db(workdir: str, ref_root: str, read_root: str, sort_path: Optional[str] = None, **kw) -> Dict[str, float]:
-    """damapper <ref> <reads> on DBs written by dazzdb.write_db (all blocks of the reads DB)."""
+def map_db(workdir: str, ref_root: str, read_root: str, sort_path: Optional[str] = None,
+           mflag: int = capi.FLAG_DOA, **kw) -> Dict[str, float]:
+    """damapper <ref> <reads> on DBs written by dazzdb.write_db (all blocks of the reads DB).
+    mflag: FLAG_DOA (default), FLAG_DOA|FLAG_DOB (-C) or FLAG_DOB (-C -N), damapper.c:709-720."""
     sort_path = sort_path or os.path.join(workdir, "las_hip")
     m = Mapper(sort_path=sort_path, **kw)
     cwd = os.getcwd()
@@ -129,6 +131,6 @@ def map_db(workdir: str, ref_root: str, read_root: str, sort_path: Optional[str]
         ref_blocks = [load_db("./" + ref_root + ".db", part=k + 1) for k in range(nb)]
         ref_whole = load_db("./" + ref_root + ".db")
         reads = load_db("./" + read_root + ".db")
-        return m.map_block(reads, read_root, ref_blocks, ref_whole, ref_root)
+        return m.map_block(reads, read_root, ref_blocks, ref_whole, ref_root, mflag=mflag)
     finally:
         os.chdir(cwd)

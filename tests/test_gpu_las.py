@@ -81,6 +81,41 @@ def test_las_identical_to_reference(case, tmp_path):
             raise AssertionError("-p track differs at %s: ref %s hip %s" % (list(idx[:20]), list(a[idx[:20]]), list(b[idx[:20]])))
 
 
+COVER_CASES = [
+    # name, kind, seed, contigs, nreads, dropouts, flags(ref), mflag, extra kwargs
+    ("C", "repeat", 51, [300000, 250000], 100, 2, ["-C"], 3, {}),
+    ("C_N", "random", 52, [250000, 200000], 80, 1, ["-C", "-N"], 2, {}),
+    ("C_s126", "repeat", 53, [250000], 60, 1, ["-C", "-s126"], 3, dict(spacing=126)),
+]
+
+
+@pytest.mark.parametrize("case", COVER_CASES, ids=[c[0] for c in COVER_CASES])
+def test_cover_files_identical_to_reference(case, tmp_path):
+    """-C / -N (map.c FLAG_DOB): the REF-vs-READS files REF.READS.R@.las carry the B view of every
+    reported alignment, complemented chains in reversed order."""
+    run_ref = _run_ref()
+    name, kind, seed, contigs, nreads, drop, flags, mflag, kw = case
+    g, reads = make_dataset(kind, seed, contigs, nreads, dropouts=drop)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=400000)
+    dazzdb.write_db(d, "READS", reads)
+    run_ref.run_reference(d, "REF", ["READS"], flags=list(flags) + ["-M8"], threads=4)
+    driver.map_db(d, "REF", "READS", threads=4, mem_limit=8 << 30, mflag=mflag, **kw)
+    pats = ["REF.READS.R@.las"] + (["READS.REF.M@.las"] if (mflag & 1) else [])
+    for pat in pats:
+        ts_r, rr = las.read_las_set(os.path.join(d, "las_ref"), pat)
+        ts_h, hr = las.read_las_set(os.path.join(d, "las_hip"), pat)
+        assert ts_r == ts_h
+        assert len(rr) == len(hr) and len(rr) > 0, "%s: %d vs %d records" % (pat, len(rr), len(hr))
+        for i, (a, b) in enumerate(zip(rr, hr)):
+            assert a == b, "%s record %d differs:\n%s\n%s" % (pat, i, a, b)
+        for t in range(1, 5):
+            fn = pat.replace("@", str(t))
+            assert len(las.read_las(os.path.join(d, "las_ref", fn))[1]) == len(las.read_las(os.path.join(d, "las_hip", fn))[1])
+    if not (mflag & 1):
+        assert not os.path.exists(os.path.join(d, "las_hip", "READS.REF.M1.las"))
+
+
 def test_reference_driver_linked_against_hip_library(tmp_path):
     """Drop-in proof: the reference's own damapper.c/DB.c/QV.c, linked against libdamapper_hip.so instead
     of map.c + align.c (oracle/_ref/damapper_hip), writes the same .las files as the all-CPU reference."""
