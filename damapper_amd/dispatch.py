@@ -3,7 +3,10 @@ HPC.damapper.c:369-442): every read block of a DAZZ_DB is an independent unit, b
 b mod N, the reference index is rebuilt on each GPU, and a block whose output files already exist
 is skipped (resume granularity = read block, as HPC.damapper.c:329-354).
 
-    python -m damapper_amd.dispatch REF.db READS.db --gpus 8 [-k20 -e.85 -s100 -T4 -p]
+    python -m damapper_amd.dispatch REF.db READS.db --gpus 8 [-k20 -e.85 -s100 -T4 -p -C -N -z] [--finish]
+
+--finish runs the LAsort/LAcat/LAmerge post-step (damapper.c:887-910) per block, leaving
+`<reads>.<b>.<ref>.las` (and `<ref>.<reads>.<b>.las` for -C) next to the reference DB.
 
 One worker process per GPU (DMH_DEVICE selects it); no communication between workers."""
 from __future__ import annotations
@@ -32,19 +35,36 @@ def _worker(args) -> None:
     nb, _ = read_stub(os.path.join(d, ref_root + ".db"))
     ref_blocks = [load_db(os.path.join(d, ref_root + ".db"), part=k + 1) for k in range(nb)]
     ref_whole = load_db(os.path.join(d, ref_root + ".db"))
+    if args.N and not args.C:
+        raise SystemExit("damapper_amd.dispatch: Cannot specify N flag without C also")     # damapper.c:716
+    if args.N and args.p:
+        raise SystemExit("damapper_amd.dispatch: Cannot specify both N and p flags together")
+    mflag = (capi.FLAG_DOB if args.N else capi.FLAG_DOA | capi.FLAG_DOB) if args.C else capi.FLAG_DOA
+    mapped = []
     for b in mine:
         name = "%s.%d" % (read_root, b)
-        done = all(os.path.exists(os.path.join(out, "%s.%s.M%d.las" % (name, ref_root, i + 1))) for i in range(m.threads_pow2()))
+        if args.finish:
+            finals = ([os.path.join(d, "%s.%s.las" % (name, ref_root))] if mflag & capi.FLAG_DOA else []) + \
+                     ([os.path.join(d, "%s.%s.las" % (ref_root, name))] if mflag & capi.FLAG_DOB else [])
+            done = all(os.path.exists(f) for f in finals)
+        else:
+            parts = (["%s.%s.M%d.las" % (name, ref_root, i + 1) for i in range(m.threads_pow2())] if mflag & capi.FLAG_DOA else []) + \
+                    (["%s.%s.R%d.las" % (ref_root, name, i + 1) for i in range(m.threads_pow2())] if mflag & capi.FLAG_DOB else [])
+            done = all(os.path.exists(os.path.join(out, f)) for f in parts)
         if done and not args.force:
             print("[gpu %d] %s: output present, skipped" % (args.rank, name), flush=True)
             continue
         reads = load_db(os.path.join(rd or ".", read_root + ".db"), part=b)
         t0 = time.time()
-        m.map_block(reads, name, ref_blocks, ref_whole, ref_root)
+        m.map_block(reads, name, ref_blocks, ref_whole, ref_root, mflag=mflag)
+        mapped.append(name)
         dt = time.time() - t0
         print("[gpu %d] %s: %d reads, %.1f Mbp in %.2f s (%.3f Gbp/s)" %
               (args.rank, name, reads.nreads, reads.db.totlen / 1e6, dt, reads.db.totlen / dt / 1e9), flush=True)
     capi.lib().dmh_report_wait()
+    if args.finish:
+        for name in mapped:
+            driver.finish_block(out, name, ref_root, mflag=mflag, map_order=not args.z, outdir=d)
 
 
 def main(argv=None) -> int:
@@ -63,6 +83,10 @@ def main(argv=None) -> int:
     ap.add_argument("-T", type=int, default=4)
     ap.add_argument("-p", action="store_true")
     ap.add_argument("-v", action="store_true")
+    ap.add_argument("-C", action="store_true", help="also write the reference-vs-reads files")
+    ap.add_argument("-N", action="store_true", help="with -C: no reads-vs-reference files")
+    ap.add_argument("-z", action="store_true", help="--finish sorts by A,B-read piles instead of map order")
+    ap.add_argument("--finish", action="store_true", help="run the LAsort/LAcat/LAmerge post-step")
     args = ap.parse_args(argv)
     if args.rank >= 0:
         _worker(args)

@@ -118,6 +118,40 @@ class Mapper:
         return t
 
 
+def finish_block(sort_path: str, reads_name: str, ref_name: str, mflag: int = capi.FLAG_DOA,
+                 map_order: bool = True, outdir: str = ".", keep_parts: bool = False) -> Dict[str, str]:
+    """The post-step of main() (damapper.c:887-910) with this package's LAsort/LAcat/LAmerge
+    (tools/latools.cpp): per-thread files -> `<reads>.<ref>.las` (and `<ref>.<reads>.las` for -C).
+    All queued Reporter output must be on disk: call after dmh_report_wait() when reports are async."""
+    import glob
+    import subprocess
+    from . import las
+    out = {}
+    a = ["-a"] if map_order else []
+
+    def cleanup(pattern):
+        if not keep_parts:
+            for f in glob.glob(pattern):
+                os.remove(f)
+
+    if mflag & capi.FLAG_DOA:
+        stem = os.path.join(sort_path, "%s.%s.M" % (reads_name, ref_name))
+        subprocess.check_call([las.tool_path("LAsort")] + a + [stem + "@.las"])
+        final = os.path.join(outdir, "%s.%s.las" % (reads_name, ref_name))
+        with open(final, "wb") as f:
+            subprocess.check_call([las.tool_path("LAcat"), stem + "@.S"], stdout=f)
+        cleanup(stem + "*.las")
+        out["map"] = final
+    if mflag & capi.FLAG_DOB:
+        stem = os.path.join(sort_path, "%s.%s.R" % (ref_name, reads_name))
+        subprocess.check_call([las.tool_path("LAsort")] + a + [stem + "@.las"])
+        final = os.path.join(outdir, "%s.%s" % (ref_name, reads_name))
+        subprocess.check_call([las.tool_path("LAmerge")] + a + [final, stem + "@.S.las"])
+        cleanup(stem + "*.las")
+        out["cover"] = final + ".las"
+    return out
+
+
 def map_db(workdir: str, ref_root: str, read_root: str, sort_path: Optional[str] = None,
            mflag: int = capi.FLAG_DOA, **kw) -> Dict[str, float]:
     """damapper <ref> <reads> on DBs written by dazzdb.write_db (all blocks of the reads DB).

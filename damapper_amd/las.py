@@ -55,6 +55,35 @@ def read_las(path: str) -> Tuple[int, List[LasRecord]]:
     return tspace, recs
 
 
+def write_las(path: str, tspace: int, recs: List[LasRecord]) -> None:
+    """Inverse of read_las (padding bytes written as zero)."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<qi", len(recs), tspace))
+        for r in recs:
+            f.write(struct.pack("<6iI2ii", r.tlen, r.diffs, r.abpos, r.bbpos, r.aepos, r.bepos, r.flags,
+                                r.aread, r.bread, 0))
+            f.write(r.trace)
+
+
+def chains(recs: List[LasRecord]) -> List[List[LasRecord]]:
+    """Group a record stream into chains: a record without NEXT_FLAG opens a chain (map.c:2741-2815)."""
+    out: List[List[LasRecord]] = []
+    for r in recs:
+        if (r.flags & NEXT_FLAG) and out:
+            out[-1].append(r)
+        else:
+            out.append([r])
+    return out
+
+
+def tool_path(name: str) -> str:
+    """Path of this package's LAsort / LAcat / LAmerge (damapper_amd/tools/latools.cpp)."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", name)
+    if not os.path.exists(p):
+        raise RuntimeError("%s is not built (run __graft_entry__.build())" % p)
+    return p
+
+
 def read_las_set(directory: str, pattern: str) -> Tuple[int, List[LasRecord]]:
     """Concatenate per-thread files `<dir>/<pattern with @ = 1..T>` in numeric order
     (the parity artefact of SURVEY.md section 8c)."""

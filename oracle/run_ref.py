@@ -18,11 +18,12 @@ def have_ref() -> bool:
 
 def run_reference(workdir: str, ref_root: str, read_roots: Sequence[str], flags: Sequence[str] = (),
                   threads: int = 4, keep: str = "las_ref", binary: str = "damapper",
-                  capture: bool = False):
+                  capture: bool = False, tools_dir: Optional[str] = None):
     """cd workdir; damapper <flags> -T<threads> <ref_root> <read_roots...>.  Returns
     (elapsed seconds, stdout text).  Per-thread files end up in workdir/<keep>/."""
     env = dict(os.environ)
-    env["PATH"] = os.path.join(REF_DIR, "bin") + ":" + env.get("PATH", "")
+    # LAsort/LAcat/LAmerge: by default the keep-and-exit shims; tools_dir selects real ones
+    env["PATH"] = (tools_dir or os.path.join(REF_DIR, "bin")) + ":" + env.get("PATH", "")
     keepdir = os.path.join(workdir, keep)
     if os.path.isdir(keepdir):
         shutil.rmtree(keepdir)

@@ -165,6 +165,41 @@ def test_dispatcher_maps_every_read_block(tmp_path):
     assert p2.returncode == 0 and p2.stdout.count("skipped") == nb
 
 
+def test_dispatcher_finish_writes_final_las(tmp_path):
+    """--finish -C: per block, `<reads>.<b>.REF.las` and `REF.<reads>.<b>.las` hold the chains of the
+    reference's per-thread files in map order (LAsort -a / LAcat / LAmerge equivalents)."""
+    import subprocess
+    import sys
+    run_ref = _run_ref()
+    g, reads = make_dataset("repeat", 49, [180000, 160000], 50, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=400000)
+    dazzdb.write_db(d, "READS", reads, block_size=270000)
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    run_ref.run_reference(d, "REF", blocks, flags=["-M8", "-C"], threads=4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "damapper_amd.dispatch", os.path.join(d, "REF.db"), os.path.join(d, "READS.db"),
+           "--gpus", "1", "--out", os.path.join(d, "las_disp"), "-C", "--finish"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+
+    def chainset(recs):
+        return sorted(tuple(r.key() for r in c) for c in las.chains(recs))
+
+    for b in blocks:
+        for final, pat in ((b + ".REF.las", b + ".REF.M@.las"), ("REF." + b + ".las", "REF." + b + ".R@.las")):
+            _, want = las.read_las_set(os.path.join(d, "las_ref"), pat)
+            _, got = las.read_las(os.path.join(d, final))
+            assert len(want) == len(got) and len(got) > 0
+            assert chainset(want) == chainset(got)
+            ks = [(c[0].aread, c[0].abpos) for c in las.chains(got)]
+            assert ks == sorted(ks)
+    p2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0 and p2.stdout.count("skipped") == nb
+
+
 def test_retained_ref_index_and_pipelining_give_identical_files(tmp_path):
     """The opt-in throughput modes of the driver (REF indices built once and kept resident, next block's
     index queued before Reporter, .las written by the worker thread) must not change a byte."""
