@@ -444,6 +444,30 @@ __global__ void k_compact(const uint64_t *__restrict__ kin, const uint32_t *__re
     }
 }
 
+// -m masks (map.c:481-543): the k-mer ending at base offset q = vals[i] of read r survives iff no
+// mask interval [b,e) of r has b <= rpos and e > rpos-(K-1), i.e. it lies inside one unmasked gap.
+__global__ void k_mask_flag(const uint32_t *__restrict__ vals, int64_t n, const int64_t *__restrict__ boff,
+                            int nreads, int K, const int64_t *__restrict__ anno, const int *__restrict__ data,
+                            uint32_t *__restrict__ keep)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t q = vals[i];
+  int lo = 0, hi = nreads;                 // largest r with boff[r] <= q
+  while (lo < hi)
+    { int m = (lo + hi + 1) >> 1;
+      if (boff[m] > q) hi = m - 1; else lo = m;
+    }
+  const int     rpos  = (int) (q - boff[lo]);
+  const int     start = rpos - (K - 1);
+  const int64_t a0 = anno[lo] >> 1, a1 = anno[lo + 1] >> 1;      // interval numbers
+  int64_t l = a0, h = a1;                  // first interval with end > start
+  while (l < h)
+    { int64_t m = (l + h) >> 1;
+      if (data[2 * m + 1] > start) h = m; else l = m + 1;
+    }
+  keep[i] = (l < a1 && data[2 * l] <= rpos) ? 0u : 1u;
+}
+
 }  // namespace dmh
 
 using namespace dmh;
@@ -601,9 +625,47 @@ void *Sort_Kmers(DAZZ_DB *block, int *len)
 
   uint64_t *k0 = keys, *k1 = st.sort.keys_alt.p;
   uint32_t *v0 = vals, *v1 = st.sort.vals_alt.p;
-  radix_sort_pairs(&k0, &v0, &k1, &v1, kmers, 0, pm.Kshift, st.sort, "kmer_sort");
 
-  if (pm.TooFrequent < INT32_MAX)
+  const DAZZ_TRACK *mask = (const DAZZ_TRACK *) block->tracks;
+  if (mask != nullptr)
+    { // masked k-mers are dropped before the sort: the stable sort then leaves exactly the list the
+      // reference obtains by sorting them to the end as all-ones sentinels and cutting them off
+      // (map.c:536-542,722-724; identical unless a T^k k-mer ties with the sentinels under -T > 1)
+      StageTimer tm("kmer_mask", 32.0 * kmers);
+      const int64_t *anno = (const int64_t *) mask->anno;
+      const int64_t  nint = anno[nreads];
+      if (mask->data == nullptr && nint > 0) fatal("Sort_Kmers: mask track '%s' has no data loaded", mask->name);
+      if (nint & 1) fatal("Sort_Kmers: mask track '%s' holds an odd number of interval ends", mask->name);
+      DevBuf<int64_t>  d_anno;
+      DevBuf<int>      d_data;
+      DevBuf<uint32_t> keep, slot;
+      d_anno.ensure(nreads + 1, "mask offsets");
+      d_data.ensure(nint + 2, "mask intervals");
+      keep.ensure(kmers, "mask flags");
+      slot.ensure(kmers + 1, "mask slots");
+      copy_h2d(d_anno.p, anno, sizeof(int64_t) * (nreads + 1));
+      if (nint > 0) copy_h2d(d_data.p, mask->data, sizeof(int) * nint);
+      int nb = ceil_div(kmers, 256);
+      hipLaunchKernelGGL(k_mask_flag, dim3(nb), dim3(256), 0, stream(), (const uint32_t *) v0, kmers,
+                         (const int64_t *) bd.d_boff, nreads, pm.Kmer, (const int64_t *) d_anno.p,
+                         (const int *) d_data.p, keep.p);
+      HIP_CHECK(hipMemcpyAsync(slot.p, keep.p, sizeof(uint32_t) * kmers, hipMemcpyDeviceToDevice, stream()));
+      exclusive_scan_u32(slot.p, kmers, st.sort.bsum, slot.p + kmers);
+      hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0,
+                         (const uint32_t *) v0, (const uint32_t *) keep.p, (const uint32_t *) slot.p, kmers, k1, v1);
+      uint32_t kept = 0;
+      copy_d2h(&kept, slot.p + kmers, sizeof(uint32_t));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      std::swap(k0, k1);
+      std::swap(v0, v1);
+      kmers = kept;
+      d_anno.release(); d_data.release(); keep.release(); slot.release();
+    }
+
+  if (kmers > 0)
+    radix_sort_pairs(&k0, &v0, &k1, &v1, kmers, 0, pm.Kshift, st.sort, "kmer_sort");
+
+  if (pm.TooFrequent < INT32_MAX && kmers > 0)
     { StageTimer tm("kmer_suppress", 32.0 * kmers);
       DevBuf<uint32_t> keep, slot;
       keep.ensure(kmers, "suppress flags");
@@ -623,9 +685,9 @@ void *Sort_Kmers(DAZZ_DB *block, int *len)
       kmers = kept;
       keep.release();
       slot.release();
-      if (VERBOSE)
-        printf("   Revised kmer count = %lld\n", (long long) kmers);
     }
+  if (VERBOSE && (pm.TooFrequent < INT32_MAX || mask != nullptr))        // map.c:793-797
+    printf("   Revised kmer count = %lld\n", (long long) kmers);
 
   delete he;
   HostTimer hf("sk_finish");

@@ -16,9 +16,6 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
   Params &pm = st.params;
   static MergeResult R;
 
-  if (ablock->tracks != nullptr || bblock->tracks != nullptr)
-    fatal("Match_Filter: mask tracks (-m) are not supported by the HIP filter");
-
   int64_t nhits = 0, nfilt = 0;
   if (start)
     chain_reset_reads(ablock);

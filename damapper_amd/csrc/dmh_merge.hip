@@ -252,10 +252,22 @@ static int ceil_log2(int64_t x)      // smallest b with 2^b >= x
   return b;
 }
 
-// DB.c:1044-1076 restated for a block without tracks
+// DB.c:1044-1076 restated (no QV pseudo-track: damapper never loads one).  A track whose size field
+// says 4 has its int64 offsets read as ints there, exactly as the reference does for the merged
+// mask (damapper.c:262 sets size = sizeof(int) on an int64 vector).
 static int64_t sizeof_db(const DAZZ_DB *db)
-{ return 112 + 40 * ((int64_t) db->nreads + 2) + (int64_t) strlen(db->path) + 1
-         + (db->totlen + db->nreads + 4);
+{ int64_t s = 112 + 40 * ((int64_t) db->nreads + 2) + (int64_t) strlen(db->path) + 1
+              + (db->totlen + db->nreads + 4);
+  for (const DAZZ_TRACK *t = (const DAZZ_TRACK *) db->tracks; t != nullptr; t = t->next)
+    { s += (int64_t) sizeof(DAZZ_TRACK) + (int64_t) strlen(t->name) + 1 + (int64_t) t->size * (db->nreads + 1);
+      if (t->data != nullptr)
+        { if (t->size == 8)
+            s += 4 * ((const int64_t *) t->anno)[db->nreads];
+          else
+            s += 4 * (int64_t) ((const int *) t->anno)[db->nreads];
+        }
+    }
+  return s;
 }
 
 void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,

@@ -42,7 +42,17 @@ class DAZZ_DB(C.Structure):
     ]
 
 
-assert C.sizeof(DAZZ_READ) == 40 and C.sizeof(DAZZ_DB) == 112
+class DAZZ_TRACK(C.Structure):
+    """DB.h:306-316 (64 bytes on x86-64)."""
+
+
+DAZZ_TRACK._fields_ = [
+    ("next", C.POINTER(DAZZ_TRACK)), ("name", C.c_char_p), ("size", C.c_int), ("nreads", C.c_int),
+    ("anno", C.c_void_p), ("alen", C.c_void_p), ("data", C.c_void_p), ("loaded", C.c_int), ("_pad0", C.c_int),
+    ("dmax", C.c_int64),
+]
+
+assert C.sizeof(DAZZ_READ) == 40 and C.sizeof(DAZZ_DB) == 112 and C.sizeof(DAZZ_TRACK) == 64
 
 READ_DTYPE = np.dtype({
     "names": ["origin", "rlen", "fpulse", "boff", "coff", "flags"],
@@ -223,6 +233,67 @@ def write_db(directory: str, root: str, seqs: Sequence[np.ndarray], block_size: 
     return firsts
 
 
+Intervals = Sequence[Sequence[Tuple[int, int]]]      # per read: sorted, disjoint [begin, end) pairs
+
+
+def write_mask_track(directory: str, root: str, name: str, intervals: Intervals) -> None:
+    """Interval ("mask") track files .<root>.<name>.anno / .data as DBdust, TANmask or REPmask leave
+    them: anno = int32 nreads, int32 0 (size 0 marks a mask track, DB.c:1677), int64 byte offsets
+    [nreads+1]; data = int32 begin/end pairs (DB.c:1853-1957)."""
+    n = len(intervals)
+    off = np.zeros(n + 1, dtype=np.int64)
+    flat: List[int] = []
+    for i, iv in enumerate(intervals):
+        for b, e in iv:
+            flat += [int(b), int(e)]
+        off[i + 1] = 4 * len(flat)
+    with open(os.path.join(directory, ".%s.%s.anno" % (root, name)), "wb") as f:
+        f.write(np.array([n, 0], dtype=np.int32).tobytes())
+        f.write(off.tobytes())
+    with open(os.path.join(directory, ".%s.%s.data" % (root, name)), "wb") as f:
+        f.write(np.array(flat, dtype=np.int32).tobytes())
+
+
+def read_mask_track(directory: str, root: str, name: str, lo: int, hi: int, total: int) -> Optional[List[List[Tuple[int, int]]]]:
+    """Intervals of reads [lo, hi) of a whole-DB mask track, or None when the DB has no such track
+    (Check_Track returning -2, damapper.c:352-366)."""
+    an = os.path.join(directory, ".%s.%s.anno" % (root, name))
+    if not os.path.exists(an):
+        return None
+    with open(an, "rb") as f:
+        tracklen, size = np.frombuffer(f.read(8), dtype=np.int32)
+        if size != 0:
+            raise ValueError("%s track is not a mask track." % name)            # damapper.c:355-358
+        if tracklen != total:
+            print("Warning: %s track not sync'd with db %s, ignored." % (name, root))
+            return None
+        off = np.frombuffer(f.read(8 * (total + 1)), dtype=np.int64)
+    data = np.fromfile(os.path.join(directory, ".%s.%s.data" % (root, name)), dtype=np.int32)
+    out = []
+    for r in range(lo, hi):
+        d = data[off[r] // 4:off[r + 1] // 4]
+        out.append([(int(d[j]), int(d[j + 1])) for j in range(0, len(d), 2)])
+    return out
+
+
+def union_intervals(tracks: Sequence[Intervals]) -> List[List[Tuple[int, int]]]:
+    """Union of several masks per read (merge_tracks, damapper.c:232-343: an event sweep that keeps
+    the outermost begin/end of every covered stretch)."""
+    n = len(tracks[0])
+    out: List[List[Tuple[int, int]]] = []
+    for r in range(n):
+        ev = sorted(iv for t in tracks for iv in t[r])
+        cur: List[Tuple[int, int]] = []
+        for b, e in ev:
+            if cur and b <= cur[-1][1]:
+                if e > cur[-1][1]:
+                    cur[-1] = (cur[-1][0], e)
+            else:
+                cur.append((b, e))
+        out.append(cur)
+    return out
+
+
 @dataclass
 class Block:
     """An in-memory DAZZ_DB block laid out exactly as Load_All_Reads leaves it
@@ -231,6 +302,47 @@ class Block:
     bases: np.ndarray        # uint8, [4] r0 [4] r1 ... [4]; db.bases points at element 1
     reads: np.ndarray        # READ_DTYPE, nreads+2 records; db.reads points at record 1
     path: bytes
+    track: Optional[DAZZ_TRACK] = None       # the k-mer mask (-m), if any
+    track_anno: Optional[np.ndarray] = None  # int64[nreads+1], in ints (damapper.c:386-388)
+    track_data: Optional[np.ndarray] = None  # int32 begin/end pairs
+    track_alen: Optional[np.ndarray] = None
+
+    def set_mask(self, intervals: Optional[Intervals], merged: bool = False) -> None:
+        """Attach the (already merged) mask as block->tracks, the way read_DB leaves it: a single
+        track keeps Open_Track's size 8, a merge of several is named "merge" with size 4
+        (damapper.c:243-262)."""
+        if intervals is None:
+            self.track = None
+            self.db.tracks = None
+            return
+        n = self.nreads
+        assert len(intervals) == n
+        anno = np.zeros(n + 1, dtype=np.int64)
+        flat: List[int] = []
+        for i, iv in enumerate(intervals):
+            for b, e in iv:
+                flat += [int(b), int(e)]
+            anno[i + 1] = len(flat)
+        self.track_anno = anno
+        self.track_data = np.array(flat + [0, 0], dtype=np.int32)
+        self.track_alen = np.diff(anno).astype(np.int32)
+        t = DAZZ_TRACK()
+        t.name = b"merge" if merged else b"mask"
+        t.size = 4 if merged else 8
+        t.nreads = n
+        t.anno = self.track_anno.ctypes.data
+        t.alen = self.track_alen.ctypes.data
+        t.data = self.track_data.ctypes.data
+        t.loaded = 1
+        t.dmax = int(self.track_alen.max()) * 4 if n else 0
+        self.track = t
+        self.db.tracks = C.cast(C.pointer(t), C.c_void_p)
+
+    def mask_intervals(self) -> Optional[List[List[Tuple[int, int]]]]:
+        if self.track is None:
+            return None
+        a, d = self.track_anno, self.track_data
+        return [[(int(d[j]), int(d[j + 1])) for j in range(int(a[i]), int(a[i + 1]), 2)] for i in range(self.nreads)]
 
     @property
     def nreads(self) -> int:
@@ -260,6 +372,12 @@ class Block:
         f = self.db.freq
         f[0], f[3] = f[3], f[0]
         f[1], f[2] = f[2], f[1]
+        if self.track is not None:              # damapper.c:505-518: intervals mirror with the read
+            a, d = self.track_anno, self.track_data
+            for i in range(self.nreads):
+                lo, hi = int(a[i]), int(a[i + 1])
+                if hi > lo:
+                    d[lo:hi] = int(self.reads[i + 1]["rlen"]) - d[lo:hi][::-1]
 
 
 def make_block(seqs: Sequence[np.ndarray], tfirst: int = 0, part: int = 0,
@@ -384,9 +502,11 @@ def read_stub(path: str) -> Tuple[int, List[Tuple[int, int]]]:
     return nblocks, firsts
 
 
-def load_db(path: str, part: int = 0) -> Block:
+def load_db(path: str, part: int = 0, masks: Sequence[str] = (), used: Optional[set] = None) -> Block:
     """Open + Load_All_Reads equivalent for DBs written by `write_db` (no trimming:
-    cutoff=0, all=1). `path` is 'dir/root.db'; part k > 0 loads block k."""
+    cutoff=0, all=1). `path` is 'dir/root.db'; part k > 0 loads block k.  `masks` are -m track
+    names: those the DB has are loaded, merged into one mask and attached (read_DB,
+    damapper.c:345-414); their names are added to `used` (the MSTAT bookkeeping)."""
     d, base = os.path.split(path)
     d = d or "."
     root = base[:-3] if base.endswith(".db") else base
@@ -407,4 +527,92 @@ def load_db(path: str, part: int = 0) -> Block:
     blk = make_block(seqs, tfirst=lo, part=part,
                      path=os.path.join(d, "." + root).encode(),
                      freq=[hdr.freq[j] for j in range(4)])
+    found = []
+    for name in masks:
+        iv = read_mask_track(d, root, name, lo, hi, int(hdr.ureads))
+        if iv is not None:
+            found.append(iv)
+            if used is not None:
+                used.add(name)
+    if len(found) == 1:
+        blk.set_mask(found[0])
+    elif len(found) > 1:
+        blk.set_mask(union_intervals(found), merged=True)
     return blk
+
+
+# ------------------------------------------------------------------------------------------
+#  FASTA import (the fasta2DB / fasta2DAM + DBsplit subset needed to feed the mapper)
+# ------------------------------------------------------------------------------------------
+
+_CODE = np.full(256, 4, dtype=np.uint8)
+for _i, _ch in enumerate("acgt"):
+    _CODE[ord(_ch)] = _i
+    _CODE[ord(_ch.upper())] = _i
+
+
+def read_fasta(path: str, split_n: bool = True, min_len: int = 1) -> Tuple[List[np.ndarray], List[str]]:
+    """Sequences of a FASTA file as 0..3 arrays.  Runs of non-ACGT letters split an entry into
+    contigs (what fasta2DAM does with scaffolds); with split_n=False such an entry is an error
+    (fasta2DB's behaviour).  Returns (sequences, names) -- a split entry yields name/1, name/2 ..."""
+    seqs: List[np.ndarray] = []
+    names: List[str] = []
+
+    def flush(name, chunks):
+        if name is None:
+            return
+        raw = np.frombuffer("".join(chunks).encode("ascii", "replace"), dtype=np.uint8)
+        code = _CODE[raw]
+        bad = code > 3
+        if not bad.any():
+            parts = [code]
+        elif not split_n:
+            raise ValueError("%s: entry %s contains letters other than ACGT" % (path, name))
+        else:
+            edges = np.flatnonzero(np.diff(np.concatenate(([1], bad.astype(np.int8), [1]))))
+            parts = [code[edges[j]:edges[j + 1]] for j in range(0, len(edges) - 1, 2)]
+        keep = [p for p in parts if len(p) >= min_len]
+        for j, p in enumerate(keep):
+            seqs.append(np.ascontiguousarray(p))
+            names.append(name if len(keep) == 1 else "%s/%d" % (name, j + 1))
+
+    name, chunks = None, []
+    with open(path) as f:
+        for line in f:
+            if line.startswith(">"):
+                flush(name, chunks)
+                name, chunks = line[1:].split()[0] if len(line) > 1 and line[1:].split() else "seq%d" % len(names), []
+            else:
+                chunks.append(line.strip())
+    flush(name, chunks)
+    return seqs, names
+
+
+def fasta_to_db(fasta: str, directory: str, root: str, block_size: int = 200_000_000, split_n: bool = True,
+                min_len: int = 1) -> List[int]:
+    """fasta2DB/fasta2DAM followed by DBsplit -s<block_size>: writes <root>.db and its hidden files."""
+    seqs, _ = read_fasta(fasta, split_n=split_n, min_len=min_len)
+    if not seqs:
+        raise ValueError("%s holds no sequence" % fasta)
+    return write_db(directory, root, seqs, block_size=block_size)
+
+
+def _main(argv=None) -> int:
+    import argparse
+    ap = argparse.ArgumentParser(prog="damapper_amd.dazzdb", description="build a DAZZ_DB from FASTA")
+    ap.add_argument("db", help="path of the DB to create, e.g. dir/REF or dir/REF.db")
+    ap.add_argument("fasta")
+    ap.add_argument("-s", type=float, default=200.0, help="block size in Mbp (DBsplit -s)")
+    ap.add_argument("-x", type=int, default=1, help="drop sequences shorter than this (DBsplit -x)")
+    ap.add_argument("--strict", action="store_true", help="reject non-ACGT letters instead of splitting contigs there")
+    a = ap.parse_args(argv)
+    d, base = os.path.split(a.db)
+    root = base[:-3] if base.endswith(".db") else base
+    firsts = fasta_to_db(a.fasta, d or ".", root, block_size=int(a.s * 1e6), split_n=not a.strict, min_len=a.x)
+    print("%s: %d sequences in %d block(s)" % (root, firsts[-1], len(firsts) - 1))
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(_main())

@@ -3,7 +3,7 @@ HPC.damapper.c:369-442): every read block of a DAZZ_DB is an independent unit, b
 b mod N, the reference index is rebuilt on each GPU, and a block whose output files already exist
 is skipped (resume granularity = read block, as HPC.damapper.c:329-354).
 
-    python -m damapper_amd.dispatch REF.db READS.db --gpus 8 [-k20 -e.85 -s100 -T4 -p -C -N -z] [--finish]
+    python -m damapper_amd.dispatch REF.db READS.db --gpus 8 [-k20 -e.85 -s100 -T4 -p -C -N -z -m<track>...] [--finish]
 
 --finish runs the LAsort/LAcat/LAmerge post-step (damapper.c:887-910) per block, leaving
 `<reads>.<b>.<ref>.las` (and `<ref>.<reads>.<b>.las` for -C) next to the reference DB.
@@ -33,7 +33,8 @@ def _worker(args) -> None:
     m = driver.Mapper(kmer=args.k, suppress=args.t, threads=args.T, ave_corr=args.e, spacing=args.s,
                       best_tie=args.n, profile=int(args.p), verbose=int(args.v), sort_path=out)
     nb, _ = read_stub(os.path.join(d, ref_root + ".db"))
-    ref_blocks = [load_db(os.path.join(d, ref_root + ".db"), part=k + 1) for k in range(nb)]
+    used: set = set()
+    ref_blocks = [load_db(os.path.join(d, ref_root + ".db"), part=k + 1, masks=args.m, used=used) for k in range(nb)]
     ref_whole = load_db(os.path.join(d, ref_root + ".db"))
     if args.N and not args.C:
         raise SystemExit("damapper_amd.dispatch: Cannot specify N flag without C also")     # damapper.c:716
@@ -54,7 +55,7 @@ def _worker(args) -> None:
         if done and not args.force:
             print("[gpu %d] %s: output present, skipped" % (args.rank, name), flush=True)
             continue
-        reads = load_db(os.path.join(rd or ".", read_root + ".db"), part=b)
+        reads = load_db(os.path.join(rd or ".", read_root + ".db"), part=b, masks=args.m, used=used)
         t0 = time.time()
         m.map_block(reads, name, ref_blocks, ref_whole, ref_root, mflag=mflag)
         mapped.append(name)
@@ -83,6 +84,7 @@ def main(argv=None) -> int:
     ap.add_argument("-T", type=int, default=4)
     ap.add_argument("-p", action="store_true")
     ap.add_argument("-v", action="store_true")
+    ap.add_argument("-m", action="append", default=[], metavar="TRACK", help="k-mer mask track (repeatable)")
     ap.add_argument("-C", action="store_true", help="also write the reference-vs-reads files")
     ap.add_argument("-N", action="store_true", help="with -C: no reads-vs-reference files")
     ap.add_argument("-z", action="store_true", help="--finish sorts by A,B-read piles instead of map order")

@@ -153,7 +153,7 @@ def finish_block(sort_path: str, reads_name: str, ref_name: str, mflag: int = ca
 
 
 def map_db(workdir: str, ref_root: str, read_root: str, sort_path: Optional[str] = None,
-           mflag: int = capi.FLAG_DOA, **kw) -> Dict[str, float]:
+           mflag: int = capi.FLAG_DOA, masks: Sequence[str] = (), **kw) -> Dict[str, float]:
     """damapper <ref> <reads> on DBs written by dazzdb.write_db (all blocks of the reads DB).
     mflag: FLAG_DOA (default), FLAG_DOA|FLAG_DOB (-C) or FLAG_DOB (-C -N), damapper.c:709-720."""
     sort_path = sort_path or os.path.join(workdir, "las_hip")
@@ -162,9 +162,14 @@ def map_db(workdir: str, ref_root: str, read_root: str, sort_path: Optional[str]
     os.chdir(workdir)        # the -p track files go to the current directory (map.c:3301-3302)
     try:
         nb, _ = read_stub(ref_root + ".db")
-        ref_blocks = [load_db("./" + ref_root + ".db", part=k + 1) for k in range(nb)]
-        ref_whole = load_db("./" + ref_root + ".db")
-        reads = load_db("./" + read_root + ".db")
-        return m.map_block(reads, read_root, ref_blocks, ref_whole, ref_root, mflag=mflag)
+        used: set = set()
+        ref_blocks = [load_db("./" + ref_root + ".db", part=k + 1, masks=masks, used=used) for k in range(nb)]
+        ref_whole = load_db("./" + ref_root + ".db")           # Reporter's copy carries no mask (damapper.c:790)
+        reads = load_db("./" + read_root + ".db", masks=masks, used=used)
+        out = m.map_block(reads, read_root, ref_blocks, ref_whole, ref_root, mflag=mflag)
+        for name in masks:
+            if name not in used:
+                print("damapper: Warning: Track %s given but never used." % name)      # damapper.c:916-918
+        return out
     finally:
         os.chdir(cwd)

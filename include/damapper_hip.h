@@ -45,8 +45,23 @@ typedef struct
     int        loaded;
     void      *bases;   /* [4] r0 [4] r1 ... [4], one byte per base 0..3 (DB.c:1402-1437)   */
     DAZZ_READ *reads;   /* valid for [-1..nreads]                                           */
-    void      *tracks;
+    void      *tracks;  /* DAZZ_TRACK list; the first one is the k-mer mask (map.c:701)         */
   } DAZZ_DB;
+
+/* DB.h:306-316.  The filter reads only the first track of a block, as an interval mask: for read i
+ * data[anno[i] .. anno[i+1]) holds sorted [begin,end) pairs, anno counted in ints (damapper.c:386-388);
+ * k-mers touching a masked base are left out of the index (map.c:481-543).                        */
+typedef struct _dmh_track
+  { struct _dmh_track *next;
+    char    *name;
+    int      size;     /* bytes per anno record as recorded by the driver (see sizeof_DB, DB.c:1063) */
+    int      nreads;
+    void    *anno;     /* int64[nreads+1]                                                          */
+    int     *alen;
+    void    *data;     /* int[]                                                                    */
+    int      loaded;
+    int64_t  dmax;
+  } DAZZ_TRACK;
 #endif
 
 typedef void Align_Spec;   /* opaque, align.h:186 */

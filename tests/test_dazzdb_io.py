@@ -1,0 +1,67 @@
+"""DAZZ_DB side formats written/read by damapper_amd.dazzdb: FASTA import, mask tracks (-m)."""
+import os
+
+import numpy as np
+
+from damapper_amd import dazzdb
+
+
+def test_fasta_import_roundtrip(tmp_path):
+    d = str(tmp_path)
+    rng = np.random.default_rng(5)
+    a = "".join("ACGT"[x] for x in rng.integers(0, 4, 700))
+    b = "".join("acgt"[x] for x in rng.integers(0, 4, 300))
+    with open(os.path.join(d, "x.fa"), "w") as f:
+        f.write(">chr1 some text\n")
+        for i in range(0, len(a), 60):
+            f.write(a[i:i + 60] + "\n")
+        f.write(">scaf\n" + b[:100] + "NNNNNNNNNN" + b[100:] + "\n>tiny\nACG\n")
+    seqs, names = dazzdb.read_fasta(os.path.join(d, "x.fa"), min_len=20)
+    assert names == ["chr1", "scaf/1", "scaf/2"]
+    assert [len(s) for s in seqs] == [700, 100, 200]
+    assert "".join("ACGT"[x] for x in seqs[0]) == a
+    assert dazzdb._main([os.path.join(d, "X.db"), os.path.join(d, "x.fa"), "-s", "0.0005", "-x", "20"]) == 0
+    nb, _ = dazzdb.read_stub(os.path.join(d, "X.db"))
+    assert nb == 2                                        # 700 | 100+200
+    blk = dazzdb.load_db(os.path.join(d, "X.db"))
+    assert blk.nreads == 3 and np.array_equal(blk.seq(2), seqs[2])
+    try:
+        dazzdb.read_fasta(os.path.join(d, "x.fa"), split_n=False)
+        assert False
+    except ValueError:
+        pass
+
+
+def test_mask_track_files_and_union(tmp_path):
+    d = str(tmp_path)
+    rng = np.random.default_rng(6)
+    g = dazzdb.random_genome(rng, [5000, 4000, 3000, 2000])
+    dazzdb.write_db(d, "G", g, block_size=9000)           # blocks: reads {0,1} and {2,3}
+    m1 = [[(10, 50), (400, 900)], [], [(0, 100)], [(1990, 2000)]]
+    m2 = [[(40, 60), (2000, 2100)], [(5, 6)], [(100, 150), (300, 301)], []]
+    dazzdb.write_mask_track(d, "G", "a", m1)
+    dazzdb.write_mask_track(d, "G", "b", m2)
+    used = set()
+    blk = dazzdb.load_db(os.path.join(d, "G.db"), part=2, masks=["a", "zz"], used=used)
+    assert used == {"a"} and blk.mask_intervals() == m1[2:]
+    assert blk.track.size == 8 and blk.track.name == b"mask"
+    blk = dazzdb.load_db(os.path.join(d, "G.db"), masks=["a", "b"])
+    assert blk.track.size == 4 and blk.track.name == b"merge"
+    assert blk.mask_intervals() == [[(10, 60), (400, 900), (2000, 2100)], [(5, 6)], [(0, 150), (300, 301)], [(1990, 2000)]]
+    # brute-force union per base
+    for r, iv in enumerate(blk.mask_intervals()):
+        cov = np.zeros(len(g[r]) + 1, dtype=bool)
+        for t in (m1, m2):
+            for b, e in t[r]:
+                cov[b:e] = True
+        got = np.zeros_like(cov)
+        for b, e in iv:
+            got[b:e] = True
+        assert np.array_equal(cov, got)
+    # the in-place complement mirrors the intervals and is an involution
+    before = blk.mask_intervals()
+    blk.complement_inplace()
+    assert blk.mask_intervals()[0] == [(5000 - 2100, 5000 - 2000), (5000 - 900, 5000 - 400), (5000 - 60, 5000 - 10)]
+    blk.complement_inplace()
+    assert blk.mask_intervals() == before
+    assert dazzdb.load_db(os.path.join(d, "G.db"), masks=["zz"]).track is None

@@ -85,3 +85,58 @@ def test_sort_kmers_matches_reference(K, supp):
     assert np.array_equal(got["rpos"], rarr["rpos"][:n])
     capi.lib().dmh_free_index(h)
     ref.free(rh)
+
+
+def _random_mask(rng, lens, K, density=6):
+    """Sorted disjoint [begin,end) intervals per read, incl. edge shapes: touching read ends,
+    zero-length, shorter than k, gaps shorter than k."""
+    out = []
+    for n in lens:
+        cuts = sorted(set(int(x) for x in rng.integers(0, n + 1, size=2 * int(rng.integers(0, density)))))
+        if len(cuts) % 2:
+            cuts = cuts[:-1]
+        iv = [(cuts[j], cuts[j + 1]) for j in range(0, len(cuts), 2)]
+        if n > 200 and rng.random() < .5:
+            iv = sorted(set(iv + [(0, 7)])) if not iv or iv[0][0] > 7 else iv
+        if n > 200 and rng.random() < .5 and (not iv or iv[-1][1] < n - K - 5):
+            iv.append((n - 3, n))
+        out.append(iv)
+    return out
+
+
+@pytest.mark.parametrize("K,supp,comp", [(20, 0, False), (20, 4, True), (12, 0, True)])
+def test_masked_sort_kmers_matches_reference(K, supp, comp):
+    """-m: k-mers touching a masked interval are left out (map.c:481-543), also after the in-place
+    complement, which mirrors the intervals (damapper.c:505-518)."""
+    ref = _ref()
+    rng = np.random.default_rng(17 + K)
+    g = dazzdb.repeat_rich_genome(rng, [60000, 30000, 500, 25, 40000])
+    blk = dazzdb.make_block(g)
+    blk.set_mask(_random_mask(rng, [len(s) for s in g], K))
+    if comp:
+        blk.complement_inplace()
+    ref.lib().Set_Filter_Params(K, supp, 4)
+    rh, rn, rarr = ref.sort_kmers(blk)
+    capi.lib().Set_Filter_Params(K, supp, 4)
+    h, n = capi.sort_kmers(blk)
+    assert n == rn and 0 < n < sum(len(s) for s in g)
+    got = capi.index_download(h, n)
+    assert np.array_equal(got["code"], rarr["code"][:n])
+    assert np.array_equal(got["read"], rarr["read"][:n])
+    assert np.array_equal(got["rpos"], rarr["rpos"][:n])
+    # every surviving k-mer lies inside one unmasked gap
+    iv = blk.mask_intervals()
+    for r, p in zip(got["read"][::97], got["rpos"][::97]):
+        assert all(not (b <= p and e > p - (K - 1)) for b, e in iv[int(r)])
+    capi.lib().dmh_free_index(h)
+    ref.free(rh)
+
+
+def test_fully_masked_block_gives_empty_index():
+    rng = np.random.default_rng(3)
+    g = dazzdb.random_genome(rng, [3000, 2000])
+    blk = dazzdb.make_block(g)
+    blk.set_mask([[(0, 3000)], [(0, 2000)]])
+    capi.lib().Set_Filter_Params(20, 0, 4)
+    h, n = capi.sort_kmers(blk)
+    assert n == 0 and not h

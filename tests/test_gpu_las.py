@@ -116,6 +116,41 @@ def test_cover_files_identical_to_reference(case, tmp_path):
         assert not os.path.exists(os.path.join(d, "las_hip", "READS.REF.M1.las"))
 
 
+def test_mask_tracks_identical_to_reference(tmp_path):
+    """-m<track>: two masks on the REF (merged, damapper.c:232-343), one on the READS, one that no DB
+    has; multi-block REF so the per-block slices of the track are exercised."""
+    run_ref = _run_ref()
+    rng = np.random.default_rng(71)
+    g, reads = make_dataset("repeat", 71, [220000, 180000, 150000], 90, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=300000)
+    dazzdb.write_db(d, "READS", reads)
+
+    def masks(seqs, k):
+        out = []
+        for s in seqs:
+            n = len(s)
+            cuts = sorted(set(int(x) for x in rng.integers(0, n, size=2 * k)))
+            cuts = cuts[:len(cuts) // 2 * 2]
+            out.append([(cuts[j], cuts[j + 1]) for j in range(0, len(cuts), 2) if cuts[j + 1] - cuts[j] < n // 6])
+        return out
+
+    dazzdb.write_mask_track(d, "REF", "dust", masks(g, 40))
+    dazzdb.write_mask_track(d, "REF", "tan", masks(g, 12))
+    dazzdb.write_mask_track(d, "READS", "dust", masks(reads, 3))
+    flags = ["-mdust", "-mtan", "-mnone"]
+    run_ref.run_reference(d, "REF", ["READS"], flags=flags + ["-M8"], threads=4)
+    run_ref.run_reference(d, "REF", ["READS"], flags=["-M8"], threads=4, keep="las_nomask")
+    driver.map_db(d, "REF", "READS", threads=4, mem_limit=8 << 30, masks=["dust", "tan", "none"])
+    ts_r, rr = las.read_las_set(os.path.join(d, "las_ref"), "READS.REF.M@.las")
+    ts_h, hr = las.read_las_set(os.path.join(d, "las_hip"), "READS.REF.M@.las")
+    _, nomask = las.read_las_set(os.path.join(d, "las_nomask"), "READS.REF.M@.las")
+    assert len(rr) > 0 and rr != nomask, "the masks must change the result for this test to mean anything"
+    assert ts_r == ts_h and len(rr) == len(hr)
+    for i, (a, b) in enumerate(zip(rr, hr)):
+        assert a == b, "record %d differs:\n%s\n%s" % (i, a, b)
+
+
 def test_reference_driver_linked_against_hip_library(tmp_path):
     """Drop-in proof: the reference's own damapper.c/DB.c/QV.c, linked against libdamapper_hip.so instead
     of map.c + align.c (oracle/_ref/damapper_hip), writes the same .las files as the all-CPU reference."""
