@@ -597,6 +597,19 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
 //  returns AL_ERR_BAND when the band outgrows the ring and the caller re-runs the pass with the
 //  LDS ring.
 // ---------------------------------------------------------------------------------------
+#ifdef DMH_ALIGN_PROFILE
+// [0] cycles in register passes, [1] in fallback passes, [2] in trace backs, [3] #register passes,
+// [4] #fallback passes, [5] sum of wave counts (trimd+mored proxy: ncell), [6] cycles per job, [7] #jobs, [8..11] passes with max band <=14, <=30, <=46, <=62, [12] sum of band widths, [13] wave steps
+__device__ unsigned long long g_aprof[16];
+#define APROF_T0() long long _t0 = clock64()
+#define APROF_ADD(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_aprof[i], (unsigned long long) (v)); } while (0)
+#define APROF_LAP(i) do { long long _t1 = clock64(); APROF_ADD(i, _t1 - _t0); _t0 = _t1; } while (0)
+#else
+#define APROF_T0() do {} while (0)
+#define APROF_ADD(i, v) do {} while (0)
+#define APROF_LAP(i) do {} while (0)
+#endif
+
 constexpr int REG_BAND = 62;
 
 __device__ __forceinline__ int dpp_from_left(int v)      // lane i <- lane i-1 (wraps)
@@ -643,10 +656,75 @@ __device__ __forceinline__ void build_trim_tab(int2 *tab, int mscore, int dscore
     }
 }
 
-template <int DIR, bool WANT_B, typename WK>
+
+// ---------------------------------------------------------------------------------------
+//  Lane groups.  An alignment occupies G lanes of a wavefront: G = 64 (one per wavefront) or G = 32
+//  (two independent alignments per wavefront; bands of 10 kb reads at 15 % error peak below 30
+//  diagonals, so half the lanes of a 64-wide band would idle).  Everything the pass needs from its
+//  neighbours goes through these five primitives.
+// ---------------------------------------------------------------------------------------
+template <int G> struct Grp;
+
+template <> struct Grp<64>
+{ static constexpr int BAND = 62;
+  static __device__ __forceinline__ int  gl()   { return threadIdx.x & 63; }
+  static __device__ __forceinline__ int  from_left(int v)  { return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xf, 0xf, false); }
+  static __device__ __forceinline__ int  from_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
+  static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+  static __device__ __forceinline__ uint64_t rot_right(uint64_t m, int r)
+  { r &= 63;
+    return r ? ((m >> r) | (m << (64 - r))) : m;
+  }
+  static __device__ __forceinline__ int  read(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+  static __device__ __forceinline__ int  excl_scan(int v, int &total)
+  { const int lane = threadIdx.x & 63;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+      { int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+      }
+    total = __shfl(x, 63);
+    return x - v;
+  }
+};
+
+template <> struct Grp<32>
+{ static constexpr int BAND = 30;
+  static __device__ __forceinline__ int  gl()   { return threadIdx.x & 31; }
+  static __device__ __forceinline__ int  base() { return threadIdx.x & 32; }
+  // cross-lane reads inside a 32-lane half go through the LDS crossbar (ds_bpermute): one LDS-pipe
+  // instruction each, off the VALU that bounds this kernel
+  static __device__ __forceinline__ int  from_left(int v)
+  { return __builtin_amdgcn_ds_bpermute((base() | ((threadIdx.x - 1) & 31)) << 2, v); }
+  static __device__ __forceinline__ int  from_right(int v)
+  { return __builtin_amdgcn_ds_bpermute((base() | ((threadIdx.x + 1) & 31)) << 2, v); }
+  static __device__ __forceinline__ uint64_t ballot(bool p)
+  { return (__ballot(p) >> base()) & 0xffffffffull; }
+  static __device__ __forceinline__ uint64_t rot_right(uint64_t m, int r)
+  { uint32_t x = (uint32_t) m;
+    r &= 31;
+    return r ? ((x >> r) | (x << (32 - r))) : x;
+  }
+  static __device__ __forceinline__ int  read(int x, int l)
+  { return __builtin_amdgcn_ds_bpermute((base() | (l & 31)) << 2, x); }
+  static __device__ __forceinline__ int  excl_scan(int v, int &total)
+  { const int gl_ = threadIdx.x & 31;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1)
+      { int y = __shfl_up(x, o, 32);
+        if (gl_ >= o) x += y;
+      }
+    total = __shfl(x, 31, 32);
+    return x - v;
+  }
+};
+
+template <int DIR, bool WANT_B, typename WK, int G = 64>
 __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView &S,
                              int k0, int mida, int aoff, int boff, WaveEnd &E)
-{ const int  lane = threadIdx.x & 63;
+{ const int  lane = Grp<G>::gl();        // lane within the alignment's group
   const int  TS   = sp.TS;
   const int  OUTV = (DIR > 0) ? -1 : AL_BIG;
   const int  soff = (DIR > 0) ? 0 : -1;
@@ -658,6 +736,9 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
   int besta, besty, trima, trimy, trimd, trimha, trimhb;
   int morea, morey, mored, moreha, morehb, morem, lasta;
   int ncell = 0;
+#ifdef DMH_ALIGN_PROFILE
+  int prof_maxw = 1, prof_sumw = 0;
+#endif
 
   // per-lane state of "my" diagonal
   int      V = OUTV, M = 0, HA = 0, HB = 0, HAM = 0, HBM = 0, NA = 0, NB = 0;
@@ -734,7 +815,7 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
         if (c < besta)
           { besta = trima = lasta = c; besty = trimy = y; trimha = ha; trimhb = hb; }
       }
-    if (lane == (k & 63))
+    if (lane == (k & (G - 1)))
       { V = c; M = AL_PATH_LEN;
         TL = (uint32_t) (AL_PATH_INT & 0xffffffffu);
         TH = (uint32_t) (AL_PATH_INT >> 32);
@@ -753,22 +834,22 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
     if (DIR > 0)
       { if (hgh >= aclip)
           { hgh = aclip - 1;
-            int l = aclip & 63;
-            int m = __builtin_amdgcn_readlane(M, l);
+            int l = aclip & (G - 1);
+            int m = Grp<G>::read(M, l);
             if (morem <= m)
-              { morem = m; morea = __builtin_amdgcn_readlane(V, l); morey = (morea - aclip) / 2;
+              { morem = m; morea = Grp<G>::read(V, l); morey = (morea - aclip) / 2;
                 if (setd) mored = dif;
-                moreha = __builtin_amdgcn_readlane(HA, l); morehb = __builtin_amdgcn_readlane(HB, l);
+                moreha = Grp<G>::read(HA, l); morehb = Grp<G>::read(HB, l);
               }
           }
         if (low <= bclip)
           { low = bclip + 1;
-            int l = bclip & 63;
-            int m = __builtin_amdgcn_readlane(M, l);
+            int l = bclip & (G - 1);
+            int m = Grp<G>::read(M, l);
             if (morem <= m)
-              { morem = m; morea = __builtin_amdgcn_readlane(V, l); morey = (morea - bclip) / 2;
+              { morem = m; morea = Grp<G>::read(V, l); morey = (morea - bclip) / 2;
                 if (setd) mored = dif;
-                moreha = __builtin_amdgcn_readlane(HA, l); morehb = __builtin_amdgcn_readlane(HB, l);
+                moreha = Grp<G>::read(HA, l); morehb = Grp<G>::read(HB, l);
               }
           }
         aclip = AL_BIG;
@@ -777,22 +858,22 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
     else
       { if (low <= aclip)
           { low = aclip + 1;
-            int l = aclip & 63;
-            int m = __builtin_amdgcn_readlane(M, l);
+            int l = aclip & (G - 1);
+            int m = Grp<G>::read(M, l);
             if (morem <= m)
-              { morem = m; morea = __builtin_amdgcn_readlane(V, l); morey = (morea - aclip) / 2;
+              { morem = m; morea = Grp<G>::read(V, l); morey = (morea - aclip) / 2;
                 if (setd) mored = dif;
-                moreha = __builtin_amdgcn_readlane(HA, l); morehb = __builtin_amdgcn_readlane(HB, l);
+                moreha = Grp<G>::read(HA, l); morehb = Grp<G>::read(HB, l);
               }
           }
         if (hgh >= bclip)
           { hgh = bclip - 1;
-            int l = bclip & 63;
-            int m = __builtin_amdgcn_readlane(M, l);
+            int l = bclip & (G - 1);
+            int m = Grp<G>::read(M, l);
             if (morem <= m)
-              { morem = m; morea = __builtin_amdgcn_readlane(V, l); morey = (morea - bclip) / 2;
+              { morem = m; morea = Grp<G>::read(V, l); morey = (morea - bclip) / 2;
                 if (setd) mored = dif;
-                moreha = __builtin_amdgcn_readlane(HA, l); morehb = __builtin_amdgcn_readlane(HB, l);
+                moreha = Grp<G>::read(HA, l); morehb = Grp<G>::read(HB, l);
               }
           }
         aclip = -AL_BIG;
@@ -807,26 +888,30 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
       if (hgh < low) return AL_ERR_BAND;
       low -= 1;
       hgh += 1;
-      if (hgh - low + 1 > REG_BAND) return AL_ERR_BAND;
+      if (hgh - low + 1 > Grp<G>::BAND) return AL_ERR_BAND;
       if (dif > S.alen + S.blen + 64) return AL_ERR_LOOP;
       dif += 1;
+#ifdef DMH_ALIGN_PROFILE
+      if (hgh - low + 1 > prof_maxw) prof_maxw = hgh - low + 1;
+      prof_sumw += hgh - low + 1;
+#endif
 
-      const int  k      = low + ((lane - low) & 63);     // the diagonal of this lane in the new band
+      const int  k      = low + ((lane - low) & (G - 1));     // the diagonal of this lane in the new band
       const bool active = (k <= hgh);
       const bool inold  = active && (k > low) && (k < hgh);
       const int  vold   = inold ? V : OUTV;
 
       // neighbours' previous-wave state (all lanes take part in the rotations)
-      const int am = dpp_from_left(vold), ap = dpp_from_right(vold), ac = vold;
-      const int nal = dpp_from_left(NA),  nar = dpp_from_right(NA);
-      const int nbl = dpp_from_left(NB),  nbr = dpp_from_right(NB);
-      const int Ml = dpp_from_left(M),    Mr = dpp_from_right(M);
-      const int TLl = dpp_from_left((int) TL), TLr = dpp_from_right((int) TL);
-      const int THl = dpp_from_left((int) TH), THr = dpp_from_right((int) TH);
-      const int HAl = dpp_from_left(HA),  HAr = dpp_from_right(HA);
-      const int HBl = dpp_from_left(HB),  HBr = dpp_from_right(HB);
-      const int HAMl = dpp_from_left(HAM), HAMr = dpp_from_right(HAM);
-      const int HBMl = dpp_from_left(HBM), HBMr = dpp_from_right(HBM);
+      const int am = Grp<G>::from_left(vold), ap = Grp<G>::from_right(vold), ac = vold;
+      const int nal = Grp<G>::from_left(NA),  nar = Grp<G>::from_right(NA);
+      const int nbl = Grp<G>::from_left(NB),  nbr = Grp<G>::from_right(NB);
+      const int Ml = Grp<G>::from_left(M),    Mr = Grp<G>::from_right(M);
+      const int TLl = Grp<G>::from_left((int) TL), TLr = Grp<G>::from_right((int) TL);
+      const int THl = Grp<G>::from_left((int) TH), THr = Grp<G>::from_right((int) TH);
+      const int HAl = Grp<G>::from_left(HA),  HAr = Grp<G>::from_right(HA);
+      const int HBl = Grp<G>::from_left(HB),  HBr = Grp<G>::from_right(HB);
+      const int HAMl = Grp<G>::from_left(HAM), HAMr = Grp<G>::from_right(HAM);
+      const int HBMl = Grp<G>::from_left(HBM), HBMr = Grp<G>::from_right(HBM);
 
       int na = NA, nb = NB;
       if (active && k == low && k != hgh) { na = nar; nb = nbr; }    // align.c:678-681
@@ -884,14 +969,14 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
 
       int tot = 0, off = 0;
       { const int      t1  = cntA + cntB;
-        const uint64_t any = __ballot(t1 != 0);
+        const uint64_t any = Grp<G>::ballot(t1 != 0);
         if (any != 0)
-          { if (__ballot(t1 > 1) == 0)
+          { if (Grp<G>::ballot(t1 > 1) == 0)
               { off = __popcll(any & ((1ull << lane) - 1ull));
                 tot = __popcll(any);
               }
             else
-              off = wave_excl_scan_i(t1, lane, tot);
+              off = Grp<G>::excl_scan(t1, tot);
           }
       }
       if (ncell + tot > wk.cellcap) return AL_ERR_PEBBLES;
@@ -923,8 +1008,8 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
       ncell += tot;
 
       // boundary clips (bit j of a rotated mask <-> diagonal low + j)
-      const int rl = low & 63;
-      { uint64_t ma = rot_right64(__ballot(active && hita), rl), mb = rot_right64(__ballot(active && hitb), rl);
+      const int rl = low & (G - 1);
+      { uint64_t ma = Grp<G>::rot_right(Grp<G>::ballot(active && hita), rl), mb = Grp<G>::rot_right(Grp<G>::ballot(active && hitb), rl);
         if (ma)
           { more = 0;
             aclip = (DIR > 0) ? low + (__ffsll((long long) ma) - 1) : low + (63 - __clzll((long long) ma));
@@ -937,21 +1022,21 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
 
       // record setters of the running best, visited in the reference's loop order
       { const bool beats = active && ((DIR > 0) ? (c > besta) : (c < besta));
-        uint64_t better = __ballot(beats);
+        uint64_t better = Grp<G>::ballot(beats);
         if (better)
           { bool lflag = false, tflag = false;
             if (beats)
               { lflag = (m >= sp.PATH_AVE);
                 if (lflag) tflag = trim_ok_tab(wk.trimtab, b);
               }
-            uint64_t rb = rot_right64(better, rl);
-            uint64_t rL = rot_right64(__ballot(lflag), rl);
-            uint64_t rT = rot_right64(__ballot(tflag), rl);
+            uint64_t rb = Grp<G>::rot_right(better, rl);
+            uint64_t rL = Grp<G>::rot_right(Grp<G>::ballot(lflag), rl);
+            uint64_t rT = Grp<G>::rot_right(Grp<G>::ballot(tflag), rl);
             while (rb)
               { int j = (DIR > 0) ? (63 - __clzll((long long) rb)) : (__ffsll((long long) rb) - 1);
                 rb &= ~(1ull << j);
-                int kk = low + j, l = kk & 63;
-                int cl = __builtin_amdgcn_readlane(c, l);
+                int kk = low + j, l = kk & (G - 1);
+                int cl = Grp<G>::read(c, l);
                 if ((DIR > 0) ? (cl > besta) : (cl < besta))
                   { besta = cl;
                     besty = (cl - kk) >> 1;
@@ -961,8 +1046,8 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
                           { trima  = cl;
                             trimy  = besty;
                             trimd  = dif;
-                            trimha = __builtin_amdgcn_readlane(ha, l);
-                            trimhb = __builtin_amdgcn_readlane(hb, l);
+                            trimha = Grp<G>::read(ha, l);
+                            trimhb = Grp<G>::read(hb, l);
                           }
                       }
                   }
@@ -974,10 +1059,10 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
 
       // keep the points within WAVE_LAG of the best (align.c:877-885)
       if (hgh >= low)
-        { const int  kk  = low + ((lane - low) & 63);
+        { const int  kk  = low + ((lane - low) & (G - 1));
           const bool act = (kk <= hgh);
           const int  n   = (DIR > 0) ? besta - AL_WAVE_LAG : besta + AL_WAVE_LAG;
-          uint64_t keep = rot_right64(__ballot(act && ((DIR > 0) ? (V >= n) : (V <= n))), low & 63);
+          uint64_t keep = Grp<G>::rot_right(Grp<G>::ballot(act && ((DIR > 0) ? (V >= n) : (V <= n))), low & (G - 1));
           if (keep)
             { int l0 = __ffsll((long long) keep) - 1, h0 = 63 - __clzll((long long) keep);
               hgh = low + h0;
@@ -992,6 +1077,11 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
   E.morea = morea; E.morey = morey; E.mored = mored; E.moreha = moreha; E.morehb = morehb;
   E.morem = morem;
   E.ncell = ncell;
+#ifdef DMH_ALIGN_PROFILE
+  APROF_ADD(prof_maxw <= 14 ? 8 : (prof_maxw <= 30 ? 9 : (prof_maxw <= 46 ? 10 : 11)), 1);
+  APROF_ADD(12, prof_sumw);
+  APROF_ADD(13, dif);
+#endif
   return AL_OK;
 }
 
@@ -1206,9 +1296,10 @@ __device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
   return AL_OK;
 }
 
-// Lane 0 ran the (sequential) trace back; publish its results to the whole wavefront through LDS.
+// Lane 0 ran the (sequential) trace back; publish its results to the whole group through LDS.
+template <int G>
 __device__ __forceinline__ void bcast_path(int *mbox, PathRes &P, int &st, int &klow)
-{ const int lane = threadIdx.x & 63;
+{ const int lane = Grp<G>::gl();
   if (lane == 0)
     { mbox[0] = P.abpos; mbox[1] = P.bbpos; mbox[2] = P.aepos; mbox[3] = P.bepos; mbox[4] = P.diffs;
       mbox[5] = P.atlen; mbox[6] = P.btlen; mbox[7] = P.aorg; mbox[8] = P.borg; mbox[9] = st; mbox[10] = klow;
@@ -1227,21 +1318,29 @@ __device__ __forceinline__ void bcast_path(int *mbox, PathRes &P, int &st, int &
 // wanted its pebbles live in the (otherwise idle) LDS ring, so the trace back chases pointers in
 // LDS.  Falls back to the LDS-ring pass with pebbles in global memory when the band or the pebble
 // count outgrows the fast path.
-template <int W, bool WANT_B, int DIR>
+
+// With G = 32 (two alignments per wavefront) there is no in-kernel fallback: the error goes back to
+// the host, which re-runs the candidate on the one-per-wavefront kernel.
+template <int W, bool WANT_B, int DIR, int G = 64>
 __device__ int run_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const SeqView &S,
                         int k0, int mida, int aoff, int boff, PathRes &P, int &klow)
-{ const int lane = threadIdx.x & 63;
+{ const int lane = Grp<G>::gl();
   WaveEnd E;
   int st;
   WaveWork<W> wf = wk;
-  if (!WANT_B)
+  if (!WANT_B && G == 64)
     { wf.cells   = (int4 *) wk.band;
       wf.cellcap = ((F_COUNT * 2 + 2) * W) / 4;
     }
-  st = wave_pass_reg<DIR, WANT_B>(wf, sp, S, k0, mida, aoff, boff, E);
-  if (st == AL_ERR_BAND || st == AL_ERR_PEBBLES)
+  APROF_T0();
+  st = wave_pass_reg<DIR, WANT_B, WaveWork<W>, G>(wf, sp, S, k0, mida, aoff, boff, E);
+  APROF_LAP(0);
+  APROF_ADD(3, 1);
+  if (G == 64 && (st == AL_ERR_BAND || st == AL_ERR_PEBBLES))
     { wf = wk;
       st = wave_pass<W, DIR>(wf, sp, S, k0, mida, aoff, boff, E);
+      APROF_LAP(1);
+      APROF_ADD(4, 1);
       if (st != AL_OK) return st;
       wave_sync();
       if (lane == 0)
@@ -1255,7 +1354,9 @@ __device__ int run_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Seq
         st = (DIR > 0) ? forward_trace<W, WANT_B>(wf, sp, E, mida, P, klow)
                        : reverse_trace<W, WANT_B>(wf, sp, E, aoff, boff, P);
     }
-  bcast_path(wk.mbox, P, st, klow);
+  APROF_ADD(5, E.ncell);
+  bcast_path<G>(wk.mbox, P, st, klow);
+  APROF_LAP(2);
   if (st != AL_OK) return st;
   wave_sync();
   return AL_OK;
@@ -1265,10 +1366,10 @@ __device__ int run_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Seq
 // On return P holds the A view in the frame the reference reports (flipped back for comp) with
 // the A trace at wk.atrace+P.aorg; B = {babpos,bbbpos,baepos,bbepos} is the B view, its trace
 // (WANT_B only) at wk.btrace+P.borg (complemented-frame order, as the reference leaves it).
-template <int W, bool WANT_B>
+template <int W, bool WANT_B, int G = 64>
 __device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, const SeqView &S,
                                int dg, int anti, PathRes &P, int *B)
-{ const int lane = threadIdx.x & 63;
+{ const int lane = Grp<G>::gl();
   int aoff = S.comp ? (S.alen % sp.TS) : 0, boff = 0;
   int hgh = dg, low = dg;
   while (((anti - hgh) >> 1) < 0) hgh -= 1;     // align.c:1774 (never taken for damapper's seeds)
@@ -1279,11 +1380,11 @@ __device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, co
   P.atlen = P.btlen = 0;
   P.aorg = P.borg = 0;
 
-  st = run_pass<W, WANT_B, +1>(wk, sp, S, low, anti, aoff, boff, P, klow);
+  st = run_pass<W, WANT_B, +1, G>(wk, sp, S, low, anti, aoff, boff, P, klow);
   if (st != AL_OK) return st;
   int fshort = ((P.aepos + P.bepos) - anti < AL_DUB_TRIM);
 
-  st = run_pass<W, WANT_B, -1>(wk, sp, S, low, anti, aoff, boff, P, klow);
+  st = run_pass<W, WANT_B, -1, G>(wk, sp, S, low, anti, aoff, boff, P, klow);
   if (st != AL_OK) return st;
   int rshort = (anti - (P.abpos + P.bbpos) < AL_DUB_TRIM);
 
@@ -1297,7 +1398,7 @@ __device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, co
         { low  = P.abpos - P.bbpos;
           anti = P.abpos + P.bbpos;
           P.atlen = P.btlen = 0;
-          st = run_pass<W, WANT_B, +1>(wk, sp, S, low, anti, aoff, boff, P, klow);
+          st = run_pass<W, WANT_B, +1, G>(wk, sp, S, low, anti, aoff, boff, P, klow);
           if (st != AL_OK) return st;
         }
     }
@@ -1306,7 +1407,7 @@ __device__ int local_alignment(const WaveWork<W> &wk, const AlignSpecDev &sp, co
       anti = P.aepos + P.bepos;
       P.atlen = P.btlen = 0;
       P.diffs = 0;
-      st = run_pass<W, WANT_B, -1>(wk, sp, S, low, anti, aoff, boff, P, klow);
+      st = run_pass<W, WANT_B, -1, G>(wk, sp, S, low, anti, aoff, boff, P, klow);
       if (st != AL_OK) return st;
     }
 

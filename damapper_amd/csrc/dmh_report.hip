@@ -149,6 +149,9 @@ __global__ __launch_bounds__(256, 4) void k_align_cands(const uint64_t *apk, con
       const int j = only ? only[t] : (int) t;
       const CandJob J = jobs[j];
       SeqView S{J.comp ? arc : apk, bpk, J.aoff, J.boff, J.alen, J.blen, J.comp};
+#ifdef DMH_ALIGN_PROFILE
+      long long tjob = clock64();
+#endif
 
       // map.c:2487-2579: walk the chain from its end; a point is a seed only if it lies left of
       // the last accepted alignment's start
@@ -198,6 +201,95 @@ __global__ __launch_bounds__(256, 4) void k_align_cands(const uint64_t *apk, con
           wave_sync();
         }
       if (lane == 0) status[j] = st;
+#ifdef DMH_ALIGN_PROFILE
+      APROF_ADD(6, clock64() - tjob);
+      APROF_ADD(7, 1);
+#endif
+      wave_sync();
+    }
+}
+
+
+// Two candidates per wavefront: each 32-lane half runs the chain walk of k_align_cands on its own
+// job with the register band on a 32-lane ring (bands up to 30 diagonals) and its pebbles in LDS.
+// The halves share one instruction stream, so a wavefront's two jobs should be alike (the host
+// orders the tickets by orientation and read length).  A band or pebble overflow ends the job with
+// AL_ERR_BAND / AL_ERR_PEBBLES; the host re-runs it on k_align_cands.
+constexpr int PEB32 = 288;     // pebbles per half-wavefront
+
+__global__ __launch_bounds__(256, 4) void k_align_cands32(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
+                                                        const CandJob *jobs, int njobs,
+                                                        const uint16_t *jumps, int hithr, AlignSpecDev sp,
+                                                        uint16_t *traces, int tcap, unsigned int *ticket, int *status,
+                                                        int *pool, unsigned int *pool_used,
+                                                        unsigned int pool_cap, const int *only)
+{ constexpr int G = 32;
+  __shared__ int4 peb[8 * PEB32];
+  __shared__ int  mbox[8 * 16];
+  __shared__ int2 trimtab[32];
+  const int lane = threadIdx.x & (G - 1), gid = threadIdx.x / G;
+  const int gg = blockIdx.x * (256 / G) + gid;
+  if (threadIdx.x < 64) build_trim_tab(trimtab, sp.mscore, sp.dscore);
+  __syncthreads();
+  WaveWork<LDS_W> wk;
+  wk.band    = nullptr;
+  wk.cells   = peb + gid * PEB32;
+  wk.cellcap = PEB32;
+  wk.tcap    = tcap;
+  wk.atrace  = traces + (size_t) gg * (4 * (size_t) tcap) + tcap;
+  wk.btrace  = wk.atrace + 2 * (size_t) tcap;
+  wk.mbox    = mbox + 16 * gid;
+  wk.trimtab = trimtab;
+  while (true)
+    { unsigned int t = 0;
+      if (lane == 0) t = atomicAdd(ticket, 1u);
+      t = __shfl(t, 0, G);
+      if (t >= (unsigned int) njobs) break;
+      const int j = only ? only[t] : (int) t;
+      const CandJob J = jobs[j];
+      SeqView S{J.comp ? arc : apk, bpk, J.aoff, J.boff, J.alen, J.blen, J.comp};
+
+      int apos = J.alast, bpos = J.blast, alast = J.alen + 1;     // map.c:2487-2579, as k_align_cands
+      int seq = 0, st = AL_OK;
+      for (int n = 0; n < J.npts; n++)
+        { apos -= (int) jumps[2 * ((size_t) J.joff + n)];
+          bpos -= (int) jumps[2 * ((size_t) J.joff + n) + 1];
+          if (apos >= alast) continue;
+          int dg, ad;
+          if (J.comp)
+            { int ac = J.alen - apos, bc = J.blen - bpos;
+              dg = ac - bc;
+              ad = ac + bc;
+            }
+          else
+            { dg = apos - bpos;
+              ad = apos + bpos;
+            }
+          PathRes P;
+          int B[4];
+          st = local_alignment<LDS_W, false, G>(wk, sp, S, dg, ad, P, B);
+          if (st != AL_OK) break;
+          if (P.aepos - P.abpos >= hithr)
+            { alast = P.abpos;
+              unsigned int need = REC_HDR + ((unsigned int) P.atlen + 1) / 2;
+              unsigned int at = 0;
+              if (lane == 0) at = atomicAdd(pool_used, need);
+              at = __shfl(at, 0, G);
+              if (at + need > pool_cap) { st = 100; break; }
+              int *r = pool + at;
+              if (lane == 0)
+                { r[0] = j; r[1] = seq; r[2] = P.abpos; r[3] = P.bbpos; r[4] = P.aepos; r[5] = P.bepos;
+                  r[6] = P.diffs; r[7] = P.atlen;
+                  r[8] = B[0]; r[9] = B[1]; r[10] = B[2]; r[11] = B[3]; r[12] = 0;
+                  r[13] = 0; r[14] = 0; r[15] = 0;
+                }
+              uint16_t *tr = (uint16_t *) (r + REC_HDR);
+              for (int i = lane; i < P.atlen; i += G) tr[i] = wk.atrace[P.aorg + i];
+              seq += 1;
+            }
+          wave_sync();
+        }
+      if (lane == 0) status[j] = st;
       wave_sync();
     }
 }
@@ -219,10 +311,10 @@ static AlignScratch &ascr()
   return s;
 }
 
-static Scratch prepare_scratch(int nblocks, int tcap, bool global_band)
+static Scratch prepare_scratch(int nblocks, int tcap, bool global_band, int groups_per_block = 4, bool arenas = true)
 { AlignScratch &a = ascr();
-  int nw = nblocks * 4;
-  a.cells.ensure((size_t) nw * CELLCAP, "pebble arenas");
+  int nw = nblocks * groups_per_block;
+  if (arenas) a.cells.ensure((size_t) nw * CELLCAP, "pebble arenas");
   a.traces.ensure((size_t) nw * 4 * tcap, "trace buffers");
   if (global_band)
     a.band.ensure((size_t) nw * (F_COUNT * 2 + 2) * GLB_W, "global d-wave bands");
@@ -941,6 +1033,17 @@ using namespace dmh;
 
 extern "C" {
 
+#ifdef DMH_ALIGN_PROFILE
+void dmh_align_profile(unsigned long long *out, int reset)
+{ HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_aprof), sizeof(unsigned long long) * 16));
+  if (reset)
+    { unsigned long long z[16] = {0};
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_aprof), z, sizeof(z)));
+    }
+}
+#endif
+
 void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_Spec *asettings, int mflag)
 { State &st = S();
   const Params &pm = st.params;
@@ -1012,9 +1115,23 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
       // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
       size_t pool_cap = (size_t) njobs * 2 * (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8)) + 4096;
       std::vector<int> status(njobs);
-      std::vector<int> todo;                 // jobs to (re)run; empty = all
-      bool global_band = false;
-      for (int round = 0; round < 6; round++)
+      std::vector<int> todo;                 // jobs to (re)run
+      // kernel ladder: 0 = two candidates per wavefront (register band <= 30 diagonals, LDS pebbles),
+      // 1 = one per wavefront (register band <= 62, LDS ring 128, global pebbles), 2 = global ring 8192
+      static const bool no_pack = getenv("DMH_NO_PACK32") != nullptr;
+      int level = (doB || no_pack) ? 1 : 0;
+      if (level == 0)
+        { // the halves of a wavefront run in lock step: hand out like jobs together (same orientation,
+          // similar length), long ones first
+          todo.resize(njobs);
+          for (int i = 0; i < njobs; i++) todo[i] = i;
+          std::sort(todo.begin(), todo.end(), [&](int x, int y)
+                    { if (jobs[x].comp != jobs[y].comp) return jobs[x].comp < jobs[y].comp;
+                      if (jobs[x].alen != jobs[y].alen) return jobs[x].alen > jobs[y].alen;
+                      return x < y;
+                    });
+        }
+      for (int round = 0; round < 8; round++)
         { if (pool_cap > 0xfffffff0ull / 4) fatal("Reporter: alignment pool too large");
           d_pool.ensure(pool_cap, "alignment pool");
           int nrun = todo.empty() ? njobs : (int) todo.size();
@@ -1024,12 +1141,18 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
               copy_h2d(d_only.p, todo.data(), sizeof(int) * todo.size());
               only = d_only.p;
             }
-          int nblocks = std::min((nrun + 3) / 4, 256 * 4);
-          Scratch sc = prepare_scratch(nblocks, tcap, global_band);
+          const int per_block = (level == 0) ? 8 : 4;
+          int nblocks = std::min((nrun + per_block - 1) / per_block, 256 * 4);
+          Scratch sc = prepare_scratch(nblocks, tcap, level == 2, per_block, level != 0);
           HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), stream()));
           HIP_CHECK(hipMemsetAsync(d_pool.p, 0xff, sizeof(int) * pool_cap, stream()));   // cand = -1 ends the parse
-          { StageTimer tm(global_band ? "align_global_band" : "align", 0.0);
-            if (global_band)
+          { StageTimer tm(level == 2 ? "align_global_band" : (level == 1 ? "align_wave64" : "align"), 0.0);
+            if (level == 0)
+              hipLaunchKernelGGL(k_align_cands32, dim3(nblocks), dim3(256), 0, stream(),
+                                 ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
+                                 (const uint16_t *) d_jumps.p, hithr, spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
+                                 d_pool.p, ascr().ctl.p + 1, (unsigned int) pool_cap, only);
+            else if (level == 2)
               { if (doB)
                   hipLaunchKernelGGL((k_align_cands<GLB_W, false, true>), dim3(nblocks), dim3(256), 0, stream(),
                                      ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
@@ -1086,12 +1209,13 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           if (todo.empty()) { ran.resize(njobs); for (int i = 0; i < njobs; i++) ran[i] = i; }
           else ran = todo;
           std::vector<int> again;
-          bool need_pool = false, need_global = false;
+          bool need_pool = false, need_up = false;
           for (int j : ran)
             if (status[j] != AL_OK)
               { again.push_back(j);
                 if (status[j] == 100) need_pool = true;
-                else if (status[j] == AL_ERR_BAND && !global_band) need_global = true;
+                else if (level == 0 && (status[j] == AL_ERR_BAND || status[j] == AL_ERR_PEBBLES)) need_up = true;
+                else if (level == 1 && status[j] == AL_ERR_BAND) need_up = true;
                 else fatal("Reporter: alignment of candidate %d failed (status %d)", j, status[j]);
               }
           // parse the records of this run (records of failed jobs are dropped below); when the whole
@@ -1105,10 +1229,11 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           parse_pool(pool, base, got, njobs, failed, recs);
           for (int j : again) recs[j].clear();
           if (again.empty()) break;
+          std::sort(again.begin(), again.end());
           todo = again;
           if (need_pool) pool_cap *= 4;
-          if (need_global && !need_pool) global_band = true;
-          if (round == 5) fatal("Reporter: alignment retries exhausted");
+          else if (need_up) level += 1;
+          if (round == 7) fatal("Reporter: alignment retries exhausted");
         }
       if (deferred_got == 0) fixup_recs(pool, recs);
     }
