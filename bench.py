@@ -71,7 +71,7 @@ def cpu_baseline(genome, sample_reads, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--block-reads", type=int, default=25000)
     ap.add_argument("--nblocks", type=int, default=4)
@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record HIP events around the kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="do not queue the next block's index before Reporter")
+    ap.add_argument("--serial-prefetch", action="store_true",
+                    help="queue the next block's whole index build before Reporter instead of spreading its "
+                         "stages over the gaps of the current block")
     ap.add_argument("--sync-report", action="store_true", help="write the .las files inside Reporter (drop-in behaviour)")
     ap.add_argument("--rebuild-ref", action="store_true",
                     help="rebuild the REF indices for every read block as damapper.c does (default: build both "
@@ -112,7 +115,7 @@ def main():
 
     sort_path = tempfile.mkdtemp(prefix="dmh_bench_%d_" % rank)
     m = driver.Mapper(kmer=20, ave_corr=0.85, spacing=100, threads=4, sort_path=sort_path, mem_limit=64 << 30,
-                      retain_ref=not args.rebuild_ref)
+                      retain_ref=not args.rebuild_ref, prefetch_deferred=not args.serial_prefetch)
     m.make_spec([ref_whole.db.freq[j] for j in range(4)])
 
     # inputs resident in HBM before the clock starts
@@ -142,7 +145,7 @@ def main():
     L.dmh_sync()
     t0 = time.time()
     bases = 0
-    host = {"index_reads": 0.0, "filter": 0.0, "report": 0.0}
+    host = {"index_reads": 0.0, "filter": 0.0, "report": 0.0, "between_blocks": 0.0}
     for i in range(args.steps):
         t = step(args.warmup + i)
         for k in host:

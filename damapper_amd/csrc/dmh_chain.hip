@@ -370,7 +370,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   std::vector<ChainSummary> sums(nsum);
   std::vector<uint32_t>     gfirst;
   if (nsum > 0)
-    { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum);
+    { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum, 1);      // host sort next
       std::sort(sums.begin(), sums.end(), [](const ChainSummary &a, const ChainSummary &b)
                 { return a.group != b.group ? a.group < b.group : a.rank < b.rank; });
     }
@@ -389,8 +389,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     if (!want.empty())
       { copy_h2d(d_idx.p, want.data(), sizeof(uint32_t) * want.size());
         gather_u64(R.skeys, d_idx.p, d_k.p, (int64_t) want.size());
-        copy_d2h(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size());
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        copy_d2h(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size(), 1);   // domination scan next
       }
   }
 
@@ -492,8 +491,9 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
                            d_len.p, (const uint32_t *) (d_len.p + n), d_j.p, 1);
         std::vector<uint16_t> jd(2 * (size_t) off[n]);
         if (off[n] > 0)
-          copy_d2h(jd.data(), d_j.p, sizeof(uint16_t) * jd.size());
-        HIP_CHECK(hipStreamSynchronize(stream()));
+          copy_d2h(jd.data(), d_j.p, sizeof(uint16_t) * jd.size(), 1);          // host stores the chains next
+        else
+          HIP_CHECK(hipStreamSynchronize(stream()));
         for (int i = 0; i < n; i++)
           { Candidate *c = keep[i];
             c->length = (int) len[i];

@@ -26,6 +26,14 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 hipStream_t stream();
 
+// Deferred index builds (dmh_sort_kmers_async): the sort of the NEXT READS block is cut into stages
+// (k-mer emit, then per radix pass a histogram stage and a scatter stage) that are queued on the
+// stream at the points where the host is about to do host-only work between two GPU round trips of
+// the CURRENT block, so the GPU has something to run while the host computes.  bg_pump(n) queues up
+// to n stages; consumers of an index flush whatever is left.
+void bg_pump(int nstages = 1);
+void bg_flush();
+
 // Device allocation that aborts through Clean_Exit on failure (the reference's behaviour
 // for a failed Malloc, e.g. map.c:689-690).
 void *dev_alloc(size_t bytes, const char *what);
@@ -34,7 +42,7 @@ void  dev_free(void *p);
 // Host <-> device transfers go through one persistent pinned staging buffer: handing pageable host
 // memory to hipMemcpyAsync makes the runtime pin and unpin those pages around the copy, and the
 // unpin was observed to delay the next kernel dispatch by ~10 ms.  Both calls are synchronous.
-void copy_d2h(void *host, const void *dev, size_t bytes);
+void copy_d2h(void *host, const void *dev, size_t bytes, int pump_stages = 0);   // pump: bg_pump() behind the copy
 void copy_h2d(void *dev, const void *host, size_t bytes);
 
 template <typename T> struct DevBuf
@@ -86,6 +94,10 @@ struct SortScratch
 // holding the result (either the originals or the alternates) and *okeys/*ovals at the others.
 void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32_t **ovals,
                       int64_t n, int lo_bit, int nbits, SortScratch &scr, const char *stage);
+
+void radix_pass_hist(const uint64_t *keys, int64_t n, int shift, int w, SortScratch &scr);
+void radix_pass_scatter(const uint64_t *keys, const uint32_t *vals, uint64_t *okeys, uint32_t *ovals, int64_t n,
+                        int shift, int w, SortScratch &scr);
 
 // Exclusive scan of n uint32 values in place; returns nothing, total is written to *d_total
 // (device pointer to one uint32) if not null.  n < 2^32, sum < 2^32.

@@ -2,6 +2,7 @@
 // and the small stage-level helpers of the C-ABI (see include/damapper_hip.h).
 
 #include "dmh_state.h"
+#include <deque>
 #include "dmh_device.h"
 #include <stdarg.h>
 #include <time.h>
@@ -73,6 +74,11 @@ static void init_device()
 hipStream_t stream()
 { init_device();
   return g_stream;
+}
+
+static void sync_all_streams()
+{ init_device();
+  HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 
 // Device memory comes from a small caching pool: hipMalloc/hipFree of multi-GB buffers cost
@@ -153,14 +159,24 @@ static void pin_init()
     HIP_CHECK(hipHostMalloc((void **) &g_pin, PIN_CHUNK, hipHostMallocDefault));
 }
 
-void copy_d2h(void *host, const void *dev, size_t bytes)
+void copy_d2h(void *host, const void *dev, size_t bytes, int pump_stages)
 { pin_init();
+  static hipEvent_t ev = nullptr;
   size_t off = 0;
   do
     { size_t c = std::min(PIN_CHUNK, bytes - off);
       if (c > 0)
         HIP_CHECK(hipMemcpyAsync(g_pin, (const uint8_t *) dev + off, c, hipMemcpyDeviceToHost, stream()));
-      HIP_CHECK(hipStreamSynchronize(stream()));
+      if (pump_stages > 0 && off + c >= bytes)
+        { // wait for the copy only; the background stages queued behind it keep the GPU busy while
+          // the caller digests the data on the host
+          if (ev == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          HIP_CHECK(hipEventRecord(ev, stream()));
+          bg_pump(pump_stages);
+          HIP_CHECK(hipEventSynchronize(ev));
+        }
+      else
+        HIP_CHECK(hipStreamSynchronize(stream()));
       if (c > 0) memcpy((uint8_t *) host + off, g_pin, c);
       off += c;
     }
@@ -240,7 +256,7 @@ HostTimer::~HostTimer()
 
 static void drain_timers()
 { if (g_pending.empty()) return;
-  HIP_CHECK(hipStreamSynchronize(stream()));
+  sync_all_streams();
   std::lock_guard<std::mutex> lk(g_tmu);
   for (auto &p : g_pending)
     { float ms = 0;
@@ -390,8 +406,12 @@ void drop_block(const DAZZ_DB *block)
 
 // ---- index registry -----------------------------------------------------------------------
 
+void index_wait_ready(IndexDev &ix)
+{ if (ix.pending) bg_flush(); }
+
 static void free_index(IndexDev &ix)
-{ dev_free(ix.keys);
+{ if (ix.pending) bg_flush();
+  dev_free(ix.keys);
   dev_free(ix.vals);
   dev_free(ix.d_boff);
   dev_free(ix.d_chunk);
@@ -468,6 +488,237 @@ __global__ void k_mask_flag(const uint32_t *__restrict__ vals, int64_t n, const 
   keep[i] = (l < a1 && data[2 * l] <= rpos) ? 0u : 1u;
 }
 
+// ---- deferred index build: stages queued by bg_pump ------------------------------------------
+struct SortJob
+{ int       id;                 // key of the index in State::indices
+  uint64_t *keys, *k0, *k1;     // buffers allocated for the index / ping-pong state
+  uint32_t *vals, *v0, *v1;
+  int64_t   kmers, kmers0;
+  int       Kshift, npass;
+  int       stage;              // 0 .. 2*npass-1: even = histogram + scan of pass stage/2, odd = its scatter
+};
+static std::deque<SortJob> g_bg;
+
+// the sorted data may sit in the scratch partner: the index then takes over the partner's buffers and
+// the sort scratch keeps the ones allocated for the index (no device copy)
+static void adopt_sorted(IndexDev &ix, SortScratch &scr, uint64_t *keys, uint32_t *vals, uint64_t *k0, uint32_t *v0,
+                         int64_t kmers0, int64_t kmers)
+{ if (k0 != keys)
+    { scr.keys_alt.p   = keys;
+      scr.keys_alt.cap = (size_t) kmers0;
+      scr.vals_alt.p   = vals;
+      scr.vals_alt.cap = (size_t) kmers0;
+      keys = k0;
+      vals = v0;
+    }
+  ix.keys = keys;
+  ix.vals = vals;
+  ix.n    = kmers;
+}
+
+static void bg_step()
+{ SortJob &J = g_bg.front();
+  State   &st = S();
+  const int p = J.stage >> 1;
+  const int w = J.Kshift - 8 * p;
+  if ((J.stage & 1) == 0)
+    radix_pass_hist(J.k0, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux);
+  else
+    { radix_pass_scatter(J.k0, J.v0, J.k1, J.v1, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux);
+      std::swap(J.k0, J.k1);
+      std::swap(J.v0, J.v1);
+    }
+  J.stage += 1;
+  if (J.stage == 2 * J.npass)
+    { auto it = st.indices.find(J.id);
+      if (it == st.indices.end()) fatal("deferred index build lost its index");
+      adopt_sorted(it->second, st.sort_aux, J.keys, J.vals, J.k0, J.v0, J.kmers0, J.kmers);
+      it->second.pending = false;
+      g_bg.pop_front();
+    }
+}
+
+void bg_pump(int nstages)
+{ for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step(); }
+
+void bg_flush()
+{ while (!g_bg.empty()) bg_step(); }
+
+static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
+{ State &st = S();
+  Params &pm = st.params;
+  if (!pm.set) fatal("Sort_Kmers called before Set_Filter_Params");
+  HostTimer ht("Sort_Kmers");
+  int     nreads = block->nreads;
+  int64_t L      = block->reads[nreads].boff;
+  int64_t kmers  = L - (int64_t) pm.Kmer * nreads;        // map.c:676
+  *len = 0;
+  if (kmers <= 0) return nullptr;
+  if (kmers > INT32_MAX) fatal("Sort_Kmers: block has %lld k-mers, limit is 2^31-1 (map.c:663)", (long long) kmers);
+  for (int i = 0; i < nreads; i++)
+    if (block->reads[i].rlen < pm.Kmer - 1)
+      fatal("Sort_Kmers: read %d is shorter than k-1 (%d < %d)", i, block->reads[i].rlen, pm.Kmer - 1);
+
+  const DAZZ_TRACK *mask = (const DAZZ_TRACK *) block->tracks;
+  // a build can only be deferred when the length of the index is known up front
+  const bool defer = deferred && mask == nullptr && pm.TooFrequent == INT32_MAX;
+  if (defer) bg_flush();                         // one deferred build at a time (it owns sort_aux)
+  SortScratch &scr = defer ? st.sort_aux : st.sort;
+
+  if (VERBOSE)
+    { printf("\n   Kmer count = %lld\n", (long long) kmers);
+      printf("   Using %.2fGb of HBM\n", (24. * kmers) / 1073741824.);
+      fflush(stdout);
+    }
+
+  HostTimer *hu = new HostTimer("sk_upload");
+  BlockDev  &bd   = upload_block(block, false);
+  delete hu;
+  HostTimer *ha = new HostTimer("sk_alloc");
+
+  IndexDev ix;
+  ix.block  = block;
+  ix.nreads = nreads;
+  ix.L      = L;
+  ix.h_boff.resize(nreads + 1);
+  for (int i = 0; i <= nreads; i++) ix.h_boff[i] = block->reads[i].boff;
+
+  // same slack as the sort scratch: the two buffer pairs may swap roles below
+  const int64_t kmers0 = kmers + kmers / 8 + 256;
+  uint64_t *keys = (uint64_t *) dev_alloc(sizeof(uint64_t) * kmers0, "k-mer codes");
+  uint32_t *vals = (uint32_t *) dev_alloc(sizeof(uint32_t) * kmers0, "k-mer positions");
+  scr.keys_alt.ensure(kmers, "k-mer sort buffer");
+  scr.vals_alt.ensure(kmers, "k-mer sort buffer");
+
+  delete ha;
+  HostTimer *he = new HostTimer("sk_enqueue");
+  kmer_emit(bd.d_bases(), L, bd.d_boff, nreads, pm.Kmer, keys, vals, kmers);
+  if (getenv("DMH_DEBUG_SYNC") != nullptr)
+    { HostTimer hs("sk_emit_sync");
+      HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+
+  uint64_t *k0 = keys, *k1 = scr.keys_alt.p;
+  uint32_t *v0 = vals, *v1 = scr.vals_alt.p;
+
+  if (mask != nullptr)
+    { // masked k-mers are dropped before the sort: the stable sort then leaves exactly the list the
+      // reference obtains by sorting them to the end as all-ones sentinels and cutting them off
+      // (map.c:536-542,722-724; identical unless a T^k k-mer ties with the sentinels under -T > 1)
+      StageTimer tm("kmer_mask", 32.0 * kmers);
+      const int64_t *anno = (const int64_t *) mask->anno;
+      const int64_t  nint = anno[nreads];
+      if (mask->data == nullptr && nint > 0) fatal("Sort_Kmers: mask track '%s' has no data loaded", mask->name);
+      if (nint & 1) fatal("Sort_Kmers: mask track '%s' holds an odd number of interval ends", mask->name);
+      DevBuf<int64_t>  d_anno;
+      DevBuf<int>      d_data;
+      DevBuf<uint32_t> keep, slot;
+      d_anno.ensure(nreads + 1, "mask offsets");
+      d_data.ensure(nint + 2, "mask intervals");
+      keep.ensure(kmers, "mask flags");
+      slot.ensure(kmers + 1, "mask slots");
+      copy_h2d(d_anno.p, anno, sizeof(int64_t) * (nreads + 1));
+      if (nint > 0) copy_h2d(d_data.p, mask->data, sizeof(int) * nint);
+      int nb = ceil_div(kmers, 256);
+      hipLaunchKernelGGL(k_mask_flag, dim3(nb), dim3(256), 0, stream(), (const uint32_t *) v0, kmers,
+                         (const int64_t *) bd.d_boff, nreads, pm.Kmer, (const int64_t *) d_anno.p,
+                         (const int *) d_data.p, keep.p);
+      HIP_CHECK(hipMemcpyAsync(slot.p, keep.p, sizeof(uint32_t) * kmers, hipMemcpyDeviceToDevice, stream()));
+      exclusive_scan_u32(slot.p, kmers, scr.bsum, slot.p + kmers);
+      hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0,
+                         (const uint32_t *) v0, (const uint32_t *) keep.p, (const uint32_t *) slot.p, kmers, k1, v1);
+      uint32_t kept = 0;
+      copy_d2h(&kept, slot.p + kmers, sizeof(uint32_t));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      std::swap(k0, k1);
+      std::swap(v0, v1);
+      kmers = kept;
+      d_anno.release(); d_data.release(); keep.release(); slot.release();
+    }
+
+  if (kmers > 0 && !defer)
+    radix_sort_pairs(&k0, &v0, &k1, &v1, kmers, 0, pm.Kshift, scr, "kmer_sort");
+
+  if (pm.TooFrequent < INT32_MAX && kmers > 0)
+    { StageTimer tm("kmer_suppress", 32.0 * kmers);
+      DevBuf<uint32_t> keep, slot;
+      keep.ensure(kmers, "suppress flags");
+      slot.ensure(kmers + 1, "suppress slots");
+      int nb = ceil_div(kmers, 256);
+      hipLaunchKernelGGL(k_suppress_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, kmers,
+                         pm.TooFrequent, keep.p);
+      HIP_CHECK(hipMemcpyAsync(slot.p, keep.p, sizeof(uint32_t) * kmers, hipMemcpyDeviceToDevice, stream()));
+      exclusive_scan_u32(slot.p, kmers, scr.bsum, slot.p + kmers);
+      hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0,
+                         (const uint32_t *) v0, (const uint32_t *) keep.p, (const uint32_t *) slot.p, kmers, k1, v1);
+      uint32_t kept = 0;
+      copy_d2h(&kept, slot.p + kmers, sizeof(uint32_t));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      std::swap(k0, k1);
+      std::swap(v0, v1);
+      kmers = kept;
+      keep.release();
+      slot.release();
+    }
+  if (VERBOSE && (pm.TooFrequent < INT32_MAX || mask != nullptr))        // map.c:793-797
+    printf("   Revised kmer count = %lld\n", (long long) kmers);
+
+  delete he;
+  HostTimer hf("sk_finish");
+  if (defer)
+    { ix.keys = nullptr;       // set when the last stage has been queued
+      ix.vals = nullptr;
+      ix.n    = kmers;
+      ix.pending = true;
+    }
+  else
+    adopt_sorted(ix, scr, keys, vals, k0, v0, kmers0, kmers);
+
+  ix.d_boff = (int64_t *) dev_alloc(sizeof(int64_t) * (nreads + 1), "index read offsets");
+  HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (nreads + 1), hipMemcpyDeviceToDevice, stream()));
+  ix.nchunk = (L >> CHUNK_SHIFT) + 1;
+  ix.d_chunk = (uint32_t *) dev_alloc(sizeof(uint32_t) * ix.nchunk, "index chunk table");
+  hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
+                     (const int64_t *) ix.d_boff, nreads, ix.nchunk, ix.d_chunk);
+  HIP_CHECK(hipGetLastError());
+  // no synchronisation here: every later use of the index is ordered on the same stream, and a
+  // driver may queue more work (e.g. the next block's Reporter) behind the sort right away
+
+  if (VERBOSE)
+    { printf("   Index occupies %.2fGb\n", (12. * kmers) / 1073741824.);
+      fflush(stdout);
+    }
+
+  if (kmers <= 0)
+    { ix.pending = false;
+      if (ix.keys == nullptr) { ix.keys = keys; ix.vals = vals; }
+      free_index(ix);
+      return nullptr;
+    }
+
+  IndexStub *stub = (IndexStub *) malloc(sizeof(IndexStub));
+  if (stub == nullptr) fatal("out of memory allocating index handle");
+  stub->magic = INDEX_MAGIC;
+  stub->id    = st.next_index_id++;
+  stub->len   = (int32_t) kmers;
+  st.indices[stub->id] = ix;
+  if (defer)
+    { SortJob J;
+      J.id = stub->id;
+      J.keys = keys; J.vals = vals;
+      J.k0 = k0; J.k1 = k1; J.v0 = v0; J.v1 = v1;
+      J.kmers = kmers; J.kmers0 = kmers0;
+      J.Kshift = pm.Kshift;
+      J.npass = (pm.Kshift + 7) / 8;
+      J.stage = 0;
+      g_bg.push_back(J);
+      if (kmers <= 1) bg_flush();
+    }
+  *len = (int) kmers;
+  return stub;
+}
+
+
 }  // namespace dmh
 
 using namespace dmh;
@@ -487,7 +738,7 @@ int dmh_device_count(void)
 const char *dmh_last_error(void) { return g_err; }
 
 void dmh_sync(void)
-{ HIP_CHECK(hipStreamSynchronize(stream())); }
+{ sync_all_streams(); }
 
 void dmh_timing_enable(int on) { g_timing = (on != 0); }
 
@@ -513,7 +764,7 @@ int dmh_timing_get(int idx, char *name, int namelen, double *ms, int64_t *launch
 
 void dmh_reset(void)
 { State &st = S();
-  if (g_init) HIP_CHECK(hipStreamSynchronize(stream()));
+  if (g_init) sync_all_streams();
   for (auto &kv : st.indices) free_index(kv.second);
   st.indices.clear();
   for (auto &kv : st.blocks) free_blockdev(kv.second);
@@ -526,6 +777,10 @@ void dmh_reset(void)
   st.sort.bsum.release();
   st.sort.keys_alt.release();
   st.sort.vals_alt.release();
+  st.sort_aux.hist.release();
+  st.sort_aux.bsum.release();
+  st.sort_aux.keys_alt.release();
+  st.sort_aux.vals_alt.release();
   pool_release();
 }
 
@@ -575,171 +830,12 @@ int Set_Filter_Params(int kmer, int suppress, int nthreads)
 
 // ---- map.c:655-822 -------------------------------------------------------------------------
 void *Sort_Kmers(DAZZ_DB *block, int *len)
-{ State &st = S();
-  Params &pm = st.params;
-  if (!pm.set) fatal("Sort_Kmers called before Set_Filter_Params");
-  HostTimer ht("Sort_Kmers");
-  int     nreads = block->nreads;
-  int64_t L      = block->reads[nreads].boff;
-  int64_t kmers  = L - (int64_t) pm.Kmer * nreads;        // map.c:676
-  *len = 0;
-  if (kmers <= 0) return nullptr;
-  if (kmers > INT32_MAX) fatal("Sort_Kmers: block has %lld k-mers, limit is 2^31-1 (map.c:663)", (long long) kmers);
-  for (int i = 0; i < nreads; i++)
-    if (block->reads[i].rlen < pm.Kmer - 1)
-      fatal("Sort_Kmers: read %d is shorter than k-1 (%d < %d)", i, block->reads[i].rlen, pm.Kmer - 1);
+{ return sort_kmers_impl(block, len, false); }
 
-  if (VERBOSE)
-    { printf("\n   Kmer count = %lld\n", (long long) kmers);
-      printf("   Using %.2fGb of HBM\n", (24. * kmers) / 1073741824.);
-      fflush(stdout);
-    }
-
-  bool       had  = st.blocks.count(block) != 0 && st.blocks[block].pinned;
-  HostTimer *hu = new HostTimer("sk_upload");
-  BlockDev  &bd   = upload_block(block, false);
-  delete hu;
-  HostTimer *ha = new HostTimer("sk_alloc");
-
-  IndexDev ix;
-  ix.block  = block;
-  ix.nreads = nreads;
-  ix.L      = L;
-  ix.h_boff.resize(nreads + 1);
-  for (int i = 0; i <= nreads; i++) ix.h_boff[i] = block->reads[i].boff;
-
-  // same slack as the sort scratch: the two buffer pairs may swap roles below
-  const int64_t kmers0 = kmers + kmers / 8 + 256;
-  uint64_t *keys = (uint64_t *) dev_alloc(sizeof(uint64_t) * kmers0, "k-mer codes");
-  uint32_t *vals = (uint32_t *) dev_alloc(sizeof(uint32_t) * kmers0, "k-mer positions");
-  st.sort.keys_alt.ensure(kmers, "k-mer sort buffer");
-  st.sort.vals_alt.ensure(kmers, "k-mer sort buffer");
-
-  delete ha;
-  HostTimer *he = new HostTimer("sk_enqueue");
-  kmer_emit(bd.d_bases(), L, bd.d_boff, nreads, pm.Kmer, keys, vals, kmers);
-  if (getenv("DMH_DEBUG_SYNC") != nullptr)
-    { HostTimer hs("sk_emit_sync");
-      HIP_CHECK(hipStreamSynchronize(stream()));
-    }
-
-  uint64_t *k0 = keys, *k1 = st.sort.keys_alt.p;
-  uint32_t *v0 = vals, *v1 = st.sort.vals_alt.p;
-
-  const DAZZ_TRACK *mask = (const DAZZ_TRACK *) block->tracks;
-  if (mask != nullptr)
-    { // masked k-mers are dropped before the sort: the stable sort then leaves exactly the list the
-      // reference obtains by sorting them to the end as all-ones sentinels and cutting them off
-      // (map.c:536-542,722-724; identical unless a T^k k-mer ties with the sentinels under -T > 1)
-      StageTimer tm("kmer_mask", 32.0 * kmers);
-      const int64_t *anno = (const int64_t *) mask->anno;
-      const int64_t  nint = anno[nreads];
-      if (mask->data == nullptr && nint > 0) fatal("Sort_Kmers: mask track '%s' has no data loaded", mask->name);
-      if (nint & 1) fatal("Sort_Kmers: mask track '%s' holds an odd number of interval ends", mask->name);
-      DevBuf<int64_t>  d_anno;
-      DevBuf<int>      d_data;
-      DevBuf<uint32_t> keep, slot;
-      d_anno.ensure(nreads + 1, "mask offsets");
-      d_data.ensure(nint + 2, "mask intervals");
-      keep.ensure(kmers, "mask flags");
-      slot.ensure(kmers + 1, "mask slots");
-      copy_h2d(d_anno.p, anno, sizeof(int64_t) * (nreads + 1));
-      if (nint > 0) copy_h2d(d_data.p, mask->data, sizeof(int) * nint);
-      int nb = ceil_div(kmers, 256);
-      hipLaunchKernelGGL(k_mask_flag, dim3(nb), dim3(256), 0, stream(), (const uint32_t *) v0, kmers,
-                         (const int64_t *) bd.d_boff, nreads, pm.Kmer, (const int64_t *) d_anno.p,
-                         (const int *) d_data.p, keep.p);
-      HIP_CHECK(hipMemcpyAsync(slot.p, keep.p, sizeof(uint32_t) * kmers, hipMemcpyDeviceToDevice, stream()));
-      exclusive_scan_u32(slot.p, kmers, st.sort.bsum, slot.p + kmers);
-      hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0,
-                         (const uint32_t *) v0, (const uint32_t *) keep.p, (const uint32_t *) slot.p, kmers, k1, v1);
-      uint32_t kept = 0;
-      copy_d2h(&kept, slot.p + kmers, sizeof(uint32_t));
-      HIP_CHECK(hipStreamSynchronize(stream()));
-      std::swap(k0, k1);
-      std::swap(v0, v1);
-      kmers = kept;
-      d_anno.release(); d_data.release(); keep.release(); slot.release();
-    }
-
-  if (kmers > 0)
-    radix_sort_pairs(&k0, &v0, &k1, &v1, kmers, 0, pm.Kshift, st.sort, "kmer_sort");
-
-  if (pm.TooFrequent < INT32_MAX && kmers > 0)
-    { StageTimer tm("kmer_suppress", 32.0 * kmers);
-      DevBuf<uint32_t> keep, slot;
-      keep.ensure(kmers, "suppress flags");
-      slot.ensure(kmers + 1, "suppress slots");
-      int nb = ceil_div(kmers, 256);
-      hipLaunchKernelGGL(k_suppress_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, kmers,
-                         pm.TooFrequent, keep.p);
-      HIP_CHECK(hipMemcpyAsync(slot.p, keep.p, sizeof(uint32_t) * kmers, hipMemcpyDeviceToDevice, stream()));
-      exclusive_scan_u32(slot.p, kmers, st.sort.bsum, slot.p + kmers);
-      hipLaunchKernelGGL(k_compact, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0,
-                         (const uint32_t *) v0, (const uint32_t *) keep.p, (const uint32_t *) slot.p, kmers, k1, v1);
-      uint32_t kept = 0;
-      copy_d2h(&kept, slot.p + kmers, sizeof(uint32_t));
-      HIP_CHECK(hipStreamSynchronize(stream()));
-      std::swap(k0, k1);
-      std::swap(v0, v1);
-      kmers = kept;
-      keep.release();
-      slot.release();
-    }
-  if (VERBOSE && (pm.TooFrequent < INT32_MAX || mask != nullptr))        // map.c:793-797
-    printf("   Revised kmer count = %lld\n", (long long) kmers);
-
-  delete he;
-  HostTimer hf("sk_finish");
-  // the sorted data may sit in the scratch partner: the index then takes over the partner's
-  // buffers and the sort scratch keeps the ones allocated above (no device copy)
-  if (k0 != keys)
-    { st.sort.keys_alt.p   = keys;
-      st.sort.keys_alt.cap = (size_t) kmers0;
-      st.sort.vals_alt.p   = vals;
-      st.sort.vals_alt.cap = (size_t) kmers0;
-      keys = k0;
-      vals = v0;
-    }
-
-  ix.keys = keys;
-  ix.vals = vals;
-  ix.n    = kmers;
-
-  ix.d_boff = (int64_t *) dev_alloc(sizeof(int64_t) * (nreads + 1), "index read offsets");
-  HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (nreads + 1), hipMemcpyDeviceToDevice, stream()));
-  ix.nchunk = (L >> CHUNK_SHIFT) + 1;
-  ix.d_chunk = (uint32_t *) dev_alloc(sizeof(uint32_t) * ix.nchunk, "index chunk table");
-  hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
-                     (const int64_t *) ix.d_boff, nreads, ix.nchunk, ix.d_chunk);
-  HIP_CHECK(hipGetLastError());
-  // no synchronisation here: every later use of the index is ordered on the same stream, and a
-  // driver may queue more work (e.g. the next block's Reporter) behind the sort right away
-
-  if (!had && st.cur_reads != block)
-    { // bases of a REF block are not needed again until Reporter re-uploads the whole REF
-      // (a READS block is kept: Reporter aligns against it)
-    }
-
-  if (VERBOSE)
-    { printf("   Index occupies %.2fGb\n", (12. * kmers) / 1073741824.);
-      fflush(stdout);
-    }
-
-  if (kmers <= 0)
-    { free_index(ix);
-      return nullptr;
-    }
-
-  IndexStub *stub = (IndexStub *) malloc(sizeof(IndexStub));
-  if (stub == nullptr) fatal("out of memory allocating index handle");
-  stub->magic = INDEX_MAGIC;
-  stub->id    = st.next_index_id++;
-  stub->len   = (int32_t) kmers;
-  st.indices[stub->id] = ix;
-  *len = (int) kmers;
-  return stub;
-}
+// Sort_Kmers whose radix passes are queued later, in the gaps of the work on the current READS block
+// (bg_pump); whatever is left is queued when Match_Filter first uses the index.  Same result.
+void *dmh_sort_kmers_async(DAZZ_DB *block, int *len)
+{ return sort_kmers_impl(block, len, true); }
 
 // KmerPos layout of the reference (map.c:78-82, little endian)
 struct KmerPosRec { uint64_t code; int32_t rpos; int32_t read; };
@@ -747,6 +843,7 @@ struct KmerPosRec { uint64_t code; int32_t rpos; int32_t read; };
 int dmh_index_download(void *table, void *out)
 { IndexDev *ix = index_of(table, "dmh_index_download");
   if (ix == nullptr) return 0;
+  index_wait_ready(*ix);
   std::vector<uint64_t> k(ix->n);
   std::vector<uint32_t> v(ix->n);
   copy_d2h(k.data(), ix->keys, sizeof(uint64_t) * ix->n);

@@ -18,7 +18,9 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
 
   int64_t nhits = 0, nfilt = 0;
   if (start)
-    chain_reset_reads(ablock);
+    { HostTimer ht("mf_reset_reads");
+      chain_reset_reads(ablock);
+    }
 
   if (alen != 0 && blen != 0 && atable != nullptr && btable != nullptr)
     { IndexDev *A = index_of(atable, "Match_Filter");
@@ -26,6 +28,8 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
       if (A->n != alen || B->n != blen)
         fatal("Match_Filter: table lengths (%d,%d) do not match the handles (%lld,%lld)", alen, blen,
               (long long) A->n, (long long) B->n);
+      index_wait_ready(*A);
+      index_wait_ready(*B);
       merge_and_sort(R, ablock, bblock, *A, *B, pm.Kshift);
       nhits = R.nhits;
       if (nhits > 0)

@@ -318,9 +318,8 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   }
   std::vector<unsigned long long> hrep(GR + HREP);
   unsigned int nent = 0;
-  copy_d2h(hrep.data(), gram.p, sizeof(unsigned long long) * (GR + HREP));
   copy_d2h(&nent, mctl.p, sizeof(unsigned int));
-  HIP_CHECK(hipStreamSynchronize(stream()));
+  copy_d2h(hrep.data(), gram.p, sizeof(unsigned long long) * (GR + HREP), 1);   // the host reduces it next
   std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
   for (int r = 0; r < HREP; r++)
     { for (int j = 0; j < MAXGRAM; j++) histo[j] += hrep[(size_t) r * (MAXGRAM + 1) + j];

@@ -7,6 +7,7 @@
 #include "dmh_align.h"
 #include <algorithm>
 #include <math.h>
+#include <atomic>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -597,6 +598,33 @@ struct AlnRec
 };
 
 
+// Pinned host buffers the alignment pool is downloaded into.  When the whole batch succeeded in one
+// launch the report context takes the buffer as it is (no copy on the critical path) and gives it back
+// when it is disposed of; acquired and recycled on the main thread only.
+struct PinBuf
+{ int   *p = nullptr;
+  size_t cap = 0;
+  std::atomic<bool> busy{false};
+};
+static std::vector<PinBuf *> g_pins;
+
+static PinBuf *pin_acquire(size_t n)
+{ PinBuf *pick = nullptr;
+  for (PinBuf *b : g_pins)
+    if (!b->busy.load() && (pick == nullptr || b->cap > pick->cap)) pick = b;
+  if (pick == nullptr)
+    { pick = new PinBuf();
+      g_pins.push_back(pick);
+    }
+  if (pick->cap < n)
+    { if (pick->p) (void) hipHostFree(pick->p);
+      pick->cap = n + n / 4 + 4096;
+      HIP_CHECK(hipHostMalloc((void **) &pick->p, sizeof(int) * pick->cap, hipHostMallocDefault));
+    }
+  pick->busy.store(true);
+  return pick;
+}
+
 // Everything the per-read select/write stage needs, detached from the library state so that it
 // can run on the report worker thread while the next read block is already being filtered.
 struct ReportCtx
@@ -608,15 +636,18 @@ struct ReportCtx
   std::vector<int> job_of_first;
   std::vector<std::vector<AlnRec>> recs;
   std::vector<int> pool;
+  PinBuf *pin = nullptr;         // the pool lives here instead when one launch aligned everything
   size_t deferred_got = 0;       // > 0: pool[0..deferred_got) still has to be parsed into recs
+  int *pool_base() { return pin ? pin->p : pool.data(); }
+  ~ReportCtx() { if (pin) pin->busy.store(false); }
 };
 
 // Records of the alignment pool: {cand, seq, abpos, bbpos, aepos, bepos, diffs, tlen} + trace
-static void parse_pool(std::vector<int> &pool, size_t base, size_t got, int njobs, const std::vector<char> &failed,
+static void parse_pool(int *pool, size_t base, size_t got, int njobs, const std::vector<char> &failed,
                        std::vector<std::vector<AlnRec>> &recs)
 { size_t p = base;
   while (p + REC_HDR <= base + got)
-    { int *r = pool.data() + p;
+    { int *r = pool + p;
       int cand = r[0], tlen = r[7];
       int btl = r[12];
       if (cand < 0 || cand >= njobs || tlen < 0 || btl < 0) break;   // unwritten tail (pool overflow)
@@ -636,11 +667,11 @@ static void parse_pool(std::vector<int> &pool, size_t base, size_t got, int njob
 }
 
 // turn the trace offsets into pointers once the host pool no longer moves; order by sequence no.
-static void fixup_recs(std::vector<int> &pool, std::vector<std::vector<AlnRec>> &recs)
+static void fixup_recs(int *pool, std::vector<std::vector<AlnRec>> &recs)
 { for (auto &v : recs)
     { for (auto &a : v)
-        { a.trace  = (const uint16_t *) (pool.data() + (size_t) a.trace);
-          a.btrace = (const uint16_t *) (pool.data() + (size_t) a.btrace);
+        { a.trace  = (const uint16_t *) (pool + (size_t) a.trace);
+          a.btrace = (const uint16_t *) (pool + (size_t) a.btrace);
         }
       if (v.size() > 1)
         std::sort(v.begin(), v.end(), [](const AlnRec &x, const AlnRec &y) { return x.seq < y.seq; });
@@ -650,8 +681,8 @@ static void fixup_recs(std::vector<int> &pool, std::vector<std::vector<AlnRec>> 
 static void select_and_write(ReportCtx &C)
 { const int S_ = C.S_, NT = C.NT, nreads = C.nreads, astart = C.astart, doA = C.doA, doB = C.doB;
   if (C.deferred_got > 0)
-    { parse_pool(C.pool, 0, C.deferred_got, (int) C.recs.size(), std::vector<char>(), C.recs);
-      fixup_recs(C.pool, C.recs);
+    { parse_pool(C.pool_base(), 0, C.deferred_got, (int) C.recs.size(), std::vector<char>(), C.recs);
+      fixup_recs(C.pool_base(), C.recs);
     }
   HostTimer ht2("report_select_write");
   // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
@@ -1064,6 +1095,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel
   HostTimer *ht1 = new HostTimer("report_align");
+  bg_pump(2);                 // something for the GPU to do while the jobs are put together
   std::vector<CandJob>   jobs;
   std::vector<uint16_t>  jumps;
   std::vector<int>       job_of_first(nreads + 1, 0);   // first job index of each read
@@ -1090,6 +1122,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   std::vector<std::vector<AlnRec>> recs(njobs);
   std::vector<int> pool;
+  PinBuf *pool_pin = nullptr;
   size_t deferred_got = 0;
   { HostTimer hj("report_jobs_built"); }
   if (njobs > 0)
@@ -1187,21 +1220,14 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           }
           HostTimer hp("report_pool_parse");
           size_t got = std::min<size_t>(used, pool_cap);
-          size_t base = pool.size();
-          pool.resize(base + got);
+          PinBuf *pb = pin_acquire(got + 16);
           if (got > 0)
-            { // through a persistent pinned staging buffer: a direct copy into pageable memory makes
-              // the runtime pin and unpin the destination pages around the transfer
-              static int   *h_stage = nullptr;
-              static size_t h_cap = 0;
-              if (got > h_cap)
-                { if (h_stage) (void) hipHostFree(h_stage);
-                  h_cap = got + got / 4 + 4096;
-                  HIP_CHECK(hipHostMalloc((void **) &h_stage, sizeof(int) * h_cap, hipHostMallocDefault));
-                }
-              HIP_CHECK(hipMemcpyAsync(h_stage, d_pool.p, sizeof(int) * got, hipMemcpyDeviceToHost, stream()));
-              HIP_CHECK(hipStreamSynchronize(stream()));
-              memcpy(pool.data() + base, h_stage, sizeof(int) * got);
+            { HIP_CHECK(hipMemcpyAsync(pb->p, d_pool.p, sizeof(int) * got, hipMemcpyDeviceToHost, stream()));
+              static hipEvent_t ev_pool = nullptr;
+              if (ev_pool == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_pool, hipEventDisableTiming));
+              HIP_CHECK(hipEventRecord(ev_pool, stream()));
+              bg_pump(2);        // runs while the records are handed to the report stage
+              HIP_CHECK(hipEventSynchronize(ev_pool));
             }
 
           // which jobs of this run failed, and why
@@ -1222,11 +1248,16 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           // batch succeeded at once the parse is left to the report stage (worker thread)
           if (again.empty() && round == 0)
             { deferred_got = got;
+              pool_pin = pb;
               break;
             }
+          size_t base = pool.size();
+          pool.resize(base + got);
+          if (got > 0) memcpy(pool.data() + base, pb->p, sizeof(int) * got);
+          pb->busy.store(false);
           std::vector<char> failed(njobs, 0);
           for (int j : again) failed[j] = 1;
-          parse_pool(pool, base, got, njobs, failed, recs);
+          parse_pool(pool.data(), base, got, njobs, failed, recs);
           for (int j : again) recs[j].clear();
           if (again.empty()) break;
           std::sort(again.begin(), again.end());
@@ -1235,10 +1266,11 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           else if (need_up) level += 1;
           if (round == 7) fatal("Reporter: alignment retries exhausted");
         }
-      if (deferred_got == 0) fixup_recs(pool, recs);
+      if (deferred_got == 0) fixup_recs(pool.data(), recs);
     }
 
   delete ht1;
+  HostTimer ht_tail("report_tail");
   { ReportCtx *C = new ReportCtx();
     C->S_ = S_; C->NT = NT; C->nshift = pm.NSHIFT; C->nreads = nreads; C->astart = astart; C->doA = doA; C->doB = doB;
     C->spacing = SPACING; C->profile = PROFILE; C->verbose = VERBOSE; C->best_tie = BEST_TIE;
@@ -1251,6 +1283,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     C->job_of_first = std::move(job_of_first);
     C->recs = std::move(recs);
     C->pool = std::move(pool);
+    C->pin = pool_pin;
     C->deferred_got = deferred_got;
     report_submit(C);
   }

@@ -264,6 +264,30 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
     }
 }
 
+// One pass of the sort above in two separately queued halves (deferred index builds, bg_pump)
+void radix_pass_hist(const uint64_t *keys, int64_t n, int shift, int w, SortScratch &scr)
+{ int ntiles = ceil_div(n, SORT_TILE);
+  scr.hist.ensure((size_t) 256 * ntiles, "radix histogram");
+  uint32_t mask = (w >= 8) ? 0xffu : ((1u << w) - 1u);
+  { StageTimer th("k_radix_hist", 0.0);
+    hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(SORT_THREADS), 0, stream(), keys, n, shift, mask, scr.hist.p, ntiles);
+  }
+  { StageTimer ts("radix_scan", 0.0);
+    exclusive_scan_u32(scr.hist.p, (int64_t) 256 * ntiles, scr.bsum, nullptr);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void radix_pass_scatter(const uint64_t *keys, const uint32_t *vals, uint64_t *okeys, uint32_t *ovals, int64_t n,
+                        int shift, int w, SortScratch &scr)
+{ int ntiles = ceil_div(n, SORT_TILE);
+  uint32_t mask = (w >= 8) ? 0xffu : ((1u << w) - 1u);
+  StageTimer tc("k_radix_scatter", 32.0 * (double) n);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, stream(), keys, vals, okeys, ovals, n,
+                     shift, mask, (const uint32_t *) scr.hist.p, ntiles);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------------------------
 //  K-mer emit
 // ---------------------------------------------------------------------------------------

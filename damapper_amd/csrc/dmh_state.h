@@ -44,6 +44,7 @@ struct IndexDev
   int64_t   L      = 0;
   std::vector<int64_t> h_boff;  // host copy
   DAZZ_DB  *block  = nullptr;
+  bool      pending = false;    // a deferred build (dmh_sort_kmers_async) has stages left to queue
 };
 
 constexpr int CHUNK_SHIFT = 9;
@@ -87,6 +88,7 @@ struct State
   int64_t  tfilt = 0;
 
   SortScratch sort;
+  SortScratch sort_aux;         // scratch of the deferred index build (lives across Match_Filter calls)
 };
 
 State &S();
@@ -101,5 +103,6 @@ void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nre
                uint64_t *d_keys, uint32_t *d_vals, int64_t nk);
 
 IndexDev *index_of(void *table, const char *who);
+void      index_wait_ready(IndexDev &ix);     // queue what is left of a deferred build
 
 }  // namespace dmh

@@ -17,7 +17,8 @@ from .dazzdb import Block, load_db, read_stub
 class Mapper:
     def __init__(self, kmer: int = 20, suppress: int = 0, threads: int = 4, ave_corr: float = 0.85,
                  spacing: int = 100, best_tie: float = 1.0, profile: int = 0, verbose: int = 0,
-                 mem_limit: int = 0, sort_path: str = "/tmp", retain_ref: bool = False):
+                 mem_limit: int = 0, sort_path: str = "/tmp", retain_ref: bool = False,
+                 prefetch_deferred: bool = True):
         self.L = capi.lib()
         self.kmer, self.suppress, self.threads = kmer, suppress, threads
         self.ave_corr, self.spacing = ave_corr, spacing
@@ -36,6 +37,7 @@ class Mapper:
         # north_star: "reference k-mer index replicated per GPU": build both orientations of every REF
         # block once and keep them in HBM for all read blocks (Match_Filter then does not consume them)
         self.retain_ref = retain_ref
+        self.prefetch_deferred = prefetch_deferred
         self._ref_cache = None
         self.L.dmh_retain_ref_index(1 if retain_ref else 0)
 
@@ -83,6 +85,7 @@ class Mapper:
         loop; results are unchanged)."""
         t = {}
         t0 = time.time()
+        t["between_blocks"] = (t0 - self._last_end) if getattr(self, "_last_end", None) else 0.0
         if self.spec is None:
             self.make_spec([ref_whole.db.freq[j] for j in range(4)])
         pre = getattr(self, "_prefetched", None)
@@ -91,6 +94,11 @@ class Mapper:
         else:
             rh, rn = capi.sort_kmers(reads)
         self._prefetched = None
+        if next_reads is not None and self.prefetch_deferred:
+            # the next block's index build is deferred: its stages are queued in the gaps of this
+            # block's filter and report phases (dmh_sort_kmers_async)
+            h2, n2 = capi.sort_kmers(next_reads, deferred=True)
+            self._prefetched = (next_reads, h2, n2)
         t["index_reads"] = time.time() - t0
         t1 = time.time()
         if self.retain_ref:
@@ -107,14 +115,15 @@ class Mapper:
                     blk.complement_inplace()
         t["filter"] = time.time() - t1
         t2 = time.time()
-        if next_reads is not None:
+        if next_reads is not None and not self.prefetch_deferred:
             h2, n2 = capi.sort_kmers(next_reads)
             self._prefetched = (next_reads, h2, n2)
         self.L.Reporter(reads_name.encode(), reads.ptr(), ref_name.encode(), ref_whole.ptr(), self.spec, mflag)
         t["report"] = time.time() - t2
         if rh:
             self.L.dmh_free_index(rh)      # Reporter released the device side; this frees the stub
-        t["total"] = time.time() - t0
+        self._last_end = time.time()
+        t["total"] = self._last_end - t0
         return t
 
 

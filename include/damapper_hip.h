@@ -123,6 +123,12 @@ const char *dmh_last_error(void);
 void        dmh_reset(void);                 /* drop every cached device buffer and all state */
 
 /* Upload `block`'s bases ahead of time so Sort_Kmers / Reporter find them resident in HBM.   */
+/* Sort_Kmers whose radix passes are queued later, in the gaps between the GPU round trips of the
+ * work on the current READS block; Match_Filter queues whatever is left before it uses the index.
+ * Same index as Sort_Kmers.  For software-pipelining the block loop (index of READS block i+1 built
+ * while block i is filtered and aligned).  Blocks with a mask track or under -t are built at once.  */
+void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
+
 int  dmh_preload_block(DAZZ_DB *block);
 void dmh_release_block(DAZZ_DB *block);
 
