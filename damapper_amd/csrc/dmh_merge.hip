@@ -90,21 +90,60 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
 
   const int rep = blockIdx.x & (HREP - 1);
   unsigned long long local = 0;
+
+  // The look-ups of a thread's MG_ITEMS codes are independent: issue them phase by phase (codes,
+  // bucket bounds, the first two keys of the bucket) so that every thread has MG_ITEMS loads in
+  // flight instead of one dependent chain after the other.  The bucket table is sized for ~0.15
+  // entries per bucket, so two keys settle all but a few look-ups per thousand; only those run the
+  // bisection (a wavefront pays its dependent loads if ANY of its lanes needs it).
+  const int64_t tile0 = (int64_t) blockIdx.x * MG_TILE + tid;
+  uint64_t c[MG_ITEMS];
+  bool     first[MG_ITEMS];
+  uint32_t bs[MG_ITEMS], be[MG_ITEMS];
+#pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
-    { int64_t i = (int64_t) blockIdx.x * MG_TILE + j * MG_THREADS + tid;
+    { int64_t i = tile0 + j * MG_THREADS;
+      c[j] = (i < na) ? akeys[i] : 0;
+      uint64_t prev = (i > 0 && i < na) ? akeys[i - 1] : 0;
+      first[j] = (i < na) && (i == 0 || prev != c[j]);
+    }
+#pragma unroll
+  for (int j = 0; j < MG_ITEMS; j++)
+    { bs[j] = be[j] = 0;
+      if (first[j])
+        { uint64_t p = c[j] >> B.shift;
+          bs[j] = B.bstart[p];
+          be[j] = B.bstart[p + 1];
+        }
+    }
+  uint64_t k0[MG_ITEMS], k1[MG_ITEMS];
+#pragma unroll
+  for (int j = 0; j < MG_ITEMS; j++)
+    { k0[j] = (bs[j] < be[j]) ? B.keys[bs[j]] : ~0ull;
+      k1[j] = (bs[j] + 1 < be[j]) ? B.keys[bs[j] + 1] : ~0ull;
+    }
+
+#pragma unroll
+  for (int j = 0; j < MG_ITEMS; j++)
+    { int64_t i = tile0 + j * MG_THREADS;
       unsigned long long ct = 0;
       uint32_t lo = 0, mb = 0;
       int64_t  e = 0;
       bool     hit = false;
-      if (i < na)
-        { uint64_t c = akeys[i];
-          if (i == 0 || akeys[i - 1] != c)              // first of its run
-            { b_range(B, c, lo, mb);
-              if (mb != 0)
-                { e   = (i + 1 < na && akeys[i + 1] == c) ? run_end(akeys, na, i) : i + 1;
-                  ct  = (unsigned long long) (e - i) * mb;
-                  hit = true;
-                }
+      if (first[j] && bs[j] < be[j] && k0[j] <= c[j])
+        { const uint32_t sz = be[j] - bs[j];
+          const uint64_t cc = c[j];
+          if (k0[j] == cc && (sz == 1 || k1[j] != cc)) { lo = bs[j]; mb = 1; }
+          else if (k0[j] == cc && sz == 2)              { lo = bs[j]; mb = 2; }
+          else if (k0[j] <  cc && sz == 1)              mb = 0;
+          else if (k0[j] <  cc && k1[j] > cc)           mb = 0;
+          else if (k0[j] <  cc && k1[j] == cc && sz == 2) { lo = bs[j] + 1; mb = 1; }
+          else if (k0[j] <  cc && k1[j] <  cc && sz == 2) mb = 0;
+          else b_range(B, cc, lo, mb);
+          if (mb != 0)
+            { e   = (i + 1 < na && akeys[i + 1] == cc) ? run_end(akeys, na, i) : i + 1;
+              ct  = (unsigned long long) (e - i) * mb;
+              hit = true;
             }
         }
       if (hit)
@@ -286,7 +325,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   int pshift = R.pbits, bshift = R.pbits + R.bbits;
 
   // --- bucket table over the REF index
-  int P = ceil_log2(Bx.n);
+  int P = ceil_log2(Bx.n) + 2;         // ~0.15 entries per bucket (up to 1 GB of table)
   if (P < 8) P = 8;
   if (P > 28) P = 28;
   if (P > Kshift) P = Kshift;
