@@ -53,42 +53,57 @@ struct ChainArgs
   uint32_t       *tmp;         // reporting scratch
   uint4          *live;        // live-set entries {hit, apos, bpos, cost}
   unsigned int   *ticket;
+  uint32_t        size_lo, size_hi;   // this launch takes the groups with size_lo <= hits < size_hi
   unsigned int   *out_count;
   ChainSummary   *out;
 };
 
+// reductions over the G lanes of a group (G a power of two, groups aligned: xor stays inside)
+template <int G>
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
+  for (int o = G / 2; o > 0; o >>= 1)
     { uint64_t t = __shfl_xor(v, o);
       v = (t < v) ? t : v;
     }
   return v;
 }
 
+template <int G>
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
 {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
+  for (int o = G / 2; o > 0; o >>= 1)
     { uint64_t t = __shfl_xor(v, o);
       v = (t > v) ? t : v;
     }
   return v;
 }
 
+// G lanes per group: the live window of a 10 kb read holds a few dozen hits, so a whole wavefront
+// per group leaves most lanes idle and -- the walk over the hits being one long dependent chain of
+// memory round trips -- the kernel is bound by how many groups are in flight, not by issue slots.
+// 64/G groups share a wavefront's instruction stream.  Groups with thousands of hits (repeats: the
+// live window itself holds thousands) want all 64 lanes on their scan instead, so the host launches
+// the kernel twice: G = 16 over the small groups, G = 64 over the big ones.
+template <int G>
 __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
-{ const int      lane = threadIdx.x & 63;
-  const uint64_t lt   = (1ull << lane) - 1ull;
-  const int      K    = A.K;
+{ const int      lane  = threadIdx.x & (G - 1);                 // lane within the group
+  const int      sbase = (threadIdx.x & 63) & ~(G - 1);         // first lane of the group in its wavefront
+  const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+  const uint64_t lt    = (1ull << lane) - 1ull;
+  const int      K     = A.K;
+  auto gballot = [&](bool p) -> uint64_t { return (__ballot(p) >> sbase) & gmask; };
 
   while (true)
     { uint32_t g = 0;
       if (lane == 0) g = atomicAdd(A.ticket, 1u);
-      g = __shfl(g, 0);
+      g = __shfl(g, 0, G);
       if (g >= A.ngroups) break;
 
       const uint32_t g0 = A.gstart[g], g1 = A.gstart[g + 1];
+      if (g1 - g0 < A.size_lo || g1 - g0 >= A.size_hi) continue;      // the other launch's group
       // The live set (hits in the reference's tree) is an unordered list of self-contained entries
       // {hit, apos, bpos, cost} in this group's slice of A.live.  One coalesced scan per hit drops
       // expired / removed entries (compacting in place) and answers both neighbour queries, so a
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
           uint32_t Lpos = 0, Rpos = 0;
           const int thresh = bpos - MAX_GAP;
           uint32_t  wr = 0;
-          for (uint32_t base = 0; base < nlive; base += 64)
+          for (uint32_t base = 0; base < nlive; base += G)
             { uint32_t i  = base + lane;
               uint4    en = make_uint4(NIL, 0, 0, 0);
               bool     keep = false;
@@ -130,21 +145,21 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
                         }
                     }
                 }
-              uint64_t km  = __ballot(keep);
+              uint64_t km  = gballot(keep);
               uint32_t dst = wr + (uint32_t) __popcll(km & lt);
-              uint64_t lm = wave_min_u64(lk);
-              uint64_t rm = wave_max_u64(rk);
+              uint64_t lm = wave_min_u64<G>(lk);
+              uint64_t rm = wave_max_u64<G>(rk);
               if (lm < Lbest)
-                { int sl = __ffsll((long long) __ballot(lk == lm)) - 1;
+                { int sl = __ffsll((long long) gballot(lk == lm)) - 1;
                   Lbest = lm;
-                  Le.x = __shfl(en.x, sl); Le.y = __shfl(en.y, sl); Le.z = __shfl(en.z, sl); Le.w = __shfl(en.w, sl);
-                  Lpos = __shfl(dst, sl);
+                  Le.x = __shfl(en.x, sl, G); Le.y = __shfl(en.y, sl, G); Le.z = __shfl(en.z, sl, G); Le.w = __shfl(en.w, sl, G);
+                  Lpos = __shfl(dst, sl, G);
                 }
               if (rm > Rbest)
-                { int sl = __ffsll((long long) __ballot(rk == rm)) - 1;
+                { int sl = __ffsll((long long) gballot(rk == rm)) - 1;
                   Rbest = rm;
-                  Re.x = __shfl(en.x, sl); Re.y = __shfl(en.y, sl); Re.z = __shfl(en.z, sl); Re.w = __shfl(en.w, sl);
-                  Rpos = __shfl(dst, sl);
+                  Re.x = __shfl(en.x, sl, G); Re.y = __shfl(en.y, sl, G); Re.z = __shfl(en.z, sl, G); Re.w = __shfl(en.w, sl, G);
+                  Rpos = __shfl(dst, sl, G);
                 }
               // in-place compaction: the write index never passes this chunk's first read index, and
               // the stored value is the loaded one, so the stores cannot overtake the loads
@@ -209,12 +224,12 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
       // ---- report the best end of every origin with cost >= hithr (map.c:1634-1649).  Order:
       //      live ends by (diag,apos) descending, then expired ends most recent first.
       uint32_t E = 0;
-      for (uint32_t base = g0; base < g1; base += 64)
+      for (uint32_t base = g0; base < g1; base += G)
         { uint32_t x = base + lane;
           bool     f = false;
           if (x < g1 && A.cost[x] >= A.hithr && A.from[x] != NIL)
             f = (A.best[A.rootof[x]] == x);
-          uint64_t m = __ballot(f);
+          uint64_t m = gballot(f);
           if (f) A.tmp[g0 + E + __popcll(m & lt)] = x;
           E += __popcll(m);
         }
@@ -223,9 +238,9 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
 
       uint32_t obase = 0;
       if (lane == 0) obase = atomicAdd(A.out_count, E);
-      obase = __shfl(obase, 0);
+      obase = __shfl(obase, 0, G);
 
-      for (uint32_t e = lane; e < E; e += 64)
+      for (uint32_t e = lane; e < E; e += G)
         { uint32_t x    = A.tmp[g0 + e];
           bool     live_x = (A.state[x] == ST_LIVE);
           int      ax   = (int) (A.keys[x] & A.pmask) + 1;
@@ -355,9 +370,28 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.out_count = ctl.p + 1;
   A.out = out.p;
 
-  int nblocks = (int) std::min<int64_t>((R.ngroups + 3) / 4, 256 * 8);
+  // small groups four to a wavefront, big ones (repeat piles) one per wavefront; DMH_CHAIN_G forces one size
+  static const int chain_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
+  constexpr uint32_t BIG_GROUP = 1024;
   { StageTimer tm("chain", 16.0 * nhits);
-    hipLaunchKernelGGL(k_chain, dim3(nblocks), dim3(256), 0, stream(), A);
+    if (chain_g == 64 || chain_g == 32 || chain_g == 16)
+      { const int gpb = 256 / chain_g;
+        int nblocks = (int) std::min<int64_t>((R.ngroups + gpb - 1) / gpb, 256 * 8);
+        A.size_lo = 0; A.size_hi = 0xffffffffu;
+        if (chain_g == 64)      hipLaunchKernelGGL(k_chain<64>, dim3(nblocks), dim3(256), 0, stream(), A);
+        else if (chain_g == 32) hipLaunchKernelGGL(k_chain<32>, dim3(nblocks), dim3(256), 0, stream(), A);
+        else                    hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
+      }
+    else
+      { int nblocks = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
+        A.size_lo = 0; A.size_hi = BIG_GROUP;
+        hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
+        // second launch: its own ticket counter (ctl[2]); on read-vs-genome data it finds nothing to do
+        A.ticket  = ctl.p + 2;
+        A.size_lo = BIG_GROUP; A.size_hi = 0xffffffffu;
+        nblocks = (int) std::min<int64_t>((R.ngroups + 3) / 4, 256 * 8);
+        hipLaunchKernelGGL(k_chain<64>, dim3(nblocks), dim3(256), 0, stream(), A);
+      }
     HIP_CHECK(hipGetLastError());
   }
   uint32_t nsum = 0;
