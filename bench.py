@@ -39,9 +39,9 @@ READ_LEN = 10_000
 HBM_PEAK_GBS = 8000.0
 
 
-def make_block(genome, nreads, seed, tfirst=0, part=0):
+def make_block(genome, nreads, seed, tfirst=0, part=0, pinned=False):
     return dazzdb.simulate_block(seed, genome[0], nreads, read_len=READ_LEN, err=0.15, tfirst=tfirst, part=part,
-                                 path=b"./.READS")
+                                 path=b"./.READS", pinned=pinned)
 
 
 def shard_blocks(nblocks, rank, world):
@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--serial-prefetch", action="store_true",
                     help="queue the next block's whole index build before Reporter instead of spreading its "
                          "stages over the gaps of the current block")
+    ap.add_argument("--pcie", choices=["pinned", "pageable"], default=None,
+                    help="PCIe-inclusive rate: read blocks are NOT resident, every step uploads its block from "
+                         "page-locked (dmh_host_alloc) or ordinary host memory inside the timed region")
     ap.add_argument("--sync-report", action="store_true", help="write the .las files inside Reporter (drop-in behaviour)")
     ap.add_argument("--rebuild-ref", action="store_true",
                     help="rebuild the REF indices for every read block as damapper.c does (default: build both "
@@ -109,7 +112,8 @@ def main():
     nblk = min(args.nblocks, max(1, args.steps + args.warmup))
     blocks = []
     for b in range(nblk):
-        blocks.append(make_block(genome, args.block_reads, 1000 + 97 * rank + b, tfirst=b * args.block_reads, part=b + 1))
+        blocks.append(make_block(genome, args.block_reads, 1000 + 97 * rank + b, tfirst=b * args.block_reads, part=b + 1,
+                                 pinned=(args.pcie == "pinned")))
     ref_blocks = [dazzdb.make_block(genome, tfirst=0, part=1, path=b"./.REF")]
     ref_whole = dazzdb.make_block(genome, path=b"./.REF")
 
@@ -119,8 +123,9 @@ def main():
     m.make_spec([ref_whole.db.freq[j] for j in range(4)])
 
     # inputs resident in HBM before the clock starts
-    for blk in blocks:
-        L.dmh_preload_block(blk.ptr())
+    if args.pcie is None:
+        for blk in blocks:
+            L.dmh_preload_block(blk.ptr())
     L.dmh_preload_block(ref_whole.ptr())
     pcie_t0 = time.time()
     L.dmh_sync()
@@ -130,7 +135,10 @@ def main():
     def step(i):
         blk = blocks[i % nblk]
         nxt = blocks[(i + 1) % nblk] if (i < last and not args.no_prefetch and nblk > 1) else None
-        return m.map_block(blk, "READS.%d" % (i % nblk + 1), ref_blocks, ref_whole, "REF", next_reads=nxt)
+        t = m.map_block(blk, "READS.%d" % (i % nblk + 1), ref_blocks, ref_whole, "REF", next_reads=nxt)
+        if args.pcie is not None:
+            L.dmh_release_block(blk.ptr())       # the next visit uploads it again
+        return t
 
     for i in range(args.warmup):
         step(i)
@@ -212,7 +220,8 @@ def main():
             "config": {"workload": "configs[1]: E.coli-sized random reference (4.6 Mbp) + simulated PacBio reads "
                                    "(10 kb, 15%% err), %d reads per block/step, %d distinct blocks per GPU, "
                                    "-k20 -e.85 -s100, REF index %s" %
-                                   (args.block_reads, nblk, "rebuilt per read block" if args.rebuild_ref else "built once per GPU, resident"),
+                                   (args.block_reads, nblk, ("rebuilt per read block" if args.rebuild_ref else "built once per GPU, resident") +
+                                    ("" if args.pcie is None else "; read blocks uploaded inside the timed region from %s host memory" % args.pcie)),
                        "read_bases_per_step": int(blocks[0].db.totlen), "parallelism": "read blocks sharded x%d" % world},
             "roofline": roof, "cpu_baseline": cpu,
             "host_seconds": {k: round(v, 3) for k, v in host.items()},

@@ -93,7 +93,7 @@ def exported_symbols() -> List[str]:
             "dmh_last_seed_count", "dmh_last_seeds", "dmh_last_limit", "dmh_read_candidates",
             "dmh_candidate_jumps", "dmh_read_cover", "dmh_sort_pairs", "dmh_local_alignment",
             "dmh_timing_enable", "dmh_timing_reset", "dmh_timing_count", "dmh_timing_get", "dmh_sync",
-            "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async"]
+            "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free"]
 
 
 def set_globals(verbose: int = 0, profile: int = 0, spacing: int = 100, best_tie: float = 1.0,

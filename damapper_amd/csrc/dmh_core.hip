@@ -27,6 +27,7 @@ namespace dmh {
 
 static char       g_err[1024] = "";
 static hipStream_t g_stream    = nullptr;
+static hipStream_t g_upstream  = nullptr;     // block uploads from page-locked host memory (DMA only, no kernels)
 static bool        g_init      = false;
 
 State &S()
@@ -68,6 +69,7 @@ static void init_device()
   HIP_CHECK(hipSetDevice(dev));
   if (getenv("DMH_SPIN") != nullptr) (void) hipSetDeviceFlags(hipDeviceScheduleSpin);
   HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&g_upstream, hipStreamNonBlocking));
   g_init = true;
 }
 
@@ -78,6 +80,7 @@ hipStream_t stream()
 
 static void sync_all_streams()
 { init_device();
+  HIP_CHECK(hipStreamSynchronize(g_upstream));
   HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 
@@ -185,14 +188,47 @@ void copy_d2h(void *host, const void *dev, size_t bytes, int pump_stages)
 
 void copy_h2d(void *dev, const void *host, size_t bytes)
 { pin_init();
-  size_t off = 0;
+  if (bytes <= PIN_CHUNK)
+    { memcpy(g_pin, host, bytes);
+      HIP_CHECK(hipMemcpyAsync(dev, g_pin, bytes, hipMemcpyHostToDevice, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      return;
+    }
+  // large transfers (whole blocks from pageable memory): two staging buffers, the host fills one
+  // while the DMA engine drains the other
+  static uint8_t   *pin2 = nullptr;
+  static hipEvent_t ev[2] = {nullptr, nullptr};
+  if (pin2 == nullptr)
+    { HIP_CHECK(hipHostMalloc((void **) &pin2, PIN_CHUNK, hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    }
+  uint8_t *buf[2] = {g_pin, pin2};
+  bool     used[2] = {false, false};
+  size_t   off = 0;
+  int      k = 0;
   while (off < bytes)
     { size_t c = std::min(PIN_CHUNK, bytes - off);
-      memcpy(g_pin, (const uint8_t *) host + off, c);
-      HIP_CHECK(hipMemcpyAsync((uint8_t *) dev + off, g_pin, c, hipMemcpyHostToDevice, stream()));
-      HIP_CHECK(hipStreamSynchronize(stream()));
+      if (used[k]) HIP_CHECK(hipEventSynchronize(ev[k]));
+      memcpy(buf[k], (const uint8_t *) host + off, c);
+      HIP_CHECK(hipMemcpyAsync((uint8_t *) dev + off, buf[k], c, hipMemcpyHostToDevice, stream()));
+      HIP_CHECK(hipEventRecord(ev[k], stream()));
+      used[k] = true;
       off += c;
+      k ^= 1;
     }
+  HIP_CHECK(hipStreamSynchronize(stream()));
+}
+
+// Is p page-locked host memory known to the runtime (dmh_host_alloc, hipHostMalloc, hipHostRegister)?
+static bool is_pinned_host(const void *p)
+{ hipPointerAttribute_t at;
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess)
+    { (void) hipGetLastError();          // pageable memory: not an error for us
+      return false;
+    }
+  return at.type == hipMemoryTypeHost;
 }
 
 // ---- stage timing -----------------------------------------------------------------------
@@ -282,8 +318,20 @@ static uint64_t block_stamp(const DAZZ_DB *b)
   return h;
 }
 
+void block_ready(BlockDev &bd)
+{ if (bd.uploaded == nullptr) return;
+  HIP_CHECK(hipStreamWaitEvent(stream(), bd.uploaded, 0));
+  HIP_CHECK(hipEventDestroy(bd.uploaded));
+  bd.uploaded = nullptr;
+}
+
 static void free_blockdev(BlockDev &bd)
-{ dev_free(bd.d_raw);
+{ if (bd.uploaded != nullptr)
+    { HIP_CHECK(hipEventSynchronize(bd.uploaded));
+      HIP_CHECK(hipEventDestroy(bd.uploaded));
+      bd.uploaded = nullptr;
+    }
+  dev_free(bd.d_raw);
   dev_free(bd.d_boff);
   dev_free(bd.d_pkraw);
   dev_free(bd.d_rcraw);
@@ -355,7 +403,7 @@ void pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int 
 }
 
 void ensure_packed(BlockDev &bd, bool want_rc)
-{ int64_t nwords = (bd.L >> 5) + 1;
+{ block_ready(bd); int64_t nwords = (bd.L >> 5) + 1;
   if (bd.d_pkraw == nullptr)
     { bd.d_pkraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * (nwords + 4), "packed bases");
       pack_bases(bd.d_bases(), bd.L, bd.d_pkraw);
@@ -386,12 +434,38 @@ BlockDev &upload_block(const DAZZ_DB *block, bool pin)
   bd.pinned = pin;
   bd.d_raw = (uint8_t *) dev_alloc((size_t) bd.L + 1, "block bases");
   // the byte before bases[0] is the leading separator (DB.c:1411)
-  copy_h2d(bd.d_raw, ((const uint8_t *) block->bases) - 1, (size_t) bd.L + 1);
-  std::vector<int64_t> off(n + 1);
-  for (int i = 0; i <= n; i++) off[i] = block->reads[i].boff;
+  const uint8_t *src = ((const uint8_t *) block->bases) - 1;
   bd.d_boff = (int64_t *) dev_alloc(sizeof(int64_t) * (n + 1), "block read offsets");
-  copy_h2d(bd.d_boff, off.data(), sizeof(int64_t) * (n + 1));
-  HIP_CHECK(hipStreamSynchronize(stream()));
+  if (is_pinned_host(src))
+    { // the driver loaded the block into page-locked memory (dmh_host_alloc): one DMA straight from it
+      // on the upload stream, next to whatever kernels the main stream is running; the first kernel
+      // that reads the copy waits for it (block_ready).  The caller keeps the block unchanged until
+      // a library call that uses it has returned (Match_Filter and Reporter synchronise).  Nothing
+      // here waits for the main stream.
+      static int64_t   *h_off = nullptr;       // page-locked staging for the offsets, reused per upload
+      static size_t     h_cap = 0;
+      static hipEvent_t h_free = nullptr;
+      if (h_free == nullptr) HIP_CHECK(hipEventCreateWithFlags(&h_free, hipEventDisableTiming));
+      else HIP_CHECK(hipEventSynchronize(h_free));
+      if ((size_t) n + 1 > h_cap)
+        { if (h_off) (void) hipHostFree(h_off);
+          h_cap = (size_t) n + 1 + 1024;
+          HIP_CHECK(hipHostMalloc((void **) &h_off, sizeof(int64_t) * h_cap, hipHostMallocDefault));
+        }
+      for (int i = 0; i <= n; i++) h_off[i] = block->reads[i].boff;
+      HIP_CHECK(hipMemcpyAsync(bd.d_boff, h_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, g_upstream));
+      HIP_CHECK(hipEventRecord(h_free, g_upstream));
+      HIP_CHECK(hipMemcpyAsync(bd.d_raw, src, (size_t) bd.L + 1, hipMemcpyHostToDevice, g_upstream));
+      HIP_CHECK(hipEventCreateWithFlags(&bd.uploaded, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(bd.uploaded, g_upstream));
+    }
+  else
+    { copy_h2d(bd.d_raw, src, (size_t) bd.L + 1);
+      std::vector<int64_t> off(n + 1);
+      for (int i = 0; i <= n; i++) off[i] = block->reads[i].boff;
+      copy_h2d(bd.d_boff, off.data(), sizeof(int64_t) * (n + 1));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+    }
   st.blocks[block] = bd;
   return st.blocks[block];
 }
@@ -495,7 +569,9 @@ struct SortJob
   uint32_t *vals, *v0, *v1;
   int64_t   kmers, kmers0;
   int       Kshift, npass;
-  int       stage;              // 0 .. 2*npass-1: even = histogram + scan of pass stage/2, odd = its scatter
+  int       stage;              // -1 = k-mer emit; 0 .. 2*npass-1: even = histogram + scan of pass stage/2, odd = its scatter
+  const DAZZ_DB *block;         // emit stage: the block whose device copy is read
+  int       Kmer;
 };
 static std::deque<SortJob> g_bg;
 
@@ -519,6 +595,22 @@ static void adopt_sorted(IndexDev &ix, SortScratch &scr, uint64_t *keys, uint32_
 static void bg_step()
 { SortJob &J = g_bg.front();
   State   &st = S();
+  if (J.stage < 0)
+    { auto b = st.blocks.find(J.block);
+      if (b == st.blocks.end()) fatal("deferred index build lost its block");
+      BlockDev &bd = b->second;
+      auto it = st.indices.find(J.id);
+      if (it == st.indices.end()) fatal("deferred index build lost its index");
+      IndexDev &ix = it->second;
+      block_ready(bd);
+      kmer_emit(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, J.Kmer, J.keys, J.vals, J.kmers);
+      HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (bd.nreads + 1), hipMemcpyDeviceToDevice, stream()));
+      hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
+                         (const int64_t *) ix.d_boff, bd.nreads, ix.nchunk, ix.d_chunk);
+      HIP_CHECK(hipGetLastError());
+      J.stage = 0;
+      return;
+    }
   const int p = J.stage >> 1;
   const int w = J.Kshift - 8 * p;
   if ((J.stage & 1) == 0)
@@ -592,7 +684,10 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
 
   delete ha;
   HostTimer *he = new HostTimer("sk_enqueue");
-  kmer_emit(bd.d_bases(), L, bd.d_boff, nreads, pm.Kmer, keys, vals, kmers);
+  if (!defer)
+    { block_ready(bd);
+      kmer_emit(bd.d_bases(), L, bd.d_boff, nreads, pm.Kmer, keys, vals, kmers);
+    }
   if (getenv("DMH_DEBUG_SYNC") != nullptr)
     { HostTimer hs("sk_emit_sync");
       HIP_CHECK(hipStreamSynchronize(stream()));
@@ -675,12 +770,14 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
     adopt_sorted(ix, scr, keys, vals, k0, v0, kmers0, kmers);
 
   ix.d_boff = (int64_t *) dev_alloc(sizeof(int64_t) * (nreads + 1), "index read offsets");
-  HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (nreads + 1), hipMemcpyDeviceToDevice, stream()));
   ix.nchunk = (L >> CHUNK_SHIFT) + 1;
   ix.d_chunk = (uint32_t *) dev_alloc(sizeof(uint32_t) * ix.nchunk, "index chunk table");
-  hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
-                     (const int64_t *) ix.d_boff, nreads, ix.nchunk, ix.d_chunk);
-  HIP_CHECK(hipGetLastError());
+  if (!defer)            // (a deferred build fills both in its first stage, once the block has arrived)
+    { HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (nreads + 1), hipMemcpyDeviceToDevice, stream()));
+      hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
+                         (const int64_t *) ix.d_boff, nreads, ix.nchunk, ix.d_chunk);
+      HIP_CHECK(hipGetLastError());
+    }
   // no synchronisation here: every later use of the index is ordered on the same stream, and a
   // driver may queue more work (e.g. the next block's Reporter) behind the sort right away
 
@@ -710,7 +807,9 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
       J.kmers = kmers; J.kmers0 = kmers0;
       J.Kshift = pm.Kshift;
       J.npass = (pm.Kshift + 7) / 8;
-      J.stage = 0;
+      J.stage = -1;
+      J.block = block;
+      J.Kmer  = pm.Kmer;
       g_bg.push_back(J);
       if (kmers <= 1) bg_flush();
     }
@@ -808,6 +907,18 @@ void dmh_free_index(void *table)
 }
 
 void dmh_capture_seeds(int on) { S().capture_seeds = (on != 0); }
+
+void *dmh_host_alloc(size_t bytes)
+{ void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess)
+    { (void) hipGetLastError();
+      return nullptr;
+    }
+  return p;
+}
+
+void dmh_host_free(void *p)
+{ if (p != nullptr) (void) hipHostFree(p); }
 
 // ---- map.c:124-150 -------------------------------------------------------------------------
 int Set_Filter_Params(int kmer, int suppress, int nthreads)

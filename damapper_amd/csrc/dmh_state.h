@@ -28,6 +28,7 @@ struct BlockDev
   uint64_t *d_rcraw = nullptr;  // same for the per-read reverse complement (READS blocks only)
   uint64_t stamp   = 0;         // cheap content fingerprint (detects in-place complement)
   bool     pinned  = false;     // uploaded through dmh_preload_block
+  hipEvent_t uploaded = nullptr; // bases still on their way (DMA on the upload stream): block_ready() waits
   const uint8_t *d_bases() const { return d_raw + 1; }
   const uint64_t *d_pk() const { return d_pkraw + 2; }
   const uint64_t *d_rc() const { return d_rcraw + 2; }
@@ -94,6 +95,7 @@ struct State
 State &S();
 
 BlockDev &upload_block(const DAZZ_DB *block, bool pin);
+void      block_ready(BlockDev &bd);        // orders the current stream behind the block's upload
 void      ensure_packed(BlockDev &bd, bool want_rc);
 void      pack_bases(const uint8_t *d_bases, int64_t L, uint64_t *d_pkraw);
 void      pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, uint64_t *d_rcraw);

@@ -380,12 +380,34 @@ class Block:
                     d[lo:hi] = int(self.reads[i + 1]["rlen"]) - d[lo:hi][::-1]
 
 
+def host_bytes(n: int, pinned: bool) -> np.ndarray:
+    """n uint8s; pinned=True asks libdamapper_hip for page-locked memory (dmh_host_alloc) so that the
+    block is uploaded by one DMA without staging.  Falls back to ordinary memory without a device."""
+    if pinned:
+        try:
+            import weakref
+            so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdamapper_hip.so")
+            L = C.CDLL(so, mode=C.RTLD_GLOBAL)
+            L.dmh_host_alloc.argtypes = [C.c_size_t]
+            L.dmh_host_alloc.restype = C.c_void_p
+            L.dmh_host_free.argtypes = [C.c_void_p]
+            L.dmh_device_count.restype = C.c_int
+            p = L.dmh_host_alloc(n) if L.dmh_device_count() > 0 else None
+            if p:
+                arr = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p))
+                weakref.finalize(arr, L.dmh_host_free, p)
+                return arr
+        except (OSError, AttributeError):
+            pass
+    return np.empty(n, dtype=np.uint8)
+
+
 def make_block(seqs: Sequence[np.ndarray], tfirst: int = 0, part: int = 0,
-               path: bytes = b"./.mem", freq: Optional[Sequence[float]] = None) -> Block:
+               path: bytes = b"./.mem", freq: Optional[Sequence[float]] = None, pinned: bool = False) -> Block:
     n = len(seqs)
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
     tot = int(lens.sum())
-    bases = np.empty(tot + n + 4, dtype=np.uint8)
+    bases = host_bytes(tot + n + 4, pinned)
     bases[:] = 4
     reads = np.zeros(n + 2, dtype=READ_DTYPE)
     o = 0
@@ -439,7 +461,7 @@ def _sim_lib():
 
 
 def simulate_block(seed: int, contig: np.ndarray, nreads: int, read_len: int = 10000, err: float = 0.15,
-                   tfirst: int = 0, part: int = 0, path: bytes = b"./.mem") -> Block:
+                   tfirst: int = 0, part: int = 0, path: bytes = b"./.mem", pinned: bool = False) -> Block:
     """Large synthetic read block straight into the in-memory DAZZ_DB layout (native, threaded
     generator in tools/simulate.c: uniform position and strand on one contig, i.i.d. errors
     ins:del:sub = 60:25:15; per-read RNG streams, so the block depends on `seed` only)."""
@@ -450,7 +472,7 @@ def simulate_block(seed: int, contig: np.ndarray, nreads: int, read_len: int = 1
     boff = np.zeros(nreads + 1, dtype=np.int64)
     np.cumsum(rlen.astype(np.int64) + 1, out=boff[1:])
     tot = int(rlen.sum())
-    bases = np.empty(tot + nreads + 4, dtype=np.uint8)
+    bases = host_bytes(tot + nreads + 4, pinned)
     bases[-4:] = 4
     L.dmh_sim_fill(g.ctypes.data, len(g), nreads, read_len, err, seed, boff.ctypes.data, bases.ctypes.data)
     reads = np.zeros(nreads + 2, dtype=READ_DTYPE)
@@ -502,7 +524,8 @@ def read_stub(path: str) -> Tuple[int, List[Tuple[int, int]]]:
     return nblocks, firsts
 
 
-def load_db(path: str, part: int = 0, masks: Sequence[str] = (), used: Optional[set] = None) -> Block:
+def load_db(path: str, part: int = 0, masks: Sequence[str] = (), used: Optional[set] = None,
+            pinned: bool = False) -> Block:
     """Open + Load_All_Reads equivalent for DBs written by `write_db` (no trimming:
     cutoff=0, all=1). `path` is 'dir/root.db'; part k > 0 loads block k.  `masks` are -m track
     names: those the DB has are loaded, merged into one mask and attached (read_DB,
@@ -526,7 +549,7 @@ def load_db(path: str, part: int = 0, masks: Sequence[str] = (), used: Optional[
         seqs.append(_unpack_2bit(bps[o:o + (n + 3) // 4], n))
     blk = make_block(seqs, tfirst=lo, part=part,
                      path=os.path.join(d, "." + root).encode(),
-                     freq=[hdr.freq[j] for j in range(4)])
+                     freq=[hdr.freq[j] for j in range(4)], pinned=pinned)
     found = []
     for name in masks:
         iv = read_mask_track(d, root, name, lo, hi, int(hdr.ureads))

@@ -55,7 +55,7 @@ def _worker(args) -> None:
         if done and not args.force:
             print("[gpu %d] %s: output present, skipped" % (args.rank, name), flush=True)
             continue
-        reads = load_db(os.path.join(rd or ".", read_root + ".db"), part=b, masks=args.m, used=used)
+        reads = load_db(os.path.join(rd or ".", read_root + ".db"), part=b, masks=args.m, used=used, pinned=True)
         t0 = time.time()
         m.map_block(reads, name, ref_blocks, ref_whole, ref_root, mflag=mflag)
         mapped.append(name)

@@ -129,6 +129,12 @@ void        dmh_reset(void);                 /* drop every cached device buffer 
  * while block i is filtered and aligned).  Blocks with a mask track or under -t are built at once.  */
 void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
 
+/* Page-locked host memory for a driver that loads blocks itself: a block whose `bases` live in such
+ * memory is uploaded by one DMA without staging (a block in ordinary malloc memory, as the reference
+ * driver's, goes through two pinned staging buffers).  NULL when no device is available.              */
+void *dmh_host_alloc(size_t bytes);
+void  dmh_host_free(void *p);
+
 int  dmh_preload_block(DAZZ_DB *block);
 void dmh_release_block(DAZZ_DB *block);
 
