@@ -116,6 +116,40 @@ def test_cover_files_identical_to_reference(case, tmp_path):
         assert not os.path.exists(os.path.join(d, "las_hip", "READS.REF.M1.las"))
 
 
+def test_ragged_and_degenerate_reads(tmp_path):
+    """Reads the simulator never makes: unmappable noise, reads barely longer than k, error-free copies
+    of the reference on both strands (bands of width 1, very long snakes), a 40 kb read next to 30 bp
+    ones (ragged block), a low-complexity read, a read that is a whole contig, reads at contig ends."""
+    run_ref = _run_ref()
+    rng = np.random.default_rng(1091)        # (not 91: the noise must not repeat the genome's stream)
+    g, reads = make_dataset("random", 91, [120000, 9000, 60000], 12)
+    rc = lambda s: (3 - s[::-1]).astype(np.uint8)
+    extra = [rng.integers(0, 4, 5000, dtype=np.uint8),                  # noise
+             rng.integers(0, 4, 21, dtype=np.uint8),                    # k+1 bases of noise
+             g[0][1000:1030].copy(), g[0][5000:5020].copy(),            # 30 / 20 bp exact
+             g[0][20000:60000].copy(),                                  # 40 kb exact
+             rc(g[2][10000:25000]),                                     # exact, other strand
+             g[1].copy(),                                               # a whole contig
+             g[0][:3000].copy(), rc(g[2][-2500:]),                      # contig ends
+             np.zeros(4000, dtype=np.uint8),                            # poly-A
+             np.tile(np.array([0, 1], dtype=np.uint8), 1500),           # dinucleotide repeat
+             np.concatenate([g[0][70000:74000], g[2][3000:8000]])]      # chimera of two contigs
+    reads = list(reads) + extra
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=130000)
+    dazzdb.write_db(d, "READS", reads)
+    run_ref.run_reference(d, "REF", ["READS"], flags=["-M8"], threads=4)
+    driver.map_db(d, "REF", "READS", threads=4, mem_limit=8 << 30)
+    ts_r, rr = las.read_las_set(os.path.join(d, "las_ref"), "READS.REF.M@.las")
+    ts_h, hr = las.read_las_set(os.path.join(d, "las_hip"), "READS.REF.M@.las")
+    assert ts_r == ts_h and len(rr) == len(hr) and len(rr) >= 15
+    for i, (a, b) in enumerate(zip(rr, hr)):
+        assert a == b, "record %d differs:\n%s\n%s" % (i, a, b)
+    mapped = {r.aread for r in hr}
+    assert 12 + 4 in mapped and 12 + 5 in mapped and 12 + 6 in mapped          # the exact copies map
+    assert 12 not in mapped and 13 not in mapped                               # the noise does not
+
+
 def test_mask_tracks_identical_to_reference(tmp_path):
     """-m<track>: two masks on the REF (merged, damapper.c:232-343), one on the READS, one that no DB
     has; multi-block REF so the per-block slices of the track are exercised."""
