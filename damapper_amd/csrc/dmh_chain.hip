@@ -404,7 +404,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   std::vector<ChainSummary> sums(nsum);
   std::vector<uint32_t>     gfirst;
   if (nsum > 0)
-    { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum, 1);      // host sort next
+    { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum, 2);      // host sort next
       std::sort(sums.begin(), sums.end(), [](const ChainSummary &a, const ChainSummary &b)
                 { return a.group != b.group ? a.group < b.group : a.rank < b.rank; });
     }
@@ -423,7 +423,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     if (!want.empty())
       { copy_h2d(d_idx.p, want.data(), sizeof(uint32_t) * want.size());
         gather_u64(R.skeys, d_idx.p, d_k.p, (int64_t) want.size());
-        copy_d2h(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size(), 1);   // domination scan next
+        copy_d2h(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size(), 2);   // domination scan next
       }
   }
 
@@ -514,8 +514,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
                            (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, (const uint32_t *) d_ends.p, n,
                            d_len.p, (const uint32_t *) nullptr, (uint16_t *) nullptr, 0);
         std::vector<uint32_t> len(n), off(n + 1);
-        copy_d2h(len.data(), d_len.p, sizeof(uint32_t) * n);
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        copy_d2h(len.data(), d_len.p, sizeof(uint32_t) * n, 1);
         off[0] = 0;
         for (int i = 0; i < n; i++) off[i + 1] = off[i] + len[i];
         d_j.ensure(2 * (size_t) off[n] + 2, "jump data");
@@ -525,7 +524,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
                            d_len.p, (const uint32_t *) (d_len.p + n), d_j.p, 1);
         std::vector<uint16_t> jd(2 * (size_t) off[n]);
         if (off[n] > 0)
-          copy_d2h(jd.data(), d_j.p, sizeof(uint16_t) * jd.size(), 1);          // host stores the chains next
+          copy_d2h(jd.data(), d_j.p, sizeof(uint16_t) * jd.size(), 2);          // host stores the chains next
         else
           HIP_CHECK(hipStreamSynchronize(stream()));
         for (int i = 0; i < n; i++)

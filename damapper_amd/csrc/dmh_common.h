@@ -95,9 +95,9 @@ struct SortScratch
 void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32_t **ovals,
                       int64_t n, int lo_bit, int nbits, SortScratch &scr, const char *stage);
 
-void radix_pass_hist(const uint64_t *keys, int64_t n, int shift, int w, SortScratch &scr);
+void radix_pass_hist(const uint64_t *keys, int64_t n, int shift, int w, SortScratch &scr, int part, int nparts);
 void radix_pass_scatter(const uint64_t *keys, const uint32_t *vals, uint64_t *okeys, uint32_t *ovals, int64_t n,
-                        int shift, int w, SortScratch &scr);
+                        int shift, int w, SortScratch &scr, int part, int nparts);
 
 // Exclusive scan of n uint32 values in place; returns nothing, total is written to *d_total
 // (device pointer to one uint32) if not null.  n < 2^32, sum < 2^32.

@@ -569,7 +569,7 @@ struct SortJob
   uint32_t *vals, *v0, *v1;
   int64_t   kmers, kmers0;
   int       Kshift, npass;
-  int       stage;              // -1 = k-mer emit; 0 .. 2*npass-1: even = histogram + scan of pass stage/2, odd = its scatter
+  int       stage;              // index into the stage list (see bg_step)
   const DAZZ_DB *block;         // emit stage: the block whose device copy is read
   int       Kmer;
 };
@@ -592,36 +592,60 @@ static void adopt_sorted(IndexDev &ix, SortScratch &scr, uint64_t *keys, uint32_
   ix.n    = kmers;
 }
 
+// Stage list of a deferred build: EMIT_PARTS pieces of the k-mer emit, then per radix pass HIST_PARTS
+// histogram pieces (the scan rides on the last) and SCAT_PARTS scatter pieces -- small enough
+// (0.25-0.5 ms on a 0.26 Gbp block) to slot into the bubbles between the host's round trips.
+// Measured on the bench workload (ms per block): 1/1/1 43.9, 1/1/2 42.9, 1/2/4 41.5, 2/2/4 42.2.
+static int EMIT_PARTS = 1, HIST_PARTS = 2, SCAT_PARTS = 4, PASS_PARTS = 6;
+static void bg_parts_init()
+{ static bool done = false;
+  if (done) return;
+  done = true;
+  const char *e = getenv("DMH_BG_PARTS");          // "emit,hist,scatter" pieces, for experiments
+  if (e != nullptr)
+    { int a = 0, b = 0, c = 0;
+      if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && b >= 1 && c >= 1 && a <= 8 && b <= 8 && c <= 16)
+        { EMIT_PARTS = a; HIST_PARTS = b; SCAT_PARTS = c; }
+    }
+  PASS_PARTS = HIST_PARTS + SCAT_PARTS;
+}
+
 static void bg_step()
-{ SortJob &J = g_bg.front();
+{ bg_parts_init();
+  SortJob &J = g_bg.front();
   State   &st = S();
-  if (J.stage < 0)
+  if (J.stage < EMIT_PARTS)
     { auto b = st.blocks.find(J.block);
       if (b == st.blocks.end()) fatal("deferred index build lost its block");
       BlockDev &bd = b->second;
       auto it = st.indices.find(J.id);
       if (it == st.indices.end()) fatal("deferred index build lost its index");
       IndexDev &ix = it->second;
-      block_ready(bd);
-      kmer_emit(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, J.Kmer, J.keys, J.vals, J.kmers);
-      HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (bd.nreads + 1), hipMemcpyDeviceToDevice, stream()));
-      hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
-                         (const int64_t *) ix.d_boff, bd.nreads, ix.nchunk, ix.d_chunk);
-      HIP_CHECK(hipGetLastError());
-      J.stage = 0;
+      if (J.stage == 0)
+        { block_ready(bd);
+          HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (bd.nreads + 1), hipMemcpyDeviceToDevice, stream()));
+          hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
+                             (const int64_t *) ix.d_boff, bd.nreads, ix.nchunk, ix.d_chunk);
+          HIP_CHECK(hipGetLastError());
+        }
+      kmer_emit(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, J.Kmer, J.keys, J.vals, J.kmers, J.stage, EMIT_PARTS);
+      J.stage += 1;
       return;
     }
-  const int p = J.stage >> 1;
+  const int q = J.stage - EMIT_PARTS;
+  const int p = q / PASS_PARTS, r = q % PASS_PARTS;
   const int w = J.Kshift - 8 * p;
-  if ((J.stage & 1) == 0)
-    radix_pass_hist(J.k0, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux);
+  if (r < HIST_PARTS)
+    radix_pass_hist(J.k0, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux, r, HIST_PARTS);
   else
-    { radix_pass_scatter(J.k0, J.v0, J.k1, J.v1, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux);
-      std::swap(J.k0, J.k1);
-      std::swap(J.v0, J.v1);
+    { radix_pass_scatter(J.k0, J.v0, J.k1, J.v1, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux, r - HIST_PARTS, SCAT_PARTS);
+      if (r == PASS_PARTS - 1)
+        { std::swap(J.k0, J.k1);
+          std::swap(J.v0, J.v1);
+        }
     }
   J.stage += 1;
-  if (J.stage == 2 * J.npass)
+  if (J.stage == EMIT_PARTS + PASS_PARTS * J.npass)
     { auto it = st.indices.find(J.id);
       if (it == st.indices.end()) fatal("deferred index build lost its index");
       adopt_sorted(it->second, st.sort_aux, J.keys, J.vals, J.k0, J.v0, J.kmers0, J.kmers);
@@ -807,7 +831,7 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
       J.kmers = kmers; J.kmers0 = kmers0;
       J.Kshift = pm.Kshift;
       J.npass = (pm.Kshift + 7) / 8;
-      J.stage = -1;
+      J.stage = 0;
       J.block = block;
       J.Kmer  = pm.Kmer;
       g_bg.push_back(J);

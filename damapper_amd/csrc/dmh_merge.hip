@@ -358,7 +358,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   std::vector<unsigned long long> hrep(GR + HREP);
   unsigned int nent = 0;
   copy_d2h(&nent, mctl.p, sizeof(unsigned int));
-  copy_d2h(hrep.data(), gram.p, sizeof(unsigned long long) * (GR + HREP), 1);   // the host reduces it next
+  copy_d2h(hrep.data(), gram.p, sizeof(unsigned long long) * (GR + HREP), 2);   // the host reduces it next
   std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
   for (int r = 0; r < HREP; r++)
     { for (int j = 0; j < MAXGRAM; j++) histo[j] += hrep[(size_t) r * (MAXGRAM + 1) + j];
@@ -437,8 +437,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
                        (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
                        (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.keys.p, R.vals.p, ebig.p, mctl.p + 1);
     copy_d2h(&total, eoff.p + nent, sizeof(uint32_t));
-    copy_d2h(&nbig, mctl.p + 1, sizeof(unsigned int));
-    HIP_CHECK(hipStreamSynchronize(stream()));
+    copy_d2h(&nbig, mctl.p + 1, sizeof(unsigned int), 1);
     if (nbig > 0)
       hipLaunchKernelGGL(k_merge_expand_big, dim3(ceil_div((int64_t) nbig * 64, 256)), dim3(256), 0, stream(),
                          (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, nbig, (const uint32_t *) eoff.p,
@@ -464,8 +463,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     hipLaunchKernelGGL(k_group_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.skeys, nhits, pshift, flag.p);
     exclusive_scan_u32(flag.p, nhits, st.sort.bsum, flag.p + nhits);
     uint32_t ng = 0;
-    copy_d2h(&ng, flag.p + nhits, sizeof(uint32_t));
-    HIP_CHECK(hipStreamSynchronize(stream()));
+    copy_d2h(&ng, flag.p + nhits, sizeof(uint32_t), 1);
     R.ngroups = ng;
     R.gstart.ensure((size_t) ng + 1, "group starts");
     hipLaunchKernelGGL(k_group_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.skeys, nhits, pshift,

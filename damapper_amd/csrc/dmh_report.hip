@@ -1095,7 +1095,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel
   HostTimer *ht1 = new HostTimer("report_align");
-  bg_pump(2);                 // something for the GPU to do while the jobs are put together
+  bg_pump(4);                 // something for the GPU to do while the jobs are put together
   std::vector<CandJob>   jobs;
   std::vector<uint16_t>  jumps;
   std::vector<int>       job_of_first(nreads + 1, 0);   // first job index of each read
@@ -1226,7 +1226,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
               static hipEvent_t ev_pool = nullptr;
               if (ev_pool == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_pool, hipEventDisableTiming));
               HIP_CHECK(hipEventRecord(ev_pool, stream()));
-              bg_pump(2);        // runs while the records are handed to the report stage
+              bg_pump(4);        // runs while the records are handed to the report stage
               HIP_CHECK(hipEventSynchronize(ev_pool));
             }
 

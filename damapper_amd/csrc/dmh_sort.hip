@@ -7,6 +7,7 @@
 // histogram -> scan -> scatter, and stability inside a tile comes from wavefront match masks
 // (ballot), so the result is the same total order (code, read, rpos) the reference produces.
 
+#include <algorithm>
 #include "dmh_common.h"
 
 namespace dmh {
@@ -115,12 +116,13 @@ constexpr int SORT_WTILE   = 64 * SORT_ITEMS;              // 1024 pairs per wav
 // exclusive scan over the whole array yields each (digit, tile)'s first output slot.
 __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__restrict__ keys, int64_t n,
                                                               int shift, uint32_t mask,
-                                                              uint32_t *__restrict__ hist, int ntiles)
+                                                              uint32_t *__restrict__ hist, int ntiles, int tile_base)
 { __shared__ uint32_t h[256];
   int tid = threadIdx.x;
   h[tid] = 0;
   __syncthreads();
-  int64_t base = (int64_t) blockIdx.x * SORT_TILE;
+  const int tile = tile_base + (int) blockIdx.x;
+  int64_t base = (int64_t) tile * SORT_TILE;
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; j++)
     { int64_t i = base + j * SORT_THREADS + tid;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
         atomicAdd(&h[(uint32_t) (keys[i] >> shift) & mask], 1u);
     }
   __syncthreads();
-  hist[(size_t) tid * ntiles + blockIdx.x] = h[tid];
+  hist[(size_t) tid * ntiles + tile] = h[tid];
 }
 
 __device__ __forceinline__ int xcd_tile(int b, int ntiles)
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
                                                                  uint64_t *__restrict__ kout,
                                                                  uint32_t *__restrict__ vout, int64_t n,
                                                                  int shift, uint32_t mask,
-                                                                 const uint32_t *__restrict__ offs, int ntiles)
+                                                                 const uint32_t *__restrict__ offs, int ntiles,
+                                                                 int tile_base)
 { __shared__ uint64_t skey[SORT_TILE];
   __shared__ uint32_t sval[SORT_TILE];
   __shared__ uint32_t wh[4][256];
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
   // L2), so give every XCD one contiguous range of tiles.  Neighbouring tiles write neighbouring
   // pieces of each digit's output run; processed back to back on one XCD they merge into whole
   // cache lines in that L2 before being written back.
-  const int tile  = xcd_tile(blockIdx.x, ntiles);
+  const int tile  = tile_base + xcd_tile(blockIdx.x, gridDim.x);     // (a launch may cover a range of tiles)
   const int64_t tile0 = (int64_t) tile * SORT_TILE;
   const int64_t base  = tile0 + (int64_t) w * SORT_WTILE + lane;
   uint64_t key[SORT_ITEMS];
@@ -247,7 +250,7 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
       uint32_t mask  = (w >= 8) ? 0xffu : ((1u << w) - 1u);
       { StageTimer th("k_radix_hist", 0.0);
         hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
-                           (const uint64_t *) *keys, n, shift, mask, scr.hist.p, ntiles);
+                           (const uint64_t *) *keys, n, shift, mask, scr.hist.p, ntiles, 0);
       }
       { StageTimer ts("radix_scan", 0.0);
         exclusive_scan_u32(scr.hist.p, (int64_t) 256 * ntiles, scr.bsum, nullptr);
@@ -256,7 +259,7 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
         StageTimer tc("k_radix_scatter", 32.0 * (double) n);
         hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
                            (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,
-                           shift, mask, (const uint32_t *) scr.hist.p, ntiles);
+                           shift, mask, (const uint32_t *) scr.hist.p, ntiles, 0);
       }
       HIP_CHECK(hipGetLastError());
       uint64_t *tk = *keys; *keys = *okeys; *okeys = tk;
@@ -264,27 +267,44 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
     }
 }
 
-// One pass of the sort above in two separately queued halves (deferred index builds, bg_pump)
-void radix_pass_hist(const uint64_t *keys, int64_t n, int shift, int w, SortScratch &scr)
+// One pass of the sort above cut into separately queued pieces (deferred index builds, bg_pump):
+// the histogram in `nparts` launches over consecutive tile ranges (the scan follows the last one),
+// the scatter likewise.
+static void part_range(int ntiles, int part, int nparts, int &t0, int &t1)
+{ int per = ((ntiles + nparts - 1) / nparts + 7) & ~7;       // whole XCD octets
+  t0 = std::min(ntiles, part * per);
+  t1 = (part == nparts - 1) ? ntiles : std::min(ntiles, t0 + per);
+}
+
+void radix_pass_hist(const uint64_t *keys, int64_t n, int shift, int w, SortScratch &scr, int part, int nparts)
 { int ntiles = ceil_div(n, SORT_TILE);
-  scr.hist.ensure((size_t) 256 * ntiles, "radix histogram");
+  if (part == 0) scr.hist.ensure((size_t) 256 * ntiles, "radix histogram");
   uint32_t mask = (w >= 8) ? 0xffu : ((1u << w) - 1u);
-  { StageTimer th("k_radix_hist", 0.0);
-    hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(SORT_THREADS), 0, stream(), keys, n, shift, mask, scr.hist.p, ntiles);
-  }
-  { StageTimer ts("radix_scan", 0.0);
-    exclusive_scan_u32(scr.hist.p, (int64_t) 256 * ntiles, scr.bsum, nullptr);
-  }
+  int t0, t1;
+  part_range(ntiles, part, nparts, t0, t1);
+  if (t1 > t0)
+    { StageTimer th("k_radix_hist", 0.0);
+      hipLaunchKernelGGL(k_radix_hist, dim3(t1 - t0), dim3(SORT_THREADS), 0, stream(), keys, n, shift, mask, scr.hist.p,
+                         ntiles, t0);
+    }
+  if (part == nparts - 1)
+    { StageTimer ts("radix_scan", 0.0);
+      exclusive_scan_u32(scr.hist.p, (int64_t) 256 * ntiles, scr.bsum, nullptr);
+    }
   HIP_CHECK(hipGetLastError());
 }
 
 void radix_pass_scatter(const uint64_t *keys, const uint32_t *vals, uint64_t *okeys, uint32_t *ovals, int64_t n,
-                        int shift, int w, SortScratch &scr)
+                        int shift, int w, SortScratch &scr, int part, int nparts)
 { int ntiles = ceil_div(n, SORT_TILE);
   uint32_t mask = (w >= 8) ? 0xffu : ((1u << w) - 1u);
-  StageTimer tc("k_radix_scatter", 32.0 * (double) n);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, stream(), keys, vals, okeys, ovals, n,
-                     shift, mask, (const uint32_t *) scr.hist.p, ntiles);
+  int t0, t1;
+  part_range(ntiles, part, nparts, t0, t1);
+  if (t1 <= t0) return;
+  int64_t recs = std::min<int64_t>(n, (int64_t) t1 * SORT_TILE) - (int64_t) t0 * SORT_TILE;
+  StageTimer tc("k_radix_scatter", 32.0 * (double) recs);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(t1 - t0), dim3(SORT_THREADS), 0, stream(), keys, vals, okeys, ovals, n,
+                     shift, mask, (const uint32_t *) scr.hist.p, ntiles, t0);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -305,7 +325,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__res
                                                             const int64_t *__restrict__ boff, int nreads,
                                                             int K, uint64_t kmask,
                                                             uint64_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ vals, int64_t nk)
+                                                            uint32_t *__restrict__ vals, int64_t nk, int block_base)
 { __shared__ uint8_t  sb[EMIT_TILE + 32];
   __shared__ uint64_t scode[EMIT_TILE];
   __shared__ uint16_t sread[EMIT_TILE];     // read index relative to the tile's first read
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__res
   __shared__ int      s_i0;
 
   const int     tid  = threadIdx.x;
-  const int64_t tile = (int64_t) blockIdx.x * EMIT_TILE;
+  const int64_t tile = (int64_t) (block_base + (int) blockIdx.x) * EMIT_TILE;
   const int     halo = K - 1;
 
   for (int x = tid; x < EMIT_TILE + halo; x += EMIT_THREADS)
@@ -372,13 +392,16 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__res
 }
 
 void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, int K,
-               uint64_t *d_keys, uint32_t *d_vals, int64_t nk)
+               uint64_t *d_keys, uint32_t *d_vals, int64_t nk, int part, int nparts)
 { if (L <= 0) return;
   uint64_t kmask = (K >= 32) ? ~0ull : ((1ull << (2 * K)) - 1ull);
   int nb = ceil_div(L, EMIT_TILE);
-  StageTimer tm("kmer_emit", (double) L + 16.0 * (double) nk);
-  hipLaunchKernelGGL(k_kmer_emit, dim3(nb), dim3(EMIT_THREADS), 0, stream(), d_bases, L, d_boff, nreads,
-                     K, kmask, d_keys, d_vals, nk);
+  int per = (nb + nparts - 1) / nparts;
+  int b0 = std::min(nb, part * per), b1 = (part == nparts - 1) ? nb : std::min(nb, b0 + per);
+  if (b1 <= b0) return;
+  StageTimer tm("kmer_emit", ((double) L + 16.0 * (double) nk) * (double) (b1 - b0) / (double) nb);
+  hipLaunchKernelGGL(k_kmer_emit, dim3(b1 - b0), dim3(EMIT_THREADS), 0, stream(), d_bases, L, d_boff, nreads,
+                     K, kmask, d_keys, d_vals, nk, b0);
   HIP_CHECK(hipGetLastError());
 }
 

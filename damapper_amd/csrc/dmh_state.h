@@ -102,7 +102,7 @@ void      pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff,
 void      drop_block(const DAZZ_DB *block);
 
 void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, int K,
-               uint64_t *d_keys, uint32_t *d_vals, int64_t nk);
+               uint64_t *d_keys, uint32_t *d_vals, int64_t nk, int part = 0, int nparts = 1);
 
 IndexDev *index_of(void *table, const char *who);
 void      index_wait_ready(IndexDev &ix);     // queue what is left of a deferred build
