@@ -371,7 +371,8 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.out = out.p;
 
   // small groups four to a wavefront, big ones (repeat piles) one per wavefront; DMH_CHAIN_G forces one size
-  static const int chain_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
+  static const int env_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
+  const int chain_g = st.opt_chain_g ? st.opt_chain_g : env_g;
   constexpr uint32_t BIG_GROUP = 1024;
   { StageTimer tm("chain", 16.0 * nhits);
     if (chain_g == 64 || chain_g == 32 || chain_g == 16)

@@ -932,6 +932,15 @@ void dmh_free_index(void *table)
 
 void dmh_capture_seeds(int on) { S().capture_seeds = (on != 0); }
 
+int dmh_test_option(const char *key, int value)
+{ State &st = S();
+  if (strcmp(key, "align_level") == 0)      st.opt_align_level = value;
+  else if (strcmp(key, "chain_g") == 0)     st.opt_chain_g = (value == 16 || value == 32 || value == 64) ? value : 0;
+  else if (strcmp(key, "pool_div") == 0)    st.opt_pool_div = value > 1 ? value : 1;
+  else return -1;
+  return 0;
+}
+
 void *dmh_host_alloc(size_t bytes)
 { void *p = nullptr;
   if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess)

@@ -1147,12 +1147,14 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
       // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
       size_t pool_cap = (size_t) njobs * 2 * (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8)) + 4096;
+      if (st.opt_pool_div > 1) pool_cap = pool_cap / st.opt_pool_div + 64;
       std::vector<int> status(njobs);
       std::vector<int> todo;                 // jobs to (re)run
       // kernel ladder: 0 = two candidates per wavefront (register band <= 30 diagonals, LDS pebbles),
       // 1 = one per wavefront (register band <= 62, LDS ring 128, global pebbles), 2 = global ring 8192
       static const bool no_pack = getenv("DMH_NO_PACK32") != nullptr;
       int level = (doB || no_pack) ? 1 : 0;
+      if (st.opt_align_level >= 0) level = std::max(level, std::min(2, st.opt_align_level));
       if (level == 0)
         { // the halves of a wavefront run in lock step: hand out like jobs together (same orientation,
           // similar length), long ones first

@@ -88,6 +88,11 @@ struct State
   int      next_cand_id = 0;
   int64_t  tfilt = 0;
 
+  // test / experiment switches (dmh_test_option): every setting must give byte-identical results
+  int  opt_align_level = -1;    // first rung of the alignment kernel ladder (0 two per wavefront, 1, 2); -1 default
+  int  opt_chain_g     = 0;     // lanes per chain group for ALL groups (16/32/64); 0 = 16 + 64 by group size
+  int  opt_pool_div    = 1;     // initial alignment pool capacity is divided by this (forces the grow path)
+
   SortScratch sort;
   SortScratch sort_aux;         // scratch of the deferred index build (lives across Match_Filter calls)
 };

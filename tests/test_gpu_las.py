@@ -150,6 +150,39 @@ def test_ragged_and_degenerate_reads(tmp_path):
     assert 12 not in mapped and 13 not in mapped                               # the noise does not
 
 
+@pytest.mark.parametrize("opts", [dict(align_level=1), dict(align_level=2), dict(pool_div=400),
+                                  dict(chain_g=64), dict(chain_g=32), dict(chain_g=16)],
+                         ids=["wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16"])
+def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
+    """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes
+    to the same bytes: force each one and compare with the default route (itself checked against the
+    reference by the tests above) on data that has repeats, dropouts and low-complexity reads."""
+    from damapper_amd import capi
+    g, reads = make_dataset("repeat", 97, [150000, 120000], 70, dropouts=2)
+    reads = list(reads) + [np.zeros(3000, dtype=np.uint8), np.tile(np.array([0, 1, 1], dtype=np.uint8), 1200)]
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=400000)
+    dazzdb.write_db(d, "READS", reads)
+
+    def run(out):
+        driver.map_db(d, "REF", "READS", threads=4, mem_limit=8 << 30, sort_path=os.path.join(d, out), profile=1)
+        return (las.read_las_set(os.path.join(d, out), "READS.REF.M@.las"),
+                open(os.path.join(d, ".READS.prof.data"), "rb").read())
+
+    base = run("las_default")
+    L = capi.lib()
+    try:
+        for k, v in opts.items():
+            assert L.dmh_test_option(k.encode(), v) == 0
+        alt = run("las_alt")
+    finally:
+        L.dmh_test_option(b"align_level", -1)
+        L.dmh_test_option(b"chain_g", 0)
+        L.dmh_test_option(b"pool_div", 1)
+    assert len(base[0][1]) > 50
+    assert base == alt
+
+
 def test_mask_tracks_identical_to_reference(tmp_path):
     """-m<track>: two masks on the REF (merged, damapper.c:232-343), one on the READS, one that no DB
     has; multi-block REF so the per-block slices of the track are exercised."""
