@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 def make_block(genome, nreads, seed, tfirst=0, part=0, pinned=False):
-    return dazzdb.simulate_block(seed, genome[0], nreads, read_len=READ_LEN, err=0.15, tfirst=tfirst, part=part,
+    return dazzdb.simulate_block(seed, genome[part % len(genome)], nreads, read_len=READ_LEN, err=0.15, tfirst=tfirst, part=part,
                                  path=b"./.READS", pinned=pinned)
 
 
@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--serial-prefetch", action="store_true",
                     help="queue the next block's whole index build before Reporter instead of spreading its "
                          "stages over the gaps of the current block")
+    ap.add_argument("--genome-mbp", type=float, default=GENOME_LEN / 1e6,
+                    help="reference size in Mbp (default 4.6 = configs[1]; 250 approximates configs[2], one contig per "
+                         "~125 Mbp, one REF block)")
     ap.add_argument("--pcie", choices=["pinned", "pageable"], default=None,
                     help="PCIe-inclusive rate: read blocks are NOT resident, every step uploads its block from "
                          "page-locked (dmh_host_alloc) or ordinary host memory inside the timed region")
@@ -108,7 +111,9 @@ def main():
 
     # ---- synthetic workload (seeded): reference shared by all ranks, reads per rank
     g_rng = np.random.default_rng(20)
-    genome = dazzdb.random_genome(g_rng, [GENOME_LEN])
+    glen = int(args.genome_mbp * 1e6)
+    ncontig = max(1, int(round(glen / 125e6)))
+    genome = dazzdb.random_genome(g_rng, [glen // ncontig] * ncontig)
     nblk = min(args.nblocks, max(1, args.steps + args.warmup))
     blocks = []
     for b in range(nblk):
@@ -212,12 +217,14 @@ def main():
                 p *= 2
             sample = dazzdb.block_reads(make_block(genome, args.cpu_sample_reads, 4242))
             cpu = cpu_baseline(genome, sample, p)
+        wl_name = ("configs[1]: E.coli-sized random reference (4.6 Mbp)" if abs(args.genome_mbp - 4.6) < 1e-6 else
+                   "random reference of %.0f Mbp in %d contig(s)" % (args.genome_mbp, ncontig))
         out = {
             "metric": "Gbp reads mapped/sec (whole node), -k20 -e.85; .las parity-checked vs CPU reference",
             "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic",
-            "config": {"workload": "configs[1]: E.coli-sized random reference (4.6 Mbp) + simulated PacBio reads "
+            "config": {"workload": wl_name + " + simulated PacBio reads "
                                    "(10 kb, 15%% err), %d reads per block/step, %d distinct blocks per GPU, "
                                    "-k20 -e.85 -s100, REF index %s" %
                                    (args.block_reads, nblk, ("rebuilt per read block" if args.rebuild_ref else "built once per GPU, resident") +

@@ -489,7 +489,8 @@ static void free_index(IndexDev &ix)
   dev_free(ix.vals);
   dev_free(ix.d_boff);
   dev_free(ix.d_chunk);
-  ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr;
+  dev_free(ix.d_bstart);
+  ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr; ix.d_bstart = nullptr;
 }
 
 IndexDev *index_of(void *table, const char *who)

@@ -324,20 +324,21 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     fatal("Match_Filter: seed key needs %d bits", R.pbits + R.bbits + R.abits);
   int pshift = R.pbits, bshift = R.pbits + R.bbits;
 
-  // --- bucket table over the REF index
-  int P = ceil_log2(Bx.n) + 2;         // ~0.15 entries per bucket (up to 1 GB of table)
-  if (P < 8) P = 8;
-  if (P > 28) P = 28;
-  if (P > Kshift) P = Kshift;
-  int     shift   = Kshift - P;
-  int64_t nbucket = (int64_t) 1 << P;
-  static DevBuf<uint32_t> bstart;
-  bstart.ensure(nbucket + 2, "bucket table");
-  { StageTimer tm("merge_buckets", 8.0 * Bx.n);
-    hipLaunchKernelGGL(k_bucket_bounds, dim3(ceil_div(Bx.n + 1, 256)), dim3(256), 0, stream(),
-                       (const uint64_t *) Bx.keys, Bx.n, shift, nbucket, bstart.p);
-  }
-  BLookup BL{Bx.keys, bstart.p, shift};
+  // --- bucket table over the REF index: part of the index, built the first time it is merged against
+  //     (a retained REF index meets every READS block)
+  if (Bx.d_bstart == nullptr)
+    { int P = ceil_log2(Bx.n) + 2;         // ~0.15 entries per bucket (up to 1 GB of table)
+      if (P < 8) P = 8;
+      if (P > 28) P = 28;
+      if (P > Kshift) P = Kshift;
+      Bx.bshift = Kshift - P;
+      int64_t nbucket = (int64_t) 1 << P;
+      Bx.d_bstart = (uint32_t *) dev_alloc(sizeof(uint32_t) * (nbucket + 2), "bucket table");
+      StageTimer tm("merge_buckets", 8.0 * Bx.n);
+      hipLaunchKernelGGL(k_bucket_bounds, dim3(ceil_div(Bx.n + 1, 256)), dim3(256), 0, stream(),
+                         (const uint64_t *) Bx.keys, Bx.n, Bx.bshift, nbucket, Bx.d_bstart);
+    }
+  BLookup BL{Bx.keys, Bx.d_bstart, Bx.bshift};
 
   // --- match + count (map.c:2984-2988)
   static DevBuf<unsigned long long> gram;

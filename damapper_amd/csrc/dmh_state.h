@@ -45,6 +45,8 @@ struct IndexDev
   int64_t   L      = 0;
   std::vector<int64_t> h_boff;  // host copy
   DAZZ_DB  *block  = nullptr;
+  uint32_t *d_bstart = nullptr; // bucket table over the top bits of the codes (merge look-ups), built at first use
+  int       bshift  = 0;        //   bucket of a code = code >> bshift
   bool      pending = false;    // a deferred build (dmh_sort_kmers_async) has stages left to queue
 };
 
