@@ -119,7 +119,14 @@ def main():
     for b in range(nblk):
         blocks.append(make_block(genome, args.block_reads, 1000 + 97 * rank + b, tfirst=b * args.block_reads, part=b + 1,
                                  pinned=(args.pcie == "pinned")))
-    ref_blocks = [dazzdb.make_block(genome, tfirst=0, part=1, path=b"./.REF")]
+    # REF blocks as DBsplit would cut them: whole contigs, at most ~375 Mbp (< 2^31 k-mers) per block
+    ref_blocks, first, acc = [], 0, 0
+    for ci in range(len(genome) + 1):
+        if ci == len(genome) or (acc > 0 and acc + len(genome[ci]) > 375_000_000):
+            ref_blocks.append(dazzdb.make_block(genome[first:ci], tfirst=first, part=len(ref_blocks) + 1, path=b"./.REF"))
+            first, acc = ci, 0
+        if ci < len(genome):
+            acc += len(genome[ci])
     ref_whole = dazzdb.make_block(genome, path=b"./.REF")
 
     sort_path = tempfile.mkdtemp(prefix="dmh_bench_%d_" % rank)

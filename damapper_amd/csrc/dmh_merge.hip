@@ -69,26 +69,25 @@ __device__ __forceinline__ void b_range(const BLookup &B, uint64_t c, uint32_t &
 constexpr int MG_THREADS = 256;
 constexpr int MG_ITEMS   = 8;
 constexpr int MG_TILE    = MG_THREADS * MG_ITEMS;
-constexpr int HREP       = 64;      // replicated histograms / counters to spread atomic traffic
 constexpr int SMALLBIN   = 32;
 
 struct MergeEntry { uint32_t a0, ma, b0, mb; };
 
 __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__restrict__ akeys, int64_t na,
                                                             BLookup B, unsigned long long *__restrict__ gram,
-                                                            unsigned long long *__restrict__ nhits,
-                                                            MergeEntry *__restrict__ entries,
-                                                            unsigned int *__restrict__ nentries)
-{ __shared__ MergeEntry stage[MG_TILE];        // matched runs of this tile, flushed with one atomic
+                                                            MergeEntry *__restrict__ tile_entries,
+                                                            uint32_t *__restrict__ tile_count,
+                                                            uint32_t *__restrict__ tile_hist,
+                                                            unsigned long long *__restrict__ tile_hits)
+{ __shared__ MergeEntry stage[MG_TILE];        // matched runs of this tile
   __shared__ uint32_t h[SMALLBIN];
   __shared__ unsigned long long s_hits[4];
-  __shared__ uint32_t s_count, s_gbase;
+  __shared__ uint32_t s_count;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid < SMALLBIN) h[tid] = 0;
   if (tid == 0) s_count = 0;
   __syncthreads();
 
-  const int rep = blockIdx.x & (HREP - 1);
   unsigned long long local = 0;
 
   // The look-ups of a thread's MG_ITEMS codes are independent: issue them phase by phase (codes,
@@ -100,12 +99,20 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
   uint64_t c[MG_ITEMS];
   bool     first[MG_ITEMS];
   uint32_t bs[MG_ITEMS], be[MG_ITEMS];
+  uint64_t pv[MG_ITEMS];
+#pragma unroll
+  for (int j = 0; j < MG_ITEMS; j++)
+    { // unconditional loads from clamped addresses: a guarded load compiles to a branch with a wait at
+      // its join, which strings the 16 loads of this phase into 16 round trips
+      int64_t i  = tile0 + j * MG_THREADS;
+      int64_t ic = i < na ? i : na - 1;
+      c[j]  = akeys[ic];
+      pv[j] = akeys[ic > 0 ? ic - 1 : 0];
+    }
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
     { int64_t i = tile0 + j * MG_THREADS;
-      c[j] = (i < na) ? akeys[i] : 0;
-      uint64_t prev = (i > 0 && i < na) ? akeys[i - 1] : 0;
-      first[j] = (i < na) && (i == 0 || prev != c[j]);
+      first[j] = (i < na) && (i == 0 || pv[j] != c[j]);
     }
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
         }
       if (hit)
         { if (ct < SMALLBIN) atomicAdd(&h[(int) ct], 1u);
-          else if (ct < MAXGRAM) atomicAdd(&gram[(size_t) rep * (MAXGRAM + 1) + ct], 1ull);
+          else if (ct < MAXGRAM) atomicAdd(&gram[ct], 1ull);         // rare (repeats)
           local += ct;
         }
       uint64_t m = __ballot(hit);
@@ -170,17 +177,60 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
   for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
   if (lane == 0) s_hits[tid >> 6] = local;
   __syncthreads();
+  // Everything a tile found goes to the tile's OWN slots: its entries (the tile's MG_TILE-entry window
+  // of tile_entries), their number, its small-bin histogram and its hit count.  No global atomic on
+  // the common path: a device-scope atomic is served at the memory side on this multi-die part at a
+  // few ns apiece, and 128 k appends + 300 k histogram updates per pass were most of the run time.
+  // k_merge_gather / k_merge_reduce put the pieces together.
   if (tid == 0)
-    { unsigned long long t = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3];
-      if (t) atomicAdd(&nhits[rep], t);
-      s_gbase = s_count ? atomicAdd(nentries, s_count) : 0;
+    { tile_hits[blockIdx.x]  = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3];
+      tile_count[blockIdx.x] = s_count;
     }
-  if (tid < SMALLBIN && h[tid])
-    atomicAdd(&gram[(size_t) rep * (MAXGRAM + 1) + tid], (unsigned long long) h[tid]);
-  __syncthreads();
-  const uint32_t cnt = s_count, gb = s_gbase;
+  if (tid < SMALLBIN) tile_hist[(size_t) blockIdx.x * SMALLBIN + tid] = h[tid];
+  const uint32_t cnt = s_count;
+  MergeEntry *dst = tile_entries + (size_t) blockIdx.x * MG_TILE;
   for (uint32_t x = tid; x < cnt; x += MG_THREADS)
-    entries[gb + x] = stage[x];
+    dst[x] = stage[x];
+}
+
+// tile_count has been scanned in place (exclusive): copy every tile's entries to its place in the list
+__global__ __launch_bounds__(256) void k_merge_gather(const MergeEntry *__restrict__ tile_entries,
+                                                      const uint32_t *__restrict__ tile_off, int64_t ntiles,
+                                                      uint32_t total, MergeEntry *__restrict__ entries)
+{ const int wave = (int) (((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (wave >= ntiles) return;
+  const uint32_t b = tile_off[wave];
+  const uint32_t e = (wave + 1 < ntiles) ? tile_off[wave + 1] : total;
+  const MergeEntry *src = tile_entries + (size_t) wave * MG_TILE;
+  for (uint32_t x = lane; x < e - b; x += 64) entries[b + x] = src[x];
+}
+
+// sums the tiles' small-bin histograms and hit counts into gram[0..SMALLBIN) and gram[MAXGRAM]
+__global__ __launch_bounds__(256) void k_merge_reduce(const uint32_t *__restrict__ tile_hist,
+                                                      const unsigned long long *__restrict__ tile_hits,
+                                                      int64_t ntiles, unsigned long long *__restrict__ gram)
+{ __shared__ unsigned long long sh[256];
+  const int tid = threadIdx.x, bin = tid & (SMALLBIN - 1), sub = tid / SMALLBIN;      // 8 tiles per step
+  unsigned long long acc = 0, hits = 0;
+  for (int64_t t = (int64_t) blockIdx.x * 8 + sub; t < ntiles; t += (int64_t) gridDim.x * 8)
+    { acc += tile_hist[(size_t) t * SMALLBIN + bin];
+      if (bin == 0) hits += tile_hits[t];
+    }
+  sh[tid] = acc;
+  __syncthreads();
+  if (tid < SMALLBIN)
+    { unsigned long long v = 0;
+      for (int k = 0; k < 8; k++) v += sh[k * SMALLBIN + tid];
+      if (v) atomicAdd(&gram[tid], v);
+    }
+  __syncthreads();
+  sh[tid] = hits;
+  __syncthreads();
+  if (tid == 0)
+    { unsigned long long v = 0;
+      for (int k = 0; k < 8; k++) v += sh[k * SMALLBIN];
+      if (v) atomicAdd(&gram[MAXGRAM], v);
+    }
 }
 
 // hits each entry will produce under the limit (map.c:978-979)
@@ -341,30 +391,35 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   BLookup BL{Bx.keys, Bx.d_bstart, Bx.bshift};
 
   // --- match + count (map.c:2984-2988)
-  static DevBuf<unsigned long long> gram;
-  static DevBuf<MergeEntry> entries;
+  static DevBuf<unsigned long long> gram, thits;
+  static DevBuf<MergeEntry> entries, tentries;
+  static DevBuf<uint32_t>   tcount, thist;
   static DevBuf<unsigned int> mctl;
-  const size_t GR = (size_t) HREP * (MAXGRAM + 1);
-  gram.ensure(GR + HREP, "hit histogram");
+  const int64_t ntiles = ceil_div(A.n, MG_TILE);
+  gram.ensure(MAXGRAM + 1, "hit histogram");
   mctl.ensure(4, "merge counters");
-  int64_t ecap = std::min<int64_t>(A.n, Bx.n) + 64;
-  entries.ensure(ecap, "matched runs");
-  HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (GR + HREP), stream()));
+  tentries.ensure((size_t) ntiles * MG_TILE, "matched runs (per tile)");
+  tcount.ensure(ntiles + 1, "matched runs per tile");
+  thist.ensure((size_t) ntiles * SMALLBIN, "hit histogram (per tile)");
+  thits.ensure(ntiles, "hits per tile");
+  HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (MAXGRAM + 1), stream()));
   HIP_CHECK(hipMemsetAsync(mctl.p, 0, 4 * sizeof(unsigned int), stream()));
   { StageTimer tm("merge_match", 16.0 * (A.n + Bx.n));
-    hipLaunchKernelGGL(k_merge_match, dim3(ceil_div(A.n, MG_TILE)), dim3(MG_THREADS), 0, stream(),
-                       (const uint64_t *) A.keys, A.n, BL, gram.p, gram.p + GR, entries.p, mctl.p);
+    hipLaunchKernelGGL(k_merge_match, dim3(ntiles), dim3(MG_THREADS), 0, stream(),
+                       (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
+    hipLaunchKernelGGL(k_merge_reduce, dim3(256), dim3(256), 0, stream(), (const uint32_t *) thist.p,
+                       (const unsigned long long *) thits.p, ntiles, gram.p);
+    exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
     HIP_CHECK(hipGetLastError());
   }
-  std::vector<unsigned long long> hrep(GR + HREP);
   unsigned int nent = 0;
-  copy_d2h(&nent, mctl.p, sizeof(unsigned int));
-  copy_d2h(hrep.data(), gram.p, sizeof(unsigned long long) * (GR + HREP), 2);   // the host reduces it next
+  copy_d2h(&nent, tcount.p + ntiles, sizeof(unsigned int));
+  entries.ensure((size_t) nent + 64, "matched runs");
+  if (nent > 0)
+    hipLaunchKernelGGL(k_merge_gather, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(),
+                       (const MergeEntry *) tentries.p, (const uint32_t *) tcount.p, ntiles, nent, entries.p);
   std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
-  for (int r = 0; r < HREP; r++)
-    { for (int j = 0; j < MAXGRAM; j++) histo[j] += hrep[(size_t) r * (MAXGRAM + 1) + j];
-      histo[MAXGRAM] += hrep[GR + r];
-    }
+  copy_d2h(histo.data(), gram.p, sizeof(unsigned long long) * (MAXGRAM + 1), 2);   // the limit rule next
 
   // --- limit (map.c:2992-3055)
   int64_t limit, nhits;

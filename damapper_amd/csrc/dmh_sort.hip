@@ -123,11 +123,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
   __syncthreads();
   const int tile = tile_base + (int) blockIdx.x;
   int64_t base = (int64_t) tile * SORT_TILE;
+  // all loads first, from clamped addresses (a guarded load ahead of its LDS atomic compiles to
+  // load - wait - atomic, SORT_ITEMS round trips in a row)
+  uint64_t k[SORT_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++)
+    { int64_t i = base + j * SORT_THREADS + tid;
+      k[j] = keys[i < n ? i : n - 1];
+    }
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; j++)
     { int64_t i = base + j * SORT_THREADS + tid;
       if (i < n)
-        atomicAdd(&h[(uint32_t) (keys[i] >> shift) & mask], 1u);
+        atomicAdd(&h[(uint32_t) (k[j] >> shift) & mask], 1u);
     }
   __syncthreads();
   hist[(size_t) tid * ntiles + tile] = h[tid];
