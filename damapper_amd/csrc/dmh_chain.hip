@@ -54,6 +54,8 @@ struct ChainArgs
   uint4          *live;        // live-set entries {hit, apos, bpos, cost}
   unsigned int   *ticket;
   uint32_t        size_lo, size_hi;   // this launch takes the groups with size_lo <= hits < size_hi
+  const uint32_t *only;               // if set: the launch walks only[0 .. *nonly) instead of all groups
+  const uint32_t *nonly;
   unsigned int   *out_count;
   ChainSummary   *out;
 };
@@ -96,11 +98,15 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
   const int      K     = A.K;
   auto gballot = [&](bool p) -> uint64_t { return (__ballot(p) >> sbase) & gmask; };
 
+  const uint32_t nwork = A.only ? *A.nonly : A.ngroups;
   while (true)
-    { uint32_t g = 0;
-      if (lane == 0) g = atomicAdd(A.ticket, 1u);
-      g = __shfl(g, 0, G);
-      if (g >= A.ngroups) break;
+    { // one ticket per wavefront covers its 64/G groups: a device-scope atomic on one address costs
+      // several ns of memory-side service time, which adds up over 10^5 groups
+      uint32_t g = 0;
+      if ((threadIdx.x & 63) == 0) g = atomicAdd(A.ticket, (uint32_t) (64 / G));
+      g = __shfl(g, 0) + (uint32_t) (sbase / G);
+      if (g >= nwork) break;
+      if (A.only) g = A.only[g];
 
       const uint32_t g0 = A.gstart[g], g1 = A.gstart[g + 1];
       if (g1 - g0 < A.size_lo || g1 - g0 >= A.size_hi) continue;      // the other launch's group
@@ -309,6 +315,14 @@ __global__ void k_chain_jumps(const uint64_t *__restrict__ keys, const uint32_t 
   if (!write) jlen[c] = cnt;
 }
 
+// groups of at least `big` hits, in any order
+__global__ void k_big_groups(const uint32_t *__restrict__ gstart, uint32_t ngroups, uint32_t big,
+                             uint32_t *__restrict__ list, unsigned int *__restrict__ nlist)
+{ uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngroups) return;
+  if (gstart[g + 1] - gstart[g] >= big) list[atomicAdd(nlist, 1u)] = g;
+}
+
 // ---------------------------------------------------------------------------------------
 //  Host: per-read candidate lists
 // ---------------------------------------------------------------------------------------
@@ -366,6 +380,8 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.live = livebuf.p;
   A.state = state.p;
   A.tmp = tmp.p;
+  A.only = nullptr;
+  A.nonly = nullptr;
   A.ticket = ctl.p;
   A.out_count = ctl.p + 1;
   A.out = out.p;
@@ -387,11 +403,17 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
       { int nblocks = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
         A.size_lo = 0; A.size_hi = BIG_GROUP;
         hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
-        // second launch: its own ticket counter (ctl[2]); on read-vs-genome data it finds nothing to do
+        // second launch over the list of big groups (its own ticket counter ctl[2], list length ctl[3]);
+        // on read-vs-genome data the list is empty
+        static DevBuf<uint32_t> biglist;
+        biglist.ensure(nhits / BIG_GROUP + 64, "big groups");
+        hipLaunchKernelGGL(k_big_groups, dim3(ceil_div(R.ngroups, 256)), dim3(256), 0, stream(),
+                           (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, BIG_GROUP, biglist.p, ctl.p + 3);
         A.ticket  = ctl.p + 2;
         A.size_lo = BIG_GROUP; A.size_hi = 0xffffffffu;
-        nblocks = (int) std::min<int64_t>((R.ngroups + 3) / 4, 256 * 8);
-        hipLaunchKernelGGL(k_chain<64>, dim3(nblocks), dim3(256), 0, stream(), A);
+        A.only    = biglist.p;
+        A.nonly   = ctl.p + 3;
+        hipLaunchKernelGGL(k_chain<64>, dim3(256), dim3(256), 0, stream(), A);
       }
     HIP_CHECK(hipGetLastError());
   }
