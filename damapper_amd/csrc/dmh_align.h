@@ -75,9 +75,24 @@ template <int W> struct WaveWork
 __device__ __forceinline__ uint64_t load32(const uint64_t *__restrict__ p, int64_t q)
 { int64_t  w  = q >> 5;
   int      sh = (int) (q & 31) << 1;
+  // both words always (the arrays are padded): a load guarded by sh != 0 would be a branch with a wait
+  // at its join, and the A and B windows of a snake step would be fetched one after the other
   uint64_t lo = p[w];
   uint64_t hi = p[w + 1];
-  return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+  return (lo >> sh) | ((hi << 1) << (63 - sh));
+}
+
+// XOR of the two 32-base windows A[qa..] and B[qb..]: all four words are requested before any is used,
+// so the two sequences cost one memory round trip per snake step, not two
+__device__ __forceinline__ uint64_t diff32(const uint64_t *__restrict__ pa, int64_t qa,
+                                           const uint64_t *__restrict__ pb, int64_t qb)
+{ const int64_t wa = qa >> 5, wb = qb >> 5;
+  const int     sa = (int) (qa & 31) << 1, sb = (int) (qb & 31) << 1;
+  const uint64_t alo = pa[wa], ahi = pa[wa + 1];
+  const uint64_t blo = pb[wb], bhi = pb[wb + 1];
+  const uint64_t a = (alo >> sa) | ((ahi << 1) << (63 - sa));
+  const uint64_t b = (blo >> sb) | ((bhi << 1) << (63 - sb));
+  return a ^ b;
 }
 
 // Length of the exact-match run A[x..] == B[y..] (forward snake, align.c:748-768), bounded by the
@@ -87,7 +102,7 @@ __device__ __forceinline__ int match_fwd(const SeqView &S, int x, int y, bool &e
   int n = 0;
   end = true;
   while (n < rem)
-    { uint64_t d = load32(S.pa, S.abase + x + n) ^ load32(S.pb, S.bbase + y + n);
+    { uint64_t d = diff32(S.pa, S.abase + x + n, S.pb, S.bbase + y + n);
       int m = d ? (__builtin_ctzll(d) >> 1) : 32;
       if (m >= rem - n) { n = rem; break; }
       n += m;
@@ -102,7 +117,7 @@ __device__ __forceinline__ int match_rev(const SeqView &S, int x, int y, bool &e
   int n = 0;
   end = true;
   while (n < rem)
-    { uint64_t d = load32(S.pa, S.abase + x - n - 32) ^ load32(S.pb, S.bbase + y - n - 32);
+    { uint64_t d = diff32(S.pa, S.abase + x - n - 32, S.pb, S.bbase + y - n - 32);
       int m = d ? (__builtin_clzll(d) >> 1) : 32;
       if (m >= rem - n) { n = rem; break; }
       n += m;
