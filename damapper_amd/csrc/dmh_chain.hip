@@ -26,8 +26,7 @@ constexpr int HITMIN    = 3;      // map.c:34
 constexpr uint32_t NIL = 0xffffffffu;
 
 constexpr uint32_t ST_LIVE    = 1;   // in the tree
-constexpr uint32_t ST_DEAD    = 0;   // removed (slope rule or expired while not a best end)
-constexpr uint32_t ST_EXPBEST = 2;   // expired while it was the best end of its origin
+constexpr uint32_t ST_DEAD    = 0;   // removed by the slope rule, or expired
 
 void gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n);
 
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
                   if (en.x != NIL)                       // NIL = removed by the slope rule
                     { int ax = (int) en.y;
                       if (ax < apos - MAX_GAP)
-                        A.state[en.x] = (A.best[A.rootof[en.x]] == en.x) ? ST_EXPBEST : ST_DEAD;
+                        A.state[en.x] = ST_DEAD;      // (only 'live or not' is ever read back)
                       else
                         { int bx = (int) en.z;
                           int dx = ax - bx;
