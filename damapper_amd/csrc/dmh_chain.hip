@@ -55,6 +55,8 @@ struct ChainArgs
   uint32_t        size_lo, size_hi;   // this launch takes the groups with size_lo <= hits < size_hi
   const uint32_t *only;               // if set: the launch walks only[0 .. *nonly) instead of all groups
   const uint32_t *nonly;
+  uint32_t       *retry;              // G < 64: groups whose live window outgrew LDS are appended here
+  unsigned int   *nretry;             //         (the 64-lane launch that follows walks this list)
   unsigned int   *out_count;
   ChainSummary   *out;
 };
@@ -97,6 +99,16 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
   const int      K     = A.K;
   auto gballot = [&](bool p) -> uint64_t { return (__ballot(p) >> sbase) & gmask; };
 
+  // G < 64: the live window sits in LDS together with each entry's chain origin, so a hit costs one
+  // LDS scan and ONE global round trip (the origin's best score) instead of three (window, origin,
+  // best score).  A window that outgrows LCAP entries hands its group to the 64-lane launch.
+  constexpr bool LDSLIVE = (G < 64);
+  constexpr int  LCAP    = 96;
+  __shared__ uint4    s_live[LDSLIVE ? (256 / G) * LCAP : 1];
+  __shared__ uint32_t s_root[LDSLIVE ? (256 / G) * LCAP : 1];
+  uint4    *const lds_live = s_live + (LDSLIVE ? (threadIdx.x / G) * LCAP : 0);
+  uint32_t *const lds_root = s_root + (LDSLIVE ? (threadIdx.x / G) * LCAP : 0);
+
   const uint32_t nwork = A.only ? *A.nonly : A.ngroups;
   while (true)
     { // one ticket per wavefront covers its 64/G groups: a device-scope atomic on one address costs
@@ -108,13 +120,14 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
       if (A.only) g = A.only[g];
 
       const uint32_t g0 = A.gstart[g], g1 = A.gstart[g + 1];
-      if (g1 - g0 < A.size_lo || g1 - g0 >= A.size_hi) continue;      // the other launch's group
+      if (!A.only && (g1 - g0 < A.size_lo || g1 - g0 >= A.size_hi)) continue;      // the other launch's group
       // The live set (hits in the reference's tree) is an unordered list of self-contained entries
       // {hit, apos, bpos, cost} in this group's slice of A.live.  One coalesced scan per hit drops
       // expired / removed entries (compacting in place) and answers both neighbour queries, so a
       // hit costs O(live/64) even when thousands of dead hits share its 1000-bp window.
       uint4   *live  = A.live + g0;
       uint32_t nlive = 0;
+      bool     spill = false;
 
       for (uint32_t j = g0; j < g1; j++)
         { const int apos = (int) (A.keys[j] & A.pmask) + 1;       // map.c:1784-1785
@@ -124,16 +137,18 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
           // ---- expiry (map.c:1787-1796) + neighbour queries (predOf/leftmost/succOf, map.c:1262-1318)
           uint64_t Lbest = ~0ull, Rbest = 0;
           uint4    Le = make_uint4(NIL, 0, 0, 0), Re = make_uint4(NIL, 0, 0, 0);
-          uint32_t Lpos = 0, Rpos = 0;
+          uint32_t Lpos = 0, Rpos = 0, Lroot = 0, Rroot = 0;
           const int thresh = bpos - MAX_GAP;
           uint32_t  wr = 0;
           for (uint32_t base = 0; base < nlive; base += G)
             { uint32_t i  = base + lane;
               uint4    en = make_uint4(NIL, 0, 0, 0);
+              uint32_t rt = 0;
               bool     keep = false;
               uint64_t lk = ~0ull, rk = 0;
               if (i < nlive)
-                { en = live[i];
+                { if (LDSLIVE) { en = lds_live[i]; rt = lds_root[i]; }
+                  else         en = live[i];
                   if (en.x != NIL)                       // NIL = removed by the slope rule
                     { int ax = (int) en.y;
                       if (ax < apos - MAX_GAP)
@@ -159,16 +174,21 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
                   Lbest = lm;
                   Le.x = __shfl(en.x, sl, G); Le.y = __shfl(en.y, sl, G); Le.z = __shfl(en.z, sl, G); Le.w = __shfl(en.w, sl, G);
                   Lpos = __shfl(dst, sl, G);
+                  if (LDSLIVE) Lroot = __shfl(rt, sl, G);
                 }
               if (rm > Rbest)
                 { int sl = __ffsll((long long) gballot(rk == rm)) - 1;
                   Rbest = rm;
                   Re.x = __shfl(en.x, sl, G); Re.y = __shfl(en.y, sl, G); Re.z = __shfl(en.z, sl, G); Re.w = __shfl(en.w, sl, G);
                   Rpos = __shfl(dst, sl, G);
+                  if (LDSLIVE) Rroot = __shfl(rt, sl, G);
                 }
               // in-place compaction: the write index never passes this chunk's first read index, and
               // the stored value is the loaded one, so the stores cannot overtake the loads
-              if (keep) live[dst] = en;
+              if (keep)
+                { if (LDSLIVE) { lds_live[dst] = en; lds_root[dst] = rt; }
+                  else         live[dst] = en;
+                }
               wr += (uint32_t) __popcll(km);
             }
           nlive = wr;
@@ -182,14 +202,28 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
           if (lcost > rcost) rcost = 0; else lcost = 0;
 
           uint4    pe = make_uint4(NIL, 0, 0, 0);
-          uint32_t ppos = 0;
+          uint32_t ppos = 0, proot = 0;
           int      c = K;
-          if (lcost > 0)      { pe = Le; ppos = Lpos; c = lcost; }
-          else if (rcost > 0) { pe = Re; ppos = Rpos; c = rcost; }
+          if (lcost > 0)      { pe = Le; ppos = Lpos; proot = Lroot; c = lcost; }
+          else if (rcost > 0) { pe = Re; ppos = Rpos; proot = Rroot; c = rcost; }
 
+          uint32_t jroot = j;                    // origin of the chain the new hit ends
           if (pe.x != NIL)
-            { uint32_t root = A.rootof[pe.x];
-              int      bc   = A.bestcost[root];
+            { uint32_t root;
+              int      bc;
+              if (LDSLIVE)
+                { // bestcost[] is written by lane 0 only: let lane 0 read it back (a thread sees its own
+                  // stores) and hand the value round
+                  root = proot;
+                  bc   = 0;
+                  if (lane == 0) bc = A.bestcost[root];
+                  bc = __shfl(bc, 0, G);
+                }
+              else
+                { root = A.rootof[pe.x];
+                  bc   = A.bestcost[root];
+                }
+              jroot = root;
               bool     kill = false;
               if (c >= bc)
                 { int pa = (int) pe.y;
@@ -208,7 +242,8 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
                       A.bestcost[root] = c;
                       if (kill)
                         { A.state[pe.x] = ST_DEAD;
-                          live[ppos].x  = NIL;
+                          if (LDSLIVE) lds_live[ppos].x = NIL;
+                          else         live[ppos].x = NIL;
                         }
                     }
                 }
@@ -221,10 +256,28 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
               A.bestcost[j] = K;
               A.state[j]    = ST_LIVE;
             }
-          if (lane == 0) live[nlive] = make_uint4(j, (uint32_t) apos, (uint32_t) bpos, (uint32_t) c);
-          nlive += 1;
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          if (LDSLIVE)
+            { if (nlive >= (uint32_t) LCAP) { spill = true; break; }
+              if (lane == 0)
+                { lds_live[nlive] = make_uint4(j, (uint32_t) apos, (uint32_t) bpos, (uint32_t) c);
+                  lds_root[nlive] = jroot;
+                }
+              nlive += 1;
+              // the lanes of a group meet again only through LDS, which serves a wavefront's accesses in order
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          else
+            { if (lane == 0) live[nlive] = make_uint4(j, (uint32_t) apos, (uint32_t) bpos, (uint32_t) c);
+              nlive += 1;
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
         }
+      if (spill)
+        { if (lane == 0) A.retry[atomicAdd(A.nretry, 1u)] = g;
+          continue;
+        }
+      if (LDSLIVE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    // the report reads what lane 0 stored
 
       // ---- report the best end of every origin with cost >= hithr (map.c:1634-1649).  Order:
       //      live ends by (diag,apos) descending, then expired ends most recent first.
@@ -385,34 +438,40 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.out_count = ctl.p + 1;
   A.out = out.p;
 
-  // small groups four to a wavefront, big ones (repeat piles) one per wavefront; DMH_CHAIN_G forces one size
+  // small groups four to a wavefront (live window in LDS), big ones (repeat piles) and windows that
+  // outgrew LDS one per wavefront; dmh_test_option("chain_g") / DMH_CHAIN_G force one size for all
   static const int env_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
   const int chain_g = st.opt_chain_g ? st.opt_chain_g : env_g;
   constexpr uint32_t BIG_GROUP = 1024;
+  static DevBuf<uint32_t> biglist;
+  biglist.ensure((size_t) R.ngroups + 64, "big groups");
+  A.retry  = biglist.p;          // list of the 64-lane launch: big groups + spilled windows
+  A.nretry = ctl.p + 3;
   { StageTimer tm("chain", 16.0 * nhits);
-    if (chain_g == 64 || chain_g == 32 || chain_g == 16)
-      { const int gpb = 256 / chain_g;
+    const bool all64 = (chain_g == 64);
+    const int  gsmall = (chain_g == 32) ? 32 : 16;
+    if (!all64)
+      { const int gpb = 256 / gsmall;
         int nblocks = (int) std::min<int64_t>((R.ngroups + gpb - 1) / gpb, 256 * 8);
-        A.size_lo = 0; A.size_hi = 0xffffffffu;
-        if (chain_g == 64)      hipLaunchKernelGGL(k_chain<64>, dim3(nblocks), dim3(256), 0, stream(), A);
-        else if (chain_g == 32) hipLaunchKernelGGL(k_chain<32>, dim3(nblocks), dim3(256), 0, stream(), A);
-        else                    hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
+        if (chain_g == 0)
+          { A.size_lo = 0; A.size_hi = BIG_GROUP;
+            hipLaunchKernelGGL(k_big_groups, dim3(ceil_div(R.ngroups, 256)), dim3(256), 0, stream(),
+                               (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, BIG_GROUP, biglist.p, ctl.p + 3);
+          }
+        else
+          { A.size_lo = 0; A.size_hi = 0xffffffffu; }
+        if (gsmall == 32) hipLaunchKernelGGL(k_chain<32>, dim3(nblocks), dim3(256), 0, stream(), A);
+        else              hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
+        // the list (its own ticket counter ctl[2], length ctl[3]); on read-vs-genome data it is empty
+        A.ticket = ctl.p + 2;
+        A.only   = biglist.p;
+        A.nonly  = ctl.p + 3;
+        hipLaunchKernelGGL(k_chain<64>, dim3(256), dim3(256), 0, stream(), A);
       }
     else
-      { int nblocks = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
-        A.size_lo = 0; A.size_hi = BIG_GROUP;
-        hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
-        // second launch over the list of big groups (its own ticket counter ctl[2], list length ctl[3]);
-        // on read-vs-genome data the list is empty
-        static DevBuf<uint32_t> biglist;
-        biglist.ensure(nhits / BIG_GROUP + 64, "big groups");
-        hipLaunchKernelGGL(k_big_groups, dim3(ceil_div(R.ngroups, 256)), dim3(256), 0, stream(),
-                           (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, BIG_GROUP, biglist.p, ctl.p + 3);
-        A.ticket  = ctl.p + 2;
-        A.size_lo = BIG_GROUP; A.size_hi = 0xffffffffu;
-        A.only    = biglist.p;
-        A.nonly   = ctl.p + 3;
-        hipLaunchKernelGGL(k_chain<64>, dim3(256), dim3(256), 0, stream(), A);
+      { int nblocks = (int) std::min<int64_t>((R.ngroups + 3) / 4, 256 * 8);
+        A.size_lo = 0; A.size_hi = 0xffffffffu;
+        hipLaunchKernelGGL(k_chain<64>, dim3(nblocks), dim3(256), 0, stream(), A);
       }
     HIP_CHECK(hipGetLastError());
   }
