@@ -350,19 +350,21 @@ __global__ void k_chain_jumps(const uint64_t *__restrict__ keys, const uint32_t 
   uint32_t cnt = 0;
   uint16_t *o = write ? jout + 2 * (size_t) joff[c] : nullptr;
   while (y != NIL)
-    { int ay = (int) (keys[y] & pmask), by = (int) vals[y];
+    { // the three loads of a step depend on y only: request them together (one round trip per link)
+      const uint64_t ky = keys[y];
+      const uint32_t vy = vals[y];
+      const uint32_t fy = from[y];
+      int ay = (int) (ky & pmask), by = (int) vy;
       int da = ax - ay, db = bx - by;
-      if (da == db && da < 100)
-        y = from[y];
-      else
+      if (!(da == db && da < 100))
         { if (write)
             { o[2 * cnt]     = (uint16_t) da;
               o[2 * cnt + 1] = (uint16_t) db;
             }
           cnt += 1;
           x = y; ax = ay; bx = by;
-          y = from[x];
         }
+      y = fy;
     }
   if (!write) jlen[c] = cnt;
 }
