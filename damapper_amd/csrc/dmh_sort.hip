@@ -153,15 +153,14 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles)
 // through LDS into digit order, so that consecutive threads write consecutive slots of each
 // digit's output run (coalesced 8-byte / 4-byte stores), the run's global start coming from the
 // scanned histogram.
-__global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *__restrict__ kin,
+__global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_t *__restrict__ kin,
                                                                  const uint32_t *__restrict__ vin,
                                                                  uint64_t *__restrict__ kout,
                                                                  uint32_t *__restrict__ vout, int64_t n,
                                                                  int shift, uint32_t mask,
                                                                  const uint32_t *__restrict__ offs, int ntiles,
                                                                  int tile_base)
-{ __shared__ uint64_t skey[SORT_TILE];
-  __shared__ uint32_t sval[SORT_TILE];
+{ __shared__ uint64_t skey[SORT_TILE];        // keys in digit order; afterwards its first half holds the values
   __shared__ uint32_t wh[4][256];
   __shared__ uint32_t gdelta[256];
   __shared__ uint32_t ws[4];
@@ -222,24 +221,40 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
   }
   __syncthreads();
 
+  // keys and values go through the SAME 32 KB of LDS one after the other (37 KB per workgroup = four
+  // workgroups per CU instead of three); the output slot of each position is kept in a register
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; j++)
     { if ((base + j * 64) < n)
         { uint32_t d = (uint32_t) (key[j] >> shift) & mask;
-          uint32_t p = wh[w][d] + rk[j];
-          skey[p] = key[j];
-          sval[p] = val[j];
+          rk[j] += wh[w][d];                    // position inside the tile
+          skey[rk[j]] = key[j];
         }
     }
   __syncthreads();
 
   const int count = (int) ((n - tile0 < (int64_t) SORT_TILE) ? (n - tile0) : (int64_t) SORT_TILE);
-  for (int i = tid; i < count; i += SORT_THREADS)
-    { uint64_t k = skey[i];
-      uint32_t d = (uint32_t) (k >> shift) & mask;
-      uint32_t o = gdelta[d] + (uint32_t) i;
-      kout[o] = k;
-      vout[o] = sval[i];
+  uint32_t slot[SORT_ITEMS];
+#pragma unroll
+  for (int k2 = 0; k2 < SORT_ITEMS; k2++)
+    { int i = tid + k2 * SORT_THREADS;
+      if (i < count)
+        { uint64_t k = skey[i];
+          uint32_t d = (uint32_t) (k >> shift) & mask;
+          slot[k2] = gdelta[d] + (uint32_t) i;
+          kout[slot[k2]] = k;
+        }
+    }
+  __syncthreads();
+  uint32_t *sval = (uint32_t *) skey;
+#pragma unroll
+  for (int j = 0; j < SORT_ITEMS; j++)
+    if ((base + j * 64) < n) sval[rk[j]] = val[j];
+  __syncthreads();
+#pragma unroll
+  for (int k2 = 0; k2 < SORT_ITEMS; k2++)
+    { int i = tid + k2 * SORT_THREADS;
+      if (i < count) vout[slot[k2]] = sval[i];
     }
 }
 
