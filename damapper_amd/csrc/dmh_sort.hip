@@ -129,7 +129,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; j++)
     { int64_t i = base + j * SORT_THREADS + tid;
-      k[j] = keys[i < n ? i : n - 1];
+      k[j] = __builtin_nontemporal_load(keys + (i < n ? i : n - 1));
     }
 #pragma unroll
   for (int j = 0; j < SORT_ITEMS; j++)
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_
   for (int j = 0; j < SORT_ITEMS; j++)
     { int64_t i = base + j * 64;
       bool ok = i < n;
-      key[j] = ok ? kin[i] : 0;
-      val[j] = ok ? vin[i] : 0;
+      key[j] = ok ? __builtin_nontemporal_load(kin + i) : 0;     // read once: keep it out of the caches' way
+      val[j] = ok ? __builtin_nontemporal_load(vin + i) : 0;
     }
 
   volatile uint32_t *mywh = wh[w];
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_
         { uint64_t k = skey[i];
           uint32_t d = (uint32_t) (k >> shift) & mask;
           slot[k2] = gdelta[d] + (uint32_t) i;
-          kout[slot[k2]] = k;
+          kout[slot[k2]] = k;                   // (plain stores: neighbouring tiles' pieces merge in L2)
         }
     }
   __syncthreads();
