@@ -202,7 +202,9 @@ def main():
             # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is)
             traffic = None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_summary.json")))
+                import glob
+                latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.json")))[-1]
+                pm = json.load(open(latest))
                 traffic = pm["derived"]["scatter_traffic_bytes_per_record"] * (sc["bytes"] / sc["launches"] / 32.0)
             except Exception:
                 pass
