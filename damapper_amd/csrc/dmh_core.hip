@@ -432,7 +432,7 @@ BlockDev &upload_block(const DAZZ_DB *block, bool pin)
   bd.L = block->reads[n].boff;
   bd.stamp = stamp;
   bd.pinned = pin;
-  bd.d_raw = (uint8_t *) dev_alloc((size_t) bd.L + 1, "block bases");
+  bd.d_raw = (uint8_t *) dev_alloc((size_t) bd.L + 1 + 64, "block bases");     // (+64: k_kmer_emit reads whole 16-byte lines)
   // the byte before bases[0] is the leading separator (DB.c:1411)
   const uint8_t *src = ((const uint8_t *) block->bases) - 1;
   bd.d_boff = (int64_t *) dev_alloc(sizeof(int64_t) * (n + 1), "block read offsets");

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__res
                                                             int K, uint64_t kmask,
                                                             uint64_t *__restrict__ keys,
                                                             uint32_t *__restrict__ vals, int64_t nk, int block_base)
-{ __shared__ uint8_t  sb[EMIT_TILE + 32];
+{ __shared__ uint4    sraw[(EMIT_TILE + 64) / 16 + 1];   // the tile's bases + halo, as fetched (16-byte lines)
   __shared__ uint64_t scode[EMIT_TILE];
   __shared__ uint16_t sread[EMIT_TILE];     // read index relative to the tile's first read
   __shared__ uint8_t  sok[EMIT_TILE];
@@ -360,9 +360,22 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__res
   const int64_t tile = (int64_t) (block_base + (int) blockIdx.x) * EMIT_TILE;
   const int     halo = K - 1;
 
-  for (int x = tid; x < EMIT_TILE + halo; x += EMIT_THREADS)
-    { int64_t q = tile - halo + x;
-      sb[x] = (q >= 0 && q < L) ? bases[q] : (uint8_t) 4;
+  // The tile and its K-1 bases of halo arrive in one round of 16-byte loads (the block copy starts
+  // 256-byte aligned one byte before bases[0] -- the leading separator -- and is padded behind).
+  const uint8_t *raw = bases - 1;                          // raw[q + 1] = bases[q]
+  const int64_t  r0  = tile - halo + 1;                    // first byte needed (negative only for the first tile)
+  const int64_t  a0  = (r0 >> 4) << 4;
+  const int      sh  = (int) (r0 - a0);
+  const int      nvec = (sh + EMIT_TILE + halo + 15) >> 4;
+  if (tid < nvec)
+    { int64_t off = a0 + 16 * (int64_t) tid;
+      sraw[tid] = (off >= 0) ? *(const uint4 *) (raw + off) : make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
+    }
+  uint8_t *sb = (uint8_t *) sraw + sh;                     // sb[x] = bases[tile - halo + x]
+  if (tile + EMIT_TILE > L)                                // the last tile: whatever lies behind the block is a separator
+    { __syncthreads();
+      for (int x = tid; x < EMIT_TILE + halo; x += EMIT_THREADS)
+        if (tile - halo + x >= L) sb[x] = (uint8_t) 4;
     }
   if (tid == 0)
     { // largest i with boff[i] <= tile  (boff[0] = 0 <= tile always)
