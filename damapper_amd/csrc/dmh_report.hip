@@ -1163,6 +1163,8 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           std::sort(todo.begin(), todo.end(), [&](int x, int y)
                     { if (jobs[x].comp != jobs[y].comp) return jobs[x].comp < jobs[y].comp;
                       if (jobs[x].alen != jobs[y].alen) return jobs[x].alen > jobs[y].alen;
+                      // the chain end is the first seed: equal ends give passes of equal length
+                      if (jobs[x].alast != jobs[y].alast) return jobs[x].alast > jobs[y].alast;
                       return x < y;
                     });
         }
