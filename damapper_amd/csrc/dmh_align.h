@@ -715,7 +715,10 @@ template <> struct Grp<32>
   static __device__ __forceinline__ int  from_right(int v)
   { return __builtin_amdgcn_ds_bpermute((base() | ((threadIdx.x + 1) & 31)) << 2, v); }
   static __device__ __forceinline__ uint64_t ballot(bool p)
-  { return (__ballot(p) >> base()) & 0xffffffffull; }
+  { // the half of the wavefront's mask that belongs to this group: one select, not a 64-bit shift
+    const uint64_t b = __ballot(p);
+    return (uint64_t) ((threadIdx.x & 32) ? (uint32_t) (b >> 32) : (uint32_t) b);
+  }
   static __device__ __forceinline__ uint64_t rot_right(uint64_t m, int r)
   { uint32_t x = (uint32_t) m;
     r &= 31;
