@@ -487,7 +487,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   std::vector<ChainSummary> sums(nsum);
   std::vector<uint32_t>     gfirst;
   if (nsum > 0)
-    { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum, 2);      // host sort next
+    { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum, 1);      // host sort next
       std::sort(sums.begin(), sums.end(), [](const ChainSummary &a, const ChainSummary &b)
                 { return a.group != b.group ? a.group < b.group : a.rank < b.rank; });
     }
@@ -506,7 +506,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     if (!want.empty())
       { copy_h2d(d_idx.p, want.data(), sizeof(uint32_t) * want.size());
         gather_u64(R.skeys, d_idx.p, d_k.p, (int64_t) want.size());
-        copy_d2h(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size(), 2);   // domination scan next
+        copy_d2h(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size(), 1);   // domination scan next
       }
   }
 

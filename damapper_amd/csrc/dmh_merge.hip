@@ -419,7 +419,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     hipLaunchKernelGGL(k_merge_gather, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(),
                        (const MergeEntry *) tentries.p, (const uint32_t *) tcount.p, ntiles, nent, entries.p);
   std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
-  copy_d2h(histo.data(), gram.p, sizeof(unsigned long long) * (MAXGRAM + 1), 2);   // the limit rule next
+  copy_d2h(histo.data(), gram.p, sizeof(unsigned long long) * (MAXGRAM + 1), 1);   // the limit rule next
 
   // --- limit (map.c:2992-3055)
   int64_t limit, nhits;

@@ -1095,7 +1095,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel
   HostTimer *ht1 = new HostTimer("report_align");
-  bg_pump(4);                 // something for the GPU to do while the jobs are put together
+  bg_pump(8);                 // something for the GPU to do while the jobs are put together
   std::vector<CandJob>   jobs;
   std::vector<uint16_t>  jumps;
   std::vector<int>       job_of_first(nreads + 1, 0);   // first job index of each read
@@ -1158,15 +1158,24 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
       if (level == 0)
         { // the halves of a wavefront run in lock step: hand out like jobs together (same orientation,
           // similar length), long ones first
-          todo.resize(njobs);
-          for (int i = 0; i < njobs; i++) todo[i] = i;
-          std::sort(todo.begin(), todo.end(), [&](int x, int y)
-                    { if (jobs[x].comp != jobs[y].comp) return jobs[x].comp < jobs[y].comp;
-                      if (jobs[x].alen != jobs[y].alen) return jobs[x].alen > jobs[y].alen;
-                      // the chain end is the first seed: equal ends give passes of equal length
-                      if (jobs[x].alast != jobs[y].alast) return jobs[x].alast > jobs[y].alast;
-                      return x < y;
-                    });
+          // (comp asc, alen desc, alast desc, index asc) packed into one integer key per job
+          std::vector<uint64_t> key(njobs);
+          for (int i = 0; i < njobs; i++)
+            { uint64_t len = 0xfffffu - (uint64_t) std::min(jobs[i].alen, 0xfffff);
+              uint64_t end = 0xfffffu - (uint64_t) std::min(std::max(jobs[i].alast, 0), 0xfffff);
+              key[i] = ((uint64_t) (jobs[i].comp != 0) << 63) | (len << 43) | (end << 23);
+            }
+          if (njobs < (1 << 23))
+            { for (int i = 0; i < njobs; i++) key[i] |= (uint64_t) i;
+              std::sort(key.begin(), key.end());
+              todo.resize(njobs);
+              for (int i = 0; i < njobs; i++) todo[i] = (int) (key[i] & 0x7fffffu);
+            }
+          else
+            { todo.resize(njobs);
+              for (int i = 0; i < njobs; i++) todo[i] = i;
+              std::stable_sort(todo.begin(), todo.end(), [&](int x, int y) { return key[x] < key[y]; });
+            }
         }
       for (int round = 0; round < 8; round++)
         { if (pool_cap > 0xfffffff0ull / 4) fatal("Reporter: alignment pool too large");
