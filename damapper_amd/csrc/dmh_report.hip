@@ -687,16 +687,18 @@ static void select_and_write(ReportCtx &C)
   HostTimer ht2("report_select_write");
   // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
   const bool small = (S_ <= TRACE_XOVR);
-  std::vector<Ovl>      am, bm;
-  std::vector<uint16_t> tb;
-  std::vector<Link>     linker;
-  std::vector<Link *>   perm;
-  std::vector<Zone>     part;
-  std::vector<uint8_t>  wbuf;
-  int64_t ncheck = 0;
   std::vector<std::vector<uint8_t>> prof(C.profile ? nreads : 0);
+  (void) special_log(2);                   // fill its table before the threads start
 
-  for (int ti = 0; ti < NT; ti++)
+  // one output file per "thread" of the reference: the files cover disjoint read ranges and are independent,
+  // so they are written by NT host threads
+  auto do_file = [&](int ti) -> int64_t
+  { std::vector<Ovl>      am, bm;
+    std::vector<uint16_t> tb;
+    std::vector<Link>     linker;
+    std::vector<Link *>   perm;
+    std::vector<Zone>     part;
+    std::vector<uint8_t>  wbuf;
     { int abeg = (int) (((int64_t) ti * nreads) >> C.nshift);
       int aend = (ti == NT - 1) ? nreads : (int) (((int64_t) (ti + 1) * nreads) >> C.nshift);
       FILE *afile = nullptr;
@@ -961,8 +963,19 @@ static void select_and_write(ReportCtx &C)
           fwrite(&bhits, sizeof(int64_t), 1, bfile);
           fclose(bfile);
         }
-      ncheck += doA ? ahits : bhits;
+      return doA ? ahits : bhits;
     }
+  };
+  std::vector<int64_t> hits(NT, 0);
+  if (NT > 1)
+    { std::vector<std::thread> th;
+      for (int ti = 0; ti < NT; ti++) th.emplace_back([&, ti] { hits[ti] = do_file(ti); });
+      for (auto &t : th) t.join();
+    }
+  else
+    hits[0] = do_file(0);
+  int64_t ncheck = 0;
+  for (int ti = 0; ti < NT; ti++) ncheck += hits[ti];
 
   if (C.verbose)
     { printf("      %lld mapped segments\n", (long long) ncheck);
