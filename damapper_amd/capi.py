@@ -36,6 +36,8 @@ def lib() -> C.CDLL:
     L.Set_Filter_Params.restype = C.c_int
     L.Sort_Kmers.argtypes = [P(DAZZ_DB), P(C.c_int)]
     L.Sort_Kmers.restype = C.c_void_p
+    L.dmh_ref_cache.argtypes = [C.c_int, C.c_double]
+    L.dmh_ref_cache.restype = None
     L.dmh_test_option.argtypes = [C.c_char_p, C.c_int]
     L.dmh_test_option.restype = C.c_int
     L.dmh_sort_kmers_async.argtypes = [P(DAZZ_DB), P(C.c_int)]
@@ -95,7 +97,7 @@ def exported_symbols() -> List[str]:
             "dmh_last_seed_count", "dmh_last_seeds", "dmh_last_limit", "dmh_read_candidates",
             "dmh_candidate_jumps", "dmh_read_cover", "dmh_sort_pairs", "dmh_local_alignment",
             "dmh_timing_enable", "dmh_timing_reset", "dmh_timing_count", "dmh_timing_get", "dmh_sync",
-            "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free", "dmh_test_option"]
+            "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free", "dmh_test_option", "dmh_ref_cache"]
 
 
 def set_globals(verbose: int = 0, profile: int = 0, spacing: int = 100, best_tie: float = 1.0,

@@ -485,6 +485,10 @@ void index_wait_ready(IndexDev &ix)
 
 static void free_index(IndexDev &ix)
 { if (ix.pending) bg_flush();
+  if (ix.borrowed)               // the buffers belong to a cache entry
+    { ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr; ix.d_bstart = nullptr;
+      return;
+    }
   dev_free(ix.keys);
   dev_free(ix.vals);
   dev_free(ix.d_boff);
@@ -561,6 +565,97 @@ __global__ void k_mask_flag(const uint32_t *__restrict__ vals, int64_t n, const 
       if (data[2 * m + 1] > start) h = m; else l = m + 1;
     }
   keep[i] = (l < a1 && data[2 * l] <= rpos) ? 0u : 1u;
+}
+
+// ---- REF index cache ----------------------------------------------------------------------------
+// Identity of a block's content for the cache: every read length, 4096 samples of 16 bases, the first
+// and last 4 KB, and the parameters the index depends on.  (Sampled, not exhaustive -- which is why
+// the cache is opt-in: two blocks that differ only between the samples would share an index.)
+static void content_key(const DAZZ_DB *b, const Params &pm, uint64_t key[4])
+{ const uint8_t *p = (const uint8_t *) b->bases;
+  const int64_t  L = b->reads[b->nreads].boff;
+  uint64_t h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull;
+  auto mix = [&](uint64_t v) { h1 = (h1 ^ v) * 1099511628211ull; h2 = (h2 + v) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 33; };
+  for (int i = 0; i <= b->nreads; i++) mix((uint64_t) b->reads[i].boff);
+  const int64_t step = L / 4096 + 1;
+  for (int64_t i = 0; i + 16 <= L; i += step)
+    { uint64_t a, c;
+      memcpy(&a, p + i, 8); memcpy(&c, p + i + 8, 8);
+      mix(a); mix(c);
+    }
+  const int64_t edge = L < 4096 ? L : 4096;
+  for (int64_t i = 0; i + 8 <= edge; i += 8)
+    { uint64_t a, c;
+      memcpy(&a, p + i, 8); memcpy(&c, p + L - edge + i, 8);
+      mix(a); mix(c);
+    }
+  key[0] = h1;
+  key[1] = h2;
+  key[2] = ((uint64_t) L << 24) ^ (uint64_t) b->nreads;
+  key[3] = ((uint64_t) pm.Kmer << 40) ^ ((uint64_t) (uint32_t) pm.TooFrequent << 4) ^ 1ull;
+}
+
+static size_t index_bytes(const IndexDev &ix)
+{ // (a bucket table attached later by a borrower is not counted: at most 1 GB per entry)
+  return (size_t) ix.n * 12 + (size_t) (ix.nreads + 1) * 8 + (size_t) ix.nchunk * 4 + ix.bstart_bytes;
+}
+
+static IndexDev *cache_find(const uint64_t key[4])
+{ State &st = S();
+  for (auto it = st.ref_cached.begin(); it != st.ref_cached.end(); ++it)
+    if (memcmp(it->ckey, key, sizeof(it->ckey)) == 0)
+      { st.ref_cached.splice(st.ref_cached.begin(), st.ref_cached, it);     // most recently used first
+        return &st.ref_cached.front();
+      }
+  return nullptr;
+}
+
+// Match_Filter is done with a REF index: keep it (cache on) or free it.  A borrowed record hands a bucket
+// table it built back to its cache entry.
+void release_ref_index(IndexDev &ix)
+{ State &st = S();
+  if (ix.borrowed)
+    { IndexDev *c = cache_find(ix.ckey);
+      if (c != nullptr)
+        { c->borrows -= 1;
+          if (c->d_bstart == nullptr)
+            { c->d_bstart = ix.d_bstart; c->bshift = ix.bshift; c->bstart_bytes = ix.bstart_bytes; }
+          else if (c->d_bstart != ix.d_bstart)
+            dev_free(ix.d_bstart);         // two borrowers built a table each
+        }
+      free_index(ix);
+      return;
+    }
+  if (!st.ref_cache || !ix.cacheable || ix.pending || cache_find(ix.ckey) != nullptr)
+    { free_index(ix);
+      return;
+    }
+  size_t bytes = index_bytes(ix);
+  while (st.ref_cache_bytes + bytes > st.ref_cache_cap)
+    { auto victim = st.ref_cached.end();
+      for (auto it = st.ref_cached.end(); it != st.ref_cached.begin();)
+        { --it;
+          if (it->borrows == 0) { victim = it; break; }
+        }
+      if (victim == st.ref_cached.end()) break;
+      st.ref_cache_bytes -= index_bytes(*victim);
+      free_index(*victim);
+      st.ref_cached.erase(victim);
+    }
+  if (st.ref_cache_bytes + bytes > st.ref_cache_cap)
+    { free_index(ix);                        // no room (everything else is in use)
+      return;
+    }
+  st.ref_cached.push_front(ix);
+  st.ref_cache_bytes += bytes;
+  ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr; ix.d_bstart = nullptr;
+}
+
+static void ref_cache_clear()
+{ State &st = S();
+  for (auto &ix : st.ref_cached) free_index(ix);
+  st.ref_cached.clear();
+  st.ref_cache_bytes = 0;
 }
 
 // ---- deferred index build: stages queued by bg_pump ------------------------------------------
@@ -677,6 +772,31 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
       fatal("Sort_Kmers: read %d is shorter than k-1 (%d < %d)", i, block->reads[i].rlen, pm.Kmer - 1);
 
   const DAZZ_TRACK *mask = (const DAZZ_TRACK *) block->tracks;
+  uint64_t ckey[4] = {0, 0, 0, 0};
+  if (st.ref_cache && mask == nullptr && !deferred)
+    { content_key(block, pm, ckey);
+      IndexDev *c = cache_find(ckey);
+      if (c != nullptr)
+        { // the index of this very content is still in HBM: no upload, no sort
+          IndexDev ix = *c;
+          c->borrows += 1;
+          ix.block    = block;
+          ix.borrowed = true;
+          ix.borrows  = 0;
+          IndexStub *stub = (IndexStub *) malloc(sizeof(IndexStub));
+          if (stub == nullptr) fatal("out of memory allocating index handle");
+          stub->magic = INDEX_MAGIC;
+          stub->id    = st.next_index_id++;
+          stub->len   = (int32_t) ix.n;
+          st.indices[stub->id] = ix;
+          *len = (int) ix.n;
+          if (VERBOSE)
+            { printf("\n   Kmer count = %lld\n   Index found in HBM (%.2fGb)\n", (long long) kmers, (12. * ix.n) / 1073741824.);
+              fflush(stdout);
+            }
+          return stub;
+        }
+    }
   // a build can only be deferred when the length of the index is known up front
   const bool defer = deferred && mask == nullptr && pm.TooFrequent == INT32_MAX;
   if (defer) bg_flush();                         // one deferred build at a time (it owns sort_aux)
@@ -697,6 +817,8 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
   ix.block  = block;
   ix.nreads = nreads;
   ix.L      = L;
+  memcpy(ix.ckey, ckey, sizeof(ckey));
+  ix.cacheable = (ckey[3] != 0);
   ix.h_boff.resize(nreads + 1);
   for (int i = 0; i <= nreads; i++) ix.h_boff[i] = block->reads[i].boff;
 
@@ -891,6 +1013,7 @@ void dmh_reset(void)
   if (g_init) sync_all_streams();
   for (auto &kv : st.indices) free_index(kv.second);
   st.indices.clear();
+  ref_cache_clear();
   for (auto &kv : st.blocks) free_blockdev(kv.second);
   st.blocks.clear();
   st.reads.clear();
@@ -918,13 +1041,21 @@ void dmh_release_block(DAZZ_DB *block)
 
 void dmh_retain_ref_index(int on) { S().retain_ref = (on != 0); }
 
+void dmh_ref_cache(int on, double max_gb)
+{ State &st = S();
+  st.ref_cache = (on != 0);
+  if (max_gb > 0) st.ref_cache_cap = (size_t) (max_gb * 1073741824.);
+  if (!st.ref_cache) ref_cache_clear();
+}
+
 void dmh_free_index(void *table)
 { if (table == nullptr) return;
   IndexStub *stub = (IndexStub *) table;
   if (stub->magic != INDEX_MAGIC) return;
   auto it = S().indices.find(stub->id);
   if (it != S().indices.end())
-    { free_index(it->second);
+    { if (it->second.borrowed) release_ref_index(it->second);     // gives the cache entry back
+      else free_index(it->second);
       S().indices.erase(it);
     }
   stub->magic = 0;
@@ -957,6 +1088,13 @@ void dmh_host_free(void *p)
 // ---- map.c:124-150 -------------------------------------------------------------------------
 int Set_Filter_Params(int kmer, int suppress, int nthreads)
 { if (kmer <= 1) return 1;
+  { static bool env_read = false;
+    if (!env_read)
+      { env_read = true;
+        const char *e = getenv("DMH_REF_CACHE");
+        if (e != nullptr && atoi(e) != 0) S().ref_cache = true;
+      }
+  }
   Params &p = S().params;
   p.Kmer = kmer;
   p.Suppress = suppress;

@@ -39,7 +39,17 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
 
   // the reference consumes the REF table here (map.c:3181-3182)
   if (btable != nullptr && !st.retain_ref)
-    dmh_free_index(btable);
+    { IndexStub *stub = (IndexStub *) btable;
+      if (stub->magic == INDEX_MAGIC)
+        { auto it = st.indices.find(stub->id);
+          if (it != st.indices.end())
+            { release_ref_index(it->second);        // into the REF cache when that is on
+              st.indices.erase(it);
+            }
+          stub->magic = 0;
+          free(stub);
+        }
+    }
 
   if (VERBOSE)
     { double atot = ablock->totlen, btot = bblock->totlen;

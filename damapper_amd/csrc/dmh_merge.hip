@@ -384,6 +384,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
       Bx.bshift = Kshift - P;
       int64_t nbucket = (int64_t) 1 << P;
       Bx.d_bstart = (uint32_t *) dev_alloc(sizeof(uint32_t) * (nbucket + 2), "bucket table");
+      Bx.bstart_bytes = sizeof(uint32_t) * (size_t) (nbucket + 2);
       StageTimer tm("merge_buckets", 8.0 * Bx.n);
       hipLaunchKernelGGL(k_bucket_bounds, dim3(ceil_div(Bx.n + 1, 256)), dim3(256), 0, stream(),
                          (const uint64_t *) Bx.keys, Bx.n, Bx.bshift, nbucket, Bx.d_bstart);

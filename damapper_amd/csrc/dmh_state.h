@@ -3,6 +3,7 @@
 #pragma once
 
 #include "dmh_common.h"
+#include <list>
 #include <map>
 #include <memory>
 
@@ -47,6 +48,13 @@ struct IndexDev
   DAZZ_DB  *block  = nullptr;
   uint32_t *d_bstart = nullptr; // bucket table over the top bits of the codes (merge look-ups), built at first use
   int       bshift  = 0;        //   bucket of a code = code >> bshift
+  size_t    bstart_bytes = 0;
+  // REF index cache (dmh_ref_cache): identity of the block the index was built from, and whether this
+  // record only borrows the device buffers of a cache entry
+  uint64_t  ckey[4] = {0, 0, 0, 0};
+  bool      cacheable = false;
+  bool      borrowed  = false;
+  int       borrows   = 0;      // cache entry: records currently borrowing its buffers (never evicted meanwhile)
   bool      pending = false;    // a deferred build (dmh_sort_kmers_async) has stages left to queue
 };
 
@@ -95,6 +103,13 @@ struct State
   int  opt_chain_g     = 0;     // lanes per chain group for ALL groups (16/32/64); 0 = 16 + 64 by group size
   int  opt_pool_div    = 1;     // initial alignment pool capacity is divided by this (forces the grow path)
 
+  // REF indices kept after Match_Filter consumed them (opt-in, dmh_ref_cache): a later Sort_Kmers of a
+  // block with the same content finds its index here -- the unmodified C driver reloads and re-sorts
+  // every REF block for every READS block (damapper.c:834-862)
+  bool   ref_cache = false;
+  size_t ref_cache_bytes = 0, ref_cache_cap = (size_t) 160 << 30;
+  std::list<IndexDev> ref_cached;      // most recently used first
+
   SortScratch sort;
   SortScratch sort_aux;         // scratch of the deferred index build (lives across Match_Filter calls)
 };
@@ -112,6 +127,7 @@ void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nre
                uint64_t *d_keys, uint32_t *d_vals, int64_t nk, int part = 0, int nparts = 1);
 
 IndexDev *index_of(void *table, const char *who);
+void      release_ref_index(IndexDev &ix);    // Match_Filter is done with a REF index: cache it or free it
 void      index_wait_ready(IndexDev &ix);     // queue what is left of a deferred build
 
 }  // namespace dmh

@@ -123,6 +123,14 @@ const char *dmh_last_error(void);
 void        dmh_reset(void);                 /* drop every cached device buffer and all state */
 
 /* Upload `block`'s bases ahead of time so Sort_Kmers / Reporter find them resident in HBM.   */
+/* REF index cache for a driver that stays with the reference's loop (damapper.c:834-862 reloads,
+ * complements and re-indexes every REF block for every READS block): with the cache on, the index
+ * Match_Filter has consumed stays in HBM (up to max_gb, least recently used first out; <= 0 keeps the
+ * default of 160 GB) and a later Sort_Kmers of a block with the same content returns it without upload
+ * or sort.  Content identity is SAMPLED (all read lengths, 4096 x 16 bases, first and last 4 KB), hence
+ * opt-in.  Also switched on by the environment variable DMH_REF_CACHE=1 (unmodified driver binary).   */
+void dmh_ref_cache(int on, double max_gb);
+
 /* Sort_Kmers whose radix passes are queued later, in the gaps between the GPU round trips of the
  * work on the current READS block; Match_Filter queues whatever is left before it uses the index.
  * Same index as Sort_Kmers.  For software-pipelining the block loop (index of READS block i+1 built

@@ -239,6 +239,31 @@ def test_reference_driver_linked_against_hip_library(tmp_path):
         assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
 
 
+def test_reference_driver_with_ref_index_cache(tmp_path, monkeypatch):
+    """DMH_REF_CACHE=1: the unmodified driver binary re-indexes every REF block for every READS block; with
+    the cache the second and later READS blocks find the REF indices in HBM.  Same files, and the
+    verbose log shows the hits."""
+    run_ref = _run_ref()
+    if not os.path.exists(os.path.join(run_ref.REF_DIR, "damapper_hip")):
+        pytest.skip("oracle/_ref/damapper_hip not built")
+    g, reads = make_dataset("repeat", 146, [200000, 150000, 120000], 75, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=260000)
+    dazzdb.write_db(d, "READS", reads, block_size=260000)      # three read blocks
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    assert nb >= 3
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    run_ref.run_reference(d, "REF", blocks, flags=["-v"], threads=4, keep="las_ref")
+    monkeypatch.setenv("DMH_REF_CACHE", "1")
+    _, log = run_ref.run_reference(d, "REF", blocks, flags=["-v"], threads=4, keep="las_drop", binary="damapper_hip")
+    nrb, _ = dazzdb.read_stub(os.path.join(d, "REF.db"))
+    assert log.count("Index found in HBM") == 2 * nrb * (nb - 1)
+    for b in blocks:
+        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        _, hr = las.read_las_set(os.path.join(d, "las_drop"), b + ".REF.M@.las")
+        assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
+
+
 def test_dispatcher_maps_every_read_block(tmp_path):
     """damapper_amd.dispatch (read blocks -> GPUs, resume by output file) against the reference run on
     the same blocks."""
