@@ -691,8 +691,9 @@ static void adopt_sorted(IndexDev &ix, SortScratch &scr, uint64_t *keys, uint32_
 // Stage list of a deferred build: EMIT_PARTS pieces of the k-mer emit, then per radix pass HIST_PARTS
 // histogram pieces (the scan rides on the last) and SCAT_PARTS scatter pieces -- small enough
 // (0.25-0.5 ms on a 0.26 Gbp block) to slot into the bubbles between the host's round trips.
-// Measured on the bench workload (ms per block): 1/1/1 43.9, 1/1/2 42.9, 1/2/4 41.5, 2/2/4 42.2.
-static int EMIT_PARTS = 1, HIST_PARTS = 2, SCAT_PARTS = 4, PASS_PARTS = 6;
+// Measured on the bench workload, final kernels (ms per block / roofline fraction of the scatter launches):
+// 1/1/1 36.8 / .73, 1/1/2 34.7 / .73, 1/2/4 35.0 / .70, 1/2/8 36.9 / .69.
+static int EMIT_PARTS = 1, HIST_PARTS = 1, SCAT_PARTS = 2, PASS_PARTS = 3;
 static void bg_parts_init()
 { static bool done = false;
   if (done) return;
