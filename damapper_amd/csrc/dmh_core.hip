@@ -280,14 +280,18 @@ HostTimer::HostTimer(const char *name)
   idx = -1;
   t0 = 0;
   if (!active) return;
-  idx = slot_of((std::string("host:") + name).c_str());
-  g_slots[idx].launches += 1;
+  { std::lock_guard<std::mutex> lk(g_tmu);        // host timers also run on the report threads
+    idx = slot_of((std::string("host:") + name).c_str());
+    g_slots[idx].launches += 1;
+  }
   t0 = now_ms();
 }
 
 HostTimer::~HostTimer()
 { if (!active) return;
-  g_slots[idx].ms += now_ms() - t0;
+  double dt = now_ms() - t0;
+  std::lock_guard<std::mutex> lk(g_tmu);
+  if (idx < (int) g_slots.size()) g_slots[idx].ms += dt;     // (the table may have been reset meanwhile)
 }
 
 static void drain_timers()
@@ -991,6 +995,7 @@ void dmh_timing_enable(int on) { g_timing = (on != 0); }
 
 void dmh_timing_reset(void)
 { drain_timers();
+  std::lock_guard<std::mutex> lk(g_tmu);
   g_slots.clear();
 }
 
