@@ -187,13 +187,31 @@ def split_blocks(lens: Sequence[int], block_size: int) -> List[int]:
 
 
 def write_db(directory: str, root: str, seqs: Sequence[np.ndarray], block_size: int = 200_000_000,
-             block_firsts: Optional[Sequence[int]] = None) -> List[int]:
-    """Write <root>.db, .<root>.idx, .<root>.bps. Returns the block boundaries."""
+             block_firsts: Optional[Sequence[int]] = None, cutoff: int = 0, all_reads: bool = True,
+             best: Optional[Sequence[bool]] = None) -> List[int]:
+    """Write <root>.db, .<root>.idx, .<root>.bps as fasta2DB + DBsplit -x<cutoff> [-a] leave them.
+    Returns the block boundaries (untrimmed read indices).  With a cutoff (or all_reads=False and
+    some reads not flagged `best`) the DB is a TRIMMED view: blocks are cut over the surviving reads
+    and the stub lists (untrimmed first, trimmed first) per block (DB.c:766-806, Trim_DB DB.c:908)."""
     os.makedirs(directory, exist_ok=True)
     n = len(seqs)
     lens = [len(s) for s in seqs]
-    firsts = list(block_firsts) if block_firsts is not None else split_blocks(lens, block_size)
+    best = [True] * n if best is None else [bool(x) for x in best]
+    keep = [lens[i] >= cutoff and (all_reads or best[i]) for i in range(n)]
+    if block_firsts is not None:
+        firsts = list(block_firsts)
+    else:                       # DBsplit: a block closes once the bases of its SURVIVING reads reach the size
+        firsts, tot = [0], 0
+        for i in range(n):
+            if not keep[i]:
+                continue
+            if tot > 0 and tot + lens[i] > block_size:
+                firsts.append(i)
+                tot = 0
+            tot += lens[i]
+        firsts.append(n)
     nblocks = len(firsts) - 1
+    tfirsts = [sum(1 for i in range(b) if keep[i]) for b in firsts]
 
     recs = np.zeros(n, dtype=READ_DTYPE)
     off = 0
@@ -201,7 +219,7 @@ def write_db(directory: str, root: str, seqs: Sequence[np.ndarray], block_size: 
         for i, s in enumerate(seqs):
             b = _pack_2bit(np.asarray(s, dtype=np.uint8))
             f.write(b)
-            recs[i] = (i, lens[i], 0, off, 0, DB_BEST)
+            recs[i] = (i, lens[i], 0, off, 0, DB_BEST if best[i] else 0)
             off += len(b)
 
     allb = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if n else np.zeros(0, np.uint8)
@@ -210,15 +228,15 @@ def write_db(directory: str, root: str, seqs: Sequence[np.ndarray], block_size: 
 
     hdr = DAZZ_DB()
     hdr.ureads = n
-    hdr.treads = n
-    hdr.cutoff = 0
-    hdr.allarr = DB_ALL
+    hdr.treads = sum(keep)
+    hdr.cutoff = cutoff
+    hdr.allarr = DB_ALL if all_reads else 0
     for j in range(4):
         hdr.freq[j] = float(freq[j])
     hdr.maxlen = max(lens) if lens else 0
     hdr.totlen = int(sum(lens))
     hdr.nreads = n
-    hdr.trimmed = 1
+    hdr.trimmed = 0
     with open(os.path.join(directory, "." + root + ".idx"), "wb") as f:
         f.write(bytes(hdr))
         f.write(recs.tobytes())
@@ -227,9 +245,9 @@ def write_db(directory: str, root: str, seqs: Sequence[np.ndarray], block_size: 
         f.write("files = %9d\n" % 1)
         f.write("  %9d %s %s\n" % (n, root, root))
         f.write("blocks = %9d\n" % nblocks)
-        f.write("size = %11d cutoff = %9d all = %1d\n" % (block_size, 0, 1))
-        for b in firsts:
-            f.write(" %9d %9d\n" % (b, b))
+        f.write("size = %11d cutoff = %9d all = %1d\n" % (block_size, cutoff, 1 if all_reads else 0))
+        for b, t in zip(firsts, tfirsts):
+            f.write(" %9d %9d\n" % (b, t))
     return firsts
 
 
@@ -510,6 +528,15 @@ def block_reads(blk: Block, lo: int = 0, hi: Optional[int] = None) -> List[np.nd
     return [blk.seq(i).copy() for i in range(lo, hi)]
 
 
+def read_stub_params(path: str) -> Tuple[int, int, bool]:
+    """(block size, cutoff, all) of a stub file (the DBsplit parameters, DB.h:431-435)."""
+    with open(path) as f:
+        lines = f.read().split("\n")
+    k = 1 + int(lines[0].split("=")[1])
+    w = lines[k + 1].replace("=", " ").split()        # size N cutoff C all A
+    return int(w[1]), int(w[3]), bool(int(w[5]))
+
+
 def read_stub(path: str) -> Tuple[int, List[Tuple[int, int]]]:
     """Parse a stub file: returns (nblocks, [(ufirst, tfirst)] * (nblocks+1))."""
     with open(path) as f:
@@ -526,10 +553,13 @@ def read_stub(path: str) -> Tuple[int, List[Tuple[int, int]]]:
 
 def load_db(path: str, part: int = 0, masks: Sequence[str] = (), used: Optional[set] = None,
             pinned: bool = False) -> Block:
-    """Open + Load_All_Reads equivalent for DBs written by `write_db` (no trimming:
-    cutoff=0, all=1). `path` is 'dir/root.db'; part k > 0 loads block k.  `masks` are -m track
-    names: those the DB has are loaded, merged into one mask and attached (read_DB,
-    damapper.c:345-414); their names are added to `used` (the MSTAT bookkeeping)."""
+    """Open_DB + Trim_DB + Load_All_Reads equivalent (DB.c:600-1007,1402-1437).  `path` is
+    'dir/root.db'; part k > 0 loads block k.  The DBsplit cutoff / all flags of the stub trim the view:
+    reads shorter than the cutoff (and, without -a, reads that are not the best of their well) are left
+    out and the block's reads are numbered from the stub's trimmed first.  `masks` are -m track names:
+    those the DB has are loaded (over the untrimmed or the trimmed reads, whichever the track was made
+    for), merged into one mask and attached (read_DB, damapper.c:345-414); their names are added to
+    `used` (the MSTAT bookkeeping)."""
     d, base = os.path.split(path)
     d = d or "."
     root = base[:-3] if base.endswith(".db") else base
@@ -537,22 +567,34 @@ def load_db(path: str, part: int = 0, masks: Sequence[str] = (), used: Optional[
     with open(os.path.join(d, "." + root + ".idx"), "rb") as f:
         hdr = DAZZ_DB.from_buffer_copy(f.read(112))
         recs = np.frombuffer(f.read(), dtype=READ_DTYPE)
+    _, cutoff, all_reads = read_stub_params(os.path.join(d, root + ".db"))
     if part > 0:
         lo, hi = firsts[part - 1][0], firsts[part][0]
+        tfirst = firsts[part - 1][1]
     else:
-        lo, hi = 0, hdr.ureads
+        lo, hi = 0, int(hdr.ureads)
+        tfirst = 0
+    keep_all = (recs["rlen"] >= cutoff) & (all_reads | ((recs["flags"] & DB_BEST) != 0))
+    keep = keep_all[lo:hi]
     bps = np.fromfile(os.path.join(d, "." + root + ".bps"), dtype=np.uint8)
     seqs = []
-    for r in recs[lo:hi]:
+    for r in recs[lo:hi][keep]:
         n = int(r["rlen"])
         o = int(r["boff"])
         seqs.append(_unpack_2bit(bps[o:o + (n + 3) // 4], n))
-    blk = make_block(seqs, tfirst=lo, part=part,
+    blk = make_block(seqs, tfirst=tfirst, part=part,
                      path=os.path.join(d, "." + root).encode(),
                      freq=[hdr.freq[j] for j in range(4)], pinned=pinned)
+    blk.db.cutoff = cutoff
+    blk.db.allarr = DB_ALL if all_reads else 0
     found = []
+    treads = int(keep_all.sum())
     for name in masks:
         iv = read_mask_track(d, root, name, lo, hi, int(hdr.ureads))
+        if iv is not None:                                   # a track over the untrimmed reads
+            iv = [x for x, k in zip(iv, keep) if k]
+        elif treads != int(hdr.ureads):                      # ... or over the trimmed ones
+            iv = read_mask_track(d, root, name, tfirst, tfirst + int(keep.sum()), treads)
         if iv is not None:
             found.append(iv)
             if used is not None:

@@ -65,3 +65,24 @@ def test_mask_track_files_and_union(tmp_path):
     blk.complement_inplace()
     assert blk.mask_intervals() == before
     assert dazzdb.load_db(os.path.join(d, "G.db"), masks=["zz"]).track is None
+
+
+def test_trimmed_view(tmp_path):
+    """DBsplit -x<cutoff> without -a: the loader applies Trim_DB's rule and the stub's trimmed firsts."""
+    d = str(tmp_path)
+    rng = np.random.default_rng(9)
+    seqs = dazzdb.random_genome(rng, [3000, 100, 2500, 50, 4000, 2000, 2600])
+    best = [True, True, True, True, False, True, True]
+    firsts = dazzdb.write_db(d, "T", seqs, block_size=6000, cutoff=500, all_reads=False, best=best)
+    assert firsts == [0, 5, 7]                 # survivors 3000+2500 | 2000+2600 (4000 is not best)
+    nb, st = dazzdb.read_stub(os.path.join(d, "T.db"))
+    assert nb == 2 and st == [(0, 0), (5, 2), (7, 4)]
+    assert dazzdb.read_stub_params(os.path.join(d, "T.db")) == (6000, 500, False)
+    b2 = dazzdb.load_db(os.path.join(d, "T.db"), part=2)
+    assert b2.nreads == 2 and b2.db.tfirst == 2 and [len(b2.seq(i)) for i in range(2)] == [2000, 2600]
+    whole = dazzdb.load_db(os.path.join(d, "T.db"))
+    assert [len(whole.seq(i)) for i in range(whole.nreads)] == [3000, 2500, 2000, 2600]
+    # a mask over the UNTRIMMED reads follows the survivors
+    dazzdb.write_mask_track(d, "T", "m", [[(1, 2)], [(3, 4)], [(5, 6)], [], [(7, 8)], [(9, 10)], []])
+    b1 = dazzdb.load_db(os.path.join(d, "T.db"), part=1, masks=["m"])
+    assert b1.mask_intervals() == [[(1, 2)], [(5, 6)]]

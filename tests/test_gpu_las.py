@@ -183,6 +183,45 @@ def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     assert base == alt
 
 
+def test_trimmed_db_view_identical_to_reference(tmp_path):
+    """A READS DB split with a cutoff and without -a (DBsplit -x1000): short reads and reads that are not
+    the best of their well are left out, blocks are cut over the survivors and A-read numbers are the
+    trimmed ones (Trim_DB, DB.c:908) -- also with a mask made over the untrimmed reads."""
+    run_ref = _run_ref()
+    rng = np.random.default_rng(5)
+    g, reads = make_dataset("random", 151, [150000, 120000], 40)
+    short = [g[0][1000:1400].copy(), g[1][500:1300].copy(), rng.integers(0, 4, 300, dtype=np.uint8)]
+    mixed, best = [], []
+    for i, r in enumerate(reads):
+        mixed.append(r)
+        best.append(i % 7 != 3)
+        if i % 9 == 4:
+            mixed.append(short[i % 3])
+            best.append(True)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=400000)
+    dazzdb.write_db(d, "READS", mixed, block_size=150000, cutoff=1000, all_reads=False, best=best)
+    dazzdb.write_mask_track(d, "READS", "dust", [[(len(s) // 3, len(s) // 3 + 200)] if len(s) > 2000 else [] for s in mixed])
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    assert nb == 3
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    run_ref.run_reference(d, "REF", blocks, flags=["-M8", "-mdust"], threads=4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "damapper_amd.dispatch", os.path.join(d, "REF.db"), os.path.join(d, "READS.db"),
+           "--gpus", "1", "--out", os.path.join(d, "las_disp"), "-m", "dust"]
+    p = subprocess.run(cmd, env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    total = 0
+    for b in blocks:
+        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        _, hr = las.read_las_set(os.path.join(d, "las_disp"), b + ".REF.M@.las")
+        assert rr == hr, b
+        total += len(rr)
+    assert total >= 30
+
+
 def test_mask_tracks_identical_to_reference(tmp_path):
     """-m<track>: two masks on the REF (merged, damapper.c:232-343), one on the READS, one that no DB
     has; multi-block REF so the per-block slices of the track are exercised."""
