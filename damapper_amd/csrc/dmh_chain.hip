@@ -135,9 +135,13 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
           const int diag = apos - bpos;
 
           // ---- expiry (map.c:1787-1796) + neighbour queries (predOf/leftmost/succOf, map.c:1262-1318)
-          uint64_t Lbest = ~0ull, Rbest = 0;
-          uint4    Le = make_uint4(NIL, 0, 0, 0), Re = make_uint4(NIL, 0, 0, 0);
-          uint32_t Lpos = 0, Rpos = 0, Lroot = 0, Rroot = 0;
+          // Every lane keeps the best candidate of ITS entries over all chunks of the window; the two
+          // group-wide reductions happen once, after the scan (a repeat pile's window has thousands of
+          // entries = dozens of chunks: reducing per chunk was most of the big groups' time).  The keys
+          // are unique per entry, so "best of the lanes' bests" picks the same entry.
+          uint64_t myL = ~0ull, myR = 0;
+          uint4    myLe = make_uint4(NIL, 0, 0, 0), myRe = make_uint4(NIL, 0, 0, 0);
+          uint32_t myLpos = 0, myRpos = 0, myLroot = 0, myRroot = 0;
           const int thresh = bpos - MAX_GAP;
           uint32_t  wr = 0;
           for (uint32_t base = 0; base < nlive; base += G)
@@ -167,22 +171,8 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
                 }
               uint64_t km  = gballot(keep);
               uint32_t dst = wr + (uint32_t) __popcll(km & lt);
-              uint64_t lm = wave_min_u64<G>(lk);
-              uint64_t rm = wave_max_u64<G>(rk);
-              if (lm < Lbest)
-                { int sl = __ffsll((long long) gballot(lk == lm)) - 1;
-                  Lbest = lm;
-                  Le.x = __shfl(en.x, sl, G); Le.y = __shfl(en.y, sl, G); Le.z = __shfl(en.z, sl, G); Le.w = __shfl(en.w, sl, G);
-                  Lpos = __shfl(dst, sl, G);
-                  if (LDSLIVE) Lroot = __shfl(rt, sl, G);
-                }
-              if (rm > Rbest)
-                { int sl = __ffsll((long long) gballot(rk == rm)) - 1;
-                  Rbest = rm;
-                  Re.x = __shfl(en.x, sl, G); Re.y = __shfl(en.y, sl, G); Re.z = __shfl(en.z, sl, G); Re.w = __shfl(en.w, sl, G);
-                  Rpos = __shfl(dst, sl, G);
-                  if (LDSLIVE) Rroot = __shfl(rt, sl, G);
-                }
+              if (lk < myL) { myL = lk; myLe = en; myLpos = dst; myLroot = rt; }
+              if (rk > myR) { myR = rk; myRe = en; myRpos = dst; myRroot = rt; }
               // in-place compaction: the write index never passes this chunk's first read index, and
               // the stored value is the loaded one, so the stores cannot overtake the loads
               if (keep)
@@ -191,6 +181,23 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
                 }
               wr += (uint32_t) __popcll(km);
             }
+          uint4    Le = make_uint4(NIL, 0, 0, 0), Re = make_uint4(NIL, 0, 0, 0);
+          uint32_t Lpos = 0, Rpos = 0, Lroot = 0, Rroot = 0;
+          { uint64_t lm = wave_min_u64<G>(myL);
+            if (lm != ~0ull)
+              { int sl = __ffsll((long long) gballot(myL == lm)) - 1;
+                Le.x = __shfl(myLe.x, sl, G); Le.y = __shfl(myLe.y, sl, G); Le.z = __shfl(myLe.z, sl, G); Le.w = __shfl(myLe.w, sl, G);
+                Lpos = __shfl(myLpos, sl, G);
+                if (LDSLIVE) Lroot = __shfl(myLroot, sl, G);
+              }
+            uint64_t rm = wave_max_u64<G>(myR);
+            if (rm != 0)
+              { int sl = __ffsll((long long) gballot(myR == rm)) - 1;
+                Re.x = __shfl(myRe.x, sl, G); Re.y = __shfl(myRe.y, sl, G); Re.z = __shfl(myRe.z, sl, G); Re.w = __shfl(myRe.w, sl, G);
+                Rpos = __shfl(myRpos, sl, G);
+                if (LDSLIVE) Rroot = __shfl(myRroot, sl, G);
+              }
+          }
           nlive = wr;
 
           // ---- extend the better neighbour's chain (map.c:1811-1862); uniform on all lanes
