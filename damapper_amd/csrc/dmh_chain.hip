@@ -31,7 +31,10 @@ constexpr uint32_t ST_DEAD    = 0;   // removed by the slope rule, or expired
 void gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n);
 
 struct ChainSummary
-{ uint32_t group, rank;
+{ uint32_t group, live;     // live: the end was still in the window when its group finished
+  // reporting order inside a group (map.c:1634-1642): live ends by (diagonal, apos) descending, then
+  // expired ends most recent first -- the host sorts on (group, live desc, okey desc)
+  uint64_t okey;
   int32_t  cost, ab, ae, bb, be;
   uint32_t end;
 };
@@ -311,26 +314,11 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
           int      ax   = (int) (A.keys[x] & A.pmask) + 1;
           int      bx   = (int) A.vals[x] + 1;
           int      dx   = ax - bx;
-          uint32_t rank = 0;
-          for (uint32_t f = 0; f < E; f++)
-            { uint32_t y     = A.tmp[g0 + f];
-              bool     ylive = (A.state[y] == ST_LIVE);
-              bool     before;
-              if (ylive != live_x)
-                before = ylive;
-              else if (live_x)
-                { int ay = (int) (A.keys[y] & A.pmask) + 1;
-                  int dy = ay - ((int) A.vals[y] + 1);
-                  before = (dy > dx) || (dy == dx && ay > ax);
-                }
-              else
-                before = (y > x);
-              rank += before ? 1u : 0u;
-            }
           uint32_t     root = A.rootof[x];
           ChainSummary s;
           s.group = g;
-          s.rank  = rank;
+          s.live  = live_x ? 1u : 0u;
+          s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax) : (uint64_t) x;
           s.cost  = A.cost[x];
           s.ab    = (int) (A.keys[root] & A.pmask) + 1 - K;
           s.bb    = (int) A.vals[root] + 1 - K;
@@ -496,7 +484,10 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   if (nsum > 0)
     { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum, 1);      // host sort next
       std::sort(sums.begin(), sums.end(), [](const ChainSummary &a, const ChainSummary &b)
-                { return a.group != b.group ? a.group < b.group : a.rank < b.rank; });
+                { if (a.group != b.group) return a.group < b.group;
+                  if (a.live != b.live) return a.live > b.live;
+                  return a.okey > b.okey;
+                });
     }
 
   // group -> (aread, bread): decode from the first hit of each summarised group
