@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
               if (rk > myR) { myR = rk; myRe = en; myRpos = dst; myRroot = rt; }
               // in-place compaction: the write index never passes this chunk's first read index, and
               // the stored value is the loaded one, so the stores cannot overtake the loads
-              if (keep)
+              if (keep && dst != i)               // (entries that stay where they are need no store)
                 { if (LDSLIVE) { lds_live[dst] = en; lds_root[dst] = rt; }
                   else         live[dst] = en;
                 }
