@@ -72,7 +72,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--block-reads", type=int, default=25000)
     ap.add_argument("--nblocks", type=int, default=4)
     ap.add_argument("--cpu-sample-reads", type=int, default=60000)
