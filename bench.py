@@ -102,7 +102,9 @@ def main():
         import torch
         import torch.distributed as dist_mod
         torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        dist_mod.init_process_group(backend="nccl")
+        # RCCL ("nccl") on a node with one GPU per rank; DMH_BENCH_BACKEND=gloo only serves to rehearse the
+        # N > 1 control flow on a box with fewer GPUs than ranks (the ranks then share a device)
+        dist_mod.init_process_group(backend=os.environ.get("DMH_BENCH_BACKEND", "nccl"))
         dist = dist_mod
 
     L = capi.lib()
@@ -182,10 +184,11 @@ def main():
     tot_bases = float(bases)
     if dist is not None:
         import torch
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tb = torch.tensor([tot_bases], dtype=torch.float64, device="cuda")
+        tb = torch.tensor([tot_bases], dtype=torch.float64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         tot_bases = float(tb.item())
 
