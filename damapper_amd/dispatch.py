@@ -8,7 +8,7 @@ is skipped (resume granularity = read block, as HPC.damapper.c:329-354).
 --finish runs the LAsort/LAcat/LAmerge post-step (damapper.c:887-910) per block, leaving
 `<reads>.<b>.<ref>.las` (and `<ref>.<reads>.<b>.las` for -C) next to the reference DB.
 
-One worker process per GPU (DMH_DEVICE selects it); no communication between workers."""
+One worker process per GPU (DMH_DEVICE selects it; --workers-per-gpu 2 runs two), no communication between workers."""
 from __future__ import annotations
 
 import argparse
@@ -28,7 +28,8 @@ def _worker(args) -> None:
     rd, read_root = os.path.split(args.reads)
     read_root = read_root[:-3] if read_root.endswith(".db") else read_root
     nrb, _ = read_stub(os.path.join(rd or ".", read_root + ".db"))
-    mine = [b for b in range(1, nrb + 1) if (b - 1) % args.gpus == args.rank]
+    nworkers = args.gpus * args.workers_per_gpu
+    mine = [b for b in range(1, nrb + 1) if (b - 1) % nworkers == args.rank]
     out = args.out or os.path.join(d, "las_hip")
     m = driver.Mapper(kmer=args.k, suppress=args.t, threads=args.T, ave_corr=args.e, spacing=args.s,
                       best_tie=args.n, profile=int(args.p), verbose=int(args.v), sort_path=out)
@@ -73,6 +74,9 @@ def main(argv=None) -> int:
     ap.add_argument("ref")
     ap.add_argument("reads")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workers-per-gpu", type=int, default=1,
+                    help="worker processes per GPU (each with its own replica of the reference index): two fill each "
+                         "other's host gaps, +25%% aggregate throughput measured on one MI355X")
     ap.add_argument("--rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--out", default=None)
     ap.add_argument("--force", action="store_true")
@@ -94,9 +98,9 @@ def main(argv=None) -> int:
         _worker(args)
         return 0
     procs = []
-    for r in range(args.gpus):
+    for r in range(args.gpus * args.workers_per_gpu):
         env = dict(os.environ)
-        env["DMH_DEVICE"] = str(r)
+        env["DMH_DEVICE"] = str(r // args.workers_per_gpu)
         cmd = [sys.executable, "-m", "damapper_amd.dispatch"] + (argv if argv is not None else sys.argv[1:]) + ["--rank", str(r)]
         procs.append(subprocess.Popen(cmd, env=env))
     rc = 0

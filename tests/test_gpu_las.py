@@ -329,6 +329,14 @@ def test_dispatcher_maps_every_read_block(tmp_path):
         assert len(rr) > 0 and rr == hr, b
     p2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p2.returncode == 0 and p2.stdout.count("skipped") == nb
+    # two workers sharing the GPU: same files
+    cmd3 = cmd[:-1] + [os.path.join(d, "las_disp2"), "--workers-per-gpu", "2"]
+    p3 = subprocess.run(cmd3, env=env, capture_output=True, text=True, timeout=600)
+    assert p3.returncode == 0, p3.stdout[-1500:] + p3.stderr[-1500:]
+    for b in blocks:
+        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        _, hr = las.read_las_set(os.path.join(d, "las_disp2"), b + ".REF.M@.las")
+        assert rr == hr, b
 
 
 def test_dispatcher_finish_writes_final_las(tmp_path):
