@@ -89,6 +89,9 @@ def main():
                     help="PCIe-inclusive rate: read blocks are NOT resident, every step uploads its block from "
                          "page-locked (dmh_host_alloc) or ordinary host memory inside the timed region")
     ap.add_argument("--sync-report", action="store_true", help="write the .las files inside Reporter (drop-in behaviour)")
+    ap.add_argument("--report-mode", type=int, default=1, choices=[0, 1, 2],
+                    help="0 = Reporter synchronous, 1 = .las selection/writing on a worker thread (default), 2 = also the "
+                         "alignment kernel of block i deferred next to the filter of block i+1 (measured slower: DESIGN.md)")
     ap.add_argument("--rebuild-ref", action="store_true",
                     help="rebuild the REF indices for every read block as damapper.c does (default: build both "
                          "orientations once per GPU and keep them resident, BASELINE.json north_star)")
@@ -157,7 +160,7 @@ def main():
     for i in range(args.warmup):
         step(i)
 
-    L.dmh_async_report(0 if args.sync_report else 1)      # .las selection/writing of block i overlaps the filtering of block i+1
+    L.dmh_async_report(0 if args.sync_report else args.report_mode)   # block i's alignments and .las writing overlap block i+1's filter
     L.dmh_timing_enable(0 if args.no_stage_timing else 1)
     L.dmh_timing_reset()
     if dist is not None:

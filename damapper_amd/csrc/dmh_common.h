@@ -33,6 +33,10 @@ hipStream_t stream();
 // to n stages; consumers of an index flush whatever is left.
 void bg_pump(int nstages = 1);
 void bg_flush();
+// true while a deferred Reporter's alignment kernel is running on the alignment stream: background
+// stages are then held back (the HBM-bound sort kernels keep the GPU to themselves, before the alignment)
+bool report_in_flight();
+void report_finish_pending();
 
 // Device allocation that aborts through Clean_Exit on failure (the reference's behaviour
 // for a failed Malloc, e.g. map.c:689-690).
@@ -63,10 +67,11 @@ template <typename T> struct DevBuf
 
 // ---- stage timing (HIP events on our stream) -----------------------------------------
 struct StageTimer
-{ StageTimer(const char *name, double bytes = 0.0);
+{ StageTimer(const char *name, double bytes = 0.0, hipStream_t on = nullptr);    // on = nullptr: the main stream
   ~StageTimer();
   int    idx;
   bool   active;
+  hipStream_t s;
   hipEvent_t e0, e1;
 };
 

@@ -248,9 +248,10 @@ static int slot_of(const char *name)
   return (int) g_slots.size() - 1;
 }
 
-StageTimer::StageTimer(const char *name, double bytes)
+StageTimer::StageTimer(const char *name, double bytes, hipStream_t on)
 { active = g_timing;
   idx = -1;
+  s = on ? on : stream();
   if (!active) return;
   { std::lock_guard<std::mutex> lk(g_tmu);
     idx = slot_of(name);
@@ -259,12 +260,12 @@ StageTimer::StageTimer(const char *name, double bytes)
   }
   HIP_CHECK(hipEventCreate(&e0));
   HIP_CHECK(hipEventCreate(&e1));
-  HIP_CHECK(hipEventRecord(e0, stream()));
+  HIP_CHECK(hipEventRecord(e0, s));
 }
 
 StageTimer::~StageTimer()
 { if (!active) return;
-  HIP_CHECK(hipEventRecord(e1, stream()));
+  HIP_CHECK(hipEventRecord(e1, s));
   std::lock_guard<std::mutex> lk(g_tmu);
   g_pending.push_back({idx, e0, e1});
 }
@@ -296,6 +297,7 @@ HostTimer::~HostTimer()
 
 static void drain_timers()
 { if (g_pending.empty()) return;
+  report_finish_pending();          // (its kernel's events live on the alignment stream)
   sync_all_streams();
   std::lock_guard<std::mutex> lk(g_tmu);
   for (auto &p : g_pending)
@@ -329,7 +331,7 @@ void block_ready(BlockDev &bd)
   bd.uploaded = nullptr;
 }
 
-static void free_blockdev(BlockDev &bd)
+void free_blockdev(BlockDev &bd)
 { if (bd.uploaded != nullptr)
     { HIP_CHECK(hipEventSynchronize(bd.uploaded));
       HIP_CHECK(hipEventDestroy(bd.uploaded));
@@ -756,7 +758,9 @@ static void bg_step()
 }
 
 void bg_pump(int nstages)
-{ for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step(); }
+{ if (g_bg.empty() || report_in_flight()) return;
+  for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step();
+}
 
 void bg_flush()
 { while (!g_bg.empty()) bg_step(); }
@@ -989,7 +993,9 @@ int dmh_device_count(void)
 const char *dmh_last_error(void) { return g_err; }
 
 void dmh_sync(void)
-{ sync_all_streams(); }
+{ report_finish_pending();
+  sync_all_streams();
+}
 
 void dmh_timing_enable(int on) { g_timing = (on != 0); }
 
@@ -1016,6 +1022,7 @@ int dmh_timing_get(int idx, char *name, int namelen, double *ms, int64_t *launch
 
 void dmh_reset(void)
 { State &st = S();
+  report_finish_pending();
   if (g_init) sync_all_streams();
   for (auto &kv : st.indices) free_index(kv.second);
   st.indices.clear();
@@ -1043,7 +1050,10 @@ int dmh_preload_block(DAZZ_DB *block)
 }
 
 void dmh_release_block(DAZZ_DB *block)
-{ drop_block(block); }
+{ if (S().blocks.count(block) == 0) return;   // (a deferred Reporter holds the copy it reads by itself)
+  report_finish_pending();                   // its kernel may still read a resident block
+  drop_block(block);
+}
 
 void dmh_retain_ref_index(int on) { S().retain_ref = (on != 0); }
 

@@ -1012,7 +1012,7 @@ static std::mutex                g_rmu;
 static std::condition_variable   g_rcv;
 static std::deque<ReportCtx *>   g_rqueue;
 static int                       g_rbusy = 0;
-static bool                      g_async = false;
+static int                       g_async = 0;      // 0 synchronous, 1 report stage on a worker, 2 also the alignment kernel deferred
 static bool                      g_stop  = false;
 static std::vector<ReportCtx *>  g_rdone;
 
@@ -1071,6 +1071,208 @@ static void report_submit(ReportCtx *C)
   g_rcv.notify_all();
 }
 
+
+// ---------------------------------------------------------------------------------------
+//  One Reporter call = prepare (host + main stream) -> [launch a rung of the kernel ladder -> collect]* ->
+//  hand the records to the report stage.  With dmh_async_report(2) the first launch goes to the
+//  alignment stream and Reporter returns; the collection happens at the next Reporter / report_wait, so
+//  the (VALU-bound) alignment kernel of block i runs next to the (latency-bound) merge and chain kernels
+//  of block i+1.  The HBM-bound index sort of block i+1 is flushed BEFORE the alignment kernel may start
+//  and held back while it runs, so the sort kernels never share the GPU.
+// ---------------------------------------------------------------------------------------
+struct PendingReport
+{ ReportCtx *C = nullptr;
+  std::vector<CandJob>  jobs;
+  std::vector<uint16_t> jumps;
+  std::vector<std::vector<AlnRec>> recs;
+  std::vector<int> pool;
+  PinBuf *pool_pin = nullptr;
+  size_t deferred_got = 0;
+  std::vector<int> status, todo;
+  int    njobs = 0, doB = 0, hithr = 0, tcap = 0, level = 0, round = 0;
+  size_t pool_cap = 0;
+  AlignSpecDev spd;
+  const uint64_t *apk = nullptr, *arc = nullptr, *bpk = nullptr;
+  BlockDev hold[2];            // device copies the kernel reads, taken out of the block registry meanwhile
+  int      nhold = 0;
+  bool     on_aux = false;     // the kernel runs on the alignment stream
+  HostTimer *ht = nullptr;
+};
+
+static PendingReport *g_pending = nullptr;
+static hipStream_t    g_astream = nullptr;
+static hipEvent_t     g_ev_ab = nullptr, g_ev_done = nullptr;
+static DevBuf<CandJob>  d_jobs;
+static DevBuf<uint16_t> d_jumps;
+static DevBuf<int>      d_status, d_pool, d_only;
+
+bool report_in_flight()
+{ if (g_pending == nullptr || !g_pending->on_aux) return false;
+  hipError_t e = hipEventQuery(g_ev_done);
+  if (e == hipErrorNotReady) { (void) hipGetLastError(); return true; }
+  return false;
+}
+
+static void launch_round(PendingReport &P)
+{ hipStream_t ks = P.on_aux ? g_astream : stream();
+  const int njobs = P.njobs;
+  if (P.pool_cap > 0xfffffff0ull / 4) fatal("Reporter: alignment pool too large");
+  d_pool.ensure(P.pool_cap, "alignment pool");
+  int nrun = P.todo.empty() ? njobs : (int) P.todo.size();
+  const int *only = nullptr;
+  if (!P.todo.empty())
+    { d_only.ensure(P.todo.size(), "retry list");
+      copy_h2d(d_only.p, P.todo.data(), sizeof(int) * P.todo.size());
+      only = d_only.p;
+    }
+  const int level = P.level, doB = P.doB;
+  const int per_block = (level == 0) ? 8 : 4;
+  int nblocks = std::min((nrun + per_block - 1) / per_block, 256 * 4);
+  Scratch sc = prepare_scratch(nblocks, P.tcap, level == 2, per_block, level != 0);
+  if (P.on_aux)
+    { // everything queued on the main stream so far (packing, uploads, the flushed index sort) comes first
+      HIP_CHECK(hipEventRecord(g_ev_ab, stream()));
+      HIP_CHECK(hipStreamWaitEvent(ks, g_ev_ab, 0));
+    }
+  HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), ks));
+  HIP_CHECK(hipMemsetAsync(d_pool.p, 0xff, sizeof(int) * P.pool_cap, ks));   // cand = -1 ends the parse
+  { StageTimer tm(level == 2 ? "align_global_band" : (level == 1 ? "align_wave64" : "align"), 0.0, ks);
+    if (level == 0)
+      hipLaunchKernelGGL(k_align_cands32, dim3(nblocks), dim3(256), 0, ks,
+                         P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
+                         (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
+                         d_pool.p, ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
+    else if (level == 2)
+      { if (doB)
+          hipLaunchKernelGGL((k_align_cands<GLB_W, false, true>), dim3(nblocks), dim3(256), 0, ks,
+                             P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
+                             (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                             ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
+        else
+          hipLaunchKernelGGL((k_align_cands<GLB_W, false, false>), dim3(nblocks), dim3(256), 0, ks,
+                             P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
+                             (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                             ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
+      }
+    else
+      { if (doB)
+          hipLaunchKernelGGL((k_align_cands<LDS_W, true, true>), dim3(nblocks), dim3(256), 0, ks,
+                             P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
+                             (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                             ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
+        else
+          hipLaunchKernelGGL((k_align_cands<LDS_W, true, false>), dim3(nblocks), dim3(256), 0, ks,
+                             P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
+                             (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                             ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
+      }
+    HIP_CHECK(hipGetLastError());
+  }
+  if (P.on_aux) HIP_CHECK(hipEventRecord(g_ev_done, ks));
+}
+
+// Waits for the launched rung, fetches its records and decides what has to run again.  True when done.
+static bool collect_round(PendingReport &P)
+{ hipStream_t ks = P.on_aux ? g_astream : stream();
+  const int njobs = P.njobs;
+  dispose_done();        // free finished report contexts while the kernel runs
+  unsigned int used = 0;
+  { HostTimer hw("report_kernel_wait");
+    if (P.on_aux)
+      { // nothing here may wait for the MAIN stream: the next block's filter is queued on it
+        PinBuf *ps = pin_acquire((size_t) njobs + 16);
+        HIP_CHECK(hipMemcpyAsync(ps->p, ascr().ctl.p + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, ks));
+        HIP_CHECK(hipMemcpyAsync(ps->p + 1, d_status.p, sizeof(int) * njobs, hipMemcpyDeviceToHost, ks));
+        HIP_CHECK(hipStreamSynchronize(ks));
+        used = (unsigned int) ps->p[0];
+        memcpy(P.status.data(), ps->p + 1, sizeof(int) * njobs);
+        ps->busy.store(false);
+      }
+    else
+      { copy_d2h(&used, ascr().ctl.p + 1, sizeof(unsigned int));
+        copy_d2h(P.status.data(), d_status.p, sizeof(int) * njobs);
+        HIP_CHECK(hipStreamSynchronize(stream()));
+      }
+  }
+  HostTimer hp("report_pool_parse");
+  size_t got = std::min<size_t>(used, P.pool_cap);
+  PinBuf *pb = pin_acquire(got + 16);
+  if (got > 0)
+    { HIP_CHECK(hipMemcpyAsync(pb->p, d_pool.p, sizeof(int) * got, hipMemcpyDeviceToHost, ks));
+      if (P.on_aux)
+        HIP_CHECK(hipStreamSynchronize(ks));
+      else
+        { static hipEvent_t ev_pool = nullptr;
+          if (ev_pool == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_pool, hipEventDisableTiming));
+          HIP_CHECK(hipEventRecord(ev_pool, ks));
+          bg_pump(4);        // runs while the records are handed to the report stage
+          HIP_CHECK(hipEventSynchronize(ev_pool));
+        }
+    }
+
+  // which jobs of this run failed, and why
+  std::vector<int> ran;
+  if (P.todo.empty()) { ran.resize(njobs); for (int i = 0; i < njobs; i++) ran[i] = i; }
+  else ran = P.todo;
+  std::vector<int> again;
+  bool need_pool = false, need_up = false;
+  for (int j : ran)
+    if (P.status[j] != AL_OK)
+      { again.push_back(j);
+        if (P.status[j] == 100) need_pool = true;
+        else if (P.level == 0 && (P.status[j] == AL_ERR_BAND || P.status[j] == AL_ERR_PEBBLES)) need_up = true;
+        else if (P.level == 1 && P.status[j] == AL_ERR_BAND) need_up = true;
+        else fatal("Reporter: alignment of candidate %d failed (status %d)", j, P.status[j]);
+      }
+  // parse the records of this run (records of failed jobs are dropped below); when the whole
+  // batch succeeded at once the parse is left to the report stage (worker thread)
+  if (again.empty() && P.round == 0)
+    { P.deferred_got = got;
+      P.pool_pin = pb;
+      return true;
+    }
+  size_t base = P.pool.size();
+  P.pool.resize(base + got);
+  if (got > 0) memcpy(P.pool.data() + base, pb->p, sizeof(int) * got);
+  pb->busy.store(false);
+  std::vector<char> failed(njobs, 0);
+  for (int j : again) failed[j] = 1;
+  parse_pool(P.pool.data(), base, got, njobs, failed, P.recs);
+  for (int j : again) P.recs[j].clear();
+  if (again.empty()) return true;
+  std::sort(again.begin(), again.end());
+  P.todo = again;
+  if (need_pool) P.pool_cap *= 4;
+  else if (need_up) P.level += 1;
+  if (P.round == 7) fatal("Reporter: alignment retries exhausted");
+  P.round += 1;
+  return false;
+}
+
+static void finish_report(PendingReport *P)
+{ if (P->njobs > 0)
+    { while (!collect_round(*P)) launch_round(*P);
+      if (P->deferred_got == 0) fixup_recs(P->pool.data(), P->recs);
+    }
+  delete P->ht;
+  HostTimer ht_tail("report_tail");
+  ReportCtx *C = P->C;
+  C->recs = std::move(P->recs);
+  C->pool = std::move(P->pool);
+  C->pin = P->pool_pin;
+  C->deferred_got = P->deferred_got;
+  report_submit(C);
+  for (int i = 0; i < P->nhold; i++) free_blockdev(P->hold[i]);
+  delete P;
+}
+
+void report_finish_pending()
+{ if (g_pending == nullptr) return;
+  PendingReport *P = g_pending;
+  finish_report(P);          // (g_pending stays set while collecting: background stages remain held back)
+  g_pending = nullptr;
+}
+
 }  // namespace dmh
 
 using namespace dmh;
@@ -1096,24 +1298,27 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     fatal("Reporter: the Align_Spec was not created by this library's New_Align_Spec");
   if (st.cur_reads != ablock || (int) st.reads.size() != ablock->nreads)
     fatal("Reporter: called for a READS block that has not been through Match_Filter");
+  const bool defer = (g_async == 2);
+  // the index sort of the NEXT block: all of it now, ahead of this block's alignment kernel and while the
+  // host collects the previous block's (deferred mode), or a few stages for the GPU to do while the jobs
+  // are put together
+  if (defer) bg_flush();
+  report_finish_pending();                     // the previous block's alignments (deferred mode)
+  if (!defer) bg_pump(8);
   const int doA = (mflag & FLAG_DOA) != 0;
   const int doB = (mflag & FLAG_DOB) != 0;
   const int S_  = SPACING;
-  const int NT  = pm.NTHREADS;
-  const int hithr = 3 * pm.Kmer;
   const int nreads = ablock->nreads;
-  const int astart = ablock->tfirst;
 
   ablock->maxlen += SPACING;                  // map.c:3246
 
+  PendingReport *P = new PendingReport();
+  P->ht = new HostTimer("report_align");
+
   // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel
-  HostTimer *ht1 = new HostTimer("report_align");
-  bg_pump(8);                 // something for the GPU to do while the jobs are put together
-  std::vector<CandJob>   jobs;
-  std::vector<uint16_t>  jumps;
-  std::vector<int>       job_of_first(nreads + 1, 0);   // first job index of each read
+  std::vector<int> job_of_first(nreads + 1, 0);   // first job index of each read
   for (int ar = 0; ar < nreads; ar++)
-    { job_of_first[ar] = (int) jobs.size();
+    { job_of_first[ar] = (int) P->jobs.size();
       for (auto &c : st.reads[ar].cands)
         { CandJob J;
           J.aoff  = ablock->reads[ar].boff;
@@ -1124,54 +1329,66 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           J.alast = c->alast;
           J.blast = c->blast;
           J.npts  = c->length;
-          J.joff  = (uint32_t) (jumps.size() / 2);
+          J.joff  = (uint32_t) (P->jumps.size() / 2);
           J.pad   = 0;
-          jumps.insert(jumps.end(), c->jumps.begin(), c->jumps.end());
-          jobs.push_back(J);
+          P->jumps.insert(P->jumps.end(), c->jumps.begin(), c->jumps.end());
+          P->jobs.push_back(J);
         }
     }
-  job_of_first[nreads] = (int) jobs.size();
-  const int njobs = (int) jobs.size();
+  job_of_first[nreads] = (int) P->jobs.size();
+  const int njobs = (int) P->jobs.size();
+  P->njobs = njobs;
+  P->doB   = doB;
+  P->hithr = 3 * pm.Kmer;
+  P->recs.resize(njobs);
 
-  std::vector<std::vector<AlnRec>> recs(njobs);
-  std::vector<int> pool;
-  PinBuf *pool_pin = nullptr;
-  size_t deferred_got = 0;
-  { HostTimer hj("report_jobs_built"); }
+  { ReportCtx *C = new ReportCtx();
+    C->S_ = S_; C->NT = pm.NTHREADS; C->nshift = pm.NSHIFT; C->nreads = nreads; C->astart = ablock->tfirst;
+    C->doA = doA; C->doB = doB;
+    C->spacing = SPACING; C->profile = PROFILE; C->verbose = VERBOSE; C->best_tie = BEST_TIE;
+    C->aname = aname; C->bname = bname; C->sort_path = SORT_PATH;
+    C->rlen.resize(nreads);
+    for (int i = 0; i < nreads; i++) C->rlen[i] = ablock->reads[i].rlen;
+    C->reads = std::move(st.reads);
+    st.reads.clear();
+    st.cur_reads = nullptr;
+    C->job_of_first = std::move(job_of_first);
+    P->C = C;
+  }
+
   if (njobs > 0)
     { BlockDev &ad = upload_block(ablock, false);
       BlockDev &bd = upload_block(bblock, false);
       ensure_packed(ad, true);
       ensure_packed(bd, false);
-      AlignSpecDev spd = spec_dev(sp);
+      P->apk = ad.d_pk(); P->arc = ad.d_rc(); P->bpk = bd.d_pk();
+      P->spd = spec_dev(sp);
       int maxalen = 0;
       for (int ar = 0; ar < nreads; ar++) maxalen = std::max(maxalen, ablock->reads[ar].rlen);
-      int tcap = trace_cap(maxalen, S_);
+      P->tcap = trace_cap(maxalen, S_);
 
-      static DevBuf<CandJob>  d_jobs;
-      static DevBuf<uint16_t> d_jumps;
-      static DevBuf<int>      d_status, d_pool, d_only;
       d_jobs.ensure(njobs, "candidate jobs");
-      d_jumps.ensure(jumps.size() + 2, "candidate jumps");
+      d_jumps.ensure(P->jumps.size() + 2, "candidate jumps");
       d_status.ensure(njobs, "candidate status");
-      copy_h2d(d_jobs.p, jobs.data(), sizeof(CandJob) * njobs);
-      if (!jumps.empty())
-        copy_h2d(d_jumps.p, jumps.data(), sizeof(uint16_t) * jumps.size());
+      copy_h2d(d_jobs.p, P->jobs.data(), sizeof(CandJob) * njobs);
+      if (!P->jumps.empty())
+        copy_h2d(d_jumps.p, P->jumps.data(), sizeof(uint16_t) * P->jumps.size());
 
       // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
-      size_t pool_cap = (size_t) njobs * 2 * (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8)) + 4096;
-      if (st.opt_pool_div > 1) pool_cap = pool_cap / st.opt_pool_div + 64;
-      std::vector<int> status(njobs);
-      std::vector<int> todo;                 // jobs to (re)run
+      P->pool_cap = (size_t) njobs * 2 * (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8)) + 4096;
+      if (st.opt_pool_div > 1) P->pool_cap = P->pool_cap / st.opt_pool_div + 64;
+      P->status.resize(njobs);
       // kernel ladder: 0 = two candidates per wavefront (register band <= 30 diagonals, LDS pebbles),
       // 1 = one per wavefront (register band <= 62, LDS ring 128, global pebbles), 2 = global ring 8192
       static const bool no_pack = getenv("DMH_NO_PACK32") != nullptr;
-      int level = (doB || no_pack) ? 1 : 0;
-      if (st.opt_align_level >= 0) level = std::max(level, std::min(2, st.opt_align_level));
-      if (level == 0)
+      P->level = (doB || no_pack) ? 1 : 0;
+      if (st.opt_align_level >= 0) P->level = std::max(P->level, std::min(2, st.opt_align_level));
+      if (P->level == 0)
         { // the halves of a wavefront run in lock step: hand out like jobs together (same orientation,
-          // similar length), long ones first
+          // similar length, equal chain end = equal first seed), long ones first:
           // (comp asc, alen desc, alast desc, index asc) packed into one integer key per job
+          const std::vector<CandJob> &jobs = P->jobs;
+          std::vector<int> &todo = P->todo;
           std::vector<uint64_t> key(njobs);
           for (int i = 0; i < njobs; i++)
             { uint64_t len = 0xfffffu - (uint64_t) std::min(jobs[i].alen, 0xfffff);
@@ -1190,131 +1407,29 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
               std::stable_sort(todo.begin(), todo.end(), [&](int x, int y) { return key[x] < key[y]; });
             }
         }
-      for (int round = 0; round < 8; round++)
-        { if (pool_cap > 0xfffffff0ull / 4) fatal("Reporter: alignment pool too large");
-          d_pool.ensure(pool_cap, "alignment pool");
-          int nrun = todo.empty() ? njobs : (int) todo.size();
-          const int *only = nullptr;
-          if (!todo.empty())
-            { d_only.ensure(todo.size(), "retry list");
-              copy_h2d(d_only.p, todo.data(), sizeof(int) * todo.size());
-              only = d_only.p;
-            }
-          const int per_block = (level == 0) ? 8 : 4;
-          int nblocks = std::min((nrun + per_block - 1) / per_block, 256 * 4);
-          Scratch sc = prepare_scratch(nblocks, tcap, level == 2, per_block, level != 0);
-          HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), stream()));
-          HIP_CHECK(hipMemsetAsync(d_pool.p, 0xff, sizeof(int) * pool_cap, stream()));   // cand = -1 ends the parse
-          { StageTimer tm(level == 2 ? "align_global_band" : (level == 1 ? "align_wave64" : "align"), 0.0);
-            if (level == 0)
-              hipLaunchKernelGGL(k_align_cands32, dim3(nblocks), dim3(256), 0, stream(),
-                                 ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
-                                 (const uint16_t *) d_jumps.p, hithr, spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
-                                 d_pool.p, ascr().ctl.p + 1, (unsigned int) pool_cap, only);
-            else if (level == 2)
-              { if (doB)
-                  hipLaunchKernelGGL((k_align_cands<GLB_W, false, true>), dim3(nblocks), dim3(256), 0, stream(),
-                                     ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
-                                     (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
-                                     ascr().ctl.p + 1, (unsigned int) pool_cap, only);
-                else
-                  hipLaunchKernelGGL((k_align_cands<GLB_W, false, false>), dim3(nblocks), dim3(256), 0, stream(),
-                                     ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
-                                     (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
-                                     ascr().ctl.p + 1, (unsigned int) pool_cap, only);
-              }
-            else
-              { if (doB)
-                  hipLaunchKernelGGL((k_align_cands<LDS_W, true, true>), dim3(nblocks), dim3(256), 0, stream(),
-                                     ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
-                                     (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
-                                     ascr().ctl.p + 1, (unsigned int) pool_cap, only);
-                else
-                  hipLaunchKernelGGL((k_align_cands<LDS_W, true, false>), dim3(nblocks), dim3(256), 0, stream(),
-                                     ad.d_pk(), ad.d_rc(), bd.d_pk(), (const CandJob *) d_jobs.p, nrun,
-                                     (const uint16_t *) d_jumps.p, hithr, spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
-                                     ascr().ctl.p + 1, (unsigned int) pool_cap, only);
-              }
-            HIP_CHECK(hipGetLastError());
-          }
-          dispose_done();        // free finished report contexts while the kernel runs
-          unsigned int used = 0;
-          { HostTimer hw("report_kernel_wait");
-            copy_d2h(&used, ascr().ctl.p + 1, sizeof(unsigned int));
-            copy_d2h(status.data(), d_status.p, sizeof(int) * njobs);
-            HIP_CHECK(hipStreamSynchronize(stream()));
-          }
-          HostTimer hp("report_pool_parse");
-          size_t got = std::min<size_t>(used, pool_cap);
-          PinBuf *pb = pin_acquire(got + 16);
-          if (got > 0)
-            { HIP_CHECK(hipMemcpyAsync(pb->p, d_pool.p, sizeof(int) * got, hipMemcpyDeviceToHost, stream()));
-              static hipEvent_t ev_pool = nullptr;
-              if (ev_pool == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_pool, hipEventDisableTiming));
-              HIP_CHECK(hipEventRecord(ev_pool, stream()));
-              bg_pump(4);        // runs while the records are handed to the report stage
-              HIP_CHECK(hipEventSynchronize(ev_pool));
-            }
 
-          // which jobs of this run failed, and why
-          std::vector<int> ran;
-          if (todo.empty()) { ran.resize(njobs); for (int i = 0; i < njobs; i++) ran[i] = i; }
-          else ran = todo;
-          std::vector<int> again;
-          bool need_pool = false, need_up = false;
-          for (int j : ran)
-            if (status[j] != AL_OK)
-              { again.push_back(j);
-                if (status[j] == 100) need_pool = true;
-                else if (level == 0 && (status[j] == AL_ERR_BAND || status[j] == AL_ERR_PEBBLES)) need_up = true;
-                else if (level == 1 && status[j] == AL_ERR_BAND) need_up = true;
-                else fatal("Reporter: alignment of candidate %d failed (status %d)", j, status[j]);
-              }
-          // parse the records of this run (records of failed jobs are dropped below); when the whole
-          // batch succeeded at once the parse is left to the report stage (worker thread)
-          if (again.empty() && round == 0)
-            { deferred_got = got;
-              pool_pin = pb;
-              break;
+      if (defer)
+        { if (g_astream == nullptr)
+            { HIP_CHECK(hipStreamCreateWithFlags(&g_astream, hipStreamNonBlocking));
+              HIP_CHECK(hipEventCreateWithFlags(&g_ev_ab, hipEventDisableTiming));
+              HIP_CHECK(hipEventCreateWithFlags(&g_ev_done, hipEventDisableTiming));
             }
-          size_t base = pool.size();
-          pool.resize(base + got);
-          if (got > 0) memcpy(pool.data() + base, pb->p, sizeof(int) * got);
-          pb->busy.store(false);
-          std::vector<char> failed(njobs, 0);
-          for (int j : again) failed[j] = 1;
-          parse_pool(pool.data(), base, got, njobs, failed, recs);
-          for (int j : again) recs[j].clear();
-          if (again.empty()) break;
-          std::sort(again.begin(), again.end());
-          todo = again;
-          if (need_pool) pool_cap *= 4;
-          else if (need_up) level += 1;
-          if (round == 7) fatal("Reporter: alignment retries exhausted");
+          P->on_aux = true;
+          // the kernel outlives this call: the device copies it reads leave the registry, so that neither
+          // the clean-up below nor a re-used host block can free them under it
+          for (const DAZZ_DB *blk : {(const DAZZ_DB *) ablock, (const DAZZ_DB *) bblock})
+            { auto it = st.blocks.find(blk);
+              if (it != st.blocks.end() && !it->second.pinned)
+                { P->hold[P->nhold++] = it->second;
+                  st.blocks.erase(it);
+                }
+            }
         }
-      if (deferred_got == 0) fixup_recs(pool.data(), recs);
+      launch_round(*P);
     }
 
-  delete ht1;
-  HostTimer ht_tail("report_tail");
-  { ReportCtx *C = new ReportCtx();
-    C->S_ = S_; C->NT = NT; C->nshift = pm.NSHIFT; C->nreads = nreads; C->astart = astart; C->doA = doA; C->doB = doB;
-    C->spacing = SPACING; C->profile = PROFILE; C->verbose = VERBOSE; C->best_tie = BEST_TIE;
-    C->aname = aname; C->bname = bname; C->sort_path = SORT_PATH;
-    C->rlen.resize(nreads);
-    for (int i = 0; i < nreads; i++) C->rlen[i] = ablock->reads[i].rlen;
-    C->reads = std::move(st.reads);
-    st.reads.clear();
-    st.cur_reads = nullptr;
-    C->job_of_first = std::move(job_of_first);
-    C->recs = std::move(recs);
-    C->pool = std::move(pool);
-    C->pin = pool_pin;
-    C->deferred_got = deferred_got;
-    report_submit(C);
-  }
-
-  // the READS index and block copies are not needed any more; the driver free()s the stub
+  // the READS index is not needed any more (the alignment kernel reads the packed bases only); the
+  // driver free()s the stub
   for (auto it = st.indices.begin(); it != st.indices.end();)
     { if (it->second.block == ablock && !st.retain_ref)
         { dev_free(it->second.keys); dev_free(it->second.vals);
@@ -1324,16 +1439,26 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
       else
         ++it;
     }
+
+  if (defer && njobs > 0)
+    { g_pending = P;           // collected by the next Reporter / dmh_report_wait
+      return;
+    }
+  finish_report(P);
   if (st.blocks.count(ablock) && !st.blocks[ablock].pinned) drop_block(ablock);
   if (st.blocks.count(bblock) && !st.blocks[bblock].pinned) drop_block(bblock);
 }
 
 void dmh_async_report(int on)
-{ report_wait();
-  g_async = (on != 0);
+{ report_finish_pending();
+  report_wait();
+  g_async = (on < 0) ? 0 : (on > 2 ? 2 : on);
 }
 
-void dmh_report_wait(void) { report_wait(); }
+void dmh_report_wait(void)
+{ report_finish_pending();
+  report_wait();
+}
 
 int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes, const uint8_t *bbases,
                         int64_t bbytes, int njobs, const int64_t *aoff, const int *alen, const int64_t *boff,

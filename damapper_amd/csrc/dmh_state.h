@@ -122,6 +122,7 @@ void      ensure_packed(BlockDev &bd, bool want_rc);
 void      pack_bases(const uint8_t *d_bases, int64_t L, uint64_t *d_pkraw);
 void      pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, uint64_t *d_rcraw);
 void      drop_block(const DAZZ_DB *block);
+void      free_blockdev(BlockDev &bd);
 
 void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, int K,
                uint64_t *d_keys, uint32_t *d_vals, int64_t nk, int part = 0, int nparts = 1);
