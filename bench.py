@@ -89,9 +89,9 @@ def main():
                     help="PCIe-inclusive rate: read blocks are NOT resident, every step uploads its block from "
                          "page-locked (dmh_host_alloc) or ordinary host memory inside the timed region")
     ap.add_argument("--sync-report", action="store_true", help="write the .las files inside Reporter (drop-in behaviour)")
-    ap.add_argument("--report-mode", type=int, default=1, choices=[0, 1, 2],
-                    help="0 = Reporter synchronous, 1 = .las selection/writing on a worker thread (default), 2 = also the "
-                         "alignment kernel of block i deferred next to the filter of block i+1 (measured slower: DESIGN.md)")
+    ap.add_argument("--report-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="0 = Reporter synchronous, 1 = .las selection/writing on a worker thread, 2 (default) = also the "
+                         "alignment kernel of block i deferred, at half grid, next to the filter of block i+1")
     ap.add_argument("--rebuild-ref", action="store_true",
                     help="rebuild the REF indices for every read block as damapper.c does (default: build both "
                          "orientations once per GPU and keep them resident, BASELINE.json north_star)")

@@ -37,6 +37,7 @@ void bg_flush();
 // stages are then held back (the HBM-bound sort kernels keep the GPU to themselves, before the alignment)
 bool report_in_flight();
 void report_finish_pending();
+bool report_adopt_block(const DAZZ_DB *block);   // a deferred Reporter takes over the resident copy it reads
 
 // Device allocation that aborts through Clean_Exit on failure (the reference's behaviour
 // for a failed Malloc, e.g. map.c:689-690).

@@ -422,8 +422,13 @@ void ensure_packed(BlockDev &bd, bool want_rc)
 
 BlockDev &upload_block(const DAZZ_DB *block, bool pin)
 { State &st = S();
-  uint64_t stamp = block_stamp(block);
   auto it = st.blocks.find(block);
+  if (it != st.blocks.end() && it->second.decoded)       // dmh_preload_block_2bit: there are no host bases
+    { if (it->second.nreads != block->nreads) fatal("block changed after dmh_preload_block_2bit");
+      return it->second;
+    }
+  if (block->bases == nullptr) fatal("block has no bases (not loaded, or released after dmh_preload_block_2bit)");
+  uint64_t stamp = block_stamp(block);
   if (it != st.blocks.end())
     { if (it->second.stamp == stamp && it->second.nreads == block->nreads)
         { if (pin) it->second.pinned = true;
@@ -482,6 +487,94 @@ void drop_block(const DAZZ_DB *block)
   if (it == st.blocks.end()) return;
   free_blockdev(it->second);
   st.blocks.erase(it);
+}
+
+// ---- Load_All_Reads on the device (DB.c:1389-1437 with Uncompress_Read, DB.c:342-361) -----------------
+// The block's slice of the .bps file: 4 bases per byte, the first in the two top bits, every read starting on
+// a byte; `coff[r]` = first byte of read r inside the slice (ascending; bytes of reads the trimmed view leaves
+// out lie between).  One workgroup decodes UNPACK_SPAN bytes of the slice: it looks up the read its first
+// byte belongs to once, each thread walks on from there.
+constexpr int UNPACK_THREADS = 256;
+constexpr int UNPACK_SPAN    = 4096;
+
+__global__ __launch_bounds__(UNPACK_THREADS) void k_unpack_2bit(const uint8_t *__restrict__ bps, int64_t nbytes,
+                                                                const int64_t *__restrict__ coff,
+                                                                const int64_t *__restrict__ boff, int nreads,
+                                                                uint8_t *__restrict__ raw)
+{ __shared__ int s_first;
+  const int64_t span0 = (int64_t) blockIdx.x * UNPACK_SPAN;
+  if (threadIdx.x == 0)
+    { int lo = 0, hi = nreads;              // last read with coff <= span0 (0 if none)
+      while (hi - lo > 1)
+        { int mid = (lo + hi) >> 1;
+          if (coff[mid] <= span0) lo = mid; else hi = mid;
+        }
+      s_first = lo;
+    }
+  __syncthreads();
+  int r = s_first;
+  for (int64_t p = span0 + threadIdx.x; p < span0 + UNPACK_SPAN && p < nbytes; p += UNPACK_THREADS)
+    { while (r + 1 < nreads && coff[r + 1] <= p) r++;
+      const int64_t c = p - coff[r];
+      const int64_t o = boff[r];
+      const int64_t rlen = boff[r + 1] - o - 1;
+      if (c < 0 || 4 * c >= rlen) continue;                    // a byte between two reads of the view
+      const uint32_t b = bps[p];
+      uint8_t *out = raw + 1 + o + 4 * c;
+      const int  m = (int) ((rlen - 4 * c < 4) ? (rlen - 4 * c) : 4);
+      out[0] = (uint8_t) (b >> 6);
+      if (m > 1) out[1] = (uint8_t) ((b >> 4) & 3);
+      if (m > 2) out[2] = (uint8_t) ((b >> 2) & 3);
+      if (m > 3) out[3] = (uint8_t) (b & 3);
+    }
+}
+
+// the separators: raw[0] and the byte behind every read (DB.c:1411,1428)
+__global__ void k_unpack_seps(const int64_t *__restrict__ boff, int nreads, uint8_t *__restrict__ raw)
+{ int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) raw[0] = 4;
+  if (i < nreads) raw[boff[i + 1]] = 4;          // raw + 1 + boff[i] + rlen
+}
+
+static int preload_block_2bit(DAZZ_DB *block, const uint8_t *bps, int64_t nbytes, const int64_t *coff)
+{ State &st = S();
+  const int n = block->nreads;
+  if (n <= 0 || nbytes <= 0) fatal("dmh_preload_block_2bit: empty block");
+  for (int i = 0; i < n; i++)
+    { if (block->reads[i + 1].boff - block->reads[i].boff != (int64_t) block->reads[i].rlen + 1)
+        fatal("dmh_preload_block_2bit: reads[%d].boff does not follow Load_All_Reads' layout", i);
+      if (coff[i] < 0 || coff[i] + (block->reads[i].rlen + 3) / 4 > nbytes || (i > 0 && coff[i] < coff[i - 1]))
+        fatal("dmh_preload_block_2bit: compressed offset of read %d out of range or out of order", i);
+    }
+  if (st.blocks.count(block))
+    { report_finish_pending();         // (a block handle re-used while a deferred kernel may read the old copy)
+      drop_block(block);
+    }
+  BlockDev bd;
+  bd.nreads  = n;
+  bd.L       = block->reads[n].boff;
+  bd.pinned  = true;
+  bd.decoded = true;
+  bd.d_raw   = (uint8_t *) dev_alloc((size_t) bd.L + 1 + 64, "block bases");
+  bd.d_boff  = (int64_t *) dev_alloc(sizeof(int64_t) * (n + 1), "block read offsets");
+  uint8_t *d_bps  = (uint8_t *) dev_alloc((size_t) nbytes, "compressed block");
+  int64_t *d_coff = (int64_t *) dev_alloc(sizeof(int64_t) * n, "compressed read offsets");
+  std::vector<int64_t> off(n + 1);
+  for (int i = 0; i <= n; i++) off[i] = block->reads[i].boff;
+  copy_h2d(bd.d_boff, off.data(), sizeof(int64_t) * (n + 1));
+  copy_h2d(d_coff, coff, sizeof(int64_t) * n);
+  copy_h2d(d_bps, bps, (size_t) nbytes);
+  { StageTimer tm("unpack_2bit", (double) nbytes + (double) bd.L);
+    hipLaunchKernelGGL(k_unpack_seps, dim3(ceil_div(n, 256)), dim3(256), 0, stream(), (const int64_t *) bd.d_boff, n, bd.d_raw);
+    hipLaunchKernelGGL(k_unpack_2bit, dim3((unsigned int) ceil_div(nbytes, UNPACK_SPAN)), dim3(UNPACK_THREADS), 0, stream(),
+                       (const uint8_t *) d_bps, nbytes, (const int64_t *) d_coff, (const int64_t *) bd.d_boff, n, bd.d_raw);
+    HIP_CHECK(hipGetLastError());
+  }
+  HIP_CHECK(hipStreamSynchronize(stream()));      // the caller may free `bps` now
+  dev_free(d_bps);
+  dev_free(d_coff);
+  st.blocks[block] = bd;
+  return 0;
 }
 
 // ---- index registry -----------------------------------------------------------------------
@@ -782,7 +875,7 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
 
   const DAZZ_TRACK *mask = (const DAZZ_TRACK *) block->tracks;
   uint64_t ckey[4] = {0, 0, 0, 0};
-  if (st.ref_cache && mask == nullptr && !deferred)
+  if (st.ref_cache && mask == nullptr && !deferred && block->bases != nullptr)
     { content_key(block, pm, ckey);
       IndexDev *c = cache_find(ckey);
       if (c != nullptr)
@@ -1049,9 +1142,22 @@ int dmh_preload_block(DAZZ_DB *block)
   return 0;
 }
 
+int dmh_preload_block_2bit(DAZZ_DB *block, const unsigned char *bps, int64_t nbytes, const int64_t *coff)
+{ return preload_block_2bit(block, bps, nbytes, coff); }
+
+int dmh_download_block(DAZZ_DB *block, unsigned char *out)
+{ State &st = S();
+  auto it = st.blocks.find(block);
+  if (it == st.blocks.end()) return -1;
+  block_ready(it->second);
+  copy_d2h(out, it->second.d_raw, (size_t) it->second.L + 1);
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  return 0;
+}
+
 void dmh_release_block(DAZZ_DB *block)
 { if (S().blocks.count(block) == 0) return;   // (a deferred Reporter holds the copy it reads by itself)
-  report_finish_pending();                   // its kernel may still read a resident block
+  if (report_adopt_block(block)) return;     // its kernel still reads this resident copy: freed when it is collected
   drop_block(block);
 }
 

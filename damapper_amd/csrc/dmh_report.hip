@@ -1093,6 +1093,7 @@ struct PendingReport
   size_t pool_cap = 0;
   AlignSpecDev spd;
   const uint64_t *apk = nullptr, *arc = nullptr, *bpk = nullptr;
+  const DAZZ_DB *ablk = nullptr, *bblk = nullptr;
   BlockDev hold[2];            // device copies the kernel reads, taken out of the block registry meanwhile
   int      nhold = 0;
   bool     on_aux = false;     // the kernel runs on the alignment stream
@@ -1127,7 +1128,10 @@ static void launch_round(PendingReport &P)
     }
   const int level = P.level, doB = P.doB;
   const int per_block = (level == 0) ? 8 : 4;
-  int nblocks = std::min((nrun + per_block - 1) / per_block, 256 * 4);
+  // four workgroups per CU take every SIMD's registers; a deferred kernel leaves half of them to the next
+  // block's merge and chain kernels (32.4 ms per block at 2 per CU, 34.9 at 2.5, 39.7 at 4)
+  static const int aux_grid = getenv("DMH_DEFER_GRID") ? std::max(64, atoi(getenv("DMH_DEFER_GRID"))) : 256 * 2;
+  int nblocks = std::min((nrun + per_block - 1) / per_block, P.on_aux ? aux_grid : 256 * 4);
   Scratch sc = prepare_scratch(nblocks, P.tcap, level == 2, per_block, level != 0);
   if (P.on_aux)
     { // everything queued on the main stream so far (packing, uploads, the flushed index sort) comes first
@@ -1264,6 +1268,17 @@ static void finish_report(PendingReport *P)
   report_submit(C);
   for (int i = 0; i < P->nhold; i++) free_blockdev(P->hold[i]);
   delete P;
+}
+
+bool report_adopt_block(const DAZZ_DB *block)
+{ PendingReport *P = g_pending;
+  if (P == nullptr || !P->on_aux || (block != P->ablk && block != P->bblk) || P->nhold >= 2) return false;
+  State &st = S();
+  auto it = st.blocks.find(block);
+  if (it == st.blocks.end()) return false;
+  P->hold[P->nhold++] = it->second;
+  st.blocks.erase(it);
+  return true;
 }
 
 void report_finish_pending()
@@ -1415,6 +1430,8 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
               HIP_CHECK(hipEventCreateWithFlags(&g_ev_done, hipEventDisableTiming));
             }
           P->on_aux = true;
+          P->ablk = ablock;
+          P->bblk = bblock;
           // the kernel outlives this call: the device copies it reads leave the registry, so that neither
           // the clean-up below nor a re-used host block can free them under it
           for (const DAZZ_DB *blk : {(const DAZZ_DB *) ablock, (const DAZZ_DB *) bblock})

@@ -324,6 +324,37 @@ class Block:
     track_anno: Optional[np.ndarray] = None  # int64[nreads+1], in ints (damapper.c:386-388)
     track_data: Optional[np.ndarray] = None  # int32 begin/end pairs
     track_alen: Optional[np.ndarray] = None
+    packed: Optional[np.ndarray] = None      # load_db(packed=True): the block's slice of the .bps file; bases is None
+    coff: Optional[np.ndarray] = None        # int64[nreads]: byte offset of each read's record inside `packed`
+    resident: bool = False                   # the device holds the block (preload() done)
+
+    def preload(self) -> None:
+        """Make the block resident in HBM before it is used: a packed block is uploaded as the 2-bit bytes
+        of the .bps file and decoded by a kernel (dmh_preload_block_2bit, the device-side Load_All_Reads);
+        an ordinary block is uploaded as it is.  Released by release()."""
+        from . import capi
+        if self.resident:
+            return
+        if self.packed is not None:
+            capi.lib().dmh_preload_block_2bit(self.ptr(), self.packed.ctypes.data, len(self.packed), self.coff.ctypes.data)
+            self.packed = None               # the device copy is the block now
+        else:
+            capi.lib().dmh_preload_block(self.ptr())
+        self.resident = True
+
+    def release(self) -> None:
+        from . import capi
+        if self.resident:
+            capi.lib().dmh_release_block(self.ptr())
+            self.resident = False
+
+    def download(self) -> np.ndarray:
+        """The device image of a resident block (separator + bases), for tests."""
+        from . import capi
+        out = np.empty(int(self.reads[self.nreads + 1]["boff"]) + 1, dtype=np.uint8)
+        if capi.lib().dmh_download_block(self.ptr(), out.ctypes.data) != 0:
+            raise RuntimeError("block is not resident")
+        return out
 
     def set_mask(self, intervals: Optional[Intervals], merged: bool = False) -> None:
         """Attach the (already merged) mask as block->tracks, the way read_DB leaves it: a single
@@ -421,19 +452,32 @@ def host_bytes(n: int, pinned: bool) -> np.ndarray:
 
 
 def make_block(seqs: Sequence[np.ndarray], tfirst: int = 0, part: int = 0,
-               path: bytes = b"./.mem", freq: Optional[Sequence[float]] = None, pinned: bool = False) -> Block:
-    n = len(seqs)
-    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+               path: bytes = b"./.mem", freq: Optional[Sequence[float]] = None, pinned: bool = False,
+               lens: Optional[np.ndarray] = None) -> Block:
+    """The in-memory block of `seqs`.  With `lens` given instead (seqs empty) only the read records are
+    laid out and `bases` stays None: the shape of a block whose bases are decoded on the device."""
+    headless = lens is not None
+    n = len(lens) if headless else len(seqs)
+    if not headless:
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    lens = np.asarray(lens, dtype=np.int64)
     tot = int(lens.sum())
-    bases = host_bytes(tot + n + 4, pinned)
-    bases[:] = 4
     reads = np.zeros(n + 2, dtype=READ_DTYPE)
-    o = 0
-    for i, s in enumerate(seqs):
-        bases[1 + o:1 + o + len(s)] = s
-        reads[i + 1] = (tfirst + i, len(s), 0, o, 0, DB_BEST)
-        o += len(s) + 1
-    reads[n + 1]["boff"] = o
+    offs = np.concatenate(([0], np.cumsum(lens + 1)))
+    reads["origin"][1:n + 1] = tfirst + np.arange(n)
+    reads["rlen"][1:n + 1] = lens
+    reads["boff"][1:n + 2] = offs
+    reads["flags"][1:n + 1] = DB_BEST
+    if headless:
+        bases = None
+        if freq is None:
+            freq = [0.25] * 4
+    else:
+        bases = host_bytes(tot + n + 4, pinned)
+        bases[:] = 4
+        for i, s in enumerate(seqs):
+            o = int(offs[i])
+            bases[1 + o:1 + o + len(s)] = s
     db = DAZZ_DB()
     db.ureads = db.treads = n
     db.cutoff = 0
@@ -451,7 +495,7 @@ def make_block(seqs: Sequence[np.ndarray], tfirst: int = 0, part: int = 0,
     db.ufirst = db.tfirst = tfirst
     db.path = path
     db.loaded = 1
-    db.bases = bases.ctypes.data + 1
+    db.bases = (bases.ctypes.data + 1) if bases is not None else None
     db.reads = reads.ctypes.data + 40
     db.tracks = None
     # Open_DB's kludge (DB.c:853-854): block read counts in the two ints before reads[0]
@@ -513,7 +557,7 @@ def simulate_block(seed: int, contig: np.ndarray, nreads: int, read_len: int = 1
     db.ufirst = db.tfirst = tfirst
     db.path = path
     db.loaded = 1
-    db.bases = bases.ctypes.data + 1
+    db.bases = (bases.ctypes.data + 1) if bases is not None else None
     db.reads = reads.ctypes.data + 40
     db.tracks = None
     iv = reads.view(np.int32)
@@ -552,14 +596,15 @@ def read_stub(path: str) -> Tuple[int, List[Tuple[int, int]]]:
 
 
 def load_db(path: str, part: int = 0, masks: Sequence[str] = (), used: Optional[set] = None,
-            pinned: bool = False) -> Block:
+            pinned: bool = False, packed: bool = False) -> Block:
     """Open_DB + Trim_DB + Load_All_Reads equivalent (DB.c:600-1007,1402-1437).  `path` is
     'dir/root.db'; part k > 0 loads block k.  The DBsplit cutoff / all flags of the stub trim the view:
     reads shorter than the cutoff (and, without -a, reads that are not the best of their well) are left
     out and the block's reads are numbered from the stub's trimmed first.  `masks` are -m track names:
     those the DB has are loaded (over the untrimmed or the trimmed reads, whichever the track was made
     for), merged into one mask and attached (read_DB, damapper.c:345-414); their names are added to
-    `used` (the MSTAT bookkeeping)."""
+    `used` (the MSTAT bookkeeping).  packed=True skips Load_All_Reads' decode: the block carries its slice
+    of the .bps file (`Block.packed`, `Block.coff`) and no `bases`; `Block.preload()` has the device decode it."""
     d, base = os.path.split(path)
     d = d or "."
     root = base[:-3] if base.endswith(".db") else base
@@ -576,15 +621,34 @@ def load_db(path: str, part: int = 0, masks: Sequence[str] = (), used: Optional[
         tfirst = 0
     keep_all = (recs["rlen"] >= cutoff) & (all_reads | ((recs["flags"] & DB_BEST) != 0))
     keep = keep_all[lo:hi]
-    bps = np.fromfile(os.path.join(d, "." + root + ".bps"), dtype=np.uint8)
-    seqs = []
-    for r in recs[lo:hi][keep]:
-        n = int(r["rlen"])
-        o = int(r["boff"])
-        seqs.append(_unpack_2bit(bps[o:o + (n + 3) // 4], n))
-    blk = make_block(seqs, tfirst=tfirst, part=part,
-                     path=os.path.join(d, "." + root).encode(),
-                     freq=[hdr.freq[j] for j in range(4)], pinned=pinned)
+    kept = recs[lo:hi][keep]
+    bps_path = os.path.join(d, "." + root + ".bps")
+    if len(kept) == 0:
+        first = last = 0
+    else:
+        first = int(kept["boff"][0])
+        last = int(kept["boff"][-1]) + (int(kept["rlen"][-1]) + 3) // 4
+    if packed and len(kept) > 0:
+        buf = host_bytes(last - first, pinned)
+        with open(bps_path, "rb") as f:
+            f.seek(first)
+            got = f.readinto(memoryview(buf))
+        if got != last - first:
+            raise IOError("%s: short read" % bps_path)
+        blk = make_block([], tfirst=tfirst, part=part, path=os.path.join(d, "." + root).encode(),
+                         freq=[hdr.freq[j] for j in range(4)], lens=kept["rlen"].astype(np.int64))
+        blk.packed = buf
+        blk.coff = np.ascontiguousarray(kept["boff"].astype(np.int64) - first)
+    else:
+        bps = np.fromfile(bps_path, dtype=np.uint8, count=last - first, offset=first)
+        seqs = []
+        for r in kept:
+            n = int(r["rlen"])
+            o = int(r["boff"]) - first
+            seqs.append(_unpack_2bit(bps[o:o + (n + 3) // 4], n))
+        blk = make_block(seqs, tfirst=tfirst, part=part,
+                         path=os.path.join(d, "." + root).encode(),
+                         freq=[hdr.freq[j] for j in range(4)], pinned=pinned)
     blk.db.cutoff = cutoff
     blk.db.allarr = DB_ALL if all_reads else 0
     found = []

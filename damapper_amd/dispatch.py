@@ -32,7 +32,8 @@ def _worker(args) -> None:
     mine = [b for b in range(1, nrb + 1) if (b - 1) % nworkers == args.rank]
     out = args.out or os.path.join(d, "las_hip")
     m = driver.Mapper(kmer=args.k, suppress=args.t, threads=args.T, ave_corr=args.e, spacing=args.s,
-                      best_tie=args.n, profile=int(args.p), verbose=int(args.v), sort_path=out)
+                      best_tie=args.n, profile=int(args.p), verbose=int(args.v), sort_path=out,
+                      retain_ref=not args.rebuild_ref)
     nb, _ = read_stub(os.path.join(d, ref_root + ".db"))
     used: set = set()
     ref_blocks = [load_db(os.path.join(d, ref_root + ".db"), part=k + 1, masks=args.m, used=used) for k in range(nb)]
@@ -42,7 +43,7 @@ def _worker(args) -> None:
     if args.N and args.p:
         raise SystemExit("damapper_amd.dispatch: Cannot specify both N and p flags together")
     mflag = (capi.FLAG_DOB if args.N else capi.FLAG_DOA | capi.FLAG_DOB) if args.C else capi.FLAG_DOA
-    mapped = []
+    todo = []
     for b in mine:
         name = "%s.%d" % (read_root, b)
         if args.finish:
@@ -56,14 +57,42 @@ def _worker(args) -> None:
         if done and not args.force:
             print("[gpu %d] %s: output present, skipped" % (args.rank, name), flush=True)
             continue
-        reads = load_db(os.path.join(rd or ".", read_root + ".db"), part=b, masks=args.m, used=used, pinned=True)
+        todo.append(b)
+
+    # The block loop, software-pipelined three deep: while block i is mapped, a loader thread reads block
+    # i+2's slice of the .bps file into page-locked memory (no decode on the host: the 2-bit bytes are
+    # uploaded and unpacked by a kernel), block i+1's index is built in the gaps of block i's filter, and
+    # block i-1's alignment kernel / .las writing are still finishing (dmh_async_report).
+    from concurrent.futures import ThreadPoolExecutor
+    loader = ThreadPoolExecutor(1)
+
+    def load(b):
+        return load_db(os.path.join(rd or ".", read_root + ".db"), part=b, masks=args.m, used=used, pinned=True,
+                       packed=not args.host_decode)
+
+    pending = [loader.submit(load, b) for b in todo[:2]]
+    capi.lib().dmh_async_report(args.report_mode)
+    mapped = []
+    cur = pending.pop(0).result() if pending else None
+    t_all = time.time()
+    for i, b in enumerate(todo):
+        name = "%s.%d" % (read_root, b)
+        nxt = pending.pop(0).result() if pending else None
+        if i + 2 < len(todo):
+            pending.append(loader.submit(load, todo[i + 2]))
         t0 = time.time()
-        m.map_block(reads, name, ref_blocks, ref_whole, ref_root, mflag=mflag)
+        m.map_block(cur, name, ref_blocks, ref_whole, ref_root, mflag=mflag, next_reads=nxt)
+        cur.release()
         mapped.append(name)
         dt = time.time() - t0
         print("[gpu %d] %s: %d reads, %.1f Mbp in %.2f s (%.3f Gbp/s)" %
-              (args.rank, name, reads.nreads, reads.db.totlen / 1e6, dt, reads.db.totlen / dt / 1e9), flush=True)
+              (args.rank, name, cur.nreads, cur.db.totlen / 1e6, dt, cur.db.totlen / dt / 1e9), flush=True)
+        cur = nxt
     capi.lib().dmh_report_wait()
+    capi.lib().dmh_async_report(0)
+    loader.shutdown()
+    if todo and args.v:
+        print("[gpu %d] %d blocks in %.2f s" % (args.rank, len(todo), time.time() - t_all), flush=True)
     if args.finish:
         for name in mapped:
             driver.finish_block(out, name, ref_root, mflag=mflag, map_order=not args.z, outdir=d)
@@ -93,6 +122,14 @@ def main(argv=None) -> int:
     ap.add_argument("-N", action="store_true", help="with -C: no reads-vs-reference files")
     ap.add_argument("-z", action="store_true", help="--finish sorts by A,B-read piles instead of map order")
     ap.add_argument("--finish", action="store_true", help="run the LAsort/LAcat/LAmerge post-step")
+    ap.add_argument("--report-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="dmh_async_report: 0 synchronous Reporter, 1 .las writing on a worker thread, 2 (default) also the "
+                         "alignment kernel left running next to the following block's filter")
+    ap.add_argument("--host-decode", action="store_true",
+                    help="decode the 2-bit reads on the host (Load_All_Reads' way) instead of on the GPU")
+    ap.add_argument("--rebuild-ref", action="store_true",
+                    help="rebuild the reference index for every read block (the reference's loop) instead of keeping "
+                         "both orientations of every reference block resident in HBM")
     args = ap.parse_args(argv)
     if args.rank >= 0:
         _worker(args)

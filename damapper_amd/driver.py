@@ -88,6 +88,9 @@ class Mapper:
         t["between_blocks"] = (t0 - self._last_end) if getattr(self, "_last_end", None) else 0.0
         if self.spec is None:
             self.make_spec([ref_whole.db.freq[j] for j in range(4)])
+        for blk in (reads, next_reads):
+            if blk is not None and blk.packed is not None:
+                blk.preload()              # 2-bit upload + device-side decode (dmh_preload_block_2bit)
         pre = getattr(self, "_prefetched", None)
         if pre is not None and pre[0] is reads:
             rh, rn = pre[1], pre[2]

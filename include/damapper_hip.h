@@ -153,6 +153,17 @@ void  dmh_host_free(void *p);
 int  dmh_preload_block(DAZZ_DB *block);
 void dmh_release_block(DAZZ_DB *block);
 
+/* Load_All_Reads on the device (replaces DB.c:1389-1437 + Uncompress_Read DB.c:342-361 for a block the
+ * driver has only opened): `bps` = the block's slice of the .bps file as it lies on disk (4 bases per byte,
+ * first base in the top bits), `coff[i]` = byte offset of read i's record inside the slice (ascending),
+ * block->reads[0..nreads] = rlen and boff exactly as Load_All_Reads sets them (boff[i+1] = boff[i] + rlen + 1).
+ * The compressed bytes (a quarter of the block) are uploaded and unpacked by a kernel into the same device
+ * layout dmh_preload_block produces; block->bases is never read and may be NULL.  The copy stays resident
+ * until dmh_release_block.  `bps` may be freed on return.  dmh_download_block copies the device image
+ * (separator + bases, reads[nreads].boff + 1 bytes) back, for tests.  Return 0.                           */
+int  dmh_preload_block_2bit(DAZZ_DB *block, const unsigned char *bps, int64_t nbytes, const int64_t *coff);
+int  dmh_download_block(DAZZ_DB *block, unsigned char *out);
+
 /* Keep REF indices after Match_Filter (index replicated per GPU): when set,
  * Match_Filter does not consume btable; release it with dmh_free_index.                     */
 void dmh_retain_ref_index(int on);

@@ -16,6 +16,7 @@ ap.add_argument("--blocks", type=int, default=2)
 ap.add_argument("--reads", type=int, default=20000)
 ap.add_argument("--repeat", action="store_true")
 ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--report-mode", type=int, default=0, help="dmh_async_report mode while mapping (0/1/2)")
 a = ap.parse_args()
 rng = np.random.default_rng(77)
 clen = int(a.ref_mbp * 1e6 / a.contigs)
@@ -36,7 +37,10 @@ print("db written %.1fs, %d reads, %.0f Mbp ref" % (time.time() - t, len(seqs), 
 capi.lib().dmh_timing_enable(1)
 capi.lib().dmh_timing_reset()
 t = time.time()
+capi.lib().dmh_async_report(a.report_mode)
 tm = driver.map_db(d, "REF", "READS", threads=4, mem_limit=64 << 30)
+capi.lib().dmh_report_wait()
+capi.lib().dmh_async_report(0)
 t_hip = time.time() - t
 print({k: round(v["ms"], 1) for k, v in sorted(capi.timings().items(), key=lambda kv: -kv[1]["ms"])[:14]})
 print("hip %.2fs (incl. DB load)" % t_hip, tm, flush=True)

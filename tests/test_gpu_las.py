@@ -337,6 +337,42 @@ def test_dispatcher_maps_every_read_block(tmp_path):
         _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
         _, hr = las.read_las_set(os.path.join(d, "las_disp2"), b + ".REF.M@.las")
         assert rr == hr, b
+    # the reference's own loop shape: reads decoded on the host, REF index rebuilt per block, synchronous Reporter
+    cmd4 = cmd[:-1] + [os.path.join(d, "las_disp3"), "--host-decode", "--rebuild-ref", "--report-mode", "0"]
+    p4 = subprocess.run(cmd4, env=env, capture_output=True, text=True, timeout=600)
+    assert p4.returncode == 0, p4.stdout[-1500:] + p4.stderr[-1500:]
+    for b in blocks:
+        for t in range(1, 5):
+            fn = "%s.REF.M%d.las" % (b, t)
+            assert open(os.path.join(d, "las_disp", fn), "rb").read() == open(os.path.join(d, "las_disp3", fn), "rb").read(), fn
+
+
+def test_device_side_block_decode_equals_load_all_reads(tmp_path):
+    """dmh_preload_block_2bit (the .bps slice uploaded as it is and unpacked by a kernel) leaves the same
+    device image as uploading the host-decoded block: read lengths of every residue mod 4, one-base reads,
+    a trimmed view whose dropped reads leave gaps in the slice, several blocks."""
+    rng = np.random.default_rng(5)
+    lens = [1, 2, 3, 4, 5, 6, 7, 8, 4095, 4096, 4097, 16383, 16385, 40001] + [int(x) for x in rng.integers(1, 9000, 300)]
+    seqs = [rng.integers(0, 4, n).astype(np.uint8) for n in lens]
+    best = [i % 5 != 2 for i in range(len(seqs))]
+    d = str(tmp_path)
+    dazzdb.write_db(d, "R", seqs, block_size=600000, cutoff=3, all_reads=False, best=best)
+    nb, _ = dazzdb.read_stub(os.path.join(d, "R.db"))
+    assert nb >= 2
+    total = 0
+    for part in list(range(1, nb + 1)) + [0]:
+        host = dazzdb.load_db(os.path.join(d, "R.db"), part=part)
+        dev = dazzdb.load_db(os.path.join(d, "R.db"), part=part, packed=True)
+        assert dev.bases is None and dev.nreads == host.nreads
+        assert (dev.reads == host.reads).all()
+        dev.preload()
+        img = dev.download()
+        L = int(host.reads[host.nreads + 1]["boff"])
+        assert (img == host.bases[:L + 1]).all(), part
+        dev.release()
+        total += host.nreads
+    kept = sum(1 for s, b in zip(seqs, best) if len(s) >= 3 and b)
+    assert total == 2 * kept
 
 
 def test_dispatcher_finish_writes_final_las(tmp_path):
