@@ -329,6 +329,8 @@ void block_ready(BlockDev &bd)
   HIP_CHECK(hipStreamWaitEvent(stream(), bd.uploaded, 0));
   HIP_CHECK(hipEventDestroy(bd.uploaded));
   bd.uploaded = nullptr;
+  for (void *&t : bd.d_tmp)          // (the main stream is behind the decode now: whoever gets this memory next, too)
+    { dev_free(t); t = nullptr; }
 }
 
 void free_blockdev(BlockDev &bd)
@@ -337,6 +339,8 @@ void free_blockdev(BlockDev &bd)
       HIP_CHECK(hipEventDestroy(bd.uploaded));
       bd.uploaded = nullptr;
     }
+  for (void *&t : bd.d_tmp)
+    { dev_free(t); t = nullptr; }
   dev_free(bd.d_raw);
   dev_free(bd.d_boff);
   dev_free(bd.d_pkraw);
@@ -559,20 +563,52 @@ static int preload_block_2bit(DAZZ_DB *block, const uint8_t *bps, int64_t nbytes
   bd.d_boff  = (int64_t *) dev_alloc(sizeof(int64_t) * (n + 1), "block read offsets");
   uint8_t *d_bps  = (uint8_t *) dev_alloc((size_t) nbytes, "compressed block");
   int64_t *d_coff = (int64_t *) dev_alloc(sizeof(int64_t) * n, "compressed read offsets");
-  std::vector<int64_t> off(n + 1);
-  for (int i = 0; i <= n; i++) off[i] = block->reads[i].boff;
-  copy_h2d(bd.d_boff, off.data(), sizeof(int64_t) * (n + 1));
-  copy_h2d(d_coff, coff, sizeof(int64_t) * n);
-  copy_h2d(d_bps, bps, (size_t) nbytes);
-  { StageTimer tm("unpack_2bit", (double) nbytes + (double) bd.L);
-    hipLaunchKernelGGL(k_unpack_seps, dim3(ceil_div(n, 256)), dim3(256), 0, stream(), (const int64_t *) bd.d_boff, n, bd.d_raw);
-    hipLaunchKernelGGL(k_unpack_2bit, dim3((unsigned int) ceil_div(nbytes, UNPACK_SPAN)), dim3(UNPACK_THREADS), 0, stream(),
+  // a slice in page-locked memory (dmh_host_alloc) goes up on the upload stream, decode included, without
+  // the host or the main stream waiting: the first kernel that reads the block waits for it (block_ready)
+  const bool async = is_pinned_host(bps);
+  hipStream_t us = async ? g_upstream : stream();
+  if (async)
+    { static int64_t   *h_off = nullptr;       // page-locked staging for both offset arrays, reused per call
+      static size_t     h_cap = 0;
+      static hipEvent_t h_free = nullptr;
+      if (h_free == nullptr) HIP_CHECK(hipEventCreateWithFlags(&h_free, hipEventDisableTiming));
+      else HIP_CHECK(hipEventSynchronize(h_free));
+      if ((size_t) 2 * n + 1 > h_cap)
+        { if (h_off) (void) hipHostFree(h_off);
+          h_cap = (size_t) 2 * n + 1 + 2048;
+          HIP_CHECK(hipHostMalloc((void **) &h_off, sizeof(int64_t) * h_cap, hipHostMallocDefault));
+        }
+      for (int i = 0; i <= n; i++) h_off[i] = block->reads[i].boff;
+      memcpy(h_off + n + 1, coff, sizeof(int64_t) * n);
+      HIP_CHECK(hipMemcpyAsync(bd.d_boff, h_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, us));
+      HIP_CHECK(hipMemcpyAsync(d_coff, h_off + n + 1, sizeof(int64_t) * n, hipMemcpyHostToDevice, us));
+      HIP_CHECK(hipEventRecord(h_free, us));
+      HIP_CHECK(hipMemcpyAsync(d_bps, bps, (size_t) nbytes, hipMemcpyHostToDevice, us));
+    }
+  else
+    { std::vector<int64_t> off(n + 1);
+      for (int i = 0; i <= n; i++) off[i] = block->reads[i].boff;
+      copy_h2d(bd.d_boff, off.data(), sizeof(int64_t) * (n + 1));
+      copy_h2d(d_coff, coff, sizeof(int64_t) * n);
+      copy_h2d(d_bps, bps, (size_t) nbytes);
+    }
+  { StageTimer tm("unpack_2bit", (double) nbytes + (double) bd.L, us);
+    hipLaunchKernelGGL(k_unpack_seps, dim3(ceil_div(n, 256)), dim3(256), 0, us, (const int64_t *) bd.d_boff, n, bd.d_raw);
+    hipLaunchKernelGGL(k_unpack_2bit, dim3((unsigned int) ceil_div(nbytes, UNPACK_SPAN)), dim3(UNPACK_THREADS), 0, us,
                        (const uint8_t *) d_bps, nbytes, (const int64_t *) d_coff, (const int64_t *) bd.d_boff, n, bd.d_raw);
     HIP_CHECK(hipGetLastError());
   }
-  HIP_CHECK(hipStreamSynchronize(stream()));      // the caller may free `bps` now
-  dev_free(d_bps);
-  dev_free(d_coff);
+  if (async)
+    { HIP_CHECK(hipEventCreateWithFlags(&bd.uploaded, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(bd.uploaded, us));
+      bd.d_tmp[0] = d_bps;              // freed once the main stream has been made to wait for the decode
+      bd.d_tmp[1] = d_coff;
+    }
+  else
+    { HIP_CHECK(hipStreamSynchronize(us));
+      dev_free(d_bps);
+      dev_free(d_coff);
+    }
   st.blocks[block] = bd;
   return 0;
 }

@@ -30,6 +30,7 @@ struct BlockDev
   uint64_t stamp   = 0;         // cheap content fingerprint (detects in-place complement)
   bool     pinned  = false;     // uploaded through dmh_preload_block
   bool     decoded = false;     // made by dmh_preload_block_2bit: the host block has no bases
+  void    *d_tmp[2] = {nullptr, nullptr};   // upload scratch of the device-side decode, until block_ready()
   hipEvent_t uploaded = nullptr; // bases still on their way (DMA on the upload stream): block_ready() waits
   const uint8_t *d_bases() const { return d_raw + 1; }
   const uint64_t *d_pk() const { return d_pkraw + 2; }

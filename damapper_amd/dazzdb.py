@@ -327,6 +327,8 @@ class Block:
     packed: Optional[np.ndarray] = None      # load_db(packed=True): the block's slice of the .bps file; bases is None
     coff: Optional[np.ndarray] = None        # int64[nreads]: byte offset of each read's record inside `packed`
     resident: bool = False                   # the device holds the block (preload() done)
+    keep: Optional[np.ndarray] = None        # the uploaded slice: a page-locked one goes up asynchronously and has
+                                             # to stay as it is until a call that uses the block has returned
 
     def preload(self) -> None:
         """Make the block resident in HBM before it is used: a packed block is uploaded as the 2-bit bytes
@@ -337,7 +339,7 @@ class Block:
             return
         if self.packed is not None:
             capi.lib().dmh_preload_block_2bit(self.ptr(), self.packed.ctypes.data, len(self.packed), self.coff.ctypes.data)
-            self.packed = None               # the device copy is the block now
+            self.keep, self.packed = self.packed, None      # the device copy is the block now
         else:
             capi.lib().dmh_preload_block(self.ptr())
         self.resident = True
@@ -347,6 +349,7 @@ class Block:
         if self.resident:
             capi.lib().dmh_release_block(self.ptr())
             self.resident = False
+            self.keep = None
 
     def download(self) -> np.ndarray:
         """The device image of a resident block (separator + bases), for tests."""
@@ -429,9 +432,23 @@ class Block:
                     d[lo:hi] = int(self.reads[i + 1]["rlen"]) - d[lo:hi][::-1]
 
 
+_pin_pool: List[Tuple[int, int]] = []       # (capacity, address) of page-locked buffers waiting for re-use
+_PIN_GRAIN = 16 << 20
+_PIN_KEEP = 6
+
+
+def _pin_return(L, cap: int, p: int) -> None:
+    if len(_pin_pool) < _PIN_KEEP:
+        _pin_pool.append((cap, p))
+    else:
+        L.dmh_host_free(p)
+
+
 def host_bytes(n: int, pinned: bool) -> np.ndarray:
     """n uint8s; pinned=True asks libdamapper_hip for page-locked memory (dmh_host_alloc) so that the
-    block is uploaded by one DMA without staging.  Falls back to ordinary memory without a device."""
+    block is uploaded by one DMA without staging.  Page-locking is slow (and stalls other HIP calls), so
+    buffers are handed back to a small pool when their array dies and re-used for the next block.
+    Falls back to ordinary memory without a device."""
     if pinned:
         try:
             import weakref
@@ -441,10 +458,17 @@ def host_bytes(n: int, pinned: bool) -> np.ndarray:
             L.dmh_host_alloc.restype = C.c_void_p
             L.dmh_host_free.argtypes = [C.c_void_p]
             L.dmh_device_count.restype = C.c_int
-            p = L.dmh_host_alloc(n) if L.dmh_device_count() > 0 else None
+            p, cap = None, 0
+            fit = [(c, a) for (c, a) in _pin_pool if c >= n]
+            if fit:
+                cap, p = min(fit)
+                _pin_pool.remove((cap, p))
+            elif L.dmh_device_count() > 0:
+                cap = (max(n, 1) + _PIN_GRAIN - 1) // _PIN_GRAIN * _PIN_GRAIN
+                p = L.dmh_host_alloc(cap)
             if p:
                 arr = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p))
-                weakref.finalize(arr, L.dmh_host_free, p)
+                weakref.finalize(arr, _pin_return, L, cap, p)
                 return arr
         except (OSError, AttributeError):
             pass

@@ -74,19 +74,22 @@ def _worker(args) -> None:
     capi.lib().dmh_async_report(args.report_mode)
     mapped = []
     cur = pending.pop(0).result() if pending else None
-    t_all = time.time()
+    t_all = t_loop = time.time()
     for i, b in enumerate(todo):
         name = "%s.%d" % (read_root, b)
         nxt = pending.pop(0).result() if pending else None
         if i + 2 < len(todo):
             pending.append(loader.submit(load, todo[i + 2]))
         t0 = time.time()
-        m.map_block(cur, name, ref_blocks, ref_whole, ref_root, mflag=mflag, next_reads=nxt)
+        tm = m.map_block(cur, name, ref_blocks, ref_whole, ref_root, mflag=mflag, next_reads=nxt)
         cur.release()
         mapped.append(name)
         dt = time.time() - t0
-        print("[gpu %d] %s: %d reads, %.1f Mbp in %.2f s (%.3f Gbp/s)" %
-              (args.rank, name, cur.nreads, cur.db.totlen / 1e6, dt, cur.db.totlen / dt / 1e9), flush=True)
+        print("[gpu %d] %s: %d reads, %.1f Mbp in %.2f s (%.3f Gbp/s)%s" %
+              (args.rank, name, cur.nreads, cur.db.totlen / 1e6, dt, cur.db.totlen / dt / 1e9,
+               "  [wait for loader %.3f, index %.3f, filter %.3f, report %.3f]" %
+               (t0 - t_loop, tm["index_reads"], tm["filter"], tm["report"]) if args.v else ""), flush=True)
+        t_loop = time.time()
         cur = nxt
     capi.lib().dmh_report_wait()
     capi.lib().dmh_async_report(0)

@@ -159,7 +159,9 @@ void dmh_release_block(DAZZ_DB *block);
  * block->reads[0..nreads] = rlen and boff exactly as Load_All_Reads sets them (boff[i+1] = boff[i] + rlen + 1).
  * The compressed bytes (a quarter of the block) are uploaded and unpacked by a kernel into the same device
  * layout dmh_preload_block produces; block->bases is never read and may be NULL.  The copy stays resident
- * until dmh_release_block.  `bps` may be freed on return.  dmh_download_block copies the device image
+ * until dmh_release_block.  `bps` may be freed on return -- unless it lies in page-locked memory
+ * (dmh_host_alloc): then upload and decode run asynchronously on the upload stream and the slice has to stay
+ * unchanged until a library call that uses the block has returned.  dmh_download_block copies the device image
  * (separator + bases, reads[nreads].boff + 1 bytes) back, for tests.  Return 0.                           */
 int  dmh_preload_block_2bit(DAZZ_DB *block, const unsigned char *bps, int64_t nbytes, const int64_t *coff);
 int  dmh_download_block(DAZZ_DB *block, unsigned char *out);
