@@ -44,6 +44,27 @@ def make_block(genome, nreads, seed, tfirst=0, part=0, pinned=False):
                                  path=b"./.READS", pinned=pinned)
 
 
+def pack_block(blk):
+    """The block as it lies in a .bps file (4 bases per byte) with Load_All_Reads' read records and no bases:
+    what `--pcie packed` uploads (dmh_preload_block_2bit decodes it on the device)."""
+    n = blk.nreads
+    lens = blk.reads["rlen"][1:n + 1].astype(np.int64)
+    offs = blk.reads["boff"][1:n + 1].astype(np.int64)
+    clen = (lens + 3) // 4
+    coff = np.concatenate(([0], np.cumsum(clen)))
+    out = dazzdb.host_bytes(int(coff[-1]), True)
+    for i in range(n):
+        s = np.zeros(int(clen[i]) * 4, dtype=np.uint8)
+        s[:lens[i]] = blk.bases[1 + offs[i]:1 + offs[i] + lens[i]]
+        q = s.reshape(-1, 4)
+        out[coff[i]:coff[i + 1]] = (q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]
+    hb = dazzdb.make_block([], tfirst=int(blk.db.tfirst), part=int(blk.db.part), path=blk.path,
+                           freq=[blk.db.freq[j] for j in range(4)], lens=lens)
+    hb.slice = out
+    hb.coff = np.ascontiguousarray(coff[:-1])
+    return hb
+
+
 def shard_blocks(nblocks, rank, world):
     """Read blocks are independent units: block b goes to rank b mod world."""
     return [b for b in range(nblocks) if b % world == rank]
@@ -85,9 +106,10 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=GENOME_LEN / 1e6,
                     help="reference size in Mbp (default 4.6 = configs[1]; 250 approximates configs[2], one contig per "
                          "~125 Mbp, one REF block)")
-    ap.add_argument("--pcie", choices=["pinned", "pageable"], default=None,
+    ap.add_argument("--pcie", choices=["pinned", "pageable", "packed"], default=None,
                     help="PCIe-inclusive rate: read blocks are NOT resident, every step uploads its block from "
-                         "page-locked (dmh_host_alloc) or ordinary host memory inside the timed region")
+                         "page-locked (dmh_host_alloc) or ordinary host memory inside the timed region; packed = "
+                         "as the 2-bit bytes of the .bps file (a quarter of the volume), decoded by a kernel")
     ap.add_argument("--sync-report", action="store_true", help="write the .las files inside Reporter (drop-in behaviour)")
     ap.add_argument("--report-mode", type=int, default=2, choices=[0, 1, 2],
                     help="0 = Reporter synchronous, 1 = .las selection/writing on a worker thread, 2 (default) = also the "
@@ -124,6 +146,8 @@ def main():
     for b in range(nblk):
         blocks.append(make_block(genome, args.block_reads, 1000 + 97 * rank + b, tfirst=b * args.block_reads, part=b + 1,
                                  pinned=(args.pcie == "pinned")))
+        if args.pcie == "packed":
+            blocks[-1] = pack_block(blocks[-1])
     # REF blocks as DBsplit would cut them: whole contigs, at most ~375 Mbp (< 2^31 k-mers) per block
     ref_blocks, first, acc = [], 0, 0
     for ci in range(len(genome) + 1):
@@ -152,8 +176,14 @@ def main():
     def step(i):
         blk = blocks[i % nblk]
         nxt = blocks[(i + 1) % nblk] if (i < last and not args.no_prefetch and nblk > 1) else None
+        if args.pcie == "packed":
+            for b in (blk, nxt):                 # map_block uploads (2-bit) and decodes what carries a slice
+                if b is not None and not b.resident:
+                    b.packed = b.slice
         t = m.map_block(blk, "READS.%d" % (i % nblk + 1), ref_blocks, ref_whole, "REF", next_reads=nxt)
-        if args.pcie is not None:
+        if args.pcie == "packed":
+            blk.release()
+        elif args.pcie is not None:
             L.dmh_release_block(blk.ptr())       # the next visit uploads it again
         return t
 
@@ -243,7 +273,9 @@ def main():
                                    "(10 kb, 15%% err), %d reads per block/step, %d distinct blocks per GPU, "
                                    "-k20 -e.85 -s100, REF index %s" %
                                    (args.block_reads, nblk, ("rebuilt per read block" if args.rebuild_ref else "built once per GPU, resident") +
-                                    ("" if args.pcie is None else "; read blocks uploaded inside the timed region from %s host memory" % args.pcie)),
+                                    ("" if args.pcie is None else ("; read blocks uploaded inside the timed region " +
+                                     ("as 2-bit .bps bytes from page-locked memory and decoded on the device" if args.pcie == "packed"
+                                      else "from %s host memory" % args.pcie)))),
                        "read_bases_per_step": int(blocks[0].db.totlen), "parallelism": "read blocks sharded x%d" % world},
             "roofline": roof, "cpu_baseline": cpu,
             "host_seconds": {k: round(v, 3) for k, v in host.items()},
