@@ -62,29 +62,52 @@ struct ChainArgs
   unsigned int   *nretry;             //         (the 64-lane launch that follows walks this list)
   unsigned int   *out_count;
   ChainSummary   *out;
+  uint32_t        pile_cap;           // k_chain_pile: entries of LDS it may use (<= PILE_CAP; smaller in tests)
 };
 
-// reductions over the G lanes of a group (G a power of two, groups aligned: xor stays inside)
-template <int G>
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
-{
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1)
-    { uint64_t t = __shfl_xor(v, o);
-      v = (t < v) ? t : v;
+// Reductions over the G lanes of a group (G = 16, 32 or 64; groups are aligned).  The 16 lanes of a DPP row
+// are reduced with four data-parallel-primitive moves (lane ^ 1, lane ^ 2, mirror within 8, mirror within 16)
+// that cost one VALU operation each -- a __shfl_xor goes through the LDS crossbar (ds_bpermute) and a
+// 64-bit butterfly of them was a third of the time of a hit.  64-bit keys are reduced in two 32-bit
+// rounds: the high words first, then the low words of the lanes that hold the winning high word.
+template <bool MAX>
+__device__ __forceinline__ uint32_t row16_reduce_u32(uint32_t v)
+{ auto op = [](uint32_t a, uint32_t b) -> uint32_t { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  v = op(v, (uint32_t) __builtin_amdgcn_update_dpp((int) v, (int) v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+  v = op(v, (uint32_t) __builtin_amdgcn_update_dpp((int) v, (int) v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+  v = op(v, (uint32_t) __builtin_amdgcn_update_dpp((int) v, (int) v, 0x141, 0xf, 0xf, false));    // row_half_mirror
+  v = op(v, (uint32_t) __builtin_amdgcn_update_dpp((int) v, (int) v, 0x140, 0xf, 0xf, false));    // row_mirror
+  return v;
+}
+
+template <int G, bool MAX>
+__device__ __forceinline__ uint32_t group_reduce_u32(uint32_t v)
+{ auto op = [](uint32_t a, uint32_t b) -> uint32_t { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  v = row16_reduce_u32<MAX>(v);
+  if (G == 32)
+    v = op(v, (uint32_t) __shfl_xor((int) v, 16));
+  else if (G == 64)
+    { uint32_t a = (uint32_t) __builtin_amdgcn_readlane((int) v, 0),  b = (uint32_t) __builtin_amdgcn_readlane((int) v, 16);
+      uint32_t c = (uint32_t) __builtin_amdgcn_readlane((int) v, 32), d = (uint32_t) __builtin_amdgcn_readlane((int) v, 48);
+      v = op(op(a, b), op(c, d));
     }
   return v;
 }
 
 template <int G>
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{ const uint32_t hi = (uint32_t) (v >> 32);
+  const uint32_t mh = group_reduce_u32<G, false>(hi);
+  const uint32_t ml = group_reduce_u32<G, false>(hi == mh ? (uint32_t) v : 0xffffffffu);
+  return ((uint64_t) mh << 32) | ml;
+}
+
+template <int G>
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
-{
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1)
-    { uint64_t t = __shfl_xor(v, o);
-      v = (t > v) ? t : v;
-    }
-  return v;
+{ const uint32_t hi = (uint32_t) (v >> 32);
+  const uint32_t mh = group_reduce_u32<G, true>(hi);
+  const uint32_t ml = group_reduce_u32<G, true>(hi == mh ? (uint32_t) v : 0u);
+  return ((uint64_t) mh << 32) | ml;
 }
 
 // G lanes per group: the live window of a 10 kb read holds a few dozen hits, so a whole wavefront
@@ -93,8 +116,8 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
 // 64/G groups share a wavefront's instruction stream.  Groups with thousands of hits (repeats: the
 // live window itself holds thousands) want all 64 lanes on their scan instead, so the host launches
 // the kernel twice: G = 16 over the small groups, G = 64 over the big ones.
-template <int G>
-__global__ __launch_bounds__(256) void k_chain(ChainArgs A)
+template <int G, int LCAP = (G < 64 ? 96 : 0), int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void k_chain(ChainArgs A)
 { const int      lane  = threadIdx.x & (G - 1);                 // lane within the group
   const int      sbase = (threadIdx.x & 63) & ~(G - 1);         // first lane of the group in its wavefront
   const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
@@ -105,10 +128,9 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
   // G < 64: the live window sits in LDS together with each entry's chain origin, so a hit costs one
   // LDS scan and ONE global round trip (the origin's best score) instead of three (window, origin,
   // best score).  A window that outgrows LCAP entries hands its group to the 64-lane launch.
-  constexpr bool LDSLIVE = (G < 64);
-  constexpr int  LCAP    = 96;
-  __shared__ uint4    s_live[LDSLIVE ? (256 / G) * LCAP : 1];
-  __shared__ uint32_t s_root[LDSLIVE ? (256 / G) * LCAP : 1];
+  constexpr bool LDSLIVE = (LCAP > 0);
+  __shared__ uint4    s_live[LDSLIVE ? (BLOCK / G) * LCAP : 1];
+  __shared__ uint32_t s_root[LDSLIVE ? (BLOCK / G) * LCAP : 1];
   uint4    *const lds_live = s_live + (LDSLIVE ? (threadIdx.x / G) * LCAP : 0);
   uint32_t *const lds_root = s_root + (LDSLIVE ? (threadIdx.x / G) * LCAP : 0);
 
@@ -330,6 +352,270 @@ __global__ __launch_bounds__(256) void k_chain(ChainArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+//  Repeat piles: one WORKGROUP per group.  A (read, contig) group of a repeat family has tens of thousands
+//  of hits and a live window of thousands; one wavefront walking it (k_chain<64>) scans dozens of 64-entry
+//  chunks of global memory per hit and sets the run time of the whole pass.  Here the window lives in LDS
+//  (PILE_CAP entries + their chain origins), PILE_THREADS lanes scan it, entries are never moved while
+//  hits are added (expired and removed ones become tombstones; the list is compacted when it has doubled),
+//  so a hit costs one strided LDS scan, one reduction over the wavefronts and the sequential update.
+//  Same rules and same results as k_chain (the window is an unordered set with unique keys).  A window
+//  that outgrows LDS sends its group to the 64-lane launch (A.retry).
+// ---------------------------------------------------------------------------------------
+constexpr int PILE_THREADS = 512;
+constexpr int PILE_WAVES   = PILE_THREADS / 64;
+constexpr int PILE_CAP     = 6912;                   // 108 KB of entries + 27 KB of origins
+constexpr int PILE_BCACHE  = 2048;                   // direct-mapped cache of bestcost[] (thread 0 is its only writer)
+
+#ifdef DMH_CHAIN_PROFILE
+__device__ unsigned long long g_cprof[16];
+#define CPROF_T0() long long _t0 = clock64()
+#define CPROF_LAP(i) do { long long _t1 = clock64(); if (threadIdx.x == 0) atomicAdd(&g_cprof[i], (unsigned long long) (_t1 - _t0)); _t0 = _t1; } while (0)
+#define CPROF_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_cprof[i], (unsigned long long) (v)); } while (0)
+#else
+#define CPROF_T0() do {} while (0)
+#define CPROF_LAP(i) do {} while (0)
+#define CPROF_ADD(i, v) do {} while (0)
+#endif
+
+// The waves of a pile's workgroup meet twice per hit and exchange LDS data only: a barrier that waits for the
+// wave's LDS operations but NOT for its global stores (thread 0's six per hit, each acknowledged by the L2
+// long after it was issued; __syncthreads would wait for them every time).
+__device__ __forceinline__ void lds_barrier()
+{ asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
+{ __shared__ uint4    s_live[PILE_CAP];
+  __shared__ uint32_t s_root[PILE_CAP];
+  __shared__ uint64_t s_key[2][PILE_WAVES];
+  __shared__ uint32_t s_idx[2][PILE_WAVES];
+  __shared__ uint32_t s_cnt[PILE_WAVES];
+  __shared__ uint32_t s_g;
+  __shared__ uint2    s_bc[PILE_BCACHE];             // {origin, its best score}: saves the global round trip per hit
+  const int      tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint64_t lt  = (1ull << lane) - 1ull;
+  const int      K   = A.K;
+  const uint32_t nwork = *A.nonly;
+
+  while (true)
+    { __syncthreads();
+      if (tid == 0) s_g = atomicAdd(A.ticket, 1u);
+      __syncthreads();
+      uint32_t g = s_g;
+      if (g >= nwork) break;
+      g = A.only[g];
+      const uint32_t g0 = A.gstart[g], g1 = A.gstart[g + 1];
+      uint32_t n = 0;                      // entries in the list, tombstones included
+      uint32_t hw = A.pile_cap < 1024u ? A.pile_cap : 1024u;      // compact when the list reaches this length
+      bool     spill = false;
+      for (int x = tid; x < PILE_BCACHE; x += PILE_THREADS) s_bc[x] = make_uint2(NIL, 0);
+      uint64_t nkey = A.keys[g0];          // the next hit, fetched one round ahead
+      uint32_t nval = A.vals[g0];
+
+      for (uint32_t j = g0; j < g1; j++)
+        { const int apos = (int) (nkey & A.pmask) + 1;            // map.c:1784-1785
+          const int bpos = (int) nval + 1;
+          const int diag = apos - bpos;
+          const int thresh = bpos - MAX_GAP;
+          { const uint32_t jn = (j + 1 < g1) ? j + 1 : j;
+            nkey = A.keys[jn];
+            nval = A.vals[jn];
+          }
+
+          // ---- expiry (map.c:1787-1796) + neighbour queries (map.c:1262-1318) over the thread's entries
+          CPROF_T0();
+          CPROF_ADD(6, 1);
+          CPROF_ADD(7, n);
+          uint64_t myL = ~0ull, myR = 0;
+          uint32_t myLi = 0, myRi = 0;
+#pragma unroll 2
+          for (uint32_t i = tid; i < n; i += PILE_THREADS)
+            { const uint4 en = s_live[i];
+              const int  ax = (int) en.y, bx = (int) en.z;
+              const int  dx = ax - bx;
+              const bool there = (en.x != NIL);
+              const bool old   = there && (ax < apos - MAX_GAP);
+              if (old)
+                { A.state[en.x] = ST_DEAD;
+                  s_live[i].x = NIL;
+                }
+              const uint64_t db = (uint64_t) ((uint32_t) dx + 0x80000000u);
+              const uint64_t lk = (db << 32) | (uint32_t) (0x7fffffff - ax);
+              const uint64_t rk = (db << 32) | (uint32_t) ax;
+              const bool cl = there && !old && dx > diag && bx >= thresh;
+              const bool cr = there && !old && dx <= diag && bx <= bpos;
+              if (cl && lk < myL) { myL = lk; myLi = i; }
+              if (cr && rk > myR) { myR = rk; myRi = i; }
+            }
+          CPROF_LAP(0);
+          { uint64_t lm = wave_min_u64<64>(myL);
+            uint64_t rm = wave_max_u64<64>(myR);
+            uint64_t bl = __ballot(myL == lm), br = __ballot(myR == rm);
+            if (lane == __ffsll((long long) bl) - 1) { s_key[0][w] = lm; s_idx[0][w] = myLi; }
+            if (lane == __ffsll((long long) br) - 1) { s_key[1][w] = rm; s_idx[1][w] = myRi; }
+          }
+          CPROF_LAP(1);
+          lds_barrier();
+          CPROF_LAP(2);
+
+          // ---- the sequential part (map.c:1811-1862), on thread 0; the others wait at the barrier
+          if (tid == 0)
+            { uint64_t lm = ~0ull, rm = 0;
+              uint32_t li = 0, ri = 0;
+              for (int x = 0; x < PILE_WAVES; x++)
+                { if (s_key[0][x] < lm) { lm = s_key[0][x]; li = s_idx[0][x]; }
+                  if (s_key[1][x] > rm) { rm = s_key[1][x]; ri = s_idx[1][x]; }
+                }
+              uint4 Le = make_uint4(NIL, 0, 0, 0), Re = make_uint4(NIL, 0, 0, 0);
+              if (lm != ~0ull) Le = s_live[li];
+              if (rm != 0)     Re = s_live[ri];
+              int lcost = 0, rcost = 0;
+              if (Le.x != NIL)
+                lcost = (apos >= (int) Le.y + K) ? (int) Le.w + K : (int) Le.w + (apos - (int) Le.y);
+              if (Re.x != NIL)
+                rcost = (bpos >= (int) Re.z + K) ? (int) Re.w + K : (int) Re.w + (bpos - (int) Re.z);
+              if (lcost > rcost) rcost = 0; else lcost = 0;
+
+              uint4    pe = make_uint4(NIL, 0, 0, 0);
+              uint32_t ppos = 0;
+              int      c = K;
+              if (lcost > 0)      { pe = Le; ppos = li; c = lcost; }
+              else if (rcost > 0) { pe = Re; ppos = ri; c = rcost; }
+
+              uint32_t jroot = j;
+              if (pe.x != NIL)
+                { const uint32_t root = s_root[ppos];
+                  const uint2    cb   = s_bc[root & (PILE_BCACHE - 1)];
+                  const int      bc   = (cb.x == root) ? (int) cb.y : A.bestcost[root];
+                  jroot = root;
+                  A.from[j]   = pe.x;
+                  A.cost[j]   = c;
+                  A.rootof[j] = root;
+                  A.state[j]  = ST_LIVE;
+                  if (c >= bc)
+                    { int pa = (int) pe.y;
+                      int pd = pa - (int) pe.z;
+                      int dd = pd - diag;
+                      if (dd < 0) dd = -dd;
+                      const bool kill = ((double) dd <= .2 * (double) (apos - pa));      // map.c:1837,1852
+                      A.best[root]     = j;
+                      A.bestcost[root] = c;
+                      s_bc[root & (PILE_BCACHE - 1)] = make_uint2(root, (uint32_t) c);
+                      if (kill)
+                        { A.state[pe.x] = ST_DEAD;
+                          s_live[ppos].x = NIL;
+                        }
+                    }
+                  else if (cb.x != root)
+                    s_bc[root & (PILE_BCACHE - 1)] = make_uint2(root, (uint32_t) bc);
+                }
+              else
+                { A.from[j]     = NIL;
+                  A.cost[j]     = K;
+                  A.rootof[j]   = j;
+                  A.best[j]     = j;
+                  A.bestcost[j] = K;
+                  A.state[j]    = ST_LIVE;
+                  s_bc[j & (PILE_BCACHE - 1)] = make_uint2(j, (uint32_t) K);
+                }
+              s_live[n] = make_uint4(j, (uint32_t) apos, (uint32_t) bpos, (uint32_t) c);      // (n < PILE_CAP, see below)
+              s_root[n] = jroot;
+            }
+          n += 1;
+          CPROF_LAP(3);
+          lds_barrier();
+          CPROF_LAP(4);
+
+          // ---- the list has doubled (or is full): squeeze the tombstones out, through the group's slice
+          //      of the global scratch arrays (any order will do)
+          if (n >= hw)
+            { uint32_t mine = 0;
+              for (uint32_t base = (uint32_t) w * 64; base < n; base += PILE_THREADS)
+                { uint32_t i = base + lane;
+                  mine += (uint32_t) __popcll(__ballot(i < n && s_live[i].x != NIL));
+                }
+              if (lane == 0) s_cnt[w] = mine;
+              __syncthreads();
+              uint32_t pre = 0, alive = 0;
+              for (int x = 0; x < PILE_WAVES; x++)
+                { if (x < w) pre += s_cnt[x];
+                  alive += s_cnt[x];
+                }
+              uint4    *gl = A.live + g0;
+              uint32_t *gr = A.tmp + g0;
+              for (uint32_t base = (uint32_t) w * 64; base < n; base += PILE_THREADS)
+                { uint32_t i = base + lane;
+                  bool     keep = (i < n && s_live[i].x != NIL);
+                  uint64_t km = __ballot(keep);
+                  if (keep)
+                    { uint32_t dst = pre + (uint32_t) __popcll(km & lt);
+                      gl[dst] = s_live[i];
+                      gr[dst] = s_root[i];
+                    }
+                  pre += (uint32_t) __popcll(km);
+                }
+              __syncthreads();
+              for (uint32_t i = tid; i < alive; i += PILE_THREADS)
+                { s_live[i] = gl[i];
+                  s_root[i] = gr[i];
+                }
+              n  = alive;
+              hw = 2 * alive + 512;
+              if (hw > A.pile_cap) hw = A.pile_cap;
+              __syncthreads();
+              CPROF_LAP(5);
+              CPROF_ADD(8, 1);
+              if (n + 64 >= A.pile_cap) { spill = true; break; }      // the window itself outgrew LDS
+            }
+        }
+      if (spill)
+        { if (tid == 0) A.retry[atomicAdd(A.nretry, 1u)] = g;
+          CPROF_ADD(9, 1);
+          continue;
+        }
+      __syncthreads();
+
+      // ---- report (as k_chain's, by the first wavefront)
+      if (w == 0)
+        { uint32_t E = 0;
+          for (uint32_t base = g0; base < g1; base += 64)
+            { uint32_t x = base + lane;
+              bool     f = false;
+              if (x < g1 && A.cost[x] >= A.hithr && A.from[x] != NIL)
+                f = (A.best[A.rootof[x]] == x);
+              uint64_t m = __ballot(f);
+              if (f) A.tmp[g0 + E + __popcll(m & lt)] = x;
+              E += __popcll(m);
+            }
+          if (E != 0)
+            { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+              uint32_t obase = 0;
+              if (lane == 0) obase = atomicAdd(A.out_count, E);
+              obase = __shfl(obase, 0);
+              for (uint32_t e = lane; e < E; e += 64)
+                { uint32_t x    = A.tmp[g0 + e];
+                  bool     live_x = (A.state[x] == ST_LIVE);
+                  int      ax   = (int) (A.keys[x] & A.pmask) + 1;
+                  int      bx   = (int) A.vals[x] + 1;
+                  int      dx   = ax - bx;
+                  uint32_t root = A.rootof[x];
+                  ChainSummary s;
+                  s.group = g;
+                  s.live  = live_x ? 1u : 0u;
+                  s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax) : (uint64_t) x;
+                  s.cost  = A.cost[x];
+                  s.ab    = (int) (A.keys[root] & A.pmask) + 1 - K;
+                  s.bb    = (int) A.vals[root] + 1 - K;
+                  s.ae    = ax;
+                  s.be    = bx;
+                  s.end   = x;
+                  A.out[obase + e] = s;
+                }
+            }
+        }
+    }
+}
+
 // Compressed Jump displacements of a kept chain (chain_length, map.c:1243-1260, and the encoding
 // loop map.c:1741-1759): links on one diagonal closer than 100 bp to the last kept point are
 // skipped.  One thread per candidate; pass 0 counts, pass 1 writes at joff[c].
@@ -364,17 +650,60 @@ __global__ void k_chain_jumps(const uint64_t *__restrict__ keys, const uint32_t 
   if (!write) jlen[c] = cnt;
 }
 
-// groups of at least `big` hits, in any order
-__global__ void k_big_groups(const uint32_t *__restrict__ gstart, uint32_t ngroups, uint32_t big,
-                             uint32_t *__restrict__ list, unsigned int *__restrict__ nlist)
+// groups of at least `big` hits, in any order; those of at least `pile` hits go to their own list
+__global__ void k_big_groups(const uint32_t *__restrict__ gstart, uint32_t ngroups, uint32_t big, uint32_t pile,
+                             uint32_t *__restrict__ list, unsigned int *__restrict__ nlist,
+                             uint32_t *__restrict__ plist, unsigned int *__restrict__ nplist)
 { uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ngroups) return;
-  if (gstart[g + 1] - gstart[g] >= big) list[atomicAdd(nlist, 1u)] = g;
+  uint32_t sz = gstart[g + 1] - gstart[g];
+  if (sz >= pile)     plist[atomicAdd(nplist, 1u)] = g;
+  else if (sz >= big) list[atomicAdd(nlist, 1u)] = g;
+}
+
+// small groups four to a wavefront (live window in LDS), big ones and windows that outgrew LDS one per
+// wavefront, repeat piles one per workgroup; dmh_test_option("chain_g") / DMH_CHAIN_G force one group width
+// for everything below the pile threshold, "chain_pile" / DMH_CHAIN_PILE move that threshold (0 = no piles)
+constexpr uint32_t BIG_GROUP = 1024;
+
+void chain_classify_groups(MergeResult &R)
+{ State &st = S();
+  static const int env_g    = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
+  static const int env_pile = getenv("DMH_CHAIN_PILE") ? atoi(getenv("DMH_CHAIN_PILE")) : 4096;
+  const int chain_g = st.opt_chain_g ? st.opt_chain_g : env_g;
+  R.pile_min = (st.opt_chain_pile >= 0) ? (uint32_t) st.opt_chain_pile : (uint32_t) env_pile;
+  R.small_hi = (chain_g == 0) ? BIG_GROUP : 0xffffffffu;
+  if (R.pile_min > 0) R.small_hi = std::min(R.small_hi, R.pile_min);
+  R.biglist.ensure((size_t) R.ngroups + 64, "big groups");
+  R.pilelist.ensure((size_t) R.ngroups + 64, "repeat piles");
+  R.gcounts.ensure(4, "group list lengths");
+  HIP_CHECK(hipMemsetAsync(R.gcounts.p, 0, 4 * sizeof(uint32_t), stream()));
+  R.npiles = 0;
+  R.classified = true;
+  if (R.ngroups == 0 || (R.small_hi == 0xffffffffu && R.pile_min == 0)) return;
+  hipLaunchKernelGGL(k_big_groups, dim3(ceil_div(R.ngroups, 256)), dim3(256), 0, stream(),
+                     (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, R.small_hi,
+                     R.pile_min > 0 ? R.pile_min : 0xffffffffu, R.biglist.p, R.gcounts.p, R.pilelist.p, R.gcounts.p + 1);
+  HIP_CHECK(hipGetLastError());
+  copy_d2h(&R.npiles, R.gcounts.p + 1, sizeof(uint32_t));
 }
 
 // ---------------------------------------------------------------------------------------
 //  Host: per-read candidate lists
 // ---------------------------------------------------------------------------------------
+
+#ifdef DMH_CHAIN_PROFILE
+}  // namespace dmh
+extern "C" void dmh_chain_profile(unsigned long long *out, int reset)
+{ HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dmh::g_cprof), sizeof(unsigned long long) * 16));
+  if (reset)
+    { unsigned long long z[16] = {0};
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(dmh::g_cprof), z, sizeof(z)));
+    }
+}
+namespace dmh {
+#endif
 
 void chain_reset_reads(const DAZZ_DB *ablock)
 { State &st = S();
@@ -409,9 +738,9 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   livebuf.ensure(nhits + 1, "chain live set");
   state.ensure(nhits, "chain state");
   tmp.ensure(nhits, "chain scratch");
-  ctl.ensure(4, "chain counters");
+  ctl.ensure(8, "chain counters");
   out.ensure(nhits / HITMIN + 64, "chain summaries");
-  HIP_CHECK(hipMemsetAsync(ctl.p, 0, 4 * sizeof(uint32_t), stream()));
+  HIP_CHECK(hipMemsetAsync(ctl.p, 0, 8 * sizeof(uint32_t), stream()));
 
   ChainArgs A;
   A.keys = R.skeys;
@@ -434,36 +763,69 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.ticket = ctl.p;
   A.out_count = ctl.p + 1;
   A.out = out.p;
+  A.pile_cap = PILE_CAP;
 
-  // small groups four to a wavefront (live window in LDS), big ones (repeat piles) and windows that
-  // outgrew LDS one per wavefront; dmh_test_option("chain_g") / DMH_CHAIN_G force one size for all
   static const int env_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
   const int chain_g = st.opt_chain_g ? st.opt_chain_g : env_g;
-  constexpr uint32_t BIG_GROUP = 1024;
-  static DevBuf<uint32_t> biglist;
-  biglist.ensure((size_t) R.ngroups + 64, "big groups");
-  A.retry  = biglist.p;          // list of the 64-lane launch: big groups + spilled windows
-  A.nretry = ctl.p + 3;
+  if (!R.classified) fatal("chain_and_filter: groups not classified");
+  A.retry  = R.biglist.p;        // list of the 64-lane launch: big groups + spilled windows
+  A.nretry = R.gcounts.p;
   { StageTimer tm("chain", 16.0 * nhits);
     const bool all64 = (chain_g == 64);
     const int  gsmall = (chain_g == 32) ? 32 : 16;
     if (!all64)
       { const int gpb = 256 / gsmall;
         int nblocks = (int) std::min<int64_t>((R.ngroups + gpb - 1) / gpb, 256 * 8);
-        if (chain_g == 0)
-          { A.size_lo = 0; A.size_hi = BIG_GROUP;
-            hipLaunchKernelGGL(k_big_groups, dim3(ceil_div(R.ngroups, 256)), dim3(256), 0, stream(),
-                               (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, BIG_GROUP, biglist.p, ctl.p + 3);
+        hipEvent_t piles_done = nullptr;
+        static DevBuf<uint32_t> pileretry;
+        if (R.npiles > 0)
+          { // the piles first: they are the longest jobs of the pass.  (Launched only when there are any:
+            // a workgroup wants nearly all of a CU's LDS and would wait for whatever else holds some.)
+            ChainArgs P = A;
+            P.ticket = ctl.p + 4;
+            P.only   = R.pilelist.p;
+            P.nonly  = R.gcounts.p + 1;
+            pileretry.ensure((size_t) R.npiles + 64, "spilled piles");
+            P.retry  = pileretry.p;
+            P.nretry = ctl.p + 6;
+            P.pile_cap = (st.opt_pile_cap >= 128 && st.opt_pile_cap < PILE_CAP) ? (uint32_t) st.opt_pile_cap : (uint32_t) PILE_CAP;
+            // on a stream of their own, next to the other two launches; piles whose window outgrows LDS are
+            // listed for a last 64-lane launch behind everything
+            static hipStream_t pstream = nullptr;
+            static hipEvent_t  ev_go = nullptr, ev_done = nullptr;
+            if (pstream == nullptr)
+              { HIP_CHECK(hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&ev_go, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+              }
+            HIP_CHECK(hipEventRecord(ev_go, stream()));
+            HIP_CHECK(hipStreamWaitEvent(pstream, ev_go, 0));
+            { StageTimer t0("chain_piles", 0.0, pstream);
+              hipLaunchKernelGGL(k_chain_pile, dim3(std::min<uint32_t>(R.npiles, 256)), dim3(PILE_THREADS), 0, pstream, P);
+            }
+            HIP_CHECK(hipEventRecord(ev_done, pstream));
+            piles_done = ev_done;
           }
-        else
-          { A.size_lo = 0; A.size_hi = 0xffffffffu; }
-        if (gsmall == 32) hipLaunchKernelGGL(k_chain<32>, dim3(nblocks), dim3(256), 0, stream(), A);
-        else              hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
-        // the list (its own ticket counter ctl[2], length ctl[3]); on read-vs-genome data it is empty
+        A.size_lo = 0; A.size_hi = R.small_hi;
+        { StageTimer t1("chain_small_groups", 0.0);
+          if (gsmall == 32) hipLaunchKernelGGL(k_chain<32>, dim3(nblocks), dim3(256), 0, stream(), A);
+          else              hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
+        }
+        // the list (its own ticket counter ctl[2]); on read-vs-genome data it is empty
         A.ticket = ctl.p + 2;
-        A.only   = biglist.p;
-        A.nonly  = ctl.p + 3;
-        hipLaunchKernelGGL(k_chain<64>, dim3(256), dim3(256), 0, stream(), A);
+        A.only   = R.biglist.p;
+        A.nonly  = R.gcounts.p;
+        { StageTimer t2("chain_listed_groups", 0.0);
+          hipLaunchKernelGGL(k_chain<64>, dim3(256), dim3(256), 0, stream(), A);
+        }
+        if (piles_done != nullptr)
+          { HIP_CHECK(hipStreamWaitEvent(stream(), piles_done, 0));
+            A.ticket = ctl.p + 7;
+            A.only   = pileretry.p;
+            A.nonly  = ctl.p + 6;
+            StageTimer t3("chain_spilled_piles", 0.0);
+            hipLaunchKernelGGL(k_chain<64>, dim3(std::min<uint32_t>((R.npiles + 3) / 4, 256)), dim3(256), 0, stream(), A);
+          }
       }
     else
       { int nblocks = (int) std::min<int64_t>((R.ngroups + 3) / 4, 256 * 8);

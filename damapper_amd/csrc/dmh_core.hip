@@ -1227,6 +1227,8 @@ int dmh_test_option(const char *key, int value)
   if (strcmp(key, "align_level") == 0)      st.opt_align_level = value;
   else if (strcmp(key, "chain_g") == 0)     st.opt_chain_g = (value == 16 || value == 32 || value == 64) ? value : 0;
   else if (strcmp(key, "pool_div") == 0)    st.opt_pool_div = value > 1 ? value : 1;
+  else if (strcmp(key, "chain_pile") == 0)  st.opt_chain_pile = value;
+  else if (strcmp(key, "pile_cap") == 0)    st.opt_pile_cap = value;
   else return -1;
   return 0;
 }

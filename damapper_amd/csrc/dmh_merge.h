@@ -14,7 +14,16 @@ struct MergeResult
   uint64_t *skeys = nullptr;                   // sorted hits (either keys/vals or the sort partner)
   uint32_t *svals = nullptr;                   // value = bpos (0-based last base of the REF k-mer)
   DevBuf<uint32_t> gstart;                     // ngroups+1 first-hit indices of the (aread,bread) groups
+  // the groups by size, for the chain kernels (chain_classify_groups): groups of small_hi..pile_min-1 hits
+  // (list of the one-wavefront-per-group launch; windows that outgrow LDS are appended later) and repeat
+  // piles of >= pile_min hits (one workgroup each)
+  DevBuf<uint32_t> biglist, pilelist, gcounts;  // gcounts[0] = length of biglist, [1] = of pilelist (device)
+  uint32_t small_hi = 0xffffffffu, pile_min = 0, npiles = 0;
+  bool     classified = false;
 };
+
+// classifies the groups of R.gstart on the device and fetches the number of piles
+void chain_classify_groups(MergeResult &R);
 
 void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
                     IndexDev &A, IndexDev &B, int Kshift);

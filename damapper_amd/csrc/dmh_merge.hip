@@ -527,7 +527,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
                        (const uint32_t *) flag.p, R.gstart.p);
     uint32_t endv = (uint32_t) nhits;
     copy_h2d(R.gstart.p + ng, &endv, sizeof(uint32_t));
-    HIP_CHECK(hipStreamSynchronize(stream()));
+    chain_classify_groups(R);
   }
 
   if (st.capture_seeds)

@@ -103,6 +103,8 @@ struct State
   // test / experiment switches (dmh_test_option): every setting must give byte-identical results
   int  opt_align_level = -1;    // first rung of the alignment kernel ladder (0 two per wavefront, 1, 2); -1 default
   int  opt_chain_g     = 0;     // lanes per chain group for ALL groups (16/32/64); 0 = 16 + 64 by group size
+  int  opt_pile_cap    = 0;     // k_chain_pile's LDS window capacity in entries (128..); 0 = all of it
+  int  opt_chain_pile  = -1;    // hits from which a group gets a whole workgroup (k_chain_pile); 0 never, -1 default
   int  opt_pool_div    = 1;     // initial alignment pool capacity is divided by this (forces the grow path)
 
   // REF indices kept after Match_Filter consumed them (opt-in, dmh_ref_cache): a later Sort_Kmers of a

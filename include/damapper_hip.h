@@ -140,8 +140,10 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
 /* Switches between code paths that must give byte-identical results (used by the parity tests to
  * drive every kernel variant): "align_level" 0/1/2 = first rung of the alignment kernel ladder (two
  * candidates per wavefront / one per wavefront with LDS fallback / global-memory band), -1 default;
- * "chain_g" 16/32/64 lanes per chain group, 0 default; "pool_div" n = start with 1/n of the alignment
- * pool (forces the grow-and-retry path).  Returns 0, or -1 for an unknown key.                       */
+ * "chain_g" 16/32/64 lanes per chain group, 0 default; "chain_pile" n = groups of >= n hits get a whole
+ * workgroup (0 never, -1 default 4096); "pile_cap" n = that kernel may hold n window entries in LDS
+ * (forces its spill path; 0 default); "pool_div" n = start with 1/n of the alignment pool (forces the
+ * grow-and-retry path).  Returns 0, or -1 for an unknown key.                                          */
 int dmh_test_option(const char *key, int value);
 
 /* Page-locked host memory for a driver that loads blocks itself: a block whose `bases` live in such
