@@ -395,19 +395,19 @@ __global__ void k_pack_rc(const uint8_t *__restrict__ bases, int64_t L, const in
   pk[w] = v;
 }
 
-void pack_bases(const uint8_t *d_bases, int64_t L, uint64_t *d_pkraw)
-{ int64_t nwords = (L >> 5) + 1;
-  HIP_CHECK(hipMemsetAsync(d_pkraw, 0, sizeof(uint64_t) * (nwords + 4), stream()));
-  StageTimer tm("pack_bases", (double) L);
-  hipLaunchKernelGGL(k_pack_fwd, dim3(ceil_div(nwords, 256)), dim3(256), 0, stream(), d_bases, L, d_pkraw + 2, nwords);
+void pack_bases(const uint8_t *d_bases, int64_t L, uint64_t *d_pkraw, hipStream_t on)
+{ if (on == nullptr) on = stream(); int64_t nwords = (L >> 5) + 1;
+  HIP_CHECK(hipMemsetAsync(d_pkraw, 0, sizeof(uint64_t) * (nwords + 4), on));
+  StageTimer tm("pack_bases", (double) L, on);
+  hipLaunchKernelGGL(k_pack_fwd, dim3(ceil_div(nwords, 256)), dim3(256), 0, on, d_bases, L, d_pkraw + 2, nwords);
   HIP_CHECK(hipGetLastError());
 }
 
-void pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, uint64_t *d_rcraw)
-{ int64_t nwords = (L >> 5) + 1;
-  HIP_CHECK(hipMemsetAsync(d_rcraw, 0, sizeof(uint64_t) * (nwords + 4), stream()));
-  StageTimer tm("pack_revcomp", (double) L);
-  hipLaunchKernelGGL(k_pack_rc, dim3(ceil_div(nwords, 256)), dim3(256), 0, stream(), d_bases, L, d_boff, nreads,
+void pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, uint64_t *d_rcraw, hipStream_t on)
+{ if (on == nullptr) on = stream(); int64_t nwords = (L >> 5) + 1;
+  HIP_CHECK(hipMemsetAsync(d_rcraw, 0, sizeof(uint64_t) * (nwords + 4), on));
+  StageTimer tm("pack_revcomp", (double) L, on);
+  hipLaunchKernelGGL(k_pack_rc, dim3(ceil_div(nwords, 256)), dim3(256), 0, on, d_bases, L, d_boff, nreads,
                      d_rcraw + 2, nwords);
   HIP_CHECK(hipGetLastError());
 }
@@ -416,11 +416,11 @@ void ensure_packed(BlockDev &bd, bool want_rc)
 { block_ready(bd); int64_t nwords = (bd.L >> 5) + 1;
   if (bd.d_pkraw == nullptr)
     { bd.d_pkraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * (nwords + 4), "packed bases");
-      pack_bases(bd.d_bases(), bd.L, bd.d_pkraw);
+      pack_bases(bd.d_bases(), bd.L, bd.d_pkraw, stream());
     }
   if (want_rc && bd.d_rcraw == nullptr)
     { bd.d_rcraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * (nwords + 4), "packed reverse complements");
-      pack_revcomp(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, bd.d_rcraw);
+      pack_revcomp(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, bd.d_rcraw, stream());
     }
 }
 
@@ -599,7 +599,14 @@ static int preload_block_2bit(DAZZ_DB *block, const uint8_t *bps, int64_t nbytes
     HIP_CHECK(hipGetLastError());
   }
   if (async)
-    { HIP_CHECK(hipEventCreateWithFlags(&bd.uploaded, hipEventDisableTiming));
+    { // the alignment kernel's 2-bit words (both strands: this is how a READS block arrives) while we are at it,
+      // off the main stream
+      const int64_t nwords = (bd.L >> 5) + 1;
+      bd.d_pkraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * (nwords + 4), "packed bases");
+      pack_bases(bd.d_bases(), bd.L, bd.d_pkraw, us);
+      bd.d_rcraw = (uint64_t *) dev_alloc(sizeof(uint64_t) * (nwords + 4), "packed reverse complements");
+      pack_revcomp(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, bd.d_rcraw, us);
+      HIP_CHECK(hipEventCreateWithFlags(&bd.uploaded, hipEventDisableTiming));
       HIP_CHECK(hipEventRecord(bd.uploaded, us));
       bd.d_tmp[0] = d_bps;              // freed once the main stream has been made to wait for the decode
       bd.d_tmp[1] = d_coff;
@@ -754,7 +761,7 @@ void release_ref_index(IndexDev &ix)
       if (c != nullptr)
         { c->borrows -= 1;
           if (c->d_bstart == nullptr)
-            { c->d_bstart = ix.d_bstart; c->bshift = ix.bshift; c->bstart_bytes = ix.bstart_bytes; }
+            { c->d_bstart = ix.d_bstart; c->bshift = ix.bshift; c->bstart_bytes = ix.bstart_bytes; c->probe_keys = ix.probe_keys; }
           else if (c->d_bstart != ix.d_bstart)
             dev_free(ix.d_bstart);         // two borrowers built a table each
         }
@@ -1229,6 +1236,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "pool_div") == 0)    st.opt_pool_div = value > 1 ? value : 1;
   else if (strcmp(key, "chain_pile") == 0)  st.opt_chain_pile = value;
   else if (strcmp(key, "pile_cap") == 0)    st.opt_pile_cap = value;
+  else if (strcmp(key, "merge_dense") == 0) st.opt_merge_dense = value;
   else return -1;
   return 0;
 }

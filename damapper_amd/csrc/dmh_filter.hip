@@ -30,6 +30,7 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
               (long long) A->n, (long long) B->n);
       index_wait_ready(*A);
       index_wait_ready(*B);
+      st.mf_calls += 1;
       merge_and_sort(R, ablock, bblock, *A, *B, pm.Kshift);
       nhits = R.nhits;
       if (nhits > 0)

@@ -73,6 +73,7 @@ constexpr int SMALLBIN   = 32;
 
 struct MergeEntry { uint32_t a0, ma, b0, mb; };
 
+template <int NK>
 __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__restrict__ akeys, int64_t na,
                                                             BLookup B, unsigned long long *__restrict__ gram,
                                                             MergeEntry *__restrict__ tile_entries,
@@ -123,11 +124,16 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
           be[j] = B.bstart[p + 1];
         }
     }
-  uint64_t k0[MG_ITEMS], k1[MG_ITEMS];
+  // the first NK keys of the bucket (NK = 2 for the sparse table of a small index, 4 for the denser table of
+  // a block of a genome): they settle the look-up unless the bucket is longer and its NK-th key does not
+  // exceed the code -- only then the bisection runs
+  uint64_t kk[NK][MG_ITEMS];
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
-    { k0[j] = (bs[j] < be[j]) ? B.keys[bs[j]] : ~0ull;
-      k1[j] = (bs[j] + 1 < be[j]) ? B.keys[bs[j] + 1] : ~0ull;
+    {
+#pragma unroll
+      for (int t = 0; t < NK; t++)
+        kk[t][j] = (bs[j] + t < be[j]) ? B.keys[bs[j] + t] : ~0ull;
     }
 
 #pragma unroll
@@ -137,16 +143,20 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
       uint32_t lo = 0, mb = 0;
       int64_t  e = 0;
       bool     hit = false;
-      if (first[j] && bs[j] < be[j] && k0[j] <= c[j])
+      if (first[j] && bs[j] < be[j] && kk[0][j] <= c[j])
         { const uint32_t sz = be[j] - bs[j];
           const uint64_t cc = c[j];
-          if (k0[j] == cc && (sz == 1 || k1[j] != cc)) { lo = bs[j]; mb = 1; }
-          else if (k0[j] == cc && sz == 2)              { lo = bs[j]; mb = 2; }
-          else if (k0[j] <  cc && sz == 1)              mb = 0;
-          else if (k0[j] <  cc && k1[j] > cc)           mb = 0;
-          else if (k0[j] <  cc && k1[j] == cc && sz == 2) { lo = bs[j] + 1; mb = 1; }
-          else if (k0[j] <  cc && k1[j] <  cc && sz == 2) mb = 0;
-          else b_range(B, cc, lo, mb);
+          if (sz > (uint32_t) NK && kk[NK - 1][j] <= cc)
+            b_range(B, cc, lo, mb);
+          else
+            {
+#pragma unroll
+              for (int t = 0; t < NK; t++)
+                if ((uint32_t) t < sz && kk[t][j] == cc)
+                  { if (mb == 0) lo = bs[j] + (uint32_t) t;
+                    mb += 1;
+                  }
+            }
           if (mb != 0)
             { e   = (i + 1 < na && akeys[i + 1] == cc) ? run_end(akeys, na, i) : i + 1;
               ct  = (unsigned long long) (e - i) * mb;
@@ -324,9 +334,10 @@ __global__ void k_group_flag(const uint64_t *__restrict__ hkeys, int64_t n, int 
 }
 
 __global__ void k_group_write(const uint64_t *__restrict__ hkeys, int64_t n, int pshift,
-                              const uint32_t *__restrict__ slot, uint32_t *__restrict__ gstart)
+                              const uint32_t *__restrict__ slot, uint32_t *__restrict__ gstart, uint32_t ngroups)
 { int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (i == 0) gstart[ngroups] = (uint32_t) n;           // the end of the last group
   if (i == 0 || (hkeys[i] >> pshift) != (hkeys[i - 1] >> pshift))
     gstart[slot[i]] = (uint32_t) i;
 }
@@ -377,10 +388,18 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   // --- bucket table over the REF index: part of the index, built the first time it is merged against
   //     (a retained REF index meets every READS block)
   if (Bx.d_bstart == nullptr)
-    { int P = ceil_log2(Bx.n) + 2;         // ~0.15 entries per bucket (up to 1 GB of table)
+    { // small index: ~0.15-0.25 entries per bucket, two-key probes (the table stays in the caches).  A block of a
+      // genome (10^8 k-mers and more): the table is streamed from HBM by every pass, so at most 2^29 buckets
+      // (2 GB; 0.65 entries per bucket for a 375 Mbp block) and four-key probes, which leave the bisection to
+      // a look-up in a thousand ("merge_dense" test option: one bucket per entry + four keys on any index)
+      const int dense = st.opt_merge_dense;
+      const bool big = (dense >= 0) ? (dense != 0) : (Bx.n >= ((int64_t) 1 << 26));
+      int P = ceil_log2(Bx.n) + 2;
       if (P < 8) P = 8;
-      if (P > 28) P = 28;
+      if (big) { if (P > 29) P = 29; } else { if (P > 28) P = 28; }
+      if (dense == 1) P = std::max(4, ceil_log2(Bx.n));
       if (P > Kshift) P = Kshift;
+      Bx.probe_keys = big ? 4 : 2;
       Bx.bshift = Kshift - P;
       int64_t nbucket = (int64_t) 1 << P;
       Bx.d_bstart = (uint32_t *) dev_alloc(sizeof(uint32_t) * (nbucket + 2), "bucket table");
@@ -406,8 +425,12 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (MAXGRAM + 1), stream()));
   HIP_CHECK(hipMemsetAsync(mctl.p, 0, 4 * sizeof(unsigned int), stream()));
   { StageTimer tm("merge_match", 16.0 * (A.n + Bx.n));
-    hipLaunchKernelGGL(k_merge_match, dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                       (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
+    if (Bx.probe_keys == 4)
+      hipLaunchKernelGGL(k_merge_match<4>, dim3(ntiles), dim3(MG_THREADS), 0, stream(),
+                         (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
+    else
+      hipLaunchKernelGGL(k_merge_match<2>, dim3(ntiles), dim3(MG_THREADS), 0, stream(),
+                         (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
     hipLaunchKernelGGL(k_merge_reduce, dim3(256), dim3(256), 0, stream(), (const uint32_t *) thist.p,
                        (const unsigned long long *) thits.p, ntiles, gram.p);
     exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
@@ -524,10 +547,8 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     R.ngroups = ng;
     R.gstart.ensure((size_t) ng + 1, "group starts");
     hipLaunchKernelGGL(k_group_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.skeys, nhits, pshift,
-                       (const uint32_t *) flag.p, R.gstart.p);
-    uint32_t endv = (uint32_t) nhits;
-    copy_h2d(R.gstart.p + ng, &endv, sizeof(uint32_t));
-    chain_classify_groups(R);
+                       (const uint32_t *) flag.p, R.gstart.p, ng);
+    chain_classify_groups(R);          // (its copy of the pile count is the synchronisation point)
   }
 
   if (st.capture_seeds)

@@ -1313,7 +1313,13 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     fatal("Reporter: the Align_Spec was not created by this library's New_Align_Spec");
   if (st.cur_reads != ablock || (int) st.reads.size() != ablock->nreads)
     fatal("Reporter: called for a READS block that has not been through Match_Filter");
-  const bool defer = (g_async == 2);
+  // Deferring the alignment kernel pays when the READS block meets a reference of one block (two passes, the
+  // filter about as long as the alignment kernel at half grid).  Against a many-block reference the filter is
+  // several times longer, the kernel would just hold half of the GPU for a part of it and the index stages,
+  // flushed in one go instead of filling the filter's many host gaps, would cost more than is won
+  // (700 Mbp reference: 45.9 ms per block un-deferred, 50.9 deferred).
+  const bool defer = (g_async == 2) && st.mf_calls <= 2;
+  st.mf_calls = 0;
   // the index sort of the NEXT block: all of it now, ahead of this block's alignment kernel and while the
   // host collects the previous block's (deferred mode), or a few stages for the GPU to do while the jobs
   // are put together

@@ -50,6 +50,7 @@ struct IndexDev
   DAZZ_DB  *block  = nullptr;
   uint32_t *d_bstart = nullptr; // bucket table over the top bits of the codes (merge look-ups), built at first use
   int       bshift  = 0;        //   bucket of a code = code >> bshift
+  int       probe_keys = 2;     //   keys of a bucket a look-up fetches before it would bisect (2 or 4)
   size_t    bstart_bytes = 0;
   // REF index cache (dmh_ref_cache): identity of the block the index was built from, and whether this
   // record only borrows the device buffers of a cache entry
@@ -103,6 +104,8 @@ struct State
   // test / experiment switches (dmh_test_option): every setting must give byte-identical results
   int  opt_align_level = -1;    // first rung of the alignment kernel ladder (0 two per wavefront, 1, 2); -1 default
   int  opt_chain_g     = 0;     // lanes per chain group for ALL groups (16/32/64); 0 = 16 + 64 by group size
+  int  mf_calls = 0;            // Match_Filter calls since the last Reporter (passes per READS block)
+  int  opt_merge_dense = -1;    // REF bucket table: 1 = one bucket per entry + four-key probes, 0 = four buckets per entry + two-key probes, -1 = by size
   int  opt_pile_cap    = 0;     // k_chain_pile's LDS window capacity in entries (128..); 0 = all of it
   int  opt_chain_pile  = -1;    // hits from which a group gets a whole workgroup (k_chain_pile); 0 never, -1 default
   int  opt_pool_div    = 1;     // initial alignment pool capacity is divided by this (forces the grow path)
@@ -123,8 +126,8 @@ State &S();
 BlockDev &upload_block(const DAZZ_DB *block, bool pin);
 void      block_ready(BlockDev &bd);        // orders the current stream behind the block's upload
 void      ensure_packed(BlockDev &bd, bool want_rc);
-void      pack_bases(const uint8_t *d_bases, int64_t L, uint64_t *d_pkraw);
-void      pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, uint64_t *d_rcraw);
+void      pack_bases(const uint8_t *d_bases, int64_t L, uint64_t *d_pkraw, hipStream_t on = nullptr);      // nullptr: the main stream
+void      pack_revcomp(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, uint64_t *d_rcraw, hipStream_t on = nullptr);
 void      drop_block(const DAZZ_DB *block);
 void      free_blockdev(BlockDev &bd);
 

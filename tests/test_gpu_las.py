@@ -152,9 +152,10 @@ def test_ragged_and_degenerate_reads(tmp_path):
 
 @pytest.mark.parametrize("opts", [dict(align_level=1), dict(align_level=2), dict(pool_div=400),
                                   dict(chain_g=64), dict(chain_g=32), dict(chain_g=16),
-                                  dict(chain_pile=16), dict(chain_pile=16, pile_cap=128), dict(chain_pile=0)],
+                                  dict(chain_pile=16), dict(chain_pile=16, pile_cap=128), dict(chain_pile=0),
+                                  dict(merge_dense=1)],
                          ids=["wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
-                              "chain_piles", "chain_piles_spill", "chain_no_piles"])
+                              "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table"])
 def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes
     to the same bytes: force each one and compare with the default route (itself checked against the
@@ -183,6 +184,7 @@ def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
         L.dmh_test_option(b"pool_div", 1)
         L.dmh_test_option(b"chain_pile", -1)
         L.dmh_test_option(b"pile_cap", 0)
+        L.dmh_test_option(b"merge_dense", -1)
     assert len(base[0][1]) > 50
     assert base == alt
 
@@ -414,13 +416,15 @@ def test_dispatcher_finish_writes_final_las(tmp_path):
     assert p2.returncode == 0 and p2.stdout.count("skipped") == nb
 
 
-def test_retained_ref_index_and_pipelining_give_identical_files(tmp_path):
+@pytest.mark.parametrize("ref_block", [260000, 1 << 30], ids=["ref_blocks", "one_ref_block"])
+def test_retained_ref_index_and_pipelining_give_identical_files(ref_block, tmp_path):
     """The opt-in throughput modes of the driver (REF indices built once and kept resident, next block's
-    index queued before Reporter, .las written by the worker thread) must not change a byte."""
+    index queued before Reporter, .las written by the worker thread, alignment kernel left running behind
+    Reporter -- the library does that only for a one-block reference) must not change a byte."""
     from damapper_amd import capi
     g, reads = make_dataset("repeat", 48, [200000, 150000, 100000], 90, dropouts=1)
     d = str(tmp_path)
-    dazzdb.write_db(d, "REF", g, block_size=260000)
+    dazzdb.write_db(d, "REF", g, block_size=ref_block)
     dazzdb.write_db(d, "READS", reads, block_size=320000)
     nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
     nrb, _ = dazzdb.read_stub(os.path.join(d, "REF.db"))
