@@ -86,3 +86,32 @@ def test_trimmed_view(tmp_path):
     dazzdb.write_mask_track(d, "T", "m", [[(1, 2)], [(3, 4)], [(5, 6)], [], [(7, 8)], [(9, 10)], []])
     b1 = dazzdb.load_db(os.path.join(d, "T.db"), part=1, masks=["m"])
     assert b1.mask_intervals() == [[(1, 2)], [(5, 6)]]
+
+
+def test_packed_block_carries_the_bps_slice(tmp_path):
+    """load_db(packed=True) -- the host half of the device-side Load_All_Reads: no bases, the same read records
+    as the decoded block, and a slice + offsets from which every read of the (trimmed) view decodes to the
+    same bases (the device half is tests/test_gpu_las.py::test_device_side_block_decode_equals_load_all_reads)."""
+    rng = np.random.default_rng(11)
+    lens = [1, 2, 3, 4, 5, 9, 4096, 4097] + [int(x) for x in rng.integers(1, 3000, 120)]
+    seqs = [rng.integers(0, 4, n).astype(np.uint8) for n in lens]
+    best = [i % 4 != 1 for i in range(len(seqs))]
+    d = str(tmp_path)
+    dazzdb.write_db(d, "R", seqs, block_size=60000, cutoff=3, all_reads=False, best=best)
+    nb, _ = dazzdb.read_stub(os.path.join(d, "R.db"))
+    assert nb >= 2
+    seen = 0
+    for part in range(0, nb + 1):
+        host = dazzdb.load_db(os.path.join(d, "R.db"), part=part)
+        pk = dazzdb.load_db(os.path.join(d, "R.db"), part=part, packed=True)
+        assert pk.bases is None and not pk.db.bases and pk.packed is not None
+        assert pk.nreads == host.nreads and (pk.reads == host.reads).all()
+        assert pk.db.totlen == host.db.totlen and pk.db.maxlen == host.db.maxlen and pk.db.tfirst == host.db.tfirst
+        assert (np.diff(pk.coff) > 0).all() and pk.coff[0] == 0
+        for i in range(host.nreads):
+            n = int(host.reads[i + 1]["rlen"])
+            o = int(pk.coff[i])
+            assert np.array_equal(dazzdb._unpack_2bit(pk.packed[o:o + (n + 3) // 4], n), host.seq(i))
+        if part > 0:
+            seen += host.nreads
+    assert seen == sum(1 for s, b in zip(seqs, best) if len(s) >= 3 and b)
