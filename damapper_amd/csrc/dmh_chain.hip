@@ -679,13 +679,17 @@ void chain_classify_groups(MergeResult &R)
   R.gcounts.ensure(4, "group list lengths");
   HIP_CHECK(hipMemsetAsync(R.gcounts.p, 0, 4 * sizeof(uint32_t), stream()));
   R.npiles = 0;
+  R.nbig   = 0;
   R.classified = true;
   if (R.ngroups == 0 || (R.small_hi == 0xffffffffu && R.pile_min == 0)) return;
   hipLaunchKernelGGL(k_big_groups, dim3(ceil_div(R.ngroups, 256)), dim3(256), 0, stream(),
                      (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, R.small_hi,
                      R.pile_min > 0 ? R.pile_min : 0xffffffffu, R.biglist.p, R.gcounts.p, R.pilelist.p, R.gcounts.p + 1);
   HIP_CHECK(hipGetLastError());
-  copy_d2h(&R.npiles, R.gcounts.p + 1, sizeof(uint32_t));
+  uint32_t cnt[2] = {0, 0};
+  copy_d2h(cnt, R.gcounts.p, 2 * sizeof(uint32_t));
+  R.nbig   = cnt[0];
+  R.npiles = cnt[1];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -815,8 +819,11 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
         A.ticket = ctl.p + 2;
         A.only   = R.biglist.p;
         A.nonly  = R.gcounts.p;
-        { StageTimer t2("chain_listed_groups", 0.0);
-          hipLaunchKernelGGL(k_chain<64>, dim3(256), dim3(256), 0, stream(), A);
+        { // one group per wavefront: a handful of big groups on read-vs-random-genome data (plus the windows
+          // that outgrew LDS), most groups of the pass on a repeat-rich genome -- size the grid for the list
+          const uint32_t lblocks = std::min<uint32_t>(std::max<uint32_t>((R.nbig + 3) / 4 + 64, 256), 256 * 8);
+          StageTimer t2("chain_listed_groups", 0.0);
+          hipLaunchKernelGGL(k_chain<64>, dim3(lblocks), dim3(256), 0, stream(), A);
         }
         if (piles_done != nullptr)
           { HIP_CHECK(hipStreamWaitEvent(stream(), piles_done, 0));

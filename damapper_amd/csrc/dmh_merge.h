@@ -18,7 +18,7 @@ struct MergeResult
   // (list of the one-wavefront-per-group launch; windows that outgrow LDS are appended later) and repeat
   // piles of >= pile_min hits (one workgroup each)
   DevBuf<uint32_t> biglist, pilelist, gcounts;  // gcounts[0] = length of biglist, [1] = of pilelist (device)
-  uint32_t small_hi = 0xffffffffu, pile_min = 0, npiles = 0;
+  uint32_t small_hi = 0xffffffffu, pile_min = 0, npiles = 0, nbig = 0;
   bool     classified = false;
 };
 
