@@ -16,9 +16,10 @@ ap.add_argument("--blocks", type=int, default=2)
 ap.add_argument("--reads", type=int, default=20000)
 ap.add_argument("--repeat", action="store_true")
 ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--seed", type=int, default=77)
 ap.add_argument("--report-mode", type=int, default=0, help="dmh_async_report mode while mapping (0/1/2)")
 a = ap.parse_args()
-rng = np.random.default_rng(77)
+rng = np.random.default_rng(a.seed)
 clen = int(a.ref_mbp * 1e6 / a.contigs)
 g = dazzdb.repeat_rich_genome(rng, [clen] * a.contigs) if a.repeat else dazzdb.random_genome(rng, [clen] * a.contigs)
 big = np.concatenate(g)
@@ -27,7 +28,7 @@ blocks = []
 per = a.reads // a.contigs
 seqs = []
 for ci, c in enumerate(g):
-    b = dazzdb.simulate_block(100 + ci, c, per)
+    b = dazzdb.simulate_block(100 + ci + 1000 * (a.seed - 77), c, per)
     seqs += dazzdb.block_reads(b)
 d = tempfile.mkdtemp()
 t = time.time()
