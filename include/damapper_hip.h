@@ -213,11 +213,18 @@ int dmh_local_alignment(Align_Spec *spec,
                         const int *dg, const int *ad,
                         int *out, uint16_t *trace_out, uint16_t *btrace_out, int trace_stride);
 
-/* Reporter's last stage (per-read selection + .las writing, host only) can run on a worker
- * thread so that the driver may start filtering the next read block at once.  Off by default
- * (the reference driver reads the files right after Reporter returns); dmh_report_wait()
- * blocks until every queued report has been written.                                        */
-void dmh_async_report(int on);
+/* mode 1: Reporter's last stage (per-read selection + .las writing, host only) runs on a worker
+ * thread so that the driver may start filtering the next read block at once.
+ * mode 2: in addition Reporter may return while the alignment kernel of its block is still
+ * running (on a second stream, at half grid, next to the next block's Match_Filter); its records
+ * are collected by the next Reporter or by dmh_report_wait().  The library does this only for a
+ * READS block that went through at most two Match_Filter passes (one-block reference); the device
+ * copies the kernel reads stay alive until it is collected, whatever the driver does with its
+ * blocks.  Output files are byte-identical in every mode.
+ * mode 0 (default): Reporter is synchronous, as the reference driver expects (it reads the
+ * files right after Reporter returns).  dmh_report_wait() blocks until every queued report has
+ * been written; a driver that uses mode 1 or 2 must call it before it reads the files or exits. */
+void dmh_async_report(int mode);
 void dmh_report_wait(void);
 
 /* Kernel timing (HIP events on the library's stream).  Stages are named; dmh_timing_get
