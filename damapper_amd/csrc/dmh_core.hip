@@ -761,7 +761,7 @@ void release_ref_index(IndexDev &ix)
       if (c != nullptr)
         { c->borrows -= 1;
           if (c->d_bstart == nullptr)
-            { c->d_bstart = ix.d_bstart; c->bshift = ix.bshift; c->bstart_bytes = ix.bstart_bytes; c->probe_keys = ix.probe_keys; }
+            { c->d_bstart = ix.d_bstart; c->bshift = ix.bshift; c->bstart_bytes = ix.bstart_bytes; c->probe_keys = ix.probe_keys; c->low_off = ix.low_off; }
           else if (c->d_bstart != ix.d_bstart)
             dev_free(ix.d_bstart);         // two borrowers built a table each
         }

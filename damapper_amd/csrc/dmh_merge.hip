@@ -13,6 +13,7 @@
 #include "dmh_device.h"
 #include "dmh_merge.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace dmh {
 
@@ -36,7 +37,13 @@ struct BLookup
 { const uint64_t *keys;
   const uint32_t *bstart;
   int             shift;
+  const uint16_t *klow;         // keys[i] & ((1 << shift) - 1) when shift <= 16 (big indices), else nullptr
 };
+
+__global__ void k_low16(const uint64_t *__restrict__ keys, int64_t n, uint32_t mask, uint16_t *__restrict__ klow)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) klow[i] = (uint16_t) ((uint32_t) keys[i] & mask);
+}
 
 // [lo, lo+cnt) = entries of the REF index with code c
 __device__ __forceinline__ void b_range(const BLookup &B, uint64_t c, uint32_t &lo, uint32_t &cnt)
@@ -73,7 +80,7 @@ constexpr int SMALLBIN   = 32;
 
 struct MergeEntry { uint32_t a0, ma, b0, mb; };
 
-template <int NK>
+template <int NK, bool LOW>
 __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__restrict__ akeys, int64_t na,
                                                             BLookup B, unsigned long long *__restrict__ gram,
                                                             MergeEntry *__restrict__ tile_entries,
@@ -127,13 +134,19 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
   // the first NK keys of the bucket (NK = 2 for the sparse table of a small index, 4 for the denser table of
   // a block of a genome): they settle the look-up unless the bucket is longer and its NK-th key does not
   // exceed the code -- only then the bisection runs
-  uint64_t kk[NK][MG_ITEMS];
+  // LOW: the entries of a bucket share the bits above `shift`, so the probe compares the low bits only, kept
+  // in a 2-byte array of their own: a quarter of the REF key traffic of a pass (the bisection uses the keys)
+  using KT = typename std::conditional<LOW, uint32_t, uint64_t>::type;      // (registers: NK * MG_ITEMS of these)
+  KT kk[NK][MG_ITEMS];
+  const uint64_t lowmask = LOW ? (((uint64_t) 1 << B.shift) - 1) : ~0ull;
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
     {
 #pragma unroll
       for (int t = 0; t < NK; t++)
-        kk[t][j] = (bs[j] + t < be[j]) ? B.keys[bs[j] + t] : ~0ull;
+        { if (LOW) kk[t][j] = (KT) ((bs[j] + t < be[j]) ? (uint32_t) B.klow[bs[j] + t] : 0xffffffffu);
+          else     kk[t][j] = (KT) ((bs[j] + t < be[j]) ? B.keys[bs[j] + t] : ~0ull);
+        }
     }
 
 #pragma unroll
@@ -143,16 +156,17 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
       uint32_t lo = 0, mb = 0;
       int64_t  e = 0;
       bool     hit = false;
-      if (first[j] && bs[j] < be[j] && kk[0][j] <= c[j])
+      const KT cq = (KT) (c[j] & lowmask);         // what the fetched keys are compared with
+      if (first[j] && bs[j] < be[j] && kk[0][j] <= cq)
         { const uint32_t sz = be[j] - bs[j];
           const uint64_t cc = c[j];
-          if (sz > (uint32_t) NK && kk[NK - 1][j] <= cc)
+          if (sz > (uint32_t) NK && kk[NK - 1][j] <= cq)
             b_range(B, cc, lo, mb);
           else
             {
 #pragma unroll
               for (int t = 0; t < NK; t++)
-                if ((uint32_t) t < sz && kk[t][j] == cc)
+                if ((uint32_t) t < sz && kk[t][j] == cq)
                   { if (mb == 0) lo = bs[j] + (uint32_t) t;
                     mb += 1;
                   }
@@ -398,17 +412,28 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
       if (P < 8) P = 8;
       if (big) { if (P > 29) P = 29; } else { if (P > 28) P = 28; }
       if (dense == 1) P = std::max(4, ceil_log2(Bx.n));
+      if (dense == 2) P = std::max(4, Kshift - 16);          // (test: the 2-byte probe array on any index)
       if (P > Kshift) P = Kshift;
       Bx.probe_keys = big ? 4 : 2;
       Bx.bshift = Kshift - P;
       int64_t nbucket = (int64_t) 1 << P;
-      Bx.d_bstart = (uint32_t *) dev_alloc(sizeof(uint32_t) * (nbucket + 2), "bucket table");
-      Bx.bstart_bytes = sizeof(uint32_t) * (size_t) (nbucket + 2);
+      // an index whose buckets leave at most 16 bits undecided also gets those bits as a 2-byte array behind the
+      // table (same allocation): the probes of a pass then read a quarter of the REF key bytes and hold half the
+      // registers (k_merge_match<4> with 8-byte keys runs at two waves per SIMD, with the low bits at four)
+      const bool low16 = Bx.bshift <= 16;
+      size_t words = (size_t) (nbucket + 2);
+      Bx.low_off = low16 ? words : 0;
+      if (low16) words += ((size_t) Bx.n + 1) / 2 + 1;
+      Bx.d_bstart = (uint32_t *) dev_alloc(sizeof(uint32_t) * words, "bucket table");
+      Bx.bstart_bytes = sizeof(uint32_t) * words;
       StageTimer tm("merge_buckets", 8.0 * Bx.n);
       hipLaunchKernelGGL(k_bucket_bounds, dim3(ceil_div(Bx.n + 1, 256)), dim3(256), 0, stream(),
                          (const uint64_t *) Bx.keys, Bx.n, Bx.bshift, nbucket, Bx.d_bstart);
+      if (low16)
+        hipLaunchKernelGGL(k_low16, dim3(ceil_div(Bx.n, 256)), dim3(256), 0, stream(), (const uint64_t *) Bx.keys, Bx.n,
+                           (uint32_t) (((uint64_t) 1 << Bx.bshift) - 1), (uint16_t *) (Bx.d_bstart + Bx.low_off));
     }
-  BLookup BL{Bx.keys, Bx.d_bstart, Bx.bshift};
+  BLookup BL{Bx.keys, Bx.d_bstart, Bx.bshift, Bx.low_off ? (const uint16_t *) (Bx.d_bstart + Bx.low_off) : nullptr};
 
   // --- match + count (map.c:2984-2988)
   static DevBuf<unsigned long long> gram, thits;
@@ -425,11 +450,17 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (MAXGRAM + 1), stream()));
   HIP_CHECK(hipMemsetAsync(mctl.p, 0, 4 * sizeof(unsigned int), stream()));
   { StageTimer tm("merge_match", 16.0 * (A.n + Bx.n));
-    if (Bx.probe_keys == 4)
-      hipLaunchKernelGGL(k_merge_match<4>, dim3(ntiles), dim3(MG_THREADS), 0, stream(),
+    if (Bx.probe_keys == 4 && BL.klow != nullptr)
+      hipLaunchKernelGGL((k_merge_match<4, true>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
+                         (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
+    else if (Bx.probe_keys == 4)
+      hipLaunchKernelGGL((k_merge_match<4, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
+                         (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
+    else if (BL.klow != nullptr)
+      hipLaunchKernelGGL((k_merge_match<2, true>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
                          (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
     else
-      hipLaunchKernelGGL(k_merge_match<2>, dim3(ntiles), dim3(MG_THREADS), 0, stream(),
+      hipLaunchKernelGGL((k_merge_match<2, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
                          (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
     hipLaunchKernelGGL(k_merge_reduce, dim3(256), dim3(256), 0, stream(), (const uint32_t *) thist.p,
                        (const unsigned long long *) thits.p, ntiles, gram.p);

@@ -51,6 +51,7 @@ struct IndexDev
   uint32_t *d_bstart = nullptr; // bucket table over the top bits of the codes (merge look-ups), built at first use
   int       bshift  = 0;        //   bucket of a code = code >> bshift
   int       probe_keys = 2;     //   keys of a bucket a look-up fetches before it would bisect (2 or 4)
+  size_t    low_off = 0;        //   != 0: 2-byte array of the keys' low `bshift` bits at d_bstart + low_off (uint32 units)
   size_t    bstart_bytes = 0;
   // REF index cache (dmh_ref_cache): identity of the block the index was built from, and whether this
   // record only borrows the device buffers of a cache entry

@@ -143,8 +143,9 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  * "chain_g" 16/32/64 lanes per chain group, 0 default; "chain_pile" n = groups of >= n hits get a whole
  * workgroup (0 never, -1 default 4096); "pile_cap" n = that kernel may hold n window entries in LDS
  * (forces its spill path; 0 default); "merge_dense" 1/0 = REF bucket table with one bucket per entry
- * and four-key probes / four buckets per entry and two-key probes (-1 default: by index size; takes
- * effect for indices built afterwards); "pool_div" n = start with 1/n of the alignment pool (forces the
+ * and four-key probes / four buckets per entry and two-key probes, 2 = 16 undecided bits per bucket,
+ * four-key probes on the 2-byte low-bits array (-1 default: by index size; takes effect for indices
+ * built afterwards); "pool_div" n = start with 1/n of the alignment pool (forces the
  * grow-and-retry path).  Returns 0, or -1 for an unknown key.                                          */
 int dmh_test_option(const char *key, int value);
 
