@@ -455,10 +455,21 @@ def test_retained_ref_index_and_pipelining_give_identical_files(ref_block, tmp_p
     run("las_plain", 0)
     run("las_fast", 1)
     run("las_deferred", 2)       # + the alignment kernel of block i runs next to the filter of block i+1
+    # ... and the deferred kernel's retry rounds (pool too small, then the wider kernels) on its own stream
+    L = capi.lib()
+    try:
+        L.dmh_test_option(b"pool_div", 400)
+        run("las_deferred_retry", 2)
+        L.dmh_test_option(b"pool_div", 1)
+        L.dmh_test_option(b"align_level", 2)
+        run("las_deferred_global_band", 2)
+    finally:
+        L.dmh_test_option(b"pool_div", 1)
+        L.dmh_test_option(b"align_level", -1)
     for b in range(nb):
         for t in range(1, 5):
             fn = "READS.%d.REF.M%d.las" % (b + 1, t)
             a = open(os.path.join(d, "las_plain", fn), "rb").read()
-            for other in ("las_fast", "las_deferred"):
+            for other in ("las_fast", "las_deferred", "las_deferred_retry", "las_deferred_global_band"):
                 c = open(os.path.join(d, other, fn), "rb").read()
                 assert a == c and len(a) > 12, (other, fn)
