@@ -849,6 +849,8 @@ static void bg_parts_init()
   PASS_PARTS = HIST_PARTS + SCAT_PARTS;
 }
 
+static bool g_bg_whole = false;
+
 static void bg_step()
 { bg_parts_init();
   SortJob &J = g_bg.front();
@@ -877,8 +879,12 @@ static void bg_step()
   if (r < HIST_PARTS)
     radix_pass_hist(J.k0, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux, r, HIST_PARTS);
   else
-    { radix_pass_scatter(J.k0, J.v0, J.k1, J.v1, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux, r - HIST_PARTS, SCAT_PARTS);
-      if (r == PASS_PARTS - 1)
+    { int  sp = r - HIST_PARTS, np = SCAT_PARTS;
+      bool last = (r == PASS_PARTS - 1);
+      if (g_bg_whole && sp == 0)              // a flush has no gaps to fill: the whole pass in one launch
+        { np = 1; last = true; J.stage += SCAT_PARTS - 1; }
+      radix_pass_scatter(J.k0, J.v0, J.k1, J.v1, J.kmers, 8 * p, w < 8 ? w : 8, st.sort_aux, sp, np);
+      if (last)
         { std::swap(J.k0, J.k1);
           std::swap(J.v0, J.v1);
         }
@@ -899,7 +905,10 @@ void bg_pump(int nstages)
 }
 
 void bg_flush()
-{ while (!g_bg.empty()) bg_step(); }
+{ g_bg_whole = true;
+  while (!g_bg.empty()) bg_step();
+  g_bg_whole = false;
+}
 
 static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
 { State &st = S();
