@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--block-reads", type=int, default=25000)
     ap.add_argument("--nblocks", type=int, default=4)
-    ap.add_argument("--cpu-sample-reads", type=int, default=60000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record HIP events around the kernels")
     ap.add_argument("--no-prefetch", action="store_true", help="do not queue the next block's index before Reporter")
