@@ -98,7 +98,10 @@ def main():
     ap.add_argument("--nblocks", type=int, default=4)
     ap.add_argument("--cpu-sample-reads", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stage-timing", action="store_true", help="do not record HIP events around the kernels")
+    ap.add_argument("--no-stage-timing", action="store_true", help="do not record HIP events around any kernel (no roofline)")
+    ap.add_argument("--stage-timing", action="store_true",
+                    help="HIP events around EVERY kernel and host timers (device_stage_ms; costs about 1 ms per step); "
+                         "by default only the roofline kernel is timed")
     ap.add_argument("--no-prefetch", action="store_true", help="do not queue the next block's index before Reporter")
     ap.add_argument("--serial-prefetch", action="store_true",
                     help="queue the next block's whole index build before Reporter instead of spreading its "
@@ -193,7 +196,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     L.dmh_report_wait()
-    L.dmh_timing_enable(0 if args.no_stage_timing else 1)
+    L.dmh_timing_enable(0 if args.no_stage_timing else (1 if args.stage_timing else 2))
     L.dmh_timing_reset()
     if dist is not None:
         import torch

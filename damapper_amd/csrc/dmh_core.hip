@@ -239,6 +239,7 @@ static std::mutex g_tmu;                 // timers are also used from the report
 static std::vector<TimerSlot> g_slots;
 static std::vector<PendingEv> g_pending;
 static bool g_timing = false;
+static bool g_timing_roofline_only = false;     // dmh_timing_enable(2): events around the roofline kernel only
 
 static int slot_of(const char *name)
 { for (size_t i = 0; i < g_slots.size(); i++)
@@ -249,7 +250,7 @@ static int slot_of(const char *name)
 }
 
 StageTimer::StageTimer(const char *name, double bytes, hipStream_t on)
-{ active = g_timing;
+{ active = g_timing && (!g_timing_roofline_only || strcmp(name, "k_radix_scatter") == 0);
   idx = -1;
   s = on ? on : stream();
   if (!active) return;
@@ -277,7 +278,7 @@ static double now_ms()
 }
 
 HostTimer::HostTimer(const char *name)
-{ active = g_timing;
+{ active = g_timing && !g_timing_roofline_only;
   idx = -1;
   t0 = 0;
   if (!active) return;
@@ -1142,7 +1143,7 @@ void dmh_sync(void)
   sync_all_streams();
 }
 
-void dmh_timing_enable(int on) { g_timing = (on != 0); }
+void dmh_timing_enable(int on) { g_timing = (on != 0); g_timing_roofline_only = (on == 2); }
 
 void dmh_timing_reset(void)
 { drain_timers();
