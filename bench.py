@@ -170,7 +170,9 @@ def main():
     if args.pcie is None:
         for blk in blocks:
             L.dmh_preload_block(blk.ptr())
+            L.dmh_prepare_block(blk.ptr(), 1)
     L.dmh_preload_block(ref_whole.ptr())
+    L.dmh_prepare_block(ref_whole.ptr(), 0)
     pcie_t0 = time.time()
     L.dmh_sync()
 

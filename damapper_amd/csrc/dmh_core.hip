@@ -1195,6 +1195,13 @@ int dmh_preload_block(DAZZ_DB *block)
   return 0;
 }
 
+int dmh_prepare_block(DAZZ_DB *block, int reads_side)
+{ auto it = S().blocks.find(block);
+  if (it == S().blocks.end()) return -1;
+  ensure_packed(it->second, reads_side != 0);
+  return 0;
+}
+
 int dmh_preload_block_2bit(DAZZ_DB *block, const unsigned char *bps, int64_t nbytes, const int64_t *coff)
 { return preload_block_2bit(block, bps, nbytes, coff); }
 

@@ -157,6 +157,10 @@ void  dmh_host_free(void *p);
 
 int  dmh_preload_block(DAZZ_DB *block);
 void dmh_release_block(DAZZ_DB *block);
+/* Also derive what Reporter's kernel reads from a resident block now instead of at its first Reporter: the
+ * 2-bit packed bases, and for the READS side (reads_side != 0) those of the reverse complements.  -1 if the
+ * block is not resident.                                                                              */
+int  dmh_prepare_block(DAZZ_DB *block, int reads_side);
 
 /* Load_All_Reads on the device (replaces DB.c:1389-1437 + Uncompress_Read DB.c:342-361 for a block the
  * driver has only opened): `bps` = the block's slice of the .bps file as it lies on disk (4 bases per byte,
