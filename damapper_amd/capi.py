@@ -55,6 +55,8 @@ def lib() -> C.CDLL:
     L.dmh_device_count.restype = C.c_int
     L.dmh_last_error.restype = C.c_char_p
     L.dmh_preload_block.argtypes = [P(DAZZ_DB)]
+    L.dmh_device_memory.argtypes = [P(C.c_ulonglong), P(C.c_ulonglong)]
+    L.dmh_device_memory.restype = C.c_int
     L.dmh_prepare_block.argtypes = [P(DAZZ_DB), C.c_int]
     L.dmh_prepare_block.restype = C.c_int
     L.dmh_preload_block_2bit.argtypes = [P(DAZZ_DB), C.c_void_p, C.c_int64, C.c_void_p]
@@ -104,7 +106,7 @@ def exported_symbols() -> List[str]:
             "dmh_candidate_jumps", "dmh_read_cover", "dmh_sort_pairs", "dmh_local_alignment",
             "dmh_timing_enable", "dmh_timing_reset", "dmh_timing_count", "dmh_timing_get", "dmh_sync",
             "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free", "dmh_test_option", "dmh_ref_cache",
-            "dmh_preload_block_2bit", "dmh_download_block", "dmh_prepare_block"]
+            "dmh_preload_block_2bit", "dmh_download_block", "dmh_prepare_block", "dmh_device_memory"]
 
 
 def set_globals(verbose: int = 0, profile: int = 0, spacing: int = 100, best_tie: float = 1.0,

@@ -1195,6 +1195,15 @@ int dmh_preload_block(DAZZ_DB *block)
   return 0;
 }
 
+int dmh_device_memory(unsigned long long *free_bytes, unsigned long long *total_bytes)
+{ S();                                   // (selects the device)
+  size_t f = 0, t = 0;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) { (void) hipGetLastError(); return -1; }
+  if (free_bytes)  *free_bytes  = f;
+  if (total_bytes) *total_bytes = t;
+  return 0;
+}
+
 int dmh_prepare_block(DAZZ_DB *block, int reads_side)
 { auto it = S().blocks.find(block);
   if (it == S().blocks.end()) return -1;

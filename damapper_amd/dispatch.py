@@ -31,13 +31,26 @@ def _worker(args) -> None:
     nworkers = args.gpus * args.workers_per_gpu
     mine = [b for b in range(1, nrb + 1) if (b - 1) % nworkers == args.rank]
     out = args.out or os.path.join(d, "las_hip")
-    m = driver.Mapper(kmer=args.k, suppress=args.t, threads=args.T, ave_corr=args.e, spacing=args.s,
-                      best_tie=args.n, profile=int(args.p), verbose=int(args.v), sort_path=out,
-                      retain_ref=not args.rebuild_ref)
     nb, _ = read_stub(os.path.join(d, ref_root + ".db"))
     used: set = set()
     ref_blocks = [load_db(os.path.join(d, ref_root + ".db"), part=k + 1, masks=args.m, used=used) for k in range(nb)]
     ref_whole = load_db(os.path.join(d, ref_root + ".db"))
+    # resident REF indices: both orientations of every block, 12 B per k-mer + the bucket table and its low-bits array
+    # (up to 6.5 B per k-mer for a genome-sized block), next to ~6 GB of working set per worker
+    retain = not args.rebuild_ref
+    if retain:
+        import ctypes as C
+        free_b, total_b = C.c_ulonglong(0), C.c_ulonglong(0)
+        need = 2 * 18.5 * float(ref_whole.db.totlen) + 6e9
+        if capi.lib().dmh_device_memory(C.byref(free_b), C.byref(total_b)) == 0 and \
+                need * args.workers_per_gpu > 0.85 * float(total_b.value):
+            print("[gpu %d] resident reference indices would need %.0f GB x %d worker(s) of %.0f GB: rebuilding them "
+                  "per read block instead (--rebuild-ref)" % (args.rank, need / 1e9, args.workers_per_gpu,
+                                                               total_b.value / 1e9), flush=True)
+            retain = False
+    m = driver.Mapper(kmer=args.k, suppress=args.t, threads=args.T, ave_corr=args.e, spacing=args.s,
+                      best_tie=args.n, profile=int(args.p), verbose=int(args.v), sort_path=out,
+                      retain_ref=retain)
     if args.N and not args.C:
         raise SystemExit("damapper_amd.dispatch: Cannot specify N flag without C also")     # damapper.c:716
     if args.N and args.p:

@@ -161,6 +161,8 @@ void dmh_release_block(DAZZ_DB *block);
  * 2-bit packed bases, and for the READS side (reads_side != 0) those of the reverse complements.  -1 if the
  * block is not resident.                                                                              */
 int  dmh_prepare_block(DAZZ_DB *block, int reads_side);
+/* Free and total memory of the device this process uses (hipMemGetInfo); 0, or -1 without a device. */
+int  dmh_device_memory(unsigned long long *free_bytes, unsigned long long *total_bytes);
 
 /* Load_All_Reads on the device (replaces DB.c:1389-1437 + Uncompress_Read DB.c:342-361 for a block the
  * driver has only opened): `bps` = the block's slice of the .bps file as it lies on disk (4 bases per byte,
