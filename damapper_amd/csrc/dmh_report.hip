@@ -1128,9 +1128,10 @@ static void launch_round(PendingReport &P)
     }
   const int level = P.level, doB = P.doB;
   const int per_block = (level == 0) ? 8 : 4;
-  // four workgroups per CU take every SIMD's registers; a deferred kernel leaves half of them to the next
-  // block's merge and chain kernels (32.4 ms per block at 2 per CU, 34.9 at 2.5, 39.7 at 4)
-  static const int aux_grid = getenv("DMH_DEFER_GRID") ? std::max(64, atoi(getenv("DMH_DEFER_GRID"))) : 256 * 2;
+  // four workgroups per CU take every SIMD's registers; a deferred kernel leaves about half of them to the next
+  // block's merge and chain kernels (ms per block 30.1 at 384 workgroups, 29.7 at 416, 29.0 at 448,
+  // 29.4 at 480, 29.5 at 512, 30.8 at 544, 31.2 at 576; 39.7 at the full 1024)
+  static const int aux_grid = getenv("DMH_DEFER_GRID") ? std::max(64, atoi(getenv("DMH_DEFER_GRID"))) : 448;
   int nblocks = std::min((nrun + per_block - 1) / per_block, P.on_aux ? aux_grid : 256 * 4);
   Scratch sc = prepare_scratch(nblocks, P.tcap, level == 2, per_block, level != 0);
   if (P.on_aux)
