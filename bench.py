@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- Gbp of reads mapped per second through the HIP hot path.
+"""bench.py -- Gbp of reads mapped per second through the HIP hot path, on the metric's configuration.
 
-A "step" maps ONE read block (default 25,000 simulated PacBio reads x 10 kb, 15 % error = 0.25 Gbp,
-a DBsplit-sized block) against the reference in both orientations, exactly as one iteration of
-damapper.c's main loop does: Sort_Kmers(reads) -> for every REF block {Sort_Kmers, Match_Filter,
-complement, Sort_Kmers, Match_Filter} -> Reporter (.las written).  The workload is BASELINE.json's
-config[1]: an E. coli-sized reference (4.6 Mbp; uniform random ACGT with a fixed seed, there is no
-network for the real K-12 FASTA) and 100 k reads = 4 blocks; K steps cycle over the blocks.
+Workload (default `--workload grch38`, BASELINE.json configs[3]): a GRCh38-SIZED reference, 3.1 Gbp in 25 contigs
+of 124 Mbp, cut into 9 REF blocks of <= 375 Mbp as DBsplit would (whole contigs, < 2^31 k-mers), built by SURVEY
+8d's repeat-rich generator scaled up -- 2 kb repeat families at 3 % divergence on both strands every 1-6 kb plus a
+60 x 150 bp tandem array per contig, ONE FAMILY PER 750 kb OF A REF BLOCK (496 families), which keeps the per-family
+copy number each Match_Filter pass sees (about 136) and the seed-hit density (0.3-0.4 hits per read base and
+orientation, 12-16 x a random genome) of the survey's one-family 750 kb probe genome; there is no network for the
+real assembly.  Reads: simulated PacBio CLR, 10 kb, 15 % error (ins:del:sub 60:25:15), uniform over the genome and
+both strands, in DBsplit-sized blocks of 25,000 reads (0.26 Gbp).  `--workload grch38-stress` is the same model
+with ONE family genome-wide (560 k copies: the generator scaled up literally; ~3.5 hits per read base and
+orientation), `chr1` a 250 Mbp one-block reference, `ecoli` the 4.6 Mbp random reference of configs[1].
 
-Read blocks shard across GPUs (one process per GPU, no collective on the data path; the reference
-index is rebuilt per GPU): rank r maps its own blocks, so per-GPU work is fixed ("weak").
-Inputs (block bases) are resident in HBM before the timed region starts.
+A STEP maps a fixed batch of `--blocks-per-step` (8) read blocks: for every block Sort_Kmers(reads), Match_Filter
+against both orientations of every REF block (18 passes; the REF indices are built once per GPU and stay in HBM,
+BASELINE north_star) and Reporter (.las written), i.e. damapper.c:825-880 per block.  The batch is FIXED and its
+blocks are dealt to the ranks b mod N ("strong" scaling; no collective on the data path, every rank holds the whole
+reference index).  Read blocks are NOT resident: every visit uploads the block's 2-bit .bps bytes from page-locked
+host memory and decodes them on the device inside the timed region (the steady state of the block loop).
 
-The JSON line also carries
-  roofline     -- the dominant HBM-bound kernel (one LSD radix-sort pass, k_radix_scatter): the
-                  reference's algorithmic bytes per pass (32 B per record) over the kernel's mean
-                  duration measured with HIP events on the library's stream;
-  cpu_baseline -- the compiled reference (oracle/_ref/damapper -T<P>) timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+After the timed region (rank 0, N = 1) the compiled reference (oracle/_ref/damapper) maps one read block against
+REF block 1 on the host cores: its wall time gives `cpu_baseline` (extrapolated to the whole reference by the
+ratio of reference bases, formula in `sample`), and the SAME sample is mapped by the HIP path and the two .las
+record streams are compared record for record -> `parity`.
+
+`roofline` is reported for the kernel with the largest share of the timed GPU time (HIP events on the stream each
+kernel runs on), against its algorithmic bytes (the reference's 16-byte records); `hbm_stage` repeats
+it for the HBM-bound radix scatter kernel when that is not the dominant one.
 """
 import argparse
 import json
 import os
+import shutil
 import sys
 import tempfile
 import time
@@ -32,37 +42,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
-from damapper_amd import capi, dazzdb, driver  # noqa: E402
+from damapper_amd import capi, dazzdb, driver, las  # noqa: E402
 
-GENOME_LEN = 4_600_000
 READ_LEN = 10_000
 HBM_PEAK_GBS = 8000.0
+REF_BLOCK_MAX = 375_000_000
+
+WORKLOADS = {
+    # name: (contig length, contigs, kind, families per genome (0 = one per 750 kb of a REF block))
+    "grch38": (124_000_000, 25, "repeat", 0),
+    "grch38-stress": (124_000_000, 25, "repeat", 1),
+    "grch38-random": (124_000_000, 25, "random", 1),
+    "chr1": (125_000_000, 2, "repeat", 0),
+    "ecoli": (4_600_000, 1, "random", 1),
+}
+
+# kernels whose time is HBM streaming: algorithmic bytes are meaningful as a bandwidth
+STAGE_KERNEL = {
+    "k_radix_scatter": "k_radix_scatter", "k_radix_hist": "k_radix_hist", "radix_scan": "k_scan_*",
+    "kmer_emit": "k_kmer_emit", "merge_match": "k_merge_match (+reduce, scan)", "merge_emit": "k_merge_expand (+sizes, scan)",
+    "seed_groups": "k_group_flag/write (+scan)", "chain_small_groups": "k_chain<16>", "chain_listed_groups": "k_chain<64>",
+    "chain_piles": "k_chain_pile", "chain_spilled_piles": "k_chain<64> (spilled piles)", "chain_jumps": "k_chain_jumps",
+    "align": "k_align_cands32", "align_wave64": "k_align_cands<128>", "align_global_band": "k_align_cands<8192>",
+    "unpack_2bit": "k_unpack_2bit", "pack_bases": "k_pack_fwd", "pack_revcomp": "k_pack_rc", "merge_buckets": "k_bucket_bounds",
+}
+# enclosing stages (their kernels are timed one by one as well): not candidates for "dominant kernel"
+ENCLOSING = {"kmer_sort", "seed_sort", "chain", "sort_pairs"}
 
 
-def make_block(genome, nreads, seed, tfirst=0, part=0, pinned=False):
-    return dazzdb.simulate_block(seed, genome[part % len(genome)], nreads, read_len=READ_LEN, err=0.15, tfirst=tfirst, part=part,
-                                 path=b"./.READS", pinned=pinned)
-
-
-def pack_block(blk):
-    """The block as it lies in a .bps file (4 bases per byte) with Load_All_Reads' read records and no bases:
-    what `--pcie packed` uploads (dmh_preload_block_2bit decodes it on the device)."""
-    n = blk.nreads
-    lens = blk.reads["rlen"][1:n + 1].astype(np.int64)
-    offs = blk.reads["boff"][1:n + 1].astype(np.int64)
-    clen = (lens + 3) // 4
-    coff = np.concatenate(([0], np.cumsum(clen)))
-    out = dazzdb.host_bytes(int(coff[-1]), True)
-    for i in range(n):
-        s = np.zeros(int(clen[i]) * 4, dtype=np.uint8)
-        s[:lens[i]] = blk.bases[1 + offs[i]:1 + offs[i] + lens[i]]
-        q = s.reshape(-1, 4)
-        out[coff[i]:coff[i + 1]] = (q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]
-    hb = dazzdb.make_block([], tfirst=int(blk.db.tfirst), part=int(blk.db.part), path=blk.path,
-                           freq=[blk.db.freq[j] for j in range(4)], lens=lens)
-    hb.slice = out
-    hb.coff = np.ascontiguousarray(coff[:-1])
-    return hb
+def ref_block_ranges(lens):
+    """REF blocks as DBsplit cuts them: whole contigs, at most REF_BLOCK_MAX bases per block."""
+    out, first, acc = [], 0, 0
+    for ci in range(len(lens) + 1):
+        if ci == len(lens) or (acc > 0 and acc + int(lens[ci]) > REF_BLOCK_MAX):
+            out.append((first, ci))
+            first, acc = ci, 0
+        if ci < len(lens):
+            acc += int(lens[ci])
+    return out
 
 
 def shard_blocks(nblocks, rank, world):
@@ -70,56 +87,97 @@ def shard_blocks(nblocks, rank, world):
     return [b for b in range(nblocks) if b % world == rank]
 
 
-def cpu_baseline(genome, sample_reads, threads):
-    """Reference `damapper -k20 -e.85 -T<threads>` on a bounded sample; wall time of the process
-    (LAsort/LAcat are shims)."""
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    p = 1
+    while 2 * p <= n:
+        p *= 2
+    return n, p
+
+
+def parity_and_cpu_baseline(G, ranges, sample_reads, threads, cores, mem_gb, mapper_kw):
+    """Reference `damapper -k20 -e.85 -T<threads> -M<mem_gb>` on ONE read block against REF block 1 (wall time of
+    the process; LAsort/LAcat are shims), then the same sample through the HIP path; record streams
+    compared.  Returns (cpu_baseline, parity)."""
     try:
         import run_ref
     except Exception:
-        return None
+        return None, None
     if not run_ref.have_ref():
-        return None
-    with tempfile.TemporaryDirectory() as d:
-        dazzdb.write_db(d, "REF", genome, block_size=400_000_000)
-        dazzdb.write_db(d, "READS", sample_reads)
-        dt, _ = run_ref.run_reference(d, "REF", ["READS"], flags=["-k20", "-e.85"], threads=threads)
-    bases = float(sum(len(r) for r in sample_reads))
-    return {"value": bases / dt / 1e9, "unit": "Gbp/s", "cores": threads, "kind": "reference",
-            "sample": "%d reads x 10 kb (%.0f Mbp) vs the same 4.6 Mbp reference, damapper -k20 -e.85 -T%d, %.1f s wall"
-                      % (len(sample_reads), bases / 1e6, threads, dt)}
+        return None, None
+    L = capi.lib()
+    f0, f1 = ranges[0]
+    d = tempfile.mkdtemp(prefix="dmh_bench_cpu_")
+    try:
+        ref1 = dazzdb.genome_block(G, f0, f1, part=1, path=b"./.REF", copy=True)
+        sample = dazzdb.simulate_block_genome(4242, G, sample_reads, read_len=READ_LEN, path=b"./.READS")
+        dazzdb.write_db_block(d, "REF", ref1, block_size=400_000_000)
+        dazzdb.write_db_block(d, "READS", sample, block_size=400_000_000)
+        dt, _ = run_ref.run_reference(d, "REF", ["READS"], flags=["-k20", "-e.85", "-M%d" % mem_gb], threads=threads)
+        bases = float(sample.db.totlen)
+        ref_bases = float(sum(int(x) for x in G.lens[f0:f1]))
+        scale = G.total / ref_bases
+        cpu = {"value": bases / (dt * scale) / 1e9, "unit": "Gbp/s", "cores": threads, "kind": "reference",
+               "host_cores_available": cores,
+               "sample": "oracle/_ref/damapper -k20 -e.85 -T%d -M%d: one block of %d reads x 10 kb (%.0f Mbp, sampled from the "
+                         "whole genome) against REF block 1 of %d (%.0f of %.0f Mbp, both orientations) in %.1f s wall; the "
+                         "reference re-indexes every REF block for every read block (damapper.c:834-862), so the whole "
+                         "reference costs (%.0f/%.0f) = %.2f x that time per read block: value = read bases / (%.2f x %.1f s)"
+                         % (threads, mem_gb, sample_reads, bases / 1e6, len(ranges), ref_bases / 1e6, G.total / 1e6, dt,
+                            G.total / 1e6, ref_bases / 1e6, scale, scale, dt)}
+        # the same sample through the HIP path (synchronous Reporter, REF indices rebuilt: the drop-in call sequence)
+        L.dmh_report_wait()
+        L.dmh_async_report(0)
+        out = os.path.join(d, "las_hip")
+        kw = dict(mapper_kw)
+        kw.update(sort_path=out, mem_limit=mem_gb << 30, retain_ref=False)
+        m2 = driver.Mapper(**kw)
+        ref1_whole = dazzdb.genome_block(G, f0, f1, part=0, path=b"./.REF")
+        t0 = time.time()
+        m2.map_block(sample, "READS", [ref1], ref1_whole, "REF")
+        L.dmh_sync()
+        t_hip = time.time() - t0
+        L.dmh_release_block(ref1_whole.ptr())
+        L.dmh_release_block(ref1.ptr())
+        ts_r, want = las.read_las_set(os.path.join(d, "las_ref"), "READS.REF.M@.las")
+        ts_h, got = las.read_las_set(out, "READS.REF.M@.las")
+        bad = sum(1 for x, y in zip(want, got) if x != y) + abs(len(want) - len(got)) + (0 if ts_r == ts_h else 1)
+        parity = {"records": len(want), "records_hip": len(got), "differing": bad,
+                  "what": "per-thread .las record streams (bytes 36-39 = struct padding masked) of the cpu_baseline sample: "
+                          "reference vs HIP path, Reporter synchronous, %.2f s on the GPU" % t_hip}
+        return cpu, parity
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="grch38")
+    ap.add_argument("--genome-mbp", type=float, default=None, help="override the reference size (contig count scales)")
+    ap.add_argument("--families", type=int, default=None, help="override the number of repeat families")
     ap.add_argument("--block-reads", type=int, default=25000)
-    ap.add_argument("--nblocks", type=int, default=4)
-    ap.add_argument("--cpu-sample-reads", type=int, default=100000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stage-timing", action="store_true", help="do not record HIP events around any kernel (no roofline)")
-    ap.add_argument("--stage-timing", action="store_true",
-                    help="HIP events around EVERY kernel and host timers (device_stage_ms; costs about 1 ms per step); "
-                         "by default only the roofline kernel is timed")
-    ap.add_argument("--no-prefetch", action="store_true", help="do not queue the next block's index before Reporter")
-    ap.add_argument("--serial-prefetch", action="store_true",
-                    help="queue the next block's whole index build before Reporter instead of spreading its "
-                         "stages over the gaps of the current block")
-    ap.add_argument("--genome-mbp", type=float, default=GENOME_LEN / 1e6,
-                    help="reference size in Mbp (default 4.6 = configs[1]; 250 approximates configs[2], one contig per "
-                         "~125 Mbp, one REF block)")
-    ap.add_argument("--pcie", choices=["pinned", "pageable", "packed"], default=None,
-                    help="PCIe-inclusive rate: read blocks are NOT resident, every step uploads its block from "
-                         "page-locked (dmh_host_alloc) or ordinary host memory inside the timed region; packed = "
-                         "as the 2-bit bytes of the .bps file (a quarter of the volume), decoded by a kernel")
-    ap.add_argument("--sync-report", action="store_true", help="write the .las files inside Reporter (drop-in behaviour)")
+    ap.add_argument("--blocks-per-step", type=int, default=8,
+                    help="read blocks in the fixed batch one step maps (dealt to the ranks b mod N)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=25000)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference run (then there is no parity check either)")
+    ap.add_argument("--mem-gb", type=int, default=64, help="-M of both sides (the limit rule of map.c:2992-3055 depends on it)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="HIP events around k_radix_scatter only (default: around every kernel, about 1 ms per read block)")
+    ap.add_argument("--no-stage-timing", action="store_true", help="no HIP events at all (no roofline)")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not queue the next block's index build early")
+    ap.add_argument("--resident-reads", action="store_true",
+                    help="read blocks pre-uploaded and pre-packed (inputs resident; the round-1 bench configuration)")
     ap.add_argument("--report-mode", type=int, default=2, choices=[0, 1, 2],
                     help="0 = Reporter synchronous, 1 = .las selection/writing on a worker thread, 2 (default) = also the "
-                         "alignment kernel of block i deferred, at half grid, next to the filter of block i+1")
+                         "alignment kernel of block i deferred next to the filter of block i+1 (one-block references only)")
     ap.add_argument("--rebuild-ref", action="store_true",
-                    help="rebuild the REF indices for every read block as damapper.c does (default: build both "
-                         "orientations once per GPU and keep them resident, BASELINE.json north_star)")
+                    help="rebuild the REF indices for every read block as damapper.c does")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,71 +192,84 @@ def main():
         # N > 1 control flow on a box with fewer GPUs than ranks (the ranks then share a device)
         dist_mod.init_process_group(backend=os.environ.get("DMH_BENCH_BACKEND", "nccl"))
         dist = dist_mod
+    cores, tpow = host_threads()
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, cores // max(1, world))))
 
     L = capi.lib()
     if L.dmh_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libdamapper_hip has no CPU fallback")
 
-    # ---- synthetic workload (seeded): reference shared by all ranks, reads per rank
-    g_rng = np.random.default_rng(20)
-    glen = int(args.genome_mbp * 1e6)
-    ncontig = max(1, int(round(glen / 125e6)))
-    genome = dazzdb.random_genome(g_rng, [glen // ncontig] * ncontig)
-    nblk = min(args.nblocks, max(1, args.steps + args.warmup))
-    blocks = []
-    for b in range(nblk):
-        blocks.append(make_block(genome, args.block_reads, 1000 + 97 * rank + b, tfirst=b * args.block_reads, part=b + 1,
-                                 pinned=(args.pcie == "pinned")))
-        if args.pcie == "packed":
-            blocks[-1] = pack_block(blocks[-1])
-    # REF blocks as DBsplit would cut them: whole contigs, at most ~375 Mbp (< 2^31 k-mers) per block
-    ref_blocks, first, acc = [], 0, 0
-    for ci in range(len(genome) + 1):
-        if ci == len(genome) or (acc > 0 and acc + len(genome[ci]) > 375_000_000):
-            ref_blocks.append(dazzdb.make_block(genome[first:ci], tfirst=first, part=len(ref_blocks) + 1, path=b"./.REF"))
-            first, acc = ci, 0
-        if ci < len(genome):
-            acc += len(genome[ci])
-    ref_whole = dazzdb.make_block(genome, path=b"./.REF")
+    # ---- synthetic workload (seeded): the reference is the same on all ranks, the batch of read blocks is fixed
+    t_setup = time.time()
+    clen, ncontig, kind, fam = WORKLOADS[args.workload]
+    if args.genome_mbp is not None:
+        ncontig = max(1, int(round(args.genome_mbp * 1e6 / clen)))
+        if args.genome_mbp * 1e6 < clen:
+            clen = int(args.genome_mbp * 1e6)
+    lens = [clen] * ncontig
+    ranges = ref_block_ranges(lens)
+    if fam == 0:
+        fam = max(1, int(round(max(sum(lens[a:b]) for a, b in ranges) / 750_000)))
+    if args.families is not None:
+        fam = args.families
+    G = dazzdb.native_genome(20, lens, kind, families=fam)
+    ref_whole = dazzdb.genome_block(G, path=b"./.REF")
+    freq = [ref_whole.db.freq[j] for j in range(4)]
 
     sort_path = tempfile.mkdtemp(prefix="dmh_bench_%d_" % rank)
-    m = driver.Mapper(kmer=20, ave_corr=0.85, spacing=100, threads=4, sort_path=sort_path, mem_limit=64 << 30,
-                      retain_ref=not args.rebuild_ref, prefetch_deferred=not args.serial_prefetch)
-    m.make_spec([ref_whole.db.freq[j] for j in range(4)])
-
-    # inputs resident in HBM before the clock starts
-    if args.pcie is None:
-        for blk in blocks:
-            L.dmh_preload_block(blk.ptr())
-            L.dmh_prepare_block(blk.ptr(), 1)
-    L.dmh_preload_block(ref_whole.ptr())
+    mapper_kw = dict(kmer=20, ave_corr=0.85, spacing=100, threads=4)
+    m = driver.Mapper(sort_path=sort_path, mem_limit=args.mem_gb << 30, retain_ref=not args.rebuild_ref, **mapper_kw)
+    m.make_spec(freq)
+    L.dmh_preload_block(ref_whole.ptr())          # Reporter's copy of the whole reference: resident
     L.dmh_prepare_block(ref_whole.ptr(), 0)
-    pcie_t0 = time.time()
+    ref_blocks = []
+    for k, (a, b) in enumerate(ranges):
+        blk = dazzdb.genome_block(G, a, b, part=k + 1, path=b"./.REF", copy=True, freq=freq)
+        ref_blocks.append(blk)
+        if not args.rebuild_ref:
+            m.add_ref_block(blk, k, drop_bases=True)      # (one block's host copy at a time)
+    t_ref = time.time() - t_setup
+
+    nbatch = args.blocks_per_step
+    mine = shard_blocks(nbatch, rank, world)
+    blocks = {}
+    for b in mine:
+        raw = dazzdb.simulate_block_genome(1000 + b, G, args.block_reads, read_len=READ_LEN, tfirst=b * args.block_reads,
+                                           part=b + 1, path=b"./.READS", pinned=args.resident_reads)
+        if args.resident_reads:
+            blocks[b] = raw
+            L.dmh_preload_block(raw.ptr())
+            L.dmh_prepare_block(raw.ptr(), 1)
+        else:
+            blocks[b] = dazzdb.pack_block(raw, pinned=True)
+            blocks[b].slice = blocks[b].packed
+            del raw
     L.dmh_sync()
+    t_setup = time.time() - t_setup
 
-    last = args.warmup + args.steps - 1
+    seq = [b for _ in range(args.warmup + args.steps) for b in mine]       # this rank's visits, in order
+    per_step = len(mine)
 
-    def step(i):
-        blk = blocks[i % nblk]
-        nxt = blocks[(i + 1) % nblk] if (i < last and not args.no_prefetch and nblk > 1) else None
-        if args.pcie == "packed":
-            for b in (blk, nxt):                 # map_block uploads (2-bit) and decodes what carries a slice
-                if b is not None and not b.resident:
-                    b.packed = b.slice
-        t = m.map_block(blk, "READS.%d" % (i % nblk + 1), ref_blocks, ref_whole, "REF", next_reads=nxt)
-        if args.pcie == "packed":
+    def visit(i):
+        blk = blocks[seq[i]]
+        nxt = blocks[seq[i + 1]] if (i + 1 < len(seq) and not args.no_prefetch and
+                                     (len(mine) > 1 or args.resident_reads)) else None
+        if not args.resident_reads:
+            for bb in (blk, nxt):                # map_block uploads (2-bit) and decodes what carries a slice
+                if bb is not None and not bb.resident:
+                    bb.packed = bb.slice
+        t = m.map_block(blk, "READS.%d" % (seq[i] + 1), ref_blocks, ref_whole, "REF", next_reads=nxt)
+        if not args.resident_reads:
             blk.release()
-        elif args.pcie is not None:
-            L.dmh_release_block(blk.ptr())       # the next visit uploads it again
         return t
 
-    # the warm-up steps run the configuration that is timed (worker thread, second stream, page-locked pool
-    # buffers and the allocator's blocks are created by them, not inside the timed region)
-    L.dmh_async_report(0 if args.sync_report else args.report_mode)   # block i's alignments and .las writing overlap block i+1's filter
-    for i in range(args.warmup):
-        step(i)
+    # the warm-up runs the configuration that is timed (worker thread, streams, pinned pools and the allocator's
+    # blocks are created by it, not inside the timed region)
+    L.dmh_async_report(args.report_mode)
+    for i in range(args.warmup * per_step):
+        visit(i)
     L.dmh_report_wait()
-    L.dmh_timing_enable(0 if args.no_stage_timing else (1 if args.stage_timing else 2))
+    L.dmh_timing_enable(0 if args.no_stage_timing else (2 if args.roofline_only else 1))
     L.dmh_timing_reset()
     if dist is not None:
         import torch
@@ -208,11 +279,11 @@ def main():
     t0 = time.time()
     bases = 0
     host = {"index_reads": 0.0, "filter": 0.0, "report": 0.0, "between_blocks": 0.0}
-    for i in range(args.steps):
-        t = step(args.warmup + i)
+    for i in range(args.warmup * per_step, len(seq)):
+        t = visit(i)
         for k in host:
             host[k] += t[k]
-        bases += int(blocks[(args.warmup + i) % nblk].db.totlen)
+        bases += int(blocks[seq[i]].db.totlen)
     L.dmh_report_wait()
     L.dmh_sync()
     if dist is not None:
@@ -237,58 +308,76 @@ def main():
 
     if rank == 0:
         value = tot_bases / dt / 1e9
-        sc = timings.get("k_radix_scatter", None)
-        roof = None
-        if sc and sc["launches"] > 0 and sc["ms"] > 0:
-            achieved = sc["bytes"] / (sc["ms"] * 1e-3) / 1e9          # GB/s, algorithmic bytes
-            # HBM bytes per record of this kernel from the PMC passes committed under profiles/
-            # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is)
-            traffic = None
-            try:
-                import glob
-                latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.json")))[-1]
-                pm = json.load(open(latest))
-                traffic = pm["derived"]["scatter_traffic_bytes_per_record"] * (sc["bytes"] / sc["launches"] / 32.0)
-            except Exception:
-                pass
-            roof = {"bound": "hbm", "kernel": "k_radix_scatter", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None if traffic is None else round(traffic),
-                    "launches": int(sc["launches"]), "avg_ms": round(sc["ms"] / sc["launches"], 4),
-                    "alg_bytes_per_launch": sc["bytes"] / sc["launches"]}
+        kern = {k: v for k, v in timings.items() if not k.startswith("host:") and k not in ENCLOSING and v["ms"] > 0}
+        gpu_ms = sum(v["ms"] for v in kern.values())
+
+        def roof_of(name):
+            v = kern.get(name)
+            if not v or v["launches"] <= 0 or v["ms"] <= 0 or v["bytes"] <= 0:
+                return None
+            achieved = v["bytes"] / (v["ms"] * 1e-3) / 1e9          # GB/s, algorithmic bytes
+            r = {"bound": "hbm", "kernel": STAGE_KERNEL.get(name, name), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                 "launches": int(v["launches"]), "avg_ms": round(v["ms"] / v["launches"], 4),
+                 "alg_bytes_per_launch": v["bytes"] / v["launches"],
+                 "share_of_gpu_time": round(v["ms"] / gpu_ms, 3) if gpu_ms > 0 else None}
+            if name == "k_radix_scatter":
+                # HBM bytes per record of this kernel from the PMC passes committed under profiles/
+                # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is)
+                try:
+                    import glob
+                    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.json")))[-1]
+                    pm = json.load(open(latest))
+                    r["traffic"] = round(pm["derived"]["scatter_traffic_bytes_per_record"] * (v["bytes"] / v["launches"] / 32.0))
+                except Exception:
+                    pass
+            return r
+
+        dominant = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+        roof = roof_of(dominant) if dominant else None
+        if roof is None and dominant:
+            v = kern[dominant]
+            roof = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dominant, dominant), "achieved": None, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": None, "traffic": None, "launches": int(v["launches"]),
+                    "avg_ms": round(v["ms"] / max(1, v["launches"]), 4),
+                    "share_of_gpu_time": round(v["ms"] / gpu_ms, 3) if gpu_ms > 0 else None}
+        hbm_stage = roof_of("k_radix_scatter") if dominant != "k_radix_scatter" else None
         stages = {k: round(v["ms"], 2) for k, v in sorted(timings.items(), key=lambda kv: -kv[1]["ms"])}
-        cpu = None
+
+        cpu, parity = None, None
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                ncores = len(os.sched_getaffinity(0))
-            except AttributeError:
-                ncores = os.cpu_count() or 1
-            ncores = min(ncores, 16)        # a 1-GPU box shares its host: 16 cores are ours
-            p = 1
-            while 2 * p <= ncores:
-                p *= 2
-            sample = dazzdb.block_reads(make_block(genome, args.cpu_sample_reads, 4242))
-            cpu = cpu_baseline(genome, sample, p)
-        wl_name = ("configs[1]: E.coli-sized random reference (4.6 Mbp)" if abs(args.genome_mbp - 4.6) < 1e-6 else
-                   "random reference of %.0f Mbp in %d contig(s)" % (args.genome_mbp, ncontig))
+            cpu, parity = parity_and_cpu_baseline(G, ranges, args.cpu_sample_reads, tpow, cores, args.mem_gb, mapper_kw)
+        nblk_total = args.steps * nbatch
         out = {
-            "metric": "Gbp reads mapped/sec (whole node), -k20 -e.85; .las parity-checked vs CPU reference",
+            "metric": "Gbp reads mapped/sec (whole node) on a GRCh38-sized reference, -k20 -e.85; .las parity-checked vs CPU reference"
+                      if args.workload.startswith("grch38") else
+                      "Gbp reads mapped/sec (whole node), -k20 -e.85; .las parity-checked vs CPU reference",
             "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic",
-            "config": {"workload": wl_name + " + simulated PacBio reads "
-                                   "(10 kb, 15%% err), %d reads per block/step, %d distinct blocks per GPU, "
-                                   "-k20 -e.85 -s100, REF index %s" %
-                                   (args.block_reads, nblk, ("rebuilt per read block" if args.rebuild_ref else "built once per GPU, resident") +
-                                    ("" if args.pcie is None else ("; read blocks uploaded inside the timed region " +
-                                     ("as 2-bit .bps bytes from page-locked memory and decoded on the device" if args.pcie == "packed"
-                                      else "from %s host memory" % args.pcie)))),
-                       "read_bases_per_step": int(blocks[0].db.totlen), "parallelism": "read blocks sharded x%d" % world},
-            "roofline": roof, "cpu_baseline": cpu,
+            "config": {"workload": "%s: %.0f Mbp %s reference (%d contigs, %d REF blocks <= 375 Mbp, %s) + simulated PacBio "
+                                   "reads (10 kb, 15%% err) in blocks of %d reads; a step = a fixed batch of %d read blocks "
+                                   "dealt to the ranks b mod N, each through %d Match_Filter passes + Reporter; -k20 -e.85 "
+                                   "-s100 -M%d; REF index %s; read blocks %s" %
+                                   (args.workload, G.total / 1e6, kind, ncontig, len(ranges),
+                                    ("%d repeat families" % fam) if kind == "repeat" else "uniform ACGT",
+                                    args.block_reads, nbatch, 2 * len(ranges), args.mem_gb,
+                                    "rebuilt per read block" if args.rebuild_ref else "built once per GPU, resident",
+                                    "resident in HBM" if args.resident_reads else
+                                    "uploaded as 2-bit .bps bytes from page-locked memory and decoded on the device inside the timed region"),
+                       "read_bases_per_step": int(tot_bases / max(1, args.steps)), "read_blocks_timed": nblk_total,
+                       "ms_per_read_block": round(dt / max(1, nblk_total) * world * 1e3, 2),
+                       "parallelism": "read blocks sharded x%d" % world,
+                       "setup_seconds": {"reference_and_indices": round(t_ref, 1), "total": round(t_setup, 1)}},
+            "roofline": roof, "hbm_stage": hbm_stage, "cpu_baseline": cpu, "parity": parity,
             "host_seconds": {k: round(v, 3) for k, v in host.items()},
             "device_stage_ms": stages,
         }
         print(json.dumps(out))
+        sys.stdout.flush()
+        if parity is not None and parity["differing"] != 0:
+            raise SystemExit("bench.py: HIP .las differs from the reference's on the parity sample")
+    shutil.rmtree(sort_path, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -542,6 +542,13 @@ def _sim_lib():
         L.dmh_sim_lengths.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_void_p]
         L.dmh_sim_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]
         L.dmh_host_complement.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.dmh_sim_genome.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                     C.c_int, C.c_int, C.c_int, C.c_int]
+        L.dmh_sim_lengths_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                            C.c_uint64, C.c_void_p]
+        L.dmh_sim_fill_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                         C.c_uint64, C.c_void_p, C.c_void_p]
+        L.dmh_pack_bps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _sim = L
     return _sim
 
@@ -588,6 +595,155 @@ def simulate_block(seed: int, contig: np.ndarray, nreads: int, read_len: int = 1
     iv[9] = nreads
     iv[8] = nreads
     return Block(db=db, bases=bases, reads=reads, path=path)
+
+
+@dataclass
+class Genome:
+    """A synthetic reference held in the in-memory layout of the WHOLE reference DB: [4] c0 [4] c1 ... [4]
+    (DB.c:1402-1437), so that the whole-DB block Reporter needs is a view and not a copy."""
+    layout: np.ndarray           # uint8
+    lens: np.ndarray             # int64 contig lengths
+    offs: np.ndarray             # int64 index of each contig's first base inside `layout`
+    kind: str = "random"
+
+    @property
+    def contigs(self) -> List[np.ndarray]:
+        return [self.layout[int(o):int(o) + int(n)] for o, n in zip(self.offs, self.lens)]
+
+    def __len__(self) -> int:
+        return len(self.lens)
+
+    @property
+    def total(self) -> int:
+        return int(self.lens.sum())
+
+
+def native_genome(seed: int, contig_lens: Sequence[int], kind: str = "repeat", family_len: int = 2000,
+                  divergence: float = 0.03, gap: Tuple[int, int] = (1000, 6000), tandem_unit: int = 150,
+                  tandem_copies: int = 60, families: int = 1) -> Genome:
+    """SURVEY 8d's reference generators at genome scale (tools/simulate.c, threaded; the result depends on
+    `seed` only): kind "random" = uniform ACGT; "repeat" = the repeat-rich model of repeat_rich_genome --
+    `families` consensus sequences of `family_len` bases shared by all contigs, a copy of a randomly drawn
+    family mutated at `divergence` on a random strand every gap[0]..gap[1] bases, and one tandem array per
+    contig.  families = 1 is repeat_rich_genome's model as it is."""
+    L = _sim_lib()
+    lens = np.asarray(contig_lens, dtype=np.int64)
+    n = len(lens)
+    offs = 1 + np.concatenate(([0], np.cumsum(lens + 1)))[:n]
+    layout = np.empty(int(lens.sum()) + n + 4, dtype=np.uint8)
+    families = max(1, int(families))
+    fam = np.random.default_rng(seed).integers(0, 4, size=max(1, family_len) * families, dtype=np.uint8)
+    rep = kind == "repeat"
+    for c in range(n):
+        o = int(offs[c])
+        layout[o - 1] = 4
+        L.dmh_sim_genome(layout.ctypes.data + o, int(lens[c]), seed * 1000003 + c, fam.ctypes.data, families,
+                         family_len if rep else 0, divergence, gap[0], gap[1],
+                         tandem_unit if rep else 0, tandem_copies if rep else 0)
+    layout[int(offs[-1]) + int(lens[-1]):] = 4
+    return Genome(layout=layout, lens=lens, offs=offs, kind=kind)
+
+
+def genome_block(G: Genome, first: int = 0, last: Optional[int] = None, part: int = 0, path: bytes = b"./.REF",
+                 copy: bool = False, freq: Optional[Sequence[float]] = None) -> Block:
+    """Contigs [first, last) of a Genome as a DAZZ_DB block (tfirst = first).  Without `copy` the block's bases are
+    a view into the genome (a block that is complemented in place needs a copy)."""
+    last = len(G) if last is None else last
+    n = last - first
+    lens = G.lens[first:last]
+    lo = int(G.offs[first]) - 1
+    hi = int(G.offs[last - 1]) + int(lens[-1]) + 1          # one past the final separator
+    bases = G.layout[lo:hi]
+    if copy:
+        b2 = np.empty(hi - lo + 3, dtype=np.uint8)
+        b2[:hi - lo] = bases
+        b2[hi - lo:] = 4
+        bases = b2
+    if freq is None:
+        cnt = np.bincount(bases[1:1 + (1 << 24)], minlength=5)[:4].astype(np.float64)
+        freq = cnt / max(1.0, cnt.sum())
+    blk = make_block([], tfirst=first, part=part, path=path, freq=freq, lens=lens)
+    blk.bases = bases
+    blk.db.bases = bases.ctypes.data + 1
+    return blk
+
+
+def simulate_block_genome(seed: int, G: Genome, nreads: int, read_len: int = 10000, err: float = 0.15,
+                          tfirst: int = 0, part: int = 0, path: bytes = b"./.mem", pinned: bool = False) -> Block:
+    """simulate_block with the template start uniform over ALL contigs of a Genome (a read never spans two)."""
+    L = _sim_lib()
+    nc = len(G)
+    coff = np.ascontiguousarray(np.concatenate((G.offs, [int(G.offs[-1]) + int(G.lens[-1])])), dtype=np.int64)
+    valid = np.maximum(G.lens - read_len + 1, 0)
+    cum = np.ascontiguousarray(np.concatenate(([0], np.cumsum(valid))), dtype=np.int64)
+    if cum[-1] <= 0:
+        raise ValueError("no contig is as long as a read")
+    rlen = np.zeros(nreads, dtype=np.int32)
+    g = G.layout
+    L.dmh_sim_lengths_multi(g.ctypes.data, coff.ctypes.data, cum.ctypes.data, nc, nreads, read_len, err, seed, rlen.ctypes.data)
+    boff = np.zeros(nreads + 1, dtype=np.int64)
+    np.cumsum(rlen.astype(np.int64) + 1, out=boff[1:])
+    tot = int(rlen.sum())
+    bases = host_bytes(tot + nreads + 4, pinned)
+    bases[-4:] = 4
+    L.dmh_sim_fill_multi(g.ctypes.data, coff.ctypes.data, cum.ctypes.data, nc, nreads, read_len, err, seed,
+                         boff.ctypes.data, bases.ctypes.data)
+    cnt = np.bincount(bases[:1 << 24], minlength=5)[:4].astype(np.float64)
+    blk = make_block([], tfirst=tfirst, part=part, path=path, freq=cnt / max(1.0, cnt.sum()), lens=rlen)
+    blk.bases = bases
+    blk.db.bases = bases.ctypes.data + 1
+    return blk
+
+
+def pack_block(blk: Block, pinned: bool = True) -> Block:
+    """The block as it lies in a .bps file (4 bases per byte, every read starting on a byte) with Load_All_Reads'
+    read records and no bases: what the block loop uploads (dmh_preload_block_2bit decodes it on the device)."""
+    n = blk.nreads
+    lens = blk.reads["rlen"][1:n + 1].astype(np.int64)
+    boff = np.ascontiguousarray(blk.reads["boff"][1:n + 2], dtype=np.int64)
+    clen = (lens + 3) // 4
+    coff = np.ascontiguousarray(np.concatenate(([0], np.cumsum(clen))), dtype=np.int64)
+    out = host_bytes(int(coff[-1]), pinned)
+    _sim_lib().dmh_pack_bps(blk.bases.ctypes.data, boff.ctypes.data, coff.ctypes.data, n, out.ctypes.data)
+    hb = make_block([], tfirst=int(blk.db.tfirst), part=int(blk.db.part), path=blk.path,
+                    freq=[blk.db.freq[j] for j in range(4)], lens=lens)
+    hb.packed = out
+    hb.coff = np.ascontiguousarray(coff[:-1])
+    return hb
+
+
+def write_db_block(directory: str, root: str, blk: Block, block_size: int = 400_000_000) -> None:
+    """write_db for the reads of an in-memory block (one DB block; native 2-bit packing)."""
+    os.makedirs(directory, exist_ok=True)
+    hb = pack_block(blk, pinned=False)
+    n = blk.nreads
+    lens = blk.reads["rlen"][1:n + 1].astype(np.int64)
+    recs = np.zeros(n, dtype=READ_DTYPE)
+    recs["origin"] = np.arange(n)
+    recs["rlen"] = lens
+    recs["boff"] = hb.coff
+    recs["flags"] = DB_BEST
+    with open(os.path.join(directory, "." + root + ".bps"), "wb") as f:
+        f.write(hb.packed.tobytes())
+    hdr = DAZZ_DB()
+    hdr.ureads = hdr.treads = n
+    hdr.cutoff = 0
+    hdr.allarr = DB_ALL
+    for j in range(4):
+        hdr.freq[j] = blk.db.freq[j]
+    hdr.maxlen = int(lens.max()) if n else 0
+    hdr.totlen = int(lens.sum())
+    hdr.nreads = n
+    hdr.trimmed = 0
+    with open(os.path.join(directory, "." + root + ".idx"), "wb") as f:
+        f.write(bytes(hdr))
+        f.write(recs.tobytes())
+    with open(os.path.join(directory, root + ".db"), "w") as f:
+        f.write("files = %9d\n" % 1)
+        f.write("  %9d %s %s\n" % (n, root, root))
+        f.write("blocks = %9d\n" % 1)
+        f.write("size = %11d cutoff = %9d all = %1d\n" % (block_size, 0, 1))
+        f.write(" %9d %9d\n %9d %9d\n" % (0, 0, n, n))
 
 
 def block_reads(blk: Block, lo: int = 0, hi: Optional[int] = None) -> List[np.ndarray]:

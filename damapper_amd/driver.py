@@ -42,25 +42,49 @@ class Mapper:
         self.L.dmh_retain_ref_index(1 if retain_ref else 0)
 
     def release_ref(self) -> None:
+        self._drop_prefetched()
         if self._ref_cache:
             for (h, n, comp, k) in self._ref_cache:
                 if h:
                     self.L.dmh_free_index(h)
         self._ref_cache = None
 
-    def _ref_indices(self, ref_blocks):
+    def add_ref_block(self, blk: Block, k: int, drop_bases: bool = False) -> None:
+        """Both orientations of REF block k, built now and kept in HBM.  The device copy of the block's bases is
+        released as soon as its two indices exist (Reporter reads the whole-reference copy); with `drop_bases`
+        the host copy goes too -- Match_Filter only reads the block's read records."""
         if self._ref_cache is None:
-            cache = []
+            self._ref_cache = []
+        h0, n0 = capi.sort_kmers(blk)
+        blk.complement_inplace()
+        h1, n1 = capi.sort_kmers(blk)
+        blk.complement_inplace()
+        self.L.dmh_sync()
+        self.L.dmh_release_block(blk.ptr())
+        if drop_bases:
+            blk.bases = None
+            blk.db.bases = None
+        self._ref_cache.append((h0, n0, 0, k))
+        self._ref_cache.append((h1, n1, 1, k))
+
+    def _ref_indices(self, ref_blocks, drop_bases: bool = False):
+        if self._ref_cache is None:
+            self._ref_cache = []
             for k, blk in enumerate(ref_blocks):
-                h0, n0 = capi.sort_kmers(blk)
-                blk.complement_inplace()
-                h1, n1 = capi.sort_kmers(blk)
-                blk.complement_inplace()
-                self.L.dmh_sync()
-                cache.append((h0, n0, 0, k))
-                cache.append((h1, n1, 1, k))
-            self._ref_cache = cache
+                self.add_ref_block(blk, k, drop_bases)
         return self._ref_cache
+
+    def build_ref(self, ref_blocks, drop_bases: bool = False) -> None:
+        """Build the resident REF indices now (retain_ref) instead of at the first map_block."""
+        if self.retain_ref:
+            self._ref_indices(ref_blocks, drop_bases)
+
+    def _drop_prefetched(self) -> None:
+        pre = getattr(self, "_prefetched", None)
+        if pre is not None and pre[1]:
+            self.L.dmh_sync()              # its deferred stages may still be queued
+            self.L.dmh_free_index(pre[1])
+        self._prefetched = None
 
     def threads_pow2(self) -> int:
         """NTHREADS of map.c:142-147: the number of per-"thread" output files."""
@@ -94,9 +118,10 @@ class Mapper:
         pre = getattr(self, "_prefetched", None)
         if pre is not None and pre[0] is reads:
             rh, rn = pre[1], pre[2]
+            self._prefetched = None
         else:
+            self._drop_prefetched()        # a prefetched index for a block that did not come next
             rh, rn = capi.sort_kmers(reads)
-        self._prefetched = None
         if next_reads is not None and self.prefetch_deferred:
             # the next block's index build is deferred: its stages are queued in the gaps of this
             # block's filter and report phases (dmh_sort_kmers_async)
@@ -121,7 +146,9 @@ class Mapper:
         if next_reads is not None and not self.prefetch_deferred:
             h2, n2 = capi.sort_kmers(next_reads)
             self._prefetched = (next_reads, h2, n2)
+        maxlen = reads.db.maxlen
         self.L.Reporter(reads_name.encode(), reads.ptr(), ref_name.encode(), ref_whole.ptr(), self.spec, mflag)
+        reads.db.maxlen = maxlen           # Reporter adds SPACING (map.c:3246); a block mapped again must not grow
         t["report"] = time.time() - t2
         if rh:
             self.L.dmh_free_index(rh)      # Reporter released the device side; this frees the stub

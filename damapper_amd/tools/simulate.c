@@ -89,3 +89,148 @@ void dmh_host_complement(uint8_t *bases, const int64_t *boff, int nreads)
   for (i = 0; i < nreads; i++)
     comp_one(bases + boff[i], boff[i+1] - boff[i] - 1);
 }
+
+/* ---- synthetic reference genomes ------------------------------------------------------
+ * dmh_sim_genome: one contig of `n` uniform random bases, seeded with copies of a repeat family `fam`
+ * (length flen) on both strands, each copy mutated i.i.d. at rate `div` (substitutions), the copies
+ * `gap_lo`..`gap_hi`-1 bases apart, plus one tandem array of `tcopies` x `tunit` random bases.  `fam` holds
+ * `nfam` consensus sequences one after the other; every copy draws its family uniformly.  With nfam = 1 the same
+ * model as dazzdb.repeat_rich_genome (one 2 kb family at 3 % divergence every 1-6 kb + a 60 x 150 bp
+ * array), generated natively so that a GRCh38-sized reference takes seconds.  Every 1 MB chunk of the
+ * background and every copy has its own RNG stream derived from (seed, index): the contig depends on
+ * `seed` only, not on the thread count.  flen = 0 gives a uniform random contig.                     */
+void dmh_sim_genome(uint8_t *out, int64_t n, uint64_t seed, const uint8_t *fam, int nfam, int flen, double div,
+                    int gap_lo, int gap_hi, int tunit, int tcopies)
+{ const int64_t CH = 1 << 20;
+  int64_t nch = (n + CH - 1) / CH, c;
+#pragma omp parallel for schedule(static)
+  for (c = 0; c < nch; c++)
+    { uint64_t s = seed * 0x9e3779b97f4a7c15ull + (uint64_t) c * 0xd1342543de82ef95ull + 7;
+      int64_t  e = (c + 1) * CH < n ? (c + 1) * CH : n, i = c * CH;
+      while (i < e)
+        { uint64_t r = splitmix(&s);
+          int k;
+          for (k = 0; k < 32 && i < e; k++, i++)
+            out[i] = (uint8_t) ((r >> (2 * k)) & 3);
+        }
+    }
+  if (flen > 0 && gap_hi > gap_lo)
+    { /* positions first (sequential, cheap), then the copies in parallel */
+      uint64_t s = seed ^ 0xa0761d6478bd642full;
+      int64_t  cap = n / (flen + gap_lo) + 2, m = 0, p;
+      int64_t *pos = (int64_t *) malloc(sizeof(int64_t) * (size_t) cap);
+      p = 500 + (int64_t) (splitmix(&s) % 2500);
+      while (p + flen < n && m < cap)
+        { pos[m++] = p;
+          p += flen + gap_lo + (int64_t) (splitmix(&s) % (uint64_t) (gap_hi - gap_lo));
+        }
+      uint32_t tdiv = (uint32_t) (div * 4294967296.0);
+      int64_t  j;
+#pragma omp parallel for schedule(static)
+      for (j = 0; j < m; j++)
+        { uint64_t t = seed * 0x2545f4914f6cdd1dull + (uint64_t) j * 0x9e3779b97f4a7c15ull + 11;
+          uint64_t r0 = splitmix(&t);
+          int      rev = (int) (r0 & 1), x;
+          const uint8_t *cons = fam + (size_t) ((r0 >> 8) % (uint64_t) nfam) * (size_t) flen;
+          uint8_t *o = out + pos[j];
+          for (x = 0; x < flen; x++)
+            { uint64_t r = splitmix(&t);
+              int      b = cons[x];
+              if ((uint32_t) r < tdiv) b = (b + 1 + (int) ((r >> 32) % 3)) & 3;
+              if (rev) o[flen - 1 - x] = (uint8_t) (3 - b);
+              else     o[x] = (uint8_t) b;
+            }
+        }
+      free(pos);
+    }
+  if (tunit > 0 && tcopies > 0 && n > 4 * (int64_t) tunit * tcopies)
+    { uint64_t s = seed ^ 0xe7037ed1a0b428dbull;
+      int64_t  tl = (int64_t) tunit * tcopies, q = (int64_t) (splitmix(&s) % (uint64_t) (n - tl)), i;
+      uint8_t *unit = (uint8_t *) malloc((size_t) tunit);
+      for (i = 0; i < tunit; i++) unit[i] = (uint8_t) (splitmix(&s) & 3);
+      for (i = 0; i < tl; i++) out[q + i] = unit[i % tunit];
+      free(unit);
+    }
+}
+
+/* Reads sampled from SEVERAL contigs laid out one after the other in `g` (contig c = g[coff[c] .. coff[c+1])):
+ * the template start is uniform over all positions that leave `rl` bases inside one contig.  Otherwise as
+ * gen_read.  cum[c] = number of valid starts in contigs 0..c-1 (cum[ncontig] = total).                  */
+static int gen_read_multi(const uint8_t *g, const int64_t *coff, const int64_t *cum, int ncontig, int rl, double err,
+                          uint64_t seed, int i, uint8_t *out)
+{ uint64_t s = seed * 0x2545f4914f6cdd1dull + (uint64_t) i * 0x9e3779b97f4a7c15ull + 3;
+  int64_t  u = (int64_t) (splitmix(&s) % (uint64_t) cum[ncontig]);
+  int lo = 0, hi = ncontig - 1;
+  while (lo < hi)
+    { int m = (lo + hi + 1) >> 1;
+      if (cum[m] <= u) lo = m; else hi = m - 1;
+    }
+  const uint8_t *c = g + coff[lo] + (u - cum[lo]);
+  /* the per-read stream continues exactly like gen_read's after its position draw */
+  int      rev = (int) (splitmix(&s) & 1);
+  uint32_t tins = (uint32_t) (err * 0.60 * 4294967296.0);
+  uint32_t tdel = (uint32_t) (err * 0.85 * 4294967296.0);
+  uint32_t tsub = (uint32_t) (err * 4294967296.0);
+  int n = 0, j;
+  for (j = 0; j < rl; j++)
+    { uint64_t r = splitmix(&s);
+      uint32_t w = (uint32_t) r;
+      int b = rev ? 3 - c[rl - 1 - j] : c[j];
+      if (w < tins)
+        { if (out) out[n] = (uint8_t) ((r >> 32) & 3);
+          n += 1;
+          if (out) out[n] = (uint8_t) b;
+          n += 1;
+        }
+      else if (w < tdel)
+        continue;
+      else if (w < tsub)
+        { if (out) out[n] = (uint8_t) ((b + 1 + ((r >> 32) % 3)) & 3);
+          n += 1;
+        }
+      else
+        { if (out) out[n] = (uint8_t) b;
+          n += 1;
+        }
+    }
+  return n;
+}
+
+void dmh_sim_lengths_multi(const uint8_t *g, const int64_t *coff, const int64_t *cum, int ncontig, int nreads, int rl,
+                           double err, uint64_t seed, int *rlen)
+{ int i;
+#pragma omp parallel for schedule(static)
+  for (i = 0; i < nreads; i++)
+    rlen[i] = gen_read_multi(g, coff, cum, ncontig, rl, err, seed, i, NULL);
+}
+
+void dmh_sim_fill_multi(const uint8_t *g, const int64_t *coff, const int64_t *cum, int ncontig, int nreads, int rl,
+                        double err, uint64_t seed, const int64_t *boff, uint8_t *bases)
+{ int i;
+  bases[0] = 4;
+#pragma omp parallel for schedule(static)
+  for (i = 0; i < nreads; i++)
+    { int n = gen_read_multi(g, coff, cum, ncontig, rl, err, seed, i, bases + 1 + boff[i]);
+      bases[1 + boff[i] + n] = 4;
+    }
+}
+
+/* The block's slice of a .bps file from its in-memory layout: read i's rlen bases at bases[1 + boff[i]] go to
+ * out[coff[i] ..] four per byte, first base in the top bits (DB.c:319-338). */
+void dmh_pack_bps(const uint8_t *bases, const int64_t *boff, const int64_t *coff, int nreads, uint8_t *out)
+{ int i;
+#pragma omp parallel for schedule(dynamic, 64)
+  for (i = 0; i < nreads; i++)
+    { const uint8_t *s = bases + 1 + boff[i];
+      int64_t  len = boff[i + 1] - boff[i] - 1, j;
+      uint8_t *o = out + coff[i];
+      for (j = 0; j + 4 <= len; j += 4)
+        *o++ = (uint8_t) ((s[j] << 6) | (s[j + 1] << 4) | (s[j + 2] << 2) | s[j + 3]);
+      if (j < len)
+        { uint8_t v = 0;
+          int     k;
+          for (k = 0; k < 4; k++) v = (uint8_t) ((v << 2) | (j + k < len ? s[j + k] : 0));
+          *o = v;
+        }
+    }
+}
