@@ -88,12 +88,22 @@ def shard_blocks(nblocks, rank, world):
 
 
 def host_threads():
+    """(cores this process may use, largest power of two <= that): the affinity mask capped by the cgroup's CPU
+    quota (a 1-GPU box of this pool shows 256 CPUs in the mask and a cpu.max of 16 cores: beyond the quota more
+    threads only time-slice).  The reference rounds -T down to a power of two (map.c:142-147) and its own radix
+    sort crashes for -T >= 64, so the power of two is capped at 32."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
     p = 1
-    while 2 * p <= n:
+    while 2 * p <= min(n, 32):
         p *= 2
     return n, p
 
@@ -237,12 +247,18 @@ def main():
         raw = dazzdb.simulate_block_genome(1000 + b, G, args.block_reads, read_len=READ_LEN, tfirst=b * args.block_reads,
                                            part=b + 1, path=b"./.READS", pinned=args.resident_reads)
         if args.resident_reads:
-            blocks[b] = raw
+            blocks[b] = (raw, raw)
             L.dmh_preload_block(raw.ptr())
             L.dmh_prepare_block(raw.ptr(), 1)
         else:
-            blocks[b] = dazzdb.pack_block(raw, pinned=True)
-            blocks[b].slice = blocks[b].packed
+            # two handles on one page-locked slice: a rank that owns a single block of the batch can then
+            # prefetch its next visit like any other (the handle is the library's identity of a block)
+            h0 = dazzdb.pack_block(raw, pinned=True)
+            h0.slice = h0.packed
+            h1 = dazzdb.make_block([], tfirst=int(h0.db.tfirst), part=int(h0.db.part), path=h0.path,
+                                   freq=[h0.db.freq[j] for j in range(4)], lens=h0.reads["rlen"][1:h0.nreads + 1])
+            h1.slice, h1.coff = h0.slice, h0.coff
+            blocks[b] = (h0, h1)
             del raw
     L.dmh_sync()
     t_setup = time.time() - t_setup
@@ -251,9 +267,10 @@ def main():
     per_step = len(mine)
 
     def visit(i):
-        blk = blocks[seq[i]]
-        nxt = blocks[seq[i + 1]] if (i + 1 < len(seq) and not args.no_prefetch and
-                                     (len(mine) > 1 or args.resident_reads)) else None
+        blk = blocks[seq[i]][(i // per_step) & 1]
+        nxt = blocks[seq[i + 1]][((i + 1) // per_step) & 1] if (i + 1 < len(seq) and not args.no_prefetch) else None
+        if nxt is blk:
+            nxt = None
         if not args.resident_reads:
             for bb in (blk, nxt):                # map_block uploads (2-bit) and decodes what carries a slice
                 if bb is not None and not bb.resident:
@@ -283,7 +300,7 @@ def main():
         t = visit(i)
         for k in host:
             host[k] += t[k]
-        bases += int(blocks[seq[i]].db.totlen)
+        bases += int(blocks[seq[i]][0].db.totlen)
     L.dmh_report_wait()
     L.dmh_sync()
     if dist is not None:

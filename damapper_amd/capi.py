@@ -169,6 +169,13 @@ def candidate_jumps(reads: Block, ar: int, k: int, maxj: int = 65536) -> Tuple[n
     return a[:max(n, 0)], b[:max(n, 0)]
 
 
+def read_cover(reads: Block, ar: int, maxn: int = 4096) -> np.ndarray:
+    """-p coverage deltas of one read (map.c:1654-1666), (rlen-1)/SPACING+2 int16 values."""
+    out = np.zeros(maxn, dtype=np.int16)
+    n = lib().dmh_read_cover(reads.ptr(), ar, out.ctypes.data, maxn)
+    return out[:max(n, 0)]
+
+
 def local_alignment(spec, abuf: np.ndarray, bbuf: np.ndarray, jobs, stride: int = 1024, want_b: bool = True):
     """jobs: list of (aoff, alen, boff, blen, comp, dg, ad) with offsets into abuf/bbuf (uint8, 4-delimited).
     Returns (out[n,12], atrace[n,stride], btrace[n,stride])."""

@@ -12,4 +12,8 @@ void chain_reset_reads(const DAZZ_DB *ablock);
 // of candidates (the reference's nfilt).
 int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock, int comp);
 
+// Brings State::reads (the host view of the candidate lists: list order, -p deltas) up to date with the
+// device lists; with_jumps also fetches every candidate's Jump list.
+void cand_mirror(bool with_jumps);
+
 }  // namespace dmh

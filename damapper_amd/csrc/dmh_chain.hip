@@ -28,7 +28,6 @@ constexpr uint32_t NIL = 0xffffffffu;
 constexpr uint32_t ST_LIVE    = 1;   // in the tree
 constexpr uint32_t ST_DEAD    = 0;   // removed by the slope rule, or expired
 
-void gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n);
 
 struct ChainSummary
 { uint32_t group, live;     // live: the end was still in the window when its group finished
@@ -62,6 +61,8 @@ struct ChainArgs
   unsigned int   *nretry;             //         (the 64-lane launch that follows walks this list)
   unsigned int   *out_count;
   ChainSummary   *out;
+  uint32_t       *gcount;             // per group: number of summaries it reported and the slot of the first one in `out`
+  uint32_t       *gbase;              //   (k_order_summaries puts them into the reference's reporting order)
   uint32_t        pile_cap;           // k_chain_pile: entries of LDS it may use (<= PILE_CAP; smaller in tests)
 };
 
@@ -327,7 +328,11 @@ __global__ __launch_bounds__(BLOCK) void k_chain(ChainArgs A)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
       uint32_t obase = 0;
-      if (lane == 0) obase = atomicAdd(A.out_count, E);
+      if (lane == 0)
+        { obase = atomicAdd(A.out_count, E);
+          A.gcount[g] = E;
+          A.gbase[g]  = obase;
+        }
       obase = __shfl(obase, 0, G);
 
       for (uint32_t e = lane; e < E; e += G)
@@ -590,7 +595,11 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
           if (E != 0)
             { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
               uint32_t obase = 0;
-              if (lane == 0) obase = atomicAdd(A.out_count, E);
+              if (lane == 0)
+                { obase = atomicAdd(A.out_count, E);
+                  A.gcount[g] = E;
+                  A.gbase[g]  = obase;
+                }
               obase = __shfl(obase, 0);
               for (uint32_t e = lane; e < E; e += 64)
                 { uint32_t x    = A.tmp[g0 + e];
@@ -616,20 +625,213 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+//  Device-side candidate lists: reporting order, domination rule, -p deltas, Jump lists
+//  (map.c:1634-1766).  The reference does this per read on the thread that owns the read; here the
+//  chain ends of a pass are put into the reference's order by rank (k_order_summaries), every read's
+//  ends are contiguous (groups are sorted by read), and one 16-lane group per read applies the
+//  domination rule to its list in that order (k_dominate).  Nothing but a few counters goes to the host.
+// ---------------------------------------------------------------------------------------
+
+struct OrdChain
+{ int32_t  cost, ab, ae, bb, be;
+  uint32_t end;
+  uint64_t gkey;          // (aread | pass | bread) of the group = its hits' sort key without the position bits
+};
+
+// Reporting order inside a group (map.c:1634-1642): live ends by (diagonal, apos) descending, then expired ends
+// most recent first -- i.e. descending (live, okey).  The keys of a group are unique, so the rank of an end is
+// the number of its siblings that precede it; the ends of group g go to ord[goff[g] ...).
+__global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__restrict__ out,
+                                                         const unsigned int *__restrict__ nsum_p,
+                                                         const uint32_t *__restrict__ gbase,
+                                                         const uint32_t *__restrict__ gcount,
+                                                         const uint32_t *__restrict__ goff,
+                                                         const uint64_t *__restrict__ skeys,
+                                                         const uint32_t *__restrict__ gstart, int pbits,
+                                                         OrdChain *__restrict__ ord)
+{ const uint32_t nsum = *nsum_p;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nsum; i += gridDim.x * blockDim.x)
+    { const ChainSummary s = out[i];
+      const uint32_t g = s.group, b = gbase[g], E = gcount[g];
+      uint32_t rank = 0;
+      for (uint32_t f = 0; f < E; f++)
+        { const uint32_t tl = out[b + f].live;
+          const uint64_t tk = out[b + f].okey;
+          rank += (tl > s.live || (tl == s.live && tk > s.okey)) ? 1u : 0u;
+        }
+      OrdChain o;
+      o.cost = s.cost; o.ab = s.ab; o.ae = s.ae; o.bb = s.bb; o.be = s.be; o.end = s.end;
+      o.gkey = skeys[gstart[g]] >> pbits;
+      ord[goff[g] + rank] = o;
+    }
+}
+
+// rgfirst[r] = first group whose read index is >= r (r = 0..nreads): read r's groups are [rgfirst[r], rgfirst[r+1])
+__global__ void k_read_groups(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ gstart,
+                              uint32_t ngroups, int ashift, int nreads, uint32_t *__restrict__ rgfirst)
+{ uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > ngroups) return;
+  int64_t cur  = (g < ngroups) ? (int64_t) (skeys[gstart[g]] >> ashift) : (int64_t) nreads;
+  int64_t prev = (g > 0) ? (int64_t) (skeys[gstart[g - 1]] >> ashift) : -1;
+  if (cur > nreads) cur = nreads;
+  for (int64_t r = prev + 1; r <= cur; r++) rgfirst[r] = g;
+}
+
+// records the new list of read r may need: what it has plus one per chain end of this pass
+__global__ void k_dom_need(const uint32_t *__restrict__ olen, const uint32_t *__restrict__ goff,
+                           const uint32_t *__restrict__ rgfirst, int nreads, uint32_t *__restrict__ need)
+{ int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nreads) return;
+  need[r] = olen[r] + (goff[rgfirst[r + 1]] - goff[rgfirst[r]]);
+}
+
+struct PassInfo { int32_t bbase, comp; };     // per pass of a batch: first contig of the REF block, orientation
+
+struct DomArgs
+{ const OrdChain *ord;
+  const uint32_t *goff, *rgfirst;
+  const DCand    *oldp;
+  const uint32_t *ooff, *olen;
+  DCand          *newp;
+  const uint32_t *noff;
+  uint32_t       *nlen;
+  int             nreads;
+  int             bbits, passbits;
+  PassInfo        pass[64];
+  int16_t        *cover;            // nullptr without -p
+  const uint32_t *cov_off;
+  int             spacing;
+  unsigned int   *ctl;              // [0] += candidates added, [1] += removed
+};
+
+// map.c:1654-1730 for all reads at once: a 16-lane group per read walks the read's chain ends of this pass in the
+// reference's order; for each, the list is scanned newest first, 16 records at a time -- the newest record that
+// dominates the chain drops it, and the records it dominates are removed up to there (map.c:1668-1713: "break"
+// leaves the deletions made so far in place); a chain that survives the scan is appended.  The list (oldest
+// first, tombstones squeezed out) is first copied from the other pool.
+constexpr int DOM_G = 16;
+
+__global__ __launch_bounds__(256) void k_dominate(DomArgs D)
+{ const int      lane  = threadIdx.x & (DOM_G - 1);
+  const int      sbase = (threadIdx.x & 63) & ~(DOM_G - 1);
+  const uint64_t lt    = (1ull << lane) - 1ull;
+  auto gballot = [&](bool p) -> uint32_t { return (uint32_t) ((__ballot(p) >> sbase) & 0xffffull); };
+  const uint64_t bmask = (D.bbits >= 64) ? ~0ull : ((1ull << D.bbits) - 1ull);
+  const uint64_t qmask = (1ull << D.passbits) - 1ull;
+
+  for (int ar = blockIdx.x * (256 / DOM_G) + threadIdx.x / DOM_G; ar < D.nreads; ar += gridDim.x * (256 / DOM_G))
+    { const uint32_t ooff = D.ooff[ar], olen = D.olen[ar], nb = D.noff[ar];
+      const uint32_t s0 = D.goff[D.rgfirst[ar]], s1 = D.goff[D.rgfirst[ar + 1]];
+      uint32_t n = 0;
+      for (uint32_t base = 0; base < olen; base += DOM_G)
+        { const uint32_t i = base + lane;
+          DCand e;
+          bool  keep = false;
+          if (i < olen)
+            { e = D.oldp[ooff + i];
+              keep = !(e.flags & DC_TOMB);
+            }
+          const uint32_t m = gballot(keep);
+          if (keep) D.newp[nb + n + (uint32_t) __popc(m & (uint32_t) lt)] = e;
+          n += (uint32_t) __popc(m);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      uint32_t added = 0, removed = 0;
+      int16_t *cov = D.cover ? D.cover + D.cov_off[ar] : nullptr;
+      for (uint32_t c = s0; c < s1; c++)
+        { const OrdChain S = D.ord[c];
+          if (cov != nullptr && lane == 0)                           // map.c:1654-1666
+            { const int tb = S.ab / D.spacing, te = (S.ae - 1) / D.spacing + 1;
+              const int cb = cov[tb], ce = cov[te];
+              if (cb < 0x7fff && ce > -0xffff)
+                { cov[tb] = (int16_t) (cb + 1);
+                  cov[te] = (int16_t) (ce - 1);
+                }
+            }
+          bool dropped = false;
+          for (int hi = (int) n; hi > 0; hi -= DOM_G)
+            { const int i = hi - 1 - lane;             // lane 0 looks at the newest record of the chunk
+              int      sc = 0, af = 0, al = 0;
+              uint32_t fl = DC_TOMB;
+              if (i >= 0)
+                { const DCand *e = D.newp + nb + i;
+                  sc = e->score; af = e->afirst; al = e->alast; fl = e->flags;
+                }
+              const bool live = !(fl & DC_TOMB);
+              const bool dhc  = live && af < S.ab + MIN_PIECE && al > S.ae - MIN_PIECE;
+              const bool chd  = live && S.ab < af + MIN_PIECE && S.ae > al - MIN_PIECE;
+              const bool dom  = dhc && (.9 * (double) sc >= (double) S.cost);
+              bool       del  = chd && !dom && ((double) sc <= .9 * (double) S.cost);
+              const uint32_t md = gballot(dom);
+              if (md != 0)
+                { del = del && lane < (__ffs((int) md) - 1);
+                  dropped = true;
+                }
+              if (del) D.newp[nb + i].flags = fl | DC_TOMB;
+              removed += (uint32_t) __popc(gballot(del));
+              if (dropped) break;
+            }
+          if (!dropped)
+            { if (lane == 0)
+                { const uint32_t q = (uint32_t) ((S.gkey >> D.bbits) & qmask);
+                  DCand e;
+                  e.score = S.cost; e.afirst = S.ab; e.alast = S.ae; e.bfirst = S.bb; e.blast = S.be;
+                  e.bread = (int32_t) (S.gkey & bmask) + D.pass[q].bbase;
+                  e.end   = S.end;
+                  e.joff  = 0; e.jlen = 0;
+                  e.flags = DC_FRESH | (D.pass[q].comp ? DC_COMP : 0u);
+                  D.newp[nb + n] = e;
+                }
+              n += 1;
+              added += 1;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // the next chain reads what the lanes stored
+        }
+      if (lane == 0)
+        { D.nlen[ar] = n;
+          if (added)   atomicAdd(D.ctl, added);
+          if (removed) atomicAdd(D.ctl + 1, removed);
+        }
+    }
+}
+
+// the records added by this pass that survived it: their Jump lists are stored next.  (One thread per read
+// walks the read's list: the slack behind a list -- a read may need fewer records than were reserved -- is
+// uninitialised memory.)
+__global__ void k_fresh_list(const DCand *__restrict__ pool, const uint32_t *__restrict__ noff,
+                             const uint32_t *__restrict__ nlen, int nreads,
+                             uint32_t *__restrict__ fresh, unsigned int *__restrict__ nfresh)
+{ const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nreads) return;
+  const uint32_t b = noff[r], n = nlen[r];
+  for (uint32_t i = 0; i < n; i++)
+    { const uint32_t fl = pool[b + i].flags;
+      if ((fl & DC_FRESH) && !(fl & DC_TOMB)) fresh[atomicAdd(nfresh, 1u)] = b + i;
+    }
+}
+
 // Compressed Jump displacements of a kept chain (chain_length, map.c:1243-1260, and the encoding
 // loop map.c:1741-1759): links on one diagonal closer than 100 bp to the last kept point are
-// skipped.  One thread per candidate; pass 0 counts, pass 1 writes at joff[c].
-__global__ void k_chain_jumps(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                              uint64_t pmask, const uint32_t *__restrict__ from,
-                              const uint32_t *__restrict__ ends, int n, uint32_t *__restrict__ jlen,
-                              const uint32_t *__restrict__ joff, uint16_t *__restrict__ jout, int write)
-{ int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  uint32_t x  = ends[c];
+// skipped.  One thread per surviving fresh candidate; pass 0 counts (jlen[c], 0 beyond the list), pass 1
+// writes the pairs at jbase + joff[c] of the jump pool and completes the candidate's record.
+__global__ void k_cand_jumps(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                             uint64_t pmask, const uint32_t *__restrict__ from, DCand *__restrict__ pool,
+                             const uint32_t *__restrict__ fresh, const unsigned int *__restrict__ nfresh, uint32_t cap,
+                             uint32_t *__restrict__ jlen, const uint32_t *__restrict__ joff, uint16_t *__restrict__ jout,
+                             uint32_t jbase, int write)
+{ const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cap) return;
+  if (c >= *nfresh)
+    { if (!write) jlen[c] = 0;
+      return;
+    }
+  const uint32_t slot = fresh[c];
+  uint32_t x  = pool[slot].end;
   int      ax = (int) (keys[x] & pmask), bx = (int) vals[x];
   uint32_t y  = from[x];
   uint32_t cnt = 0;
-  uint16_t *o = write ? jout + 2 * (size_t) joff[c] : nullptr;
+  uint16_t *o = write ? jout + 2 * ((size_t) jbase + joff[c]) : nullptr;
   while (y != NIL)
     { // the three loads of a step depend on y only: request them together (one round trip per link)
       const uint64_t ky = keys[y];
@@ -648,6 +850,11 @@ __global__ void k_chain_jumps(const uint64_t *__restrict__ keys, const uint32_t 
       y = fy;
     }
   if (!write) jlen[c] = cnt;
+  else
+    { pool[slot].joff  = jbase + joff[c];
+      pool[slot].jlen  = cnt;
+      pool[slot].flags &= ~DC_FRESH;
+    }
 }
 
 // groups of at least `big` hits, in any order; those of at least `pile` hits go to their own list
@@ -711,22 +918,47 @@ namespace dmh {
 
 void chain_reset_reads(const DAZZ_DB *ablock)
 { State &st = S();
+  CandStore &cs = st.cands;
+  const int n = ablock->nreads;
   st.cur_reads = ablock;
   st.reads.clear();
-  st.reads.resize(ablock->nreads);
   st.next_cand_id = 0;
   st.tfilt = 0;
+  cs.block  = ablock;
+  cs.nreads = n;
+  cs.cur    = 0;
+  cs.total_len = 0;
+  cs.jtop   = 0;
+  cs.mirror_valid = false;
+  cs.mirror_jumps = false;
+  cs.seg_off[0].ensure((size_t) n + 1, "candidate list offsets");
+  cs.seg_len[0].ensure((size_t) n + 1, "candidate list lengths");
+  cs.ctl.ensure(16, "candidate counters");
+  HIP_CHECK(hipMemsetAsync(cs.seg_off[0].p, 0, sizeof(uint32_t) * ((size_t) n + 1), stream()));
+  HIP_CHECK(hipMemsetAsync(cs.seg_len[0].p, 0, sizeof(uint32_t) * ((size_t) n + 1), stream()));
   if (PROFILE)
-    for (int i = 0; i < ablock->nreads; i++)
-      st.reads[i].cover.assign((ablock->reads[i].rlen - 1) / SPACING + 2, 0);
-  for (int i = 0; i < ablock->nreads; i++)
+    { cs.h_cov_off.resize((size_t) n + 1);
+      uint32_t tot = 0;
+      for (int i = 0; i < n; i++)
+        { cs.h_cov_off[i] = tot;
+          tot += (uint32_t) ((ablock->reads[i].rlen - 1) / SPACING + 2);
+        }
+      cs.h_cov_off[n] = tot;
+      cs.cov_off.ensure((size_t) n + 1, "cover offsets");
+      cs.cover.ensure((size_t) tot + 1, "cover deltas");
+      copy_h2d(cs.cov_off.p, cs.h_cov_off.data(), sizeof(uint32_t) * ((size_t) n + 1));
+      HIP_CHECK(hipMemsetAsync(cs.cover.p, 0, sizeof(int16_t) * ((size_t) tot + 1), stream()));
+    }
+  else
+    cs.h_cov_off.clear();
+  for (int i = 0; i < n; i++)
     ablock->reads[i].coff = -1;
 }
 
 int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock, int comp)
 { State &st = S();
   const Params &pm = st.params;
-  if (st.cur_reads != ablock || (int) st.reads.size() != ablock->nreads)
+  if (st.cur_reads != ablock || st.cands.nreads != ablock->nreads)
     fatal("Match_Filter: first call for a READS block must have start != 0 (map.c:1574)");
 
   const int64_t nhits = R.nhits;
@@ -744,7 +976,11 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   tmp.ensure(nhits, "chain scratch");
   ctl.ensure(8, "chain counters");
   out.ensure(nhits / HITMIN + 64, "chain summaries");
+  static DevBuf<uint32_t> gcnt, gbase;
+  gcnt.ensure((size_t) R.ngroups + 1, "chain ends per group");
+  gbase.ensure((size_t) R.ngroups + 1, "first chain end per group");
   HIP_CHECK(hipMemsetAsync(ctl.p, 0, 8 * sizeof(uint32_t), stream()));
+  HIP_CHECK(hipMemsetAsync(gcnt.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
 
   ChainArgs A;
   A.keys = R.skeys;
@@ -767,6 +1003,8 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.ticket = ctl.p;
   A.out_count = ctl.p + 1;
   A.out = out.p;
+  A.gcount = gcnt.p;
+  A.gbase  = gbase.p;
   A.pile_cap = PILE_CAP;
 
   static const int env_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
@@ -843,160 +1081,143 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   }
   uint32_t nsum = 0;
   { HostTimer ht("chain_wait");
-    copy_d2h(&nsum, ctl.p + 1, sizeof(uint32_t));
-    HIP_CHECK(hipStreamSynchronize(stream()));
+    copy_d2h(&nsum, ctl.p + 1, sizeof(uint32_t), 1);
   }
-  HostTimer ht_all("chain_host");
+  if (nsum == 0) return 0;             // no chain reached the threshold: the lists stay as they are
 
-  std::vector<ChainSummary> sums(nsum);
-  std::vector<uint32_t>     gfirst;
-  if (nsum > 0)
-    { copy_d2h(sums.data(), out.p, sizeof(ChainSummary) * nsum, 1);      // host sort next
-      std::sort(sums.begin(), sums.end(), [](const ChainSummary &a, const ChainSummary &b)
-                { if (a.group != b.group) return a.group < b.group;
-                  if (a.live != b.live) return a.live > b.live;
-                  return a.okey > b.okey;
-                });
-    }
-
-  // group -> (aread, bread): decode from the first hit of each summarised group
-  std::vector<uint32_t> want;
-  for (uint32_t i = 0; i < nsum; i++)
-    if (i == 0 || sums[i].group != sums[i - 1].group) want.push_back(sums[i].end);
-  std::vector<uint64_t> wkeys(want.size());
-  { // gather the keys of those hits (few): one small copy each would be slow, so fetch via a
-    // device gather through the jump kernel's buffers is overkill; copy key by key in batches
-    static DevBuf<uint32_t> d_idx;
-    static DevBuf<uint64_t> d_k;
-    d_idx.ensure(want.size() + 1, "gather idx");
-    d_k.ensure(want.size() + 1, "gather keys");
-    if (!want.empty())
-      { copy_h2d(d_idx.p, want.data(), sizeof(uint32_t) * want.size());
-        gather_u64(R.skeys, d_idx.p, d_k.p, (int64_t) want.size());
-        copy_d2h(wkeys.data(), d_k.p, sizeof(uint64_t) * want.size(), 1);   // domination scan next
+  // ---- reporting order, domination rule and -p deltas on the device (map.c:1634-1730)
+  CandStore &cs = st.cands;
+  const int nreads = ablock->nreads;
+  const uint32_t ng = (uint32_t) R.ngroups;
+  static DevBuf<OrdChain> ord;
+  static DevBuf<uint32_t> goff, rgfirst, fresh, jl;
+  ord.ensure(nsum, "ordered chain ends");
+  goff.ensure((size_t) ng + 2, "chain ends per group");
+  rgfirst.ensure((size_t) nreads + 2, "groups per read");
+  fresh.ensure(nsum, "fresh candidates");
+  jl.ensure(2 * (size_t) nsum + 4, "jump lengths");
+  const int nx = cs.cur ^ 1;
+  cs.pool[nx].ensure(cs.total_len + nsum, "candidate lists");
+  cs.seg_off[nx].ensure((size_t) nreads + 1, "candidate list offsets");
+  cs.seg_len[nx].ensure((size_t) nreads + 1, "candidate list lengths");
+  if (cs.pool[cs.cur].p == nullptr) cs.pool[cs.cur].ensure(16, "candidate lists");
+  uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  { StageTimer tm("chain_dominate", 40.0 * nsum);
+    HIP_CHECK(hipMemsetAsync(cs.ctl.p, 0, 16 * sizeof(unsigned int), stream()));
+    HIP_CHECK(hipMemcpyAsync(goff.p, gcnt.p, sizeof(uint32_t) * ng, hipMemcpyDeviceToDevice, stream()));
+    exclusive_scan_u32(goff.p, ng, st.sort.bsum, goff.p + ng);
+    hipLaunchKernelGGL(k_order_summaries, dim3(std::min<uint32_t>(ceil_div(nsum, 256), 4096)), dim3(256), 0, stream(),
+                       (const ChainSummary *) out.p, (const unsigned int *) (ctl.p + 1), (const uint32_t *) gbase.p,
+                       (const uint32_t *) gcnt.p, (const uint32_t *) goff.p, (const uint64_t *) R.skeys,
+                       (const uint32_t *) R.gstart.p, R.pbits, ord.p);
+    hipLaunchKernelGGL(k_read_groups, dim3(ceil_div((int64_t) ng + 1, 256)), dim3(256), 0, stream(),
+                       (const uint64_t *) R.skeys, (const uint32_t *) R.gstart.p, ng, R.pbits + R.bbits, nreads, rgfirst.p);
+    hipLaunchKernelGGL(k_dom_need, dim3(ceil_div(nreads, 256)), dim3(256), 0, stream(),
+                       (const uint32_t *) cs.seg_len[cs.cur].p, (const uint32_t *) goff.p, (const uint32_t *) rgfirst.p,
+                       nreads, cs.seg_off[nx].p);
+    exclusive_scan_u32(cs.seg_off[nx].p, nreads, st.sort.bsum, cs.seg_off[nx].p + nreads);
+    DomArgs D;
+    D.ord = ord.p; D.goff = goff.p; D.rgfirst = rgfirst.p;
+    D.oldp = cs.pool[cs.cur].p; D.ooff = cs.seg_off[cs.cur].p; D.olen = cs.seg_len[cs.cur].p;
+    D.newp = cs.pool[nx].p; D.noff = cs.seg_off[nx].p; D.nlen = cs.seg_len[nx].p;
+    D.nreads = nreads;
+    D.bbits = R.bbits; D.passbits = 0;
+    D.pass[0].bbase = bblock->tfirst;
+    D.pass[0].comp  = comp;
+    D.cover = PROFILE ? cs.cover.p : nullptr;
+    D.cov_off = cs.cov_off.p;
+    D.spacing = SPACING;
+    D.ctl = cs.ctl.p;
+    hipLaunchKernelGGL(k_dominate, dim3(std::min(ceil_div(nreads, 256 / DOM_G), 256 * 8)), dim3(256), 0, stream(), D);
+    HIP_CHECK(hipGetLastError());
+  }
+  { StageTimer tm("chain_jumps", 0.0);
+    hipLaunchKernelGGL(k_fresh_list, dim3(ceil_div(nreads, 64)), dim3(64), 0, stream(), (const DCand *) cs.pool[nx].p,
+                       (const uint32_t *) cs.seg_off[nx].p, (const uint32_t *) cs.seg_len[nx].p, nreads, fresh.p, cs.ctl.p + 2);
+    hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
+                       (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, cs.pool[nx].p,
+                       (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,
+                       (const uint32_t *) nullptr, (uint16_t *) nullptr, 0u, 0);
+    HIP_CHECK(hipMemcpyAsync(jl.p + nsum + 1, jl.p, sizeof(uint32_t) * nsum, hipMemcpyDeviceToDevice, stream()));
+    exclusive_scan_u32(jl.p + nsum + 1, nsum, st.sort.bsum, cs.ctl.p + 3);
+    HIP_CHECK(hipMemcpyAsync(cs.ctl.p + 4, cs.seg_off[nx].p + nreads, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+    copy_d2h(h, cs.ctl.p, 8 * sizeof(uint32_t), 2);      // added, removed, fresh survivors, jump pairs, records in the new lists
+    const size_t need = cs.jtop + h[3];
+    if (need > cs.jumps.cap / 2)
+      { // grow the jump pool, keeping what earlier passes stored
+        DevBuf<uint16_t> nj;
+        nj.ensure(2 * (need + need / 2) + 1024, "jump pool");
+        if (cs.jtop > 0)
+          HIP_CHECK(hipMemcpyAsync(nj.p, cs.jumps.p, sizeof(uint16_t) * 2 * cs.jtop, hipMemcpyDeviceToDevice, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        cs.jumps.release();
+        cs.jumps = nj;
       }
+    if (h[2] > 0)
+      hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
+                         (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, cs.pool[nx].p,
+                         (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,
+                         (const uint32_t *) (jl.p + nsum + 1), cs.jumps.p, (uint32_t) cs.jtop, 1);
+    HIP_CHECK(hipGetLastError());
   }
+  cs.jtop += h[3];
+  if (cs.jtop >= 0x7fffffffull) fatal("Match_Filter: Jump lists of one READS block exceed 2^31 pairs");
+  cs.cur = nx;
+  cs.total_len = h[4];
+  cs.mirror_valid = false;
+  cs.mirror_jumps = false;
+  return (int64_t) h[0] - (int64_t) h[1];
+}
 
-  const int bshift = R.pbits + R.bbits;
-  const uint64_t bmask = ((uint64_t) 1 << R.bbits) - 1;
-  const int bstart = bblock->tfirst;
-
-  int64_t nfilt = 0;
-  std::vector<Candidate *> fresh;           // candidates added in this call, still alive or not
-  std::vector<uint32_t>    fresh_end;
-  std::vector<char>        fresh_dead;
-  const int                id0 = st.next_cand_id;
-  size_t gi = 0;
-  for (uint32_t i = 0; i < nsum; i++)
-    { if (i > 0 && sums[i].group != sums[i - 1].group) gi += 1;
-      const ChainSummary &h = sums[i];
-      int ar = (int) (wkeys[gi] >> bshift);
-      int br = (int) ((wkeys[gi] >> R.pbits) & bmask);
-      ReadState &rs = st.reads[ar];
-      int ab = h.ab, ae = h.ae;
-
-      if (PROFILE)                                                     // map.c:1654-1666
-        { int tb = ab / SPACING, te = (ae - 1) / SPACING + 1;
-          int cb = rs.cover[tb], ce = rs.cover[te];
-          if (cb < 0x7fff && ce > -0xffff)
-            { rs.cover[tb] = (int16_t) (cb + 1);
-              rs.cover[te] = (int16_t) (ce - 1);
-            }
-        }
-
-      // domination scan from the list head (map.c:1668-1713)
-      auto &L = rs.cands;
-      bool dropped = false;
-      size_t d = 0;
-      while (d < L.size())
-        { Candidate &cd = *L[d];
-          bool d_has_c = (cd.afirst < ab + MIN_PIECE && cd.alast > ae - MIN_PIECE);
-          bool c_has_d = (ab < cd.afirst + MIN_PIECE && ae > cd.alast - MIN_PIECE);
-          if (d_has_c && .9 * cd.score >= h.cost)
-            { dropped = true;
-              break;
-            }
-          if (c_has_d && cd.score <= .9 * h.cost)
-            { if (cd.id >= id0) fresh_dead[cd.id - id0] = 1;
-              L.erase(L.begin() + d);
-              nfilt -= 1;
-              continue;
-            }
-          d += 1;
-        }
-      if (dropped) continue;
-
-      std::unique_ptr<Candidate> nc(new Candidate());
-      nc->score  = h.cost;
-      nc->length = 0;
-      nc->bread  = br + bstart;
-      nc->comp   = comp;
-      nc->afirst = ab;
-      nc->alast  = ae;
-      nc->bfirst = h.bb;
-      nc->blast  = h.be;
-      nc->id     = st.next_cand_id++;
-      fresh.push_back(nc.get());
-      fresh_end.push_back(h.end);
-      fresh_dead.push_back(0);
-      L.insert(L.begin(), std::move(nc));
-      nfilt += 1;
+// ---------------------------------------------------------------------------------------
+//  Host view of the device lists (Reporter, stage-level API)
+// ---------------------------------------------------------------------------------------
+void cand_mirror(bool with_jumps)
+{ State &st = S();
+  CandStore &cs = st.cands;
+  if (cs.mirror_valid && (cs.mirror_jumps || !with_jumps)) return;
+  const int n = cs.nreads;
+  std::vector<DCand>    pool(cs.total_len);
+  std::vector<uint32_t> off((size_t) n + 1), len((size_t) n + 1);
+  std::vector<uint16_t> jd;
+  std::vector<int16_t>  cov;
+  if (cs.total_len > 0)
+    { copy_d2h(pool.data(), cs.pool[cs.cur].p, sizeof(DCand) * cs.total_len);
+      copy_d2h(off.data(), cs.seg_off[cs.cur].p, sizeof(uint32_t) * ((size_t) n + 1));
+      copy_d2h(len.data(), cs.seg_len[cs.cur].p, sizeof(uint32_t) * (size_t) n);
     }
-
-  // Jump chains of the candidates added in this call that survived it
-  { std::vector<uint32_t> ends;
-    std::vector<Candidate *> keep;
-    // a fresh candidate may already have been erased again by a later chain of this call
-    for (size_t i = 0; i < fresh.size(); i++)
-      if (!fresh_dead[i])
-        { keep.push_back(fresh[i]);
-          ends.push_back(fresh_end[i]);
-        }
-    int n = (int) ends.size();
-    if (n > 0)
-      { static DevBuf<uint32_t> d_ends, d_len;
-        static DevBuf<uint16_t> d_j;
-        d_ends.ensure(n, "jump ends");
-        d_len.ensure(2 * (size_t) n + 2, "jump lengths");
-        copy_h2d(d_ends.p, ends.data(), sizeof(uint32_t) * n);
-        StageTimer tm("chain_jumps", 0.0);
-        hipLaunchKernelGGL(k_chain_jumps, dim3(ceil_div(n, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
-                           (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, (const uint32_t *) d_ends.p, n,
-                           d_len.p, (const uint32_t *) nullptr, (uint16_t *) nullptr, 0);
-        std::vector<uint32_t> len(n), off(n + 1);
-        copy_d2h(len.data(), d_len.p, sizeof(uint32_t) * n, 1);
-        off[0] = 0;
-        for (int i = 0; i < n; i++) off[i + 1] = off[i] + len[i];
-        d_j.ensure(2 * (size_t) off[n] + 2, "jump data");
-        copy_h2d(d_len.p + n, off.data(), sizeof(uint32_t) * n);
-        hipLaunchKernelGGL(k_chain_jumps, dim3(ceil_div(n, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
-                           (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, (const uint32_t *) d_ends.p, n,
-                           d_len.p, (const uint32_t *) (d_len.p + n), d_j.p, 1);
-        std::vector<uint16_t> jd(2 * (size_t) off[n]);
-        if (off[n] > 0)
-          copy_d2h(jd.data(), d_j.p, sizeof(uint16_t) * jd.size(), 2);          // host stores the chains next
-        else
-          HIP_CHECK(hipStreamSynchronize(stream()));
-        for (int i = 0; i < n; i++)
-          { Candidate *c = keep[i];
-            c->length = (int) len[i];
-            c->jumps.assign(jd.begin() + 2 * (size_t) off[i], jd.begin() + 2 * ((size_t) off[i] + len[i]));
+  if (with_jumps && cs.jtop > 0)
+    { jd.resize(2 * cs.jtop);
+      copy_d2h(jd.data(), cs.jumps.p, sizeof(uint16_t) * 2 * cs.jtop);
+    }
+  if (!cs.h_cov_off.empty())
+    { cov.resize(cs.h_cov_off[n]);
+      if (!cov.empty()) copy_d2h(cov.data(), cs.cover.p, sizeof(int16_t) * cov.size());
+    }
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  st.reads.clear();
+  st.reads.resize(n);
+  int id = 0;
+  for (int r = 0; r < n; r++)
+    { ReadState &rs = st.reads[r];
+      if (cs.total_len > 0)
+        for (uint32_t i = len[r]; i-- > 0;)            // newest first: the reference's list order
+          { const DCand &d = pool[off[r] + i];
+            if (d.flags & DC_TOMB) continue;
+            std::unique_ptr<Candidate> c(new Candidate());
+            c->score = d.score; c->length = (int) d.jlen; c->bread = d.bread; c->comp = (d.flags & DC_COMP) ? 1 : 0;
+            c->afirst = d.afirst; c->alast = d.alast; c->bfirst = d.bfirst; c->blast = d.blast;
+            c->id = id++;
+            c->joff = d.joff;
+            if (with_jumps && d.jlen > 0)
+              c->jumps.assign(jd.begin() + 2 * (size_t) d.joff, jd.begin() + 2 * ((size_t) d.joff + d.jlen));
+            rs.cands.push_back(std::move(c));
           }
-      }
-  }
-  return nfilt;
-}
-
-__global__ void k_gather_u64(const uint64_t *__restrict__ src, const uint32_t *__restrict__ idx,
-                             uint64_t *__restrict__ dst, int64_t n)
-{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
-}
-
-void gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, int64_t n)
-{ if (n <= 0) return;
-  hipLaunchKernelGGL(k_gather_u64, dim3(ceil_div(n, 256)), dim3(256), 0, stream(), src, idx, dst, n);
-  HIP_CHECK(hipGetLastError());
+      if (!cs.h_cov_off.empty())
+        rs.cover.assign(cov.begin() + cs.h_cov_off[r], cov.begin() + cs.h_cov_off[r + 1]);
+    }
+  cs.mirror_valid = true;
+  cs.mirror_jumps = with_jumps;
 }
 
 }  // namespace dmh
@@ -1007,6 +1228,7 @@ extern "C" {
 
 int dmh_read_candidates(DAZZ_DB *ablock, int ar, int *out, int maxc)
 { State &st = S();
+  if (st.cur_reads == ablock) cand_mirror(true);
   if (st.cur_reads != ablock || ar < 0 || ar >= (int) st.reads.size()) return -1;
   auto &L = st.reads[ar].cands;
   int n = 0;
@@ -1023,6 +1245,7 @@ int dmh_read_candidates(DAZZ_DB *ablock, int ar, int *out, int maxc)
 
 int dmh_candidate_jumps(DAZZ_DB *ablock, int ar, int k, uint16_t *adisp, uint16_t *bdisp, int maxj)
 { State &st = S();
+  if (st.cur_reads == ablock) cand_mirror(true);
   if (st.cur_reads != ablock || ar < 0 || ar >= (int) st.reads.size()) return -1;
   auto &L = st.reads[ar].cands;
   if (k < 0 || k >= (int) L.size()) return -1;
@@ -1037,6 +1260,7 @@ int dmh_candidate_jumps(DAZZ_DB *ablock, int ar, int k, uint16_t *adisp, uint16_
 
 int dmh_read_cover(DAZZ_DB *ablock, int ar, int16_t *out, int maxn)
 { State &st = S();
+  if (st.cur_reads == ablock) cand_mirror(false);
   if (st.cur_reads != ablock || ar < 0 || ar >= (int) st.reads.size()) return -1;
   auto &cv = st.reads[ar].cover;
   int n = (int) cv.size();

@@ -5,6 +5,7 @@
 #include "dmh_state.h"
 #include "dmh_spec.h"
 #include "dmh_align.h"
+#include "dmh_chain.h"
 #include <algorithm>
 #include <math.h>
 #include <atomic>
@@ -1083,7 +1084,7 @@ static void report_submit(ReportCtx *C)
 struct PendingReport
 { ReportCtx *C = nullptr;
   std::vector<CandJob>  jobs;
-  std::vector<uint16_t> jumps;
+  DevBuf<uint16_t> jumps;        // the block's jump pool, taken over from the candidate store (freed when collected)
   std::vector<std::vector<AlnRec>> recs;
   std::vector<int> pool;
   PinBuf *pool_pin = nullptr;
@@ -1104,7 +1105,6 @@ static PendingReport *g_pending = nullptr;
 static hipStream_t    g_astream = nullptr;
 static hipEvent_t     g_ev_ab = nullptr, g_ev_done = nullptr;
 static DevBuf<CandJob>  d_jobs;
-static DevBuf<uint16_t> d_jumps;
 static DevBuf<int>      d_status, d_pool, d_only;
 
 bool report_in_flight()
@@ -1145,30 +1145,30 @@ static void launch_round(PendingReport &P)
     if (level == 0)
       hipLaunchKernelGGL(k_align_cands32, dim3(nblocks), dim3(256), 0, ks,
                          P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
-                         (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
+                         (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
                          d_pool.p, ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
     else if (level == 2)
       { if (doB)
           hipLaunchKernelGGL((k_align_cands<GLB_W, false, true>), dim3(nblocks), dim3(256), 0, ks,
                              P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
-                             (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                             (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
                              ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
         else
           hipLaunchKernelGGL((k_align_cands<GLB_W, false, false>), dim3(nblocks), dim3(256), 0, ks,
                              P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
-                             (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                             (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
                              ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
       }
     else
       { if (doB)
           hipLaunchKernelGGL((k_align_cands<LDS_W, true, true>), dim3(nblocks), dim3(256), 0, ks,
                              P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
-                             (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                             (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
                              ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
         else
           hipLaunchKernelGGL((k_align_cands<LDS_W, true, false>), dim3(nblocks), dim3(256), 0, ks,
                              P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
-                             (const uint16_t *) d_jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
+                             (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc, ascr().ctl.p, d_status.p, d_pool.p,
                              ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
       }
     HIP_CHECK(hipGetLastError());
@@ -1268,6 +1268,7 @@ static void finish_report(PendingReport *P)
   C->deferred_got = P->deferred_got;
   report_submit(C);
   for (int i = 0; i < P->nhold; i++) free_blockdev(P->hold[i]);
+  P->jumps.release();
   delete P;
 }
 
@@ -1312,7 +1313,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   Spec *sp = (Spec *) asettings;
   if (sp == nullptr || sp->magic != SPEC_MAGIC)
     fatal("Reporter: the Align_Spec was not created by this library's New_Align_Spec");
-  if (st.cur_reads != ablock || (int) st.reads.size() != ablock->nreads)
+  if (st.cur_reads != ablock || st.cands.nreads != ablock->nreads)
     fatal("Reporter: called for a READS block that has not been through Match_Filter");
   // Deferring the alignment kernel pays when the READS block meets a reference of one block (two passes, the
   // filter about as long as the alignment kernel at half grid).  Against a many-block reference the filter is
@@ -1336,6 +1337,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   PendingReport *P = new PendingReport();
   P->ht = new HostTimer("report_align");
+  cand_mirror(false);                         // the candidate lists (without their Jump lists, which stay in HBM)
 
   // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel
   std::vector<int> job_of_first(nreads + 1, 0);   // first job index of each read
@@ -1351,9 +1353,8 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
           J.alast = c->alast;
           J.blast = c->blast;
           J.npts  = c->length;
-          J.joff  = (uint32_t) (P->jumps.size() / 2);
+          J.joff  = c->joff;
           J.pad   = 0;
-          P->jumps.insert(P->jumps.end(), c->jumps.begin(), c->jumps.end());
           P->jobs.push_back(J);
         }
     }
@@ -1374,6 +1375,12 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     C->reads = std::move(st.reads);
     st.reads.clear();
     st.cur_reads = nullptr;
+    st.cands.block = nullptr;
+    st.cands.nreads = 0;
+    st.cands.mirror_valid = false;
+    P->jumps = st.cands.jumps;               // the kernel reads the Jump lists where the filter stored them
+    st.cands.jumps = DevBuf<uint16_t>();
+    st.cands.jtop = 0;
     C->job_of_first = std::move(job_of_first);
     P->C = C;
   }
@@ -1390,11 +1397,9 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
       P->tcap = trace_cap(maxalen, S_);
 
       d_jobs.ensure(njobs, "candidate jobs");
-      d_jumps.ensure(P->jumps.size() + 2, "candidate jumps");
+      if (P->jumps.p == nullptr) P->jumps.ensure(16, "candidate jumps");
       d_status.ensure(njobs, "candidate status");
       copy_h2d(d_jobs.p, P->jobs.data(), sizeof(CandJob) * njobs);
-      if (!P->jumps.empty())
-        copy_h2d(d_jumps.p, P->jumps.data(), sizeof(uint16_t) * P->jumps.size());
 
       // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
       P->pool_cap = (size_t) njobs * 2 * (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8)) + 4096;

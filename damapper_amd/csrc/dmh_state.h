@@ -78,7 +78,39 @@ struct Candidate
 { int score, length, bread, comp;
   int afirst, alast, bfirst, blast;
   int id;
-  std::vector<uint16_t> jumps;           // (adisp, bdisp) pairs, end -> start (map.c:1380-1384)
+  uint32_t joff = 0;                     // first (adisp, bdisp) pair of the chain in the device jump pool
+  std::vector<uint16_t> jumps;           // (adisp, bdisp) pairs, end -> start (map.c:1380-1384); filled on request
+};
+
+// The candidate lists live on the DEVICE between Match_Filter calls (map.c:1386-1397 keeps them behind
+// DAZZ_READ.coff): one segment of DCand records per read, oldest first (the reference's list order --
+// newest first -- is the segment read backwards), rewritten into the other pool by every domination pass.
+struct DCand
+{ int32_t  score, afirst, alast, bfirst, blast;
+  int32_t  bread;              // contig index in the whole reference
+  uint32_t end;                // hit index of the chain's end (valid until its Jump list has been stored)
+  uint32_t joff, jlen;         // Jump list: jlen (adisp, bdisp) pairs from pair joff of the jump pool
+  uint32_t flags;              // DC_*
+};
+constexpr uint32_t DC_COMP  = 1u;            // found against the complemented REF block
+constexpr uint32_t DC_FRESH = 2u;            // added by the current pass: Jump list not stored yet
+constexpr uint32_t DC_TOMB  = 0x80000000u;   // removed by the domination rule
+
+struct CandStore
+{ const DAZZ_DB *block = nullptr;
+  int      nreads = 0;
+  int      cur = 0;                           // pool[cur] / seg_*[cur] hold the lists
+  DevBuf<DCand>    pool[2];
+  DevBuf<uint32_t> seg_off[2], seg_len[2];    // per read: first record and number of records (tombstones included)
+  size_t   total_len = 0;                     // sum of seg_len[cur] (host copy)
+  DevBuf<uint16_t> jumps;                     // jump pool, 2 values per pair
+  size_t   jtop = 0;                          // pairs in use
+  DevBuf<int16_t>  cover;                     // -p deltas, read r at cov_off[r] (map.c:1654-1666)
+  DevBuf<uint32_t> cov_off;
+  std::vector<uint32_t> h_cov_off;
+  DevBuf<unsigned int> ctl;                   // [0] candidates added, [1] removed (current pass), [2] fresh survivors, ...
+  bool     mirror_valid = false;              // State::reads reflects the device lists
+  bool     mirror_jumps = false;              //   ... including the Jump lists
 };
 
 struct ReadState
@@ -98,7 +130,8 @@ struct State
 
   // cross-call filter state (map.c:2885-2887 + DAZZ_READ.coff lists)
   const DAZZ_DB *cur_reads = nullptr;
-  std::vector<ReadState> reads;
+  CandStore cands;                  // the candidate lists (device)
+  std::vector<ReadState> reads;     // host mirror of them, built on demand (cand_mirror)
   int      next_cand_id = 0;
   int64_t  tfilt = 0;
 

@@ -144,6 +144,24 @@ int ref_candidate_jumps(DAZZ_DB *ablock, int ar, int k, uint16 *adisp, uint16 *b
   return (n);
 }
 
+/* -p coverage deltas of block-local read ar (map.c:1580-1604,1654-1666): its (rlen-1)/SPACING+2 int16 slots
+   inside the vector of the stage thread that owns the read.  Returns the slot count, -1 without an owner. */
+int ref_read_cover(DAZZ_DB *ablock, int ar, int16 *out, int maxn)
+{ Report_Arg *r = owner_of(ar);
+  int16 *cnt;
+  int    x, n, i;
+
+  if (r == NULL || r->cover == NULL)
+    return (-1);
+  cnt = r->cover;
+  for (x = r->abeg; x < ar; x++)
+    cnt += (ablock->reads[x].rlen-1) / SPACING + 2;
+  n = (ablock->reads[ar].rlen-1) / SPACING + 2;
+  for (i = 0; i < n && i < maxn; i++)
+    out[i] = cnt[i];
+  return (n);
+}
+
 /* -p coverage delta vector of stage thread i (map.c:1580-1587) */
 void *ref_cover(int i, int *comax)
 { *comax = parmr[i].comax;

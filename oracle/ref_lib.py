@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
     L.ref_read_candidates.restype = C.c_int
     L.ref_candidate_jumps.argtypes = [P(DAZZ_DB), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.ref_candidate_jumps.restype = C.c_int
+    L.ref_read_cover.argtypes = [P(DAZZ_DB), C.c_int, C.c_void_p, C.c_int]
+    L.ref_read_cover.restype = C.c_int
     L.ref_cover.argtypes = [C.c_int, P(C.c_int)]
     L.ref_cover.restype = C.c_void_p
     L.ref_nthreads.restype = C.c_int
@@ -108,6 +110,13 @@ def candidate_jumps(reads: Block, ar: int, k: int, maxj: int = 65536):
     b = np.zeros(maxj, dtype=np.uint16)
     n = lib().ref_candidate_jumps(reads.ptr(), ar, k, a.ctypes.data, b.ctypes.data, maxj)
     return a[:max(n, 0)], b[:max(n, 0)]
+
+
+def read_cover(reads: Block, ar: int, maxn: int = 4096) -> np.ndarray:
+    """-p coverage deltas of one read as chain_thread leaves them (before Reporter's special_log pass)."""
+    out = np.zeros(maxn, dtype=np.int16)
+    n = lib().ref_read_cover(reads.ptr(), ar, out.ctypes.data, maxn)
+    return out[:max(n, 0)]
 
 
 def free(h):

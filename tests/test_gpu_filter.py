@@ -44,3 +44,32 @@ def test_seeds_and_candidates_match_reference(case):
             assert np.array_equal(a1, a2) and np.array_equal(b1, b2), "read %d cand %d jumps" % (ar, k)
         nc += len(ca)
     assert nc > 0
+
+
+COVER_CASES = [
+    # kind, seed, contigs, nreads, dropouts, spacing, firsts
+    ("repeat", 6, [250000, 250000], 40, 1, 100, [0, 1, 2]),
+    ("random", 7, [200000, 150000, 100000], 40, 2, 126, [0, 2, 3]),
+    ("repeat", 8, [300000], 25, 0, 100, [0, 1]),
+]
+
+
+@pytest.mark.parametrize("case", COVER_CASES, ids=[str(i) for i in range(len(COVER_CASES))])
+def test_profile_deltas_match_reference(case):
+    """R11 (map.c:1654-1666): the -p coverage deltas of every read after all Match_Filter passes -- every EXAMINED
+    chain counts, dominated or not -- equal the reference's stage vector (ref_harness.c ref_read_cover), before
+    Reporter turns them into special_log bytes."""
+    if not _ref_available():
+        pytest.skip("oracle/_ref not built")
+    kind, seed, contigs, nreads, drop, spacing, firsts = case
+    g, reads = make_dataset(kind, seed, contigs, nreads, dropouts=drop)
+    ref = run_filter(Api("ref"), reads, g, firsts, profile=1, spacing=spacing, want_seeds=False)
+    hip = run_filter(Api("hip"), reads, g, firsts, profile=1, spacing=spacing, want_seeds=False)
+    nz = 0
+    for ar, (a, b) in enumerate(zip(ref["cover"], hip["cover"])):
+        assert len(a) == len(b) == (len(reads[ar]) - 1) // spacing + 2, "read %d: %d vs %d slots" % (ar, len(a), len(b))
+        assert np.array_equal(a, b), "read %d cover deltas differ\n%s\n%s" % (ar, a, b)
+        nz += int(np.count_nonzero(a))
+    assert nz > 0
+    for (ca, _), (cb, _) in zip(ref["cands"], hip["cands"]):
+        assert np.array_equal(ca, cb)

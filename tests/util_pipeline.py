@@ -62,6 +62,9 @@ class Api:
     def jumps(self, reads, ar, k):
         return self.m.candidate_jumps(reads, ar, k)
 
+    def cover(self, reads, ar):
+        return self.m.read_cover(reads, ar)
+
     def free_reads_index(self, h):
         if self.kind == "hip":
             self.m.lib().dmh_free_index(h)
@@ -94,4 +97,5 @@ def run_filter(api: Api, reads_seqs, genome, firsts, K=20, supp=0, T=4, mem_limi
         c = api.candidates(reads, ar)
         js = [api.jumps(reads, ar, k) for k in range(len(c))]
         cands.append((c[:, :8].copy(), js))
-    return dict(reads=reads, blocks=blocks, rh=rh, rn=rn, seeds=seeds, cands=cands)
+    cover = [api.cover(reads, ar).copy() for ar in range(reads.nreads)] if profile else None
+    return dict(reads=reads, blocks=blocks, rh=rh, rn=rn, seeds=seeds, cands=cands, cover=cover)
