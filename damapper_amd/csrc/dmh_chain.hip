@@ -63,6 +63,7 @@ struct ChainArgs
   ChainSummary   *out;
   uint32_t       *gcount;             // per group: number of summaries it reported and the slot of the first one in `out`
   uint32_t       *gbase;              //   (k_order_summaries puts them into the reference's reporting order)
+  const uint32_t *glast;              // cluster mode: per group the largest apos + 1 of its (aread, bread) pair; else nullptr
   uint32_t        pile_cap;           // k_chain_pile: entries of LDS it may use (<= PILE_CAP; smaller in tests)
 };
 
@@ -337,15 +338,18 @@ __global__ __launch_bounds__(BLOCK) void k_chain(ChainArgs A)
 
       for (uint32_t e = lane; e < E; e += G)
         { uint32_t x    = A.tmp[g0 + e];
-          bool     live_x = (A.state[x] == ST_LIVE);
           int      ax   = (int) (A.keys[x] & A.pmask) + 1;
           int      bx   = (int) A.vals[x] + 1;
           int      dx   = ax - bx;
+          // still in the tree when the PAIR's last hit has been processed (a cluster's own hits may end earlier)
+          bool     live_x = (A.state[x] == ST_LIVE) && (A.glast == nullptr || ax >= (int) A.glast[g] - MAX_GAP);
           uint32_t     root = A.rootof[x];
           ChainSummary s;
           s.group = g;
           s.live  = live_x ? 1u : 0u;
-          s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax) : (uint64_t) x;
+          // expired ends are reported most recent first = by descending position in the pair's (apos, bpos) order
+          s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax)
+                           : (((uint64_t) (uint32_t) ax << 32) | (uint32_t) bx);
           s.cost  = A.cost[x];
           s.ab    = (int) (A.keys[root] & A.pmask) + 1 - K;
           s.bb    = (int) A.vals[root] + 1 - K;
@@ -603,15 +607,16 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
               obase = __shfl(obase, 0);
               for (uint32_t e = lane; e < E; e += 64)
                 { uint32_t x    = A.tmp[g0 + e];
-                  bool     live_x = (A.state[x] == ST_LIVE);
                   int      ax   = (int) (A.keys[x] & A.pmask) + 1;
                   int      bx   = (int) A.vals[x] + 1;
                   int      dx   = ax - bx;
+                  bool     live_x = (A.state[x] == ST_LIVE) && (A.glast == nullptr || ax >= (int) A.glast[g] - MAX_GAP);
                   uint32_t root = A.rootof[x];
                   ChainSummary s;
                   s.group = g;
                   s.live  = live_x ? 1u : 0u;
-                  s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax) : (uint64_t) x;
+                  s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax)
+                                   : (((uint64_t) (uint32_t) ax << 32) | (uint32_t) bx);
                   s.cost  = A.cost[x];
                   s.ab    = (int) (A.keys[root] & A.pmask) + 1 - K;
                   s.bb    = (int) A.vals[root] + 1 - K;
@@ -647,33 +652,45 @@ __global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__r
                                                          const uint32_t *__restrict__ gbase,
                                                          const uint32_t *__restrict__ gcount,
                                                          const uint32_t *__restrict__ goff,
-                                                         const uint64_t *__restrict__ skeys,
-                                                         const uint32_t *__restrict__ gstart, int pbits,
+                                                         const uint64_t *__restrict__ gkey,
+                                                         const uint32_t *__restrict__ cog,
+                                                         const uint32_t *__restrict__ ocfirst,
                                                          OrdChain *__restrict__ ord)
 { const uint32_t nsum = *nsum_p;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nsum; i += gridDim.x * blockDim.x)
     { const ChainSummary s = out[i];
-      const uint32_t g = s.group, b = gbase[g], E = gcount[g];
+      const uint32_t g = s.group;
+      // the siblings: the ends of all groups of the same (aread, bread) pair -- the group itself, or in cluster
+      // mode the pair's clusters c0..c1-1 (their numbers are consecutive)
+      uint32_t c0 = g, c1 = g + 1;
+      if (cog != nullptr)
+        { const uint32_t p = cog[g];
+          c0 = ocfirst[p];
+          c1 = ocfirst[p + 1];
+        }
       uint32_t rank = 0;
-      for (uint32_t f = 0; f < E; f++)
-        { const uint32_t tl = out[b + f].live;
-          const uint64_t tk = out[b + f].okey;
-          rank += (tl > s.live || (tl == s.live && tk > s.okey)) ? 1u : 0u;
+      for (uint32_t c = c0; c < c1; c++)
+        { const uint32_t b = gbase[c], E = gcount[c];
+          for (uint32_t f = 0; f < E; f++)
+            { const uint32_t tl = out[b + f].live;
+              const uint64_t tk = out[b + f].okey;
+              rank += (tl > s.live || (tl == s.live && tk > s.okey)) ? 1u : 0u;
+            }
         }
       OrdChain o;
       o.cost = s.cost; o.ab = s.ab; o.ae = s.ae; o.bb = s.bb; o.be = s.be; o.end = s.end;
-      o.gkey = skeys[gstart[g]] >> pbits;
-      ord[goff[g] + rank] = o;
+      o.gkey = gkey[g];
+      ord[goff[c0] + rank] = o;
     }
 }
 
 // rgfirst[r] = first group whose read index is >= r (r = 0..nreads): read r's groups are [rgfirst[r], rgfirst[r+1])
-__global__ void k_read_groups(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ gstart,
-                              uint32_t ngroups, int ashift, int nreads, uint32_t *__restrict__ rgfirst)
+__global__ void k_read_groups(const uint64_t *__restrict__ gkey, uint32_t ngroups, int ashift, int nreads,
+                              uint32_t *__restrict__ rgfirst)
 { uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g > ngroups) return;
-  int64_t cur  = (g < ngroups) ? (int64_t) (skeys[gstart[g]] >> ashift) : (int64_t) nreads;
-  int64_t prev = (g > 0) ? (int64_t) (skeys[gstart[g - 1]] >> ashift) : -1;
+  int64_t cur  = (g < ngroups) ? (int64_t) (gkey[g] >> ashift) : (int64_t) nreads;
+  int64_t prev = (g > 0) ? (int64_t) (gkey[g - 1] >> ashift) : -1;
   if (cur > nreads) cur = nreads;
   for (int64_t r = prev + 1; r <= cur; r++) rgfirst[r] = g;
 }
@@ -1005,6 +1022,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.out = out.p;
   A.gcount = gcnt.p;
   A.gbase  = gbase.p;
+  A.glast  = R.clustered ? R.glast.p : nullptr;
   A.pile_cap = PILE_CAP;
 
   static const int env_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
@@ -1108,10 +1126,11 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     exclusive_scan_u32(goff.p, ng, st.sort.bsum, goff.p + ng);
     hipLaunchKernelGGL(k_order_summaries, dim3(std::min<uint32_t>(ceil_div(nsum, 256), 4096)), dim3(256), 0, stream(),
                        (const ChainSummary *) out.p, (const unsigned int *) (ctl.p + 1), (const uint32_t *) gbase.p,
-                       (const uint32_t *) gcnt.p, (const uint32_t *) goff.p, (const uint64_t *) R.skeys,
-                       (const uint32_t *) R.gstart.p, R.pbits, ord.p);
+                       (const uint32_t *) gcnt.p, (const uint32_t *) goff.p, (const uint64_t *) R.gkey.p,
+                       R.clustered ? (const uint32_t *) R.cog.p : (const uint32_t *) nullptr,
+                       R.clustered ? (const uint32_t *) R.ocfirst.p : (const uint32_t *) nullptr, ord.p);
     hipLaunchKernelGGL(k_read_groups, dim3(ceil_div((int64_t) ng + 1, 256)), dim3(256), 0, stream(),
-                       (const uint64_t *) R.skeys, (const uint32_t *) R.gstart.p, ng, R.pbits + R.bbits, nreads, rgfirst.p);
+                       (const uint64_t *) R.gkey.p, ng, R.bbits, nreads, rgfirst.p);
     hipLaunchKernelGGL(k_dom_need, dim3(ceil_div(nreads, 256)), dim3(256), 0, stream(),
                        (const uint32_t *) cs.seg_len[cs.cur].p, (const uint32_t *) goff.p, (const uint32_t *) rgfirst.p,
                        nreads, cs.seg_off[nx].p);

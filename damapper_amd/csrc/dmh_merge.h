@@ -13,7 +13,16 @@ struct MergeResult
   DevBuf<uint32_t> vals;
   uint64_t *skeys = nullptr;                   // sorted hits (either keys/vals or the sort partner)
   uint32_t *svals = nullptr;                   // value = bpos (0-based last base of the REF k-mer)
-  DevBuf<uint32_t> gstart;                     // ngroups+1 first-hit indices of the (aread,bread) groups
+  DevBuf<uint32_t> gstart;                     // ngroups+1 first-hit indices of the groups
+  // A group is what one lane group of the chain kernels walks: all hits of an (aread, bread) pair, or -- in
+  // cluster mode -- one B-CLUSTER of such a pair: a maximal run of its hits whose bpos values lie at most
+  // MAX_GAP apart when sorted.  Hits only interact within MAX_GAP in A and in B (map.c:1262-1318,1787-1796),
+  // so the clusters of a pair chain independently; the hits are then sorted (cluster, apos, bpos) and the
+  // sort key holds the cluster number instead of (aread, bread).
+  bool     clustered = false;
+  DevBuf<uint64_t> gkey;                       // per group: (aread << bbits) | bread
+  DevBuf<uint32_t> cog, ocfirst, glast;        // cluster mode: pair number of each cluster, first cluster of each pair
+                                               // (+ end), and per cluster its pair's largest apos + 1
   // the groups by size, for the chain kernels (chain_classify_groups): groups of small_hi..pile_min-1 hits
   // (list of the one-wavefront-per-group launch; windows that outgrow LDS are appended later) and repeat
   // piles of >= pile_min hits (one workgroup each)

@@ -286,7 +286,7 @@ constexpr uint32_t BIG_ENTRY = 64;
 __global__ void k_merge_expand(const MergeEntry *__restrict__ entries, uint32_t n,
                                const uint32_t *__restrict__ offs, const uint32_t *__restrict__ sizes,
                                const uint32_t *__restrict__ avals, const uint32_t *__restrict__ bvals,
-                               PosMap MA, PosMap MB, int bshift, int pshift,
+                               PosMap MA, PosMap MB, int bshift, int pshift, int swap,
                                uint64_t *__restrict__ hkeys, uint32_t *__restrict__ hvals,
                                uint32_t *__restrict__ biglist, unsigned int *__restrict__ nbig)
 { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,12 +302,13 @@ __global__ void k_merge_expand(const MergeEntry *__restrict__ entries, uint32_t 
   for (uint32_t a = 0; a < e.ma; a++)
     { uint32_t ar, ap;
       locate(MA, avals[e.a0 + a], ar, ap);
-      uint64_t kbase = ((uint64_t) ar << bshift) | (uint64_t) ap;
+      // key = aread | bread | apos with value bpos -- or, for the cluster sort (swap), bpos in the key and apos as value
+      uint64_t kbase = ((uint64_t) ar << bshift) | (swap ? 0ull : (uint64_t) ap);
       for (uint32_t b = 0; b < e.mb; b++)
         { uint32_t br, bp;
           locate(MB, bvals[e.b0 + b], br, bp);
-          hkeys[off] = kbase | ((uint64_t) br << pshift);
-          hvals[off] = bp;
+          hkeys[off] = kbase | ((uint64_t) br << pshift) | (swap ? (uint64_t) bp : 0ull);
+          hvals[off] = swap ? ap : bp;
           off += 1;
         }
     }
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
                                                           const uint32_t *__restrict__ offs,
                                                           const uint32_t *__restrict__ avals,
                                                           const uint32_t *__restrict__ bvals,
-                                                          PosMap MA, PosMap MB, int bshift, int pshift,
+                                                          PosMap MA, PosMap MB, int bshift, int pshift, int swap,
                                                           uint64_t *__restrict__ hkeys, uint32_t *__restrict__ hvals)
 { const int lane = threadIdx.x & 63;
   uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -332,8 +333,8 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
       uint32_t ar, ap, br, bp;
       locate(MA, avals[e.a0 + a], ar, ap);
       locate(MB, bvals[e.b0 + b], br, bp);
-      hkeys[off + t] = ((uint64_t) ar << bshift) | ((uint64_t) br << pshift) | (uint64_t) ap;
-      hvals[off + t] = bp;
+      hkeys[off + t] = ((uint64_t) ar << bshift) | ((uint64_t) br << pshift) | (uint64_t) (swap ? bp : ap);
+      hvals[off + t] = swap ? ap : bp;
     }
 }
 
@@ -348,12 +349,94 @@ __global__ void k_group_flag(const uint64_t *__restrict__ hkeys, int64_t n, int 
 }
 
 __global__ void k_group_write(const uint64_t *__restrict__ hkeys, int64_t n, int pshift,
-                              const uint32_t *__restrict__ slot, uint32_t *__restrict__ gstart, uint32_t ngroups)
+                              const uint32_t *__restrict__ slot, uint32_t *__restrict__ gstart, uint32_t ngroups,
+                              uint64_t *__restrict__ gkey)
 { int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (i == 0) gstart[ngroups] = (uint32_t) n;           // the end of the last group
   if (i == 0 || (hkeys[i] >> pshift) != (hkeys[i - 1] >> pshift))
-    gstart[slot[i]] = (uint32_t) i;
+    { gstart[slot[i]] = (uint32_t) i;
+      gkey[slot[i]]   = hkeys[i] >> pshift;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+//  B-clusters (cluster mode): the hits arrive sorted (aread, bread, bpos) with bpos in the low qbits of the key
+//  and apos as the value.  A cluster starts where the pair changes or the gap to the previous bpos exceeds
+//  MAX_GAP.  k_cluster_rekey then gives every hit the key (cluster << pbits) | apos and the value bpos: the
+//  second sort puts each cluster into (apos, bpos) order without moving a hit out of its cluster's range.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t MAX_GAP_B = 1000;      // map.c:36
+
+__global__ void k_cluster_flag(const uint64_t *__restrict__ hkeys, int64_t n, int qbits, uint32_t *__restrict__ flag)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t f = 1;
+  if (i > 0)
+    { const uint64_t a = hkeys[i - 1], b = hkeys[i];
+      const uint64_t qm = (1ull << qbits) - 1ull;
+      f = ((a >> qbits) != (b >> qbits) || (b & qm) - (a & qm) > (uint64_t) MAX_GAP_B) ? 1u : 0u;
+    }
+  flag[i] = f;
+}
+
+// slot[] = exclusive scan of the flags: hit i belongs to cluster slot[i] + flag[i] - 1.  Out of place (the
+// neighbour's key is read): (hkeys, hvals) -> (okeys, ovals).
+__global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32_t *__restrict__ hvals, int64_t n,
+                                int qbits, int pbits, const uint32_t *__restrict__ slot,
+                                uint64_t *__restrict__ okeys, uint32_t *__restrict__ ovals,
+                                uint32_t *__restrict__ gstart, uint32_t ncl, uint64_t *__restrict__ gkey)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = hkeys[i];
+  const uint64_t qm = (1ull << qbits) - 1ull;
+  bool start = (i == 0);
+  if (i > 0)
+    { const uint64_t a = hkeys[i - 1];
+      start = ((a >> qbits) != (k >> qbits) || (k & qm) - (a & qm) > (uint64_t) MAX_GAP_B);
+    }
+  const uint32_t c = slot[i] + (start ? 1u : 0u) - 1u;
+  okeys[i] = ((uint64_t) c << pbits) | (uint64_t) hvals[i];
+  ovals[i] = (uint32_t) (k & qm);
+  if (start)
+    { gstart[c] = (uint32_t) i;
+      gkey[c]   = k >> qbits;
+    }
+  if (i == 0) gstart[ncl] = (uint32_t) n;
+}
+
+// pairs of the clusters: flag[c] = cluster c opens a new (aread, bread) pair
+__global__ void k_pair_flag(const uint64_t *__restrict__ gkey, uint32_t ncl, uint32_t *__restrict__ flag)
+{ uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncl) return;
+  flag[c] = (c == 0 || gkey[c] != gkey[c - 1]) ? 1u : 0u;
+}
+
+// cog[] = exclusive scan of those flags on entry; on exit cog[c] = pair of cluster c, ocfirst[p] = first cluster
+// of pair p (ocfirst[npairs] = ncl), glast[c] = largest apos + 1 among the hits of c's pair (the apos of the pair's
+// last hit in the reference's order) -- the sorted hits' keys are (cluster << pbits) | apos.
+__global__ void k_pair_write(const uint64_t *__restrict__ gkey, uint32_t ncl, uint32_t *__restrict__ cog,
+                             const uint32_t *__restrict__ npairs_p, uint32_t *__restrict__ ocfirst,
+                             const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ gstart, uint64_t pmask,
+                             uint32_t *__restrict__ glast)
+{ uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncl) return;
+  const bool start = (c == 0 || gkey[c] != gkey[c - 1]);
+  if (c == 0) ocfirst[*npairs_p] = ncl;
+  if (!start) return;
+  const uint32_t p = cog[c];               // (exclusive scan: the number of pairs opened before c)
+  ocfirst[p] = c;
+  const uint64_t k = gkey[c];
+  uint32_t e = c, m = 0;
+  while (e < ncl && gkey[e] == k)
+    { uint32_t a = (uint32_t) (skeys[gstart[e + 1] - 1] & pmask) + 1u;
+      m = a > m ? a : m;
+      e += 1;
+    }
+  for (uint32_t x = c; x < e; x++)
+    { if (x != c) cog[x] = p;
+      glast[x] = m;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -397,7 +480,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   R.abits = ceil_log2(ablock->nreads);
   if (R.pbits + R.bbits + R.abits > 64)
     fatal("Match_Filter: seed key needs %d bits", R.pbits + R.bbits + R.abits);
-  int pshift = R.pbits, bshift = R.pbits + R.bbits;
+  int pshift = R.pbits, bshift = R.pbits + R.bbits;        // (revised below for the cluster sort)
 
   // --- bucket table over the REF index: part of the index, built the first time it is merged against
   //     (a retained REF index meets every READS block)
@@ -528,6 +611,19 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   R.nhits = nhits;
   if (nhits == 0) return;
 
+  // --- cluster mode (dmh_merge.h): when a read meets thousands of hits per pass (repeat families), the hits of an
+  //     (aread, bread) pair are cut into B-clusters, which chain independently -- a pair's live window would hold
+  //     hundreds of hits of unrelated loci, a cluster's holds a few dozen.  "cluster" test option: 1 always, 0 never.
+  static const int env_cl = getenv("DMH_CLUSTER") ? atoi(getenv("DMH_CLUSTER")) : -1;
+  const int optcl = st.opt_cluster >= 0 ? st.opt_cluster : env_cl;
+  const int qbits = ceil_log2(bblock->maxlen > 1 ? (int64_t) bblock->maxlen + 1 : 2);
+  bool cluster = (optcl >= 0) ? (optcl != 0) : (nhits >= (int64_t) 1024 * ablock->nreads);
+  if (qbits + R.bbits + R.abits > 64 || nhits >= (int64_t) 0x7fffffff) cluster = false;
+  R.clustered = cluster;
+  const int lowbits = cluster ? qbits : R.pbits;           // bits below (aread | bread) in the first sort's key
+  pshift = lowbits;
+  bshift = lowbits + R.bbits;
+
   // --- expand the entries under the limit into hits (map.c:3095-3099)
   R.keys.ensure(nhits, "seed keys");
   R.vals.ensure(nhits, "seed positions");
@@ -546,13 +642,13 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     PosMap MA{A.d_boff, A.d_chunk}, MB{Bx.d_boff, Bx.d_chunk};
     hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                        (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
-                       (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.keys.p, R.vals.p, ebig.p, mctl.p + 1);
+                       (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, cluster ? 1 : 0, R.keys.p, R.vals.p, ebig.p, mctl.p + 1);
     copy_d2h(&total, eoff.p + nent, sizeof(uint32_t));
     copy_d2h(&nbig, mctl.p + 1, sizeof(unsigned int), 1);
     if (nbig > 0)
       hipLaunchKernelGGL(k_merge_expand_big, dim3(ceil_div((int64_t) nbig * 64, 256)), dim3(256), 0, stream(),
                          (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, nbig, (const uint32_t *) eoff.p,
-                         (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift,
+                         (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, cluster ? 1 : 0,
                          R.keys.p, R.vals.p);
     HIP_CHECK(hipGetLastError());
   }
@@ -562,25 +658,57 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   // --- seed sort (map.c:3110-3126)
   uint64_t *k0 = R.keys.p, *k1 = st.sort.keys_alt.p;
   uint32_t *v0 = R.vals.p, *v1 = st.sort.vals_alt.p;
-  radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, R.pbits + R.bbits + R.abits, st.sort, "seed_sort");
-  R.skeys = k0;
-  R.svals = v0;
+  radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, lowbits + R.bbits + R.abits, st.sort, "seed_sort");
 
   // --- groups
   static DevBuf<uint32_t> flag;
   flag.ensure(nhits + 1, "group flags");
-  { StageTimer tm("seed_groups", 24.0 * nhits);
-    int nb = ceil_div(nhits, 256);
-    hipLaunchKernelGGL(k_group_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.skeys, nhits, pshift, flag.p);
-    exclusive_scan_u32(flag.p, nhits, st.sort.bsum, flag.p + nhits);
-    uint32_t ng = 0;
-    copy_d2h(&ng, flag.p + nhits, sizeof(uint32_t), 1);
-    R.ngroups = ng;
-    R.gstart.ensure((size_t) ng + 1, "group starts");
-    hipLaunchKernelGGL(k_group_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.skeys, nhits, pshift,
-                       (const uint32_t *) flag.p, R.gstart.p, ng);
-    chain_classify_groups(R);          // (its copy of the pile count is the synchronisation point)
-  }
+  if (!cluster)
+    { StageTimer tm("seed_groups", 24.0 * nhits);
+      int nb = ceil_div(nhits, 256);
+      hipLaunchKernelGGL(k_group_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, pshift, flag.p);
+      exclusive_scan_u32(flag.p, nhits, st.sort.bsum, flag.p + nhits);
+      uint32_t ng = 0;
+      copy_d2h(&ng, flag.p + nhits, sizeof(uint32_t), 1);
+      R.ngroups = ng;
+      R.gstart.ensure((size_t) ng + 1, "group starts");
+      R.gkey.ensure((size_t) ng + 1, "group keys");
+      hipLaunchKernelGGL(k_group_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, pshift,
+                         (const uint32_t *) flag.p, R.gstart.p, ng, R.gkey.p);
+    }
+  else
+    { uint32_t ncl = 0;
+      { StageTimer tm("seed_clusters", 40.0 * nhits);
+        int nb = ceil_div(nhits, 256);
+        hipLaunchKernelGGL(k_cluster_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, qbits, flag.p);
+        exclusive_scan_u32(flag.p, nhits, st.sort.bsum, flag.p + nhits);
+        copy_d2h(&ncl, flag.p + nhits, sizeof(uint32_t), 1);
+        R.ngroups = ncl;
+        R.gstart.ensure((size_t) ncl + 1, "cluster starts");
+        R.gkey.ensure((size_t) ncl + 1, "cluster keys");
+        hipLaunchKernelGGL(k_cluster_rekey, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, (const uint32_t *) v0,
+                           nhits, qbits, R.pbits, (const uint32_t *) flag.p, k1, v1, R.gstart.p, ncl, R.gkey.p);
+        std::swap(k0, k1);
+        std::swap(v0, v1);
+      }
+      // every cluster into (apos, bpos) order: stable sort on (cluster, apos); nothing leaves its cluster's range
+      radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, R.pbits + ceil_log2((int64_t) ncl + 1), st.sort, "cluster_sort");
+      { StageTimer tm("seed_pairs", 0.0);
+        R.cog.ensure((size_t) ncl + 2, "pair of cluster");
+        R.ocfirst.ensure((size_t) ncl + 2, "first cluster of pair");
+        R.glast.ensure((size_t) ncl + 1, "last apos of pair");
+        int nb = ceil_div(ncl, 256);
+        hipLaunchKernelGGL(k_pair_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p);
+        exclusive_scan_u32(R.cog.p, ncl, st.sort.bsum, R.cog.p + ncl);
+        hipLaunchKernelGGL(k_pair_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p,
+                           (const uint32_t *) (R.cog.p + ncl), R.ocfirst.p, (const uint64_t *) k0,
+                           (const uint32_t *) R.gstart.p, ((uint64_t) 1 << R.pbits) - 1, R.glast.p);
+      }
+    }
+  R.skeys = k0;
+  R.svals = v0;
+  chain_classify_groups(R);          // (its copy of the pile count is the synchronisation point)
+  HIP_CHECK(hipGetLastError());
 
   if (st.capture_seeds)
     { std::vector<uint64_t> hk(nhits);
@@ -588,15 +716,37 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
       copy_d2h(hk.data(), R.skeys, sizeof(uint64_t) * nhits);
       copy_d2h(hv.data(), R.svals, sizeof(uint32_t) * nhits);
       st.last_seeds.resize((size_t) nhits * 4);
-      uint64_t pm = ((uint64_t) 1 << R.pbits) - 1, bm = ((uint64_t) 1 << R.bbits) - 1;
-      for (int64_t i = 0; i < nhits; i++)
-        { int apos  = (int) (hk[i] & pm);
-          int bread = (int) ((hk[i] >> pshift) & bm);
-          int aread = (int) (hk[i] >> bshift);
-          st.last_seeds[4 * i + 0] = apos - (int) hv[i];
-          st.last_seeds[4 * i + 1] = apos;
-          st.last_seeds[4 * i + 2] = bread;
-          st.last_seeds[4 * i + 3] = aread;
+      const uint64_t pm = ((uint64_t) 1 << R.pbits) - 1, bm = ((uint64_t) 1 << R.bbits) - 1;
+      if (!cluster)
+        for (int64_t i = 0; i < nhits; i++)
+          { int apos  = (int) (hk[i] & pm);
+            int bread = (int) ((hk[i] >> R.pbits) & bm);
+            int aread = (int) (hk[i] >> (R.pbits + R.bbits));
+            st.last_seeds[4 * i + 0] = apos - (int) hv[i];
+            st.last_seeds[4 * i + 1] = apos;
+            st.last_seeds[4 * i + 2] = bread;
+            st.last_seeds[4 * i + 3] = aread;
+          }
+      else
+        { // cluster order -> the reference's (aread, bread, apos, bpos) order, on the host (stage-level API only)
+          std::vector<uint64_t> gk((size_t) R.ngroups);
+          copy_d2h(gk.data(), R.gkey.p, sizeof(uint64_t) * (size_t) R.ngroups);
+          HIP_CHECK(hipStreamSynchronize(stream()));
+          struct Hit { uint64_t pair; uint32_t apos, bpos; };
+          std::vector<Hit> hs((size_t) nhits);
+          for (int64_t i = 0; i < nhits; i++)
+            hs[i] = Hit{gk[(size_t) (hk[i] >> R.pbits)], (uint32_t) (hk[i] & pm), hv[i]};
+          std::sort(hs.begin(), hs.end(), [](const Hit &x, const Hit &y)
+                    { if (x.pair != y.pair) return x.pair < y.pair;
+                      if (x.apos != y.apos) return x.apos < y.apos;
+                      return x.bpos < y.bpos;
+                    });
+          for (int64_t i = 0; i < nhits; i++)
+            { st.last_seeds[4 * i + 0] = (int) hs[i].apos - (int) hs[i].bpos;
+              st.last_seeds[4 * i + 1] = (int) hs[i].apos;
+              st.last_seeds[4 * i + 2] = (int) (hs[i].pair & bm);
+              st.last_seeds[4 * i + 3] = (int) (hs[i].pair >> R.bbits);
+            }
         }
     }
 }

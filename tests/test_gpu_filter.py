@@ -23,14 +23,21 @@ def _ref_available():
     return ref_lib.available()
 
 
+@pytest.mark.parametrize("cluster", [0, 1], ids=["pairs", "clusters"])
 @pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
-def test_seeds_and_candidates_match_reference(case):
+def test_seeds_and_candidates_match_reference(case, cluster):
+    """`cluster` forces the chain groups: whole (aread, bread) pairs, or their B-clusters (dmh_merge.h)."""
     if not _ref_available():
         pytest.skip("oracle/_ref not built")
+    from damapper_amd import capi
     kind, seed, contigs, nreads, drop, K, supp, mem, firsts = case
     g, reads = make_dataset(kind, seed, contigs, nreads, dropouts=drop)
     ref = run_filter(Api("ref"), reads, g, firsts, K=K, supp=supp, mem_limit=mem)
-    hip = run_filter(Api("hip"), reads, g, firsts, K=K, supp=supp, mem_limit=mem)
+    capi.lib().dmh_test_option(b"cluster", cluster)
+    try:
+        hip = run_filter(Api("hip"), reads, g, firsts, K=K, supp=supp, mem_limit=mem)
+    finally:
+        capi.lib().dmh_test_option(b"cluster", -1)
     assert len(ref["seeds"]) == len(hip["seeds"])
     for p, (a, b) in enumerate(zip(ref["seeds"], hip["seeds"])):
         assert len(a) == len(b), "pass %d: %d vs %d seed hits" % (p, len(a), len(b))
@@ -63,8 +70,13 @@ def test_profile_deltas_match_reference(case):
         pytest.skip("oracle/_ref not built")
     kind, seed, contigs, nreads, drop, spacing, firsts = case
     g, reads = make_dataset(kind, seed, contigs, nreads, dropouts=drop)
+    from damapper_amd import capi
     ref = run_filter(Api("ref"), reads, g, firsts, profile=1, spacing=spacing, want_seeds=False)
-    hip = run_filter(Api("hip"), reads, g, firsts, profile=1, spacing=spacing, want_seeds=False)
+    capi.lib().dmh_test_option(b"cluster", seed & 1)        # (both kinds of chain groups over the cases)
+    try:
+        hip = run_filter(Api("hip"), reads, g, firsts, profile=1, spacing=spacing, want_seeds=False)
+    finally:
+        capi.lib().dmh_test_option(b"cluster", -1)
     nz = 0
     for ar, (a, b) in enumerate(zip(ref["cover"], hip["cover"])):
         assert len(a) == len(b) == (len(reads[ar]) - 1) // spacing + 2, "read %d: %d vs %d slots" % (ar, len(a), len(b))
