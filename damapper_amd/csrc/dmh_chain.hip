@@ -59,7 +59,6 @@ struct ChainArgs
   const uint32_t *nonly;
   uint32_t       *retry;              // G < 64: groups whose live window outgrew LDS are appended here
   unsigned int   *nretry;             //         (the 64-lane launch that follows walks this list)
-  unsigned int   *out_count;
   ChainSummary   *out;
   uint32_t       *gcount;             // per group: number of summaries it reported and the slot of the first one in `out`
   uint32_t       *gbase;              //   (k_order_summaries puts them into the reference's reporting order)
@@ -328,13 +327,14 @@ __global__ __launch_bounds__(BLOCK) void k_chain(ChainArgs A)
       if (E == 0) continue;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
-      uint32_t obase = 0;
+      // A reported end closes a chain of at least HITMIN hits and belongs to a tree of its own, so a group of n
+      // hits reports at most n / HITMIN ends: its summaries go to the slots from ceil(g0 / HITMIN) on -- no counter
+      // shared by 10^6 groups, and the ranges of consecutive groups cannot overlap.
+      const uint32_t obase = (g0 + HITMIN - 1) / HITMIN;
       if (lane == 0)
-        { obase = atomicAdd(A.out_count, E);
-          A.gcount[g] = E;
+        { A.gcount[g] = E;
           A.gbase[g]  = obase;
         }
-      obase = __shfl(obase, 0, G);
 
       for (uint32_t e = lane; e < E; e += G)
         { uint32_t x    = A.tmp[g0 + e];
@@ -358,6 +358,173 @@ __global__ __launch_bounds__(BLOCK) void k_chain(ChainArgs A)
           s.end   = x;
           A.out[obase + e] = s;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+//  Small groups (<= CAP hits; in cluster mode nearly all of them): everything in LDS.  G lanes load the group's
+//  hits, walk them with the per-hit state (cost / from / origin / the origin's best end) in LDS arrays indexed by
+//  the hit's position in the group, and write `from[]` and the summaries at the end -- no global round trip
+//  inside the walk, no ticket (groups are dealt to the lane groups round-robin: they are small and there are
+//  millions of them), no live-window list: hit j scans the earlier hits of the group from the first that has
+//  not expired.
+// ---------------------------------------------------------------------------------------
+template <int G, int CAP>
+__global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_max)
+{ constexpr int      GPB = 256 / G;
+  constexpr uint16_t NIL16 = 0xffff;
+  __shared__ uint32_t s_ap[GPB][CAP], s_bp[GPB][CAP];
+  __shared__ int32_t  s_cost[GPB][CAP], s_bcost[GPB][CAP];
+  __shared__ uint16_t s_from[GPB][CAP], s_root[GPB][CAP], s_best[GPB][CAP];
+  __shared__ uint8_t  s_alive[GPB][CAP];
+  const int      lane  = threadIdx.x & (G - 1);
+  const int      sbase = (threadIdx.x & 63) & ~(G - 1);
+  const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+  const uint64_t lt    = (1ull << lane) - 1ull;
+  const int      K     = A.K;
+  const int      gi    = threadIdx.x / G;
+  auto gballot = [&](bool p) -> uint64_t { return (__ballot(p) >> sbase) & gmask; };
+  uint32_t *ap = s_ap[gi], *bp = s_bp[gi];
+  int32_t  *cs = s_cost[gi], *bc = s_bcost[gi];
+  uint16_t *fr = s_from[gi], *rt = s_root[gi], *be = s_best[gi];
+  uint8_t  *al = s_alive[gi];
+
+  const uint32_t stride = gridDim.x * GPB;
+  for (uint32_t g = blockIdx.x * GPB + gi; g < A.ngroups; g += stride)
+    { const uint32_t g0 = A.gstart[g], g1 = A.gstart[g + 1];
+      const uint32_t n = g1 - g0;
+      if (n > size_max) continue;
+      for (uint32_t i = lane; i < n; i += G)
+        { ap[i] = (uint32_t) (A.keys[g0 + i] & A.pmask) + 1u;        // map.c:1784-1785
+          bp[i] = A.vals[g0 + i] + 1u;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+      uint32_t head = 0;
+      for (uint32_t j = 0; j < n; j++)
+        { const int apos = (int) ap[j], bpos = (int) bp[j];
+          const int diag = apos - bpos, thresh = bpos - MAX_GAP, old = apos - MAX_GAP;
+          // ---- neighbour queries (map.c:1262-1318) over the hits [head, j) that are still in the tree; hits
+          //      expire in order (map.c:1787-1796), so whole chunks of expired hits are left behind for good
+          uint64_t myL = ~0ull, myR = 0;
+          uint32_t myLi = 0, myRi = 0;
+          for (uint32_t base = head; base < j; base += G)
+            { const uint32_t i = base + lane;
+              const bool in = i < j;
+              const int  ax = in ? (int) ap[i] : 0;
+              const bool fresh = in && ax >= old;
+              if (gballot(fresh) == 0 && base == head && base + G <= j) { head += G; continue; }
+              if (fresh && al[i])
+                { const int bx = (int) bp[i];
+                  const int dx = ax - bx;
+                  const uint64_t db = (uint64_t) ((uint32_t) dx + 0x80000000u);
+                  if (dx > diag)
+                    { if (bx >= thresh)
+                        { const uint64_t lk = (db << 32) | (uint32_t) (0x7fffffff - ax);
+                          if (lk < myL) { myL = lk; myLi = i; }
+                        }
+                    }
+                  else if (bx <= bpos)
+                    { const uint64_t rk = (db << 32) | (uint32_t) ax;
+                      if (rk > myR) { myR = rk; myRi = i; }
+                    }
+                }
+            }
+          uint32_t li = NIL, ri = NIL;
+          { const uint64_t lm = wave_min_u64<G>(myL);
+            if (lm != ~0ull) li = (uint32_t) __shfl((int) myLi, __ffsll((long long) gballot(myL == lm)) - 1, G);
+            const uint64_t rm = wave_max_u64<G>(myR);
+            if (rm != 0) ri = (uint32_t) __shfl((int) myRi, __ffsll((long long) gballot(myR == rm)) - 1, G);
+          }
+          // ---- extend the better neighbour's chain (map.c:1811-1862); uniform on the lanes of the group
+          int lcost = 0, rcost = 0;
+          if (li != NIL)
+            { const int la = (int) ap[li], lc = cs[li];
+              lcost = (apos >= la + K) ? lc + K : lc + (apos - la);
+            }
+          if (ri != NIL)
+            { const int rb = (int) bp[ri], rc = cs[ri];
+              rcost = (bpos >= rb + K) ? rc + K : rc + (bpos - rb);
+            }
+          if (lcost > rcost) rcost = 0; else lcost = 0;
+          uint32_t pi = NIL;
+          int      c = K;
+          if (lcost > 0)      { pi = li; c = lcost; }
+          else if (rcost > 0) { pi = ri; c = rcost; }
+          if (pi != NIL)
+            { const uint32_t root = rt[pi];
+              const int      bcst = bc[root];
+              bool kill = false;
+              if (c >= bcst)
+                { const int pa = (int) ap[pi];
+                  const int pd = pa - (int) bp[pi];
+                  int dd = pd - diag;
+                  if (dd < 0) dd = -dd;
+                  kill = ((double) dd <= .2 * (double) (apos - pa));      // map.c:1837,1852
+                }
+              if (lane == 0)
+                { fr[j] = (uint16_t) pi;
+                  cs[j] = c;
+                  rt[j] = (uint16_t) root;
+                  al[j] = 1;
+                  if (c >= bcst)
+                    { be[root] = (uint16_t) j;
+                      bc[root] = c;
+                      if (kill) al[pi] = 0;
+                    }
+                }
+            }
+          else if (lane == 0)
+            { fr[j] = NIL16;
+              cs[j] = K;
+              rt[j] = (uint16_t) j;
+              be[j] = (uint16_t) j;
+              bc[j] = K;
+              al[j] = 1;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+
+      // ---- from[] for the Jump lists, and the best end of every origin with cost >= hithr (map.c:1634-1649)
+      const int last = A.glast ? (int) A.glast[g] : (int) ap[n - 1];
+      const uint32_t obase = (g0 + HITMIN - 1) / HITMIN;
+      uint32_t E = 0;
+      for (uint32_t base = 0; base < n; base += G)
+        { const uint32_t x = base + lane;
+          bool f = false;
+          if (x < n)
+            { const uint16_t fx = fr[x];
+              A.from[g0 + x] = (fx == NIL16) ? NIL : g0 + fx;
+              f = cs[x] >= A.hithr && fx != NIL16 && be[rt[x]] == (uint16_t) x;
+            }
+          const uint64_t m = gballot(f);
+          if (f)
+            { const int  ax = (int) ap[x], bx = (int) bp[x], dx = ax - bx;
+              const bool live_x = al[x] && ax >= last - MAX_GAP;
+              const uint32_t root = rt[x];
+              ChainSummary s;
+              s.group = g;
+              s.live  = live_x ? 1u : 0u;
+              s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax)
+                               : (((uint64_t) (uint32_t) ax << 32) | (uint32_t) bx);
+              s.cost  = cs[x];
+              s.ab    = (int) ap[root] - K;
+              s.bb    = (int) bp[root] - K;
+              s.ae    = ax;
+              s.be    = bx;
+              s.end   = g0 + x;
+              A.out[obase + E + (uint32_t) __popcll(m & lt)] = s;
+            }
+          E += (uint32_t) __popcll(m);
+        }
+      if (lane == 0)
+        { A.gcount[g] = E;
+          A.gbase[g]  = obase;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -598,13 +765,11 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
             }
           if (E != 0)
             { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-              uint32_t obase = 0;
+              const uint32_t obase = (g0 + HITMIN - 1) / HITMIN;
               if (lane == 0)
-                { obase = atomicAdd(A.out_count, E);
-                  A.gcount[g] = E;
+                { A.gcount[g] = E;
                   A.gbase[g]  = obase;
                 }
-              obase = __shfl(obase, 0);
               for (uint32_t e = lane; e < E; e += 64)
                 { uint32_t x    = A.tmp[g0 + e];
                   int      ax   = (int) (A.keys[x] & A.pmask) + 1;
@@ -647,8 +812,7 @@ struct OrdChain
 // Reporting order inside a group (map.c:1634-1642): live ends by (diagonal, apos) descending, then expired ends
 // most recent first -- i.e. descending (live, okey).  The keys of a group are unique, so the rank of an end is
 // the number of its siblings that precede it; the ends of group g go to ord[goff[g] ...).
-__global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__restrict__ out,
-                                                         const unsigned int *__restrict__ nsum_p,
+__global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__restrict__ out, uint32_t ngroups,
                                                          const uint32_t *__restrict__ gbase,
                                                          const uint32_t *__restrict__ gcount,
                                                          const uint32_t *__restrict__ goff,
@@ -656,10 +820,9 @@ __global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__r
                                                          const uint32_t *__restrict__ cog,
                                                          const uint32_t *__restrict__ ocfirst,
                                                          OrdChain *__restrict__ ord)
-{ const uint32_t nsum = *nsum_p;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nsum; i += gridDim.x * blockDim.x)
-    { const ChainSummary s = out[i];
-      const uint32_t g = s.group;
+{ for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x)
+    { const uint32_t En = gcount[g];
+      if (En == 0) continue;
       // the siblings: the ends of all groups of the same (aread, bread) pair -- the group itself, or in cluster
       // mode the pair's clusters c0..c1-1 (their numbers are consecutive)
       uint32_t c0 = g, c1 = g + 1;
@@ -668,19 +831,24 @@ __global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__r
           c0 = ocfirst[p];
           c1 = ocfirst[p + 1];
         }
-      uint32_t rank = 0;
-      for (uint32_t c = c0; c < c1; c++)
-        { const uint32_t b = gbase[c], E = gcount[c];
-          for (uint32_t f = 0; f < E; f++)
-            { const uint32_t tl = out[b + f].live;
-              const uint64_t tk = out[b + f].okey;
-              rank += (tl > s.live || (tl == s.live && tk > s.okey)) ? 1u : 0u;
+      const uint64_t gk = gkey[g];
+      const uint32_t dst = goff[c0], mb = gbase[g];
+      for (uint32_t e = 0; e < En; e++)
+        { const ChainSummary s = out[mb + e];
+          uint32_t rank = 0;
+          for (uint32_t c = c0; c < c1; c++)
+            { const uint32_t b = gbase[c], E = gcount[c];
+              for (uint32_t f = 0; f < E; f++)
+                { const uint32_t tl = out[b + f].live;
+                  const uint64_t tk = out[b + f].okey;
+                  rank += (tl > s.live || (tl == s.live && tk > s.okey)) ? 1u : 0u;
+                }
             }
+          OrdChain o;
+          o.cost = s.cost; o.ab = s.ab; o.ae = s.ae; o.bb = s.bb; o.be = s.be; o.end = s.end;
+          o.gkey = gk;
+          ord[dst + rank] = o;
         }
-      OrdChain o;
-      o.cost = s.cost; o.ab = s.ab; o.ae = s.ae; o.bb = s.bb; o.be = s.be; o.end = s.end;
-      o.gkey = gkey[g];
-      ord[goff[c0] + rank] = o;
     }
 }
 
@@ -874,15 +1042,29 @@ __global__ void k_cand_jumps(const uint64_t *__restrict__ keys, const uint32_t *
     }
 }
 
-// groups of at least `big` hits, in any order; those of at least `pile` hits go to their own list
-__global__ void k_big_groups(const uint32_t *__restrict__ gstart, uint32_t ngroups, uint32_t big, uint32_t pile,
+// groups by size, in any order: more than `small` and fewer than `big` hits -> mlist (the 16-lane launch with the
+// window in LDS), at least `big` -> list (one wavefront each), at least `pile` -> plist (one workgroup each).
+// One atomic per wavefront and list.
+__global__ void k_big_groups(const uint32_t *__restrict__ gstart, uint32_t ngroups, uint32_t small, uint32_t big,
+                             uint32_t pile, uint32_t *__restrict__ mlist, unsigned int *__restrict__ nmlist,
                              uint32_t *__restrict__ list, unsigned int *__restrict__ nlist,
                              uint32_t *__restrict__ plist, unsigned int *__restrict__ nplist)
-{ uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ngroups) return;
-  uint32_t sz = gstart[g + 1] - gstart[g];
-  if (sz >= pile)     plist[atomicAdd(nplist, 1u)] = g;
-  else if (sz >= big) list[atomicAdd(nlist, 1u)] = g;
+{ const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t sz = (g < ngroups) ? gstart[g + 1] - gstart[g] : 0;
+  const bool isp = sz >= pile, isb = !isp && sz >= big, ism = !isp && !isb && sz > small;
+  const uint64_t mp = __ballot(isp), mb = __ballot(isb), mm = __ballot(ism);
+  uint32_t bp = 0, bb = 0, bm = 0;
+  if (lane == 0)
+    { if (mp) bp = atomicAdd(nplist, (uint32_t) __popcll(mp));
+      if (mb) bb = atomicAdd(nlist, (uint32_t) __popcll(mb));
+      if (mm) bm = atomicAdd(nmlist, (uint32_t) __popcll(mm));
+    }
+  bp = __shfl(bp, 0); bb = __shfl(bb, 0); bm = __shfl(bm, 0);
+  if (isp) plist[bp + (uint32_t) __popcll(mp & lt)] = g;
+  if (isb) list[bb + (uint32_t) __popcll(mb & lt)] = g;
+  if (ism) mlist[bm + (uint32_t) __popcll(mm & lt)] = g;
 }
 
 // small groups four to a wavefront (live window in LDS), big ones and windows that outgrew LDS one per
@@ -890,30 +1072,42 @@ __global__ void k_big_groups(const uint32_t *__restrict__ gstart, uint32_t ngrou
 // for everything below the pile threshold, "chain_pile" / DMH_CHAIN_PILE move that threshold (0 = no piles)
 constexpr uint32_t BIG_GROUP = 1024;
 
+constexpr uint32_t SMALL_CAP = 64;       // k_chain_small<16, 64>
+
 void chain_classify_groups(MergeResult &R)
 { State &st = S();
   static const int env_g    = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
   static const int env_pile = getenv("DMH_CHAIN_PILE") ? atoi(getenv("DMH_CHAIN_PILE")) : 4096;
+  static const int env_small = getenv("DMH_CHAIN_SMALL") ? atoi(getenv("DMH_CHAIN_SMALL")) : (int) SMALL_CAP;
   const int chain_g = st.opt_chain_g ? st.opt_chain_g : env_g;
   R.pile_min = (st.opt_chain_pile >= 0) ? (uint32_t) st.opt_chain_pile : (uint32_t) env_pile;
   R.small_hi = (chain_g == 0) ? BIG_GROUP : 0xffffffffu;
   if (R.pile_min > 0) R.small_hi = std::min(R.small_hi, R.pile_min);
+  // groups of up to small_cap hits go to the all-LDS kernel (not when a group width is forced for everything)
+  int sc = (st.opt_chain_small >= 0) ? st.opt_chain_small : env_small;
+  if (chain_g != 0) sc = 0;
+  R.small_cap = (uint32_t) std::min<int>(std::max(sc, 0), (int) SMALL_CAP);
+  if (R.small_cap >= R.small_hi) R.small_cap = R.small_hi - 1;
   R.biglist.ensure((size_t) R.ngroups + 64, "big groups");
   R.pilelist.ensure((size_t) R.ngroups + 64, "repeat piles");
+  R.medlist.ensure((size_t) R.ngroups + 64, "medium groups");
   R.gcounts.ensure(4, "group list lengths");
   HIP_CHECK(hipMemsetAsync(R.gcounts.p, 0, 4 * sizeof(uint32_t), stream()));
   R.npiles = 0;
   R.nbig   = 0;
+  R.nmed   = 0;
   R.classified = true;
-  if (R.ngroups == 0 || (R.small_hi == 0xffffffffu && R.pile_min == 0)) return;
+  if (R.ngroups == 0) return;
   hipLaunchKernelGGL(k_big_groups, dim3(ceil_div(R.ngroups, 256)), dim3(256), 0, stream(),
-                     (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, R.small_hi,
-                     R.pile_min > 0 ? R.pile_min : 0xffffffffu, R.biglist.p, R.gcounts.p, R.pilelist.p, R.gcounts.p + 1);
+                     (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, R.small_cap, R.small_hi,
+                     R.pile_min > 0 ? R.pile_min : 0xffffffffu, R.medlist.p, R.gcounts.p + 2, R.biglist.p, R.gcounts.p,
+                     R.pilelist.p, R.gcounts.p + 1);
   HIP_CHECK(hipGetLastError());
-  uint32_t cnt[2] = {0, 0};
-  copy_d2h(cnt, R.gcounts.p, 2 * sizeof(uint32_t));
+  uint32_t cnt[3] = {0, 0, 0};
+  copy_d2h(cnt, R.gcounts.p, 3 * sizeof(uint32_t));
   R.nbig   = cnt[0];
   R.npiles = cnt[1];
+  R.nmed   = cnt[2];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1018,7 +1212,6 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.only = nullptr;
   A.nonly = nullptr;
   A.ticket = ctl.p;
-  A.out_count = ctl.p + 1;
   A.out = out.p;
   A.gcount = gcnt.p;
   A.gbase  = gbase.p;
@@ -1035,7 +1228,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     const int  gsmall = (chain_g == 32) ? 32 : 16;
     if (!all64)
       { const int gpb = 256 / gsmall;
-        int nblocks = (int) std::min<int64_t>((R.ngroups + gpb - 1) / gpb, 256 * 8);
+        (void) gpb;
         hipEvent_t piles_done = nullptr;
         static DevBuf<uint32_t> pileretry;
         if (R.npiles > 0)
@@ -1066,11 +1259,25 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
             HIP_CHECK(hipEventRecord(ev_done, pstream));
             piles_done = ev_done;
           }
-        A.size_lo = 0; A.size_hi = R.small_hi;
-        { StageTimer t1("chain_small_groups", 0.0);
-          if (gsmall == 32) hipLaunchKernelGGL(k_chain<32>, dim3(nblocks), dim3(256), 0, stream(), A);
-          else              hipLaunchKernelGGL(k_chain<16>, dim3(nblocks), dim3(256), 0, stream(), A);
-        }
+        if (R.small_cap > 0)
+          { // the all-LDS kernel: groups dealt round-robin, as many lane groups as the GPU holds
+            StageTimer t0("chain_lds_groups", 0.0);
+            const int nb = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
+            hipLaunchKernelGGL((k_chain_small<16, (int) SMALL_CAP>), dim3(nb), dim3(256), 0, stream(), A, R.small_cap);
+          }
+        if (R.nmed > 0)
+          { // medium groups: window in LDS, a list with its own ticket counter (ctl[3])
+            ChainArgs M = A;
+            M.size_lo = 0; M.size_hi = 0xffffffffu;
+            M.ticket = ctl.p + 3;
+            M.only   = R.medlist.p;
+            M.nonly  = R.gcounts.p + 2;
+            const int gpbm = 256 / gsmall;
+            const int nbm = (int) std::min<int64_t>(((int64_t) R.nmed + gpbm - 1) / gpbm, 256 * 8);
+            StageTimer t1("chain_small_groups", 0.0);
+            if (gsmall == 32) hipLaunchKernelGGL(k_chain<32>, dim3(nbm), dim3(256), 0, stream(), M);
+            else              hipLaunchKernelGGL(k_chain<16>, dim3(nbm), dim3(256), 0, stream(), M);
+          }
         // the list (its own ticket counter ctl[2]); on read-vs-genome data it is empty
         A.ticket = ctl.p + 2;
         A.only   = R.biglist.p;
@@ -1097,20 +1304,29 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
       }
     HIP_CHECK(hipGetLastError());
   }
+  // chain ends per group -> first slot of every group's ends in the reference's order, and their number
+  const uint32_t ng = (uint32_t) R.ngroups;
+  static DevBuf<uint32_t> goff;
+  goff.ensure((size_t) ng + 2, "chain ends per group");
+  HIP_CHECK(hipMemcpyAsync(goff.p, gcnt.p, sizeof(uint32_t) * ng, hipMemcpyDeviceToDevice, stream()));
+  exclusive_scan_u32(goff.p, ng, st.sort.bsum, goff.p + ng);
   uint32_t nsum = 0;
   { HostTimer ht("chain_wait");
-    copy_d2h(&nsum, ctl.p + 1, sizeof(uint32_t), 1);
+    copy_d2h(&nsum, goff.p + ng, sizeof(uint32_t), 1);
+  }
+  { static const bool stats = getenv("DMH_STATS") != nullptr;
+    if (stats)
+      fprintf(stderr, "dmh: pass hits %lld groups %lld (clustered %d) lds<=%u medium %u big %u piles %u chain ends %u\n",
+              (long long) nhits, (long long) R.ngroups, (int) R.clustered, R.small_cap, R.nmed, R.nbig, R.npiles, nsum);
   }
   if (nsum == 0) return 0;             // no chain reached the threshold: the lists stay as they are
 
   // ---- reporting order, domination rule and -p deltas on the device (map.c:1634-1730)
   CandStore &cs = st.cands;
   const int nreads = ablock->nreads;
-  const uint32_t ng = (uint32_t) R.ngroups;
   static DevBuf<OrdChain> ord;
-  static DevBuf<uint32_t> goff, rgfirst, fresh, jl;
+  static DevBuf<uint32_t> rgfirst, fresh, jl;
   ord.ensure(nsum, "ordered chain ends");
-  goff.ensure((size_t) ng + 2, "chain ends per group");
   rgfirst.ensure((size_t) nreads + 2, "groups per read");
   fresh.ensure(nsum, "fresh candidates");
   jl.ensure(2 * (size_t) nsum + 4, "jump lengths");
@@ -1122,10 +1338,8 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   { StageTimer tm("chain_dominate", 40.0 * nsum);
     HIP_CHECK(hipMemsetAsync(cs.ctl.p, 0, 16 * sizeof(unsigned int), stream()));
-    HIP_CHECK(hipMemcpyAsync(goff.p, gcnt.p, sizeof(uint32_t) * ng, hipMemcpyDeviceToDevice, stream()));
-    exclusive_scan_u32(goff.p, ng, st.sort.bsum, goff.p + ng);
-    hipLaunchKernelGGL(k_order_summaries, dim3(std::min<uint32_t>(ceil_div(nsum, 256), 4096)), dim3(256), 0, stream(),
-                       (const ChainSummary *) out.p, (const unsigned int *) (ctl.p + 1), (const uint32_t *) gbase.p,
+    hipLaunchKernelGGL(k_order_summaries, dim3(std::min<uint32_t>(ceil_div(ng, 256), 8192)), dim3(256), 0, stream(),
+                       (const ChainSummary *) out.p, ng, (const uint32_t *) gbase.p,
                        (const uint32_t *) gcnt.p, (const uint32_t *) goff.p, (const uint64_t *) R.gkey.p,
                        R.clustered ? (const uint32_t *) R.cog.p : (const uint32_t *) nullptr,
                        R.clustered ? (const uint32_t *) R.ocfirst.p : (const uint32_t *) nullptr, ord.p);

@@ -26,8 +26,9 @@ struct MergeResult
   // the groups by size, for the chain kernels (chain_classify_groups): groups of small_hi..pile_min-1 hits
   // (list of the one-wavefront-per-group launch; windows that outgrow LDS are appended later) and repeat
   // piles of >= pile_min hits (one workgroup each)
-  DevBuf<uint32_t> biglist, pilelist, gcounts;  // gcounts[0] = length of biglist, [1] = of pilelist (device)
-  uint32_t small_hi = 0xffffffffu, pile_min = 0, npiles = 0, nbig = 0;
+  DevBuf<uint32_t> biglist, pilelist, medlist, gcounts;  // gcounts[0] = length of biglist, [1] = of pilelist, [2] = of medlist (device)
+  uint32_t small_hi = 0xffffffffu, pile_min = 0, npiles = 0, nbig = 0, nmed = 0;
+  uint32_t small_cap = 0;                      // groups of up to this many hits go to the all-LDS kernel
   bool     classified = false;
 };
 
