@@ -529,6 +529,220 @@ __global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_
 }
 
 // ---------------------------------------------------------------------------------------
+//  One LANE per group.  A lane group per chain group keeps 15 of its 16 lanes idle through the sequential part of
+//  every hit, and the 10^6-10^7 groups of a pass on a repeat-rich genome (B-clusters of some twenty hits) offer all
+//  the parallelism a GPU wants without any inside a group.  Here every lane walks groups of its own: the live
+//  window sits in registers (RW slots, scanned by an unrolled loop; a hit takes the first free slot), the chain
+//  trees with a live member in a small LDS table private to the lane (best score, origin, best end: all a
+//  summary needs, so nothing is read back from global memory), hits are fetched one ahead, and a lane that
+//  finishes a group starts its next one in the same iteration while the other lanes carry on (the group after
+//  that is looked up in the background).  A window of more than RW live hits, or more than RT trees with live
+//  members, sends the group to the lane-group kernels (A.retry).  Same rules, same results.
+// ---------------------------------------------------------------------------------------
+constexpr int RW = 16;
+constexpr int RT = 8;
+
+__global__ __launch_bounds__(256) void k_chain_lane(ChainArgs A, uint32_t size_max)
+{ __shared__ int32_t  t_bc[4][RT][64];                       // per tree slot: best score ...
+  __shared__ uint32_t t_oa[4][RT][64], t_ob[4][RT][64];      //   origin (apos, bpos)
+  __shared__ uint32_t t_ea[4][RT][64], t_eb[4][RT][64];      //   best end (apos, bpos)
+  __shared__ uint32_t t_ex[4][RT][64];                       //   best end's position in the group
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int K = A.K;
+  const uint32_t nthreads = gridDim.x * 256;
+
+  // the window: slot s holds a live hit iff bit s of vmask
+  uint32_t w_ap[RW], w_bp[RW], w_meta[RW];     // meta = position in the group | tree slot << 24
+  int32_t  w_cost[RW];
+#pragma unroll
+  for (int s = 0; s < RW; s++) { w_ap[s] = 0; w_bp[s] = 0; w_meta[s] = 0; w_cost[s] = 0; }
+  uint32_t vmask = 0, tmask = 0;
+
+  // the group being walked
+  bool     active = false;
+  uint32_t g = 0, g0 = 0, n = 0, j = 0, E = 0, obase = 0;
+  uint64_t hk = 0;            // the next hit of the group (fetched one iteration ahead)
+  uint32_t hv = 0;
+  // the group after it: pst 1 = look its bounds up, 2 = bounds on their way, 3 = first hit on its way / there, 9 = none left
+  uint32_t pg = blockIdx.x * 256 + threadIdx.x, q0 = 0, q1 = 0;
+  int      pst = 1;
+  uint64_t pk = 0;
+  uint32_t pv = 0;
+
+  auto emit = [&](uint32_t t, bool at_end)
+  { // the best end of tree slot t, if it scores (map.c:1642-1649)
+    const int bcst = t_bc[wv][t][lane];
+    if (bcst < A.hithr) return;
+    const uint32_t oa = t_oa[wv][t][lane], ob = t_ob[wv][t][lane];
+    const uint32_t ea = t_ea[wv][t][lane], eb = t_eb[wv][t][lane], ex = t_ex[wv][t][lane];
+    bool live_x = false;
+    if (at_end)
+      {
+#pragma unroll
+        for (int s = 0; s < RW; s++)
+          if (((vmask >> s) & 1u) && (w_meta[s] & 0xffffffu) == ex) live_x = true;
+        const int last = A.glast ? (int) A.glast[g] : (int) (A.keys[g0 + n - 1] & A.pmask) + 1;
+        live_x = live_x && (int) ea >= last - MAX_GAP;
+      }
+    ChainSummary sm;
+    sm.group = g;
+    sm.live  = live_x ? 1u : 0u;
+    const int dx = (int) ea - (int) eb;
+    sm.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | ea) : (((uint64_t) ea << 32) | eb);
+    sm.cost  = bcst;
+    sm.ab    = (int) oa - K;
+    sm.bb    = (int) ob - K;
+    sm.ae    = (int) ea;
+    sm.be    = (int) eb;
+    sm.end   = g0 + ex;
+    A.out[obase + E] = sm;
+    E += 1;
+  };
+
+  while (true)
+    { // ---- look-ahead: bounds and first hit of this lane's next group
+      if (pst == 2)
+        { if (q1 - q0 <= size_max)
+            { pk = A.keys[q0];
+              pv = A.vals[q0];
+              pst = 3;
+            }
+          else
+            { pg += nthreads;
+              pst = 1;
+            }
+        }
+      if (pst == 1)
+        { if (pg < A.ngroups)
+            { q0 = A.gstart[pg];
+              q1 = A.gstart[pg + 1];
+              pst = 2;
+            }
+          else
+            pst = 9;
+        }
+      // ---- a lane without a group takes the one that has been looked up
+      if (!active && pst == 3)
+        { active = true;
+          g = pg; g0 = q0; n = q1 - q0; j = 0; E = 0;
+          obase = (g0 + HITMIN - 1) / HITMIN;
+          hk = pk; hv = pv;
+          vmask = 0; tmask = 0;
+          pg += nthreads;
+          pst = 1;
+        }
+      if (__ballot(active || pst != 9) == 0) break;
+      if (!active) continue;
+
+      // ---- hit j of the group (map.c:1781-1872)
+      const int apos = (int) (hk & A.pmask) + 1, bpos = (int) hv + 1;
+      const int diag = apos - bpos, thresh = bpos - MAX_GAP, old = apos - MAX_GAP;
+      if (j + 1 < n)                       // the next one, for the next iteration
+        { hk = A.keys[g0 + j + 1];
+          hv = A.vals[g0 + j + 1];
+        }
+      uint64_t bL = ~0ull, bR = 0;
+      int      Lc = 0, La = 0, Rc = 0, Rb = 0;
+      uint32_t Lm = 0, Rm = 0, Ls = 0, Rs = 0;
+      int      Ld = 0, Rd = 0, Rax = 0, Lbx = 0;
+#pragma unroll
+      for (int s = 0; s < RW; s++)
+        { if (!((vmask >> s) & 1u)) continue;
+          const int ax = (int) w_ap[s];
+          if (ax < old) { vmask &= ~(1u << s); continue; }          // expired (map.c:1787-1796)
+          const int bx = (int) w_bp[s];
+          const int dx = ax - bx;
+          const uint64_t db = (uint64_t) ((uint32_t) dx + 0x80000000u);
+          if (dx > diag)
+            { if (bx >= thresh)
+                { const uint64_t lk = (db << 32) | (uint32_t) (0x7fffffff - ax);
+                  if (lk < bL) { bL = lk; Lc = w_cost[s]; La = ax; Lbx = bx; Lm = w_meta[s]; Ls = (uint32_t) s; Ld = dx; }
+                }
+            }
+          else if (bx <= bpos)
+            { const uint64_t rk = (db << 32) | (uint32_t) ax;
+              if (rk > bR) { bR = rk; Rc = w_cost[s]; Rb = bx; Rax = ax; Rm = w_meta[s]; Rs = (uint32_t) s; Rd = dx; }
+            }
+        }
+      int lcost = 0, rcost = 0;
+      if (bL != ~0ull) lcost = (apos >= La + K) ? Lc + K : Lc + (apos - La);
+      if (bR != 0)     rcost = (bpos >= Rb + K) ? Rc + K : Rc + (bpos - Rb);
+      if (lcost > rcost) rcost = 0; else lcost = 0;
+      bool     havep = false, overflow = false;
+      uint32_t pm = 0, ps = 0;
+      int      c = K, pa = 0, pd = 0;
+      if (lcost > 0)      { havep = true; pm = Lm; ps = Ls; c = lcost; pa = La;  pd = Ld; }
+      else if (rcost > 0) { havep = true; pm = Rm; ps = Rs; c = rcost; pa = Rax; pd = Rd; }
+      (void) Lbx;
+      uint32_t tj;
+      if (havep)
+        { tj = pm >> 24;
+          A.from[g0 + j] = g0 + (pm & 0xffffffu);
+          const int bcst = t_bc[wv][tj][lane];
+          if (c >= bcst)
+            { int dd = pd - diag;
+              if (dd < 0) dd = -dd;
+              t_bc[wv][tj][lane] = c;
+              t_ea[wv][tj][lane] = (uint32_t) apos;
+              t_eb[wv][tj][lane] = (uint32_t) bpos;
+              t_ex[wv][tj][lane] = j;
+              if ((double) dd <= .2 * (double) (apos - pa)) vmask &= ~(1u << ps);      // map.c:1837,1852
+            }
+        }
+      else
+        { A.from[g0 + j] = NIL;
+          if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
+            { // no tree slot left: the trees without a live member are complete -- report them and take their slots
+              uint32_t used = 0;
+#pragma unroll
+              for (int s = 0; s < RW; s++)
+                if ((vmask >> s) & 1u) used |= 1u << (w_meta[s] >> 24);
+              const uint32_t dead = tmask & ~used;
+              for (uint32_t m = dead; m != 0; m &= m - 1)
+                emit((uint32_t) __ffs((int) m) - 1u, false);
+              tmask &= ~dead;
+            }
+          if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
+            { overflow = true; tj = 0; }
+          else
+            { tj = (uint32_t) __ffs((int) ~tmask) - 1u;
+              tmask |= 1u << tj;
+              t_bc[wv][tj][lane] = K;
+              t_oa[wv][tj][lane] = (uint32_t) apos;
+              t_ob[wv][tj][lane] = (uint32_t) bpos;
+              t_ea[wv][tj][lane] = (uint32_t) apos;
+              t_eb[wv][tj][lane] = (uint32_t) bpos;
+              t_ex[wv][tj][lane] = j;
+            }
+        }
+      if (!overflow)
+        { const uint32_t fm = ~vmask & ((1u << RW) - 1u);
+          if (fm == 0) overflow = true;
+          else
+            { const int f = __ffs((int) fm) - 1;
+#pragma unroll
+              for (int s = 0; s < RW; s++)
+                if (s == f)
+                  { w_ap[s] = (uint32_t) apos; w_bp[s] = (uint32_t) bpos; w_cost[s] = c; w_meta[s] = j | (tj << 24); }
+              vmask |= 1u << f;
+            }
+        }
+      j += 1;
+      if (overflow)
+        { A.retry[atomicAdd(A.nretry, 1u)] = g;          // (the lane-group kernel starts the group afresh)
+          active = false;
+        }
+      else if (j == n)
+        { for (uint32_t m = tmask; m != 0; m &= m - 1)
+            emit((uint32_t) __ffs((int) m) - 1u, true);
+          A.gcount[g] = E;
+          A.gbase[g]  = obase;
+          active = false;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 //  Repeat piles: one WORKGROUP per group.  A (read, contig) group of a repeat family has tens of thousands
 //  of hits and a live window of thousands; one wavefront walking it (k_chain<64>) scans dozens of 64-entry
 //  chunks of global memory per hit and sets the run time of the whole pass.  Here the window lives in LDS
@@ -1088,6 +1302,11 @@ void chain_classify_groups(MergeResult &R)
   if (chain_g != 0) sc = 0;
   R.small_cap = (uint32_t) std::min<int>(std::max(sc, 0), (int) SMALL_CAP);
   if (R.small_cap >= R.small_hi) R.small_cap = R.small_hi - 1;
+  // one lane per group (k_chain_lane) for everything below small_hi instead; "chain_lane" test option / DMH_CHAIN_LANE: 0 off
+  static const int env_lane = getenv("DMH_CHAIN_LANE") ? atoi(getenv("DMH_CHAIN_LANE")) : 1;
+  const int ln = (st.opt_chain_lane >= 0) ? st.opt_chain_lane : env_lane;
+  R.lane_max = (ln != 0 && chain_g == 0 && sc != 0) ? std::min<uint32_t>(R.small_hi - 1, 0xffffffu) : 0;
+  const uint32_t list_from = R.lane_max > 0 ? R.lane_max : R.small_cap;      // smaller groups are not listed
   R.biglist.ensure((size_t) R.ngroups + 64, "big groups");
   R.pilelist.ensure((size_t) R.ngroups + 64, "repeat piles");
   R.medlist.ensure((size_t) R.ngroups + 64, "medium groups");
@@ -1099,7 +1318,7 @@ void chain_classify_groups(MergeResult &R)
   R.classified = true;
   if (R.ngroups == 0) return;
   hipLaunchKernelGGL(k_big_groups, dim3(ceil_div(R.ngroups, 256)), dim3(256), 0, stream(),
-                     (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, R.small_cap, R.small_hi,
+                     (const uint32_t *) R.gstart.p, (uint32_t) R.ngroups, list_from, R.small_hi,
                      R.pile_min > 0 ? R.pile_min : 0xffffffffu, R.medlist.p, R.gcounts.p + 2, R.biglist.p, R.gcounts.p,
                      R.pilelist.p, R.gcounts.p + 1);
   HIP_CHECK(hipGetLastError());
@@ -1259,13 +1478,34 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
             HIP_CHECK(hipEventRecord(ev_done, pstream));
             piles_done = ev_done;
           }
-        if (R.small_cap > 0)
+        if (R.lane_max > 0)
+          { // one lane per group: every group below the wavefront-per-group size tries this first; the ones whose
+            // window or tree table overflows are appended to the medium list
+            ChainArgs Q = A;
+            Q.retry  = R.medlist.p;
+            Q.nretry = R.gcounts.p + 2;
+            StageTimer t0("chain_lane_groups", 0.0);
+            // persistent lanes: exactly as many workgroups as the GPU holds at once (a second round of them would run
+            // on a half-empty GPU)
+            static int resident = 0;
+            if (resident == 0)
+              { int per_cu = 0, dev = 0;
+                hipDeviceProp_t prop;
+                HIP_CHECK(hipGetDevice(&dev));
+                HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_lane, 256, 0));
+                resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+              }
+            const int nb = (int) std::min<int64_t>((R.ngroups + 255) / 256, resident);
+            hipLaunchKernelGGL(k_chain_lane, dim3(nb), dim3(256), 0, stream(), Q, R.lane_max);
+          }
+        else if (R.small_cap > 0)
           { // the all-LDS kernel: groups dealt round-robin, as many lane groups as the GPU holds
             StageTimer t0("chain_lds_groups", 0.0);
             const int nb = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
             hipLaunchKernelGGL((k_chain_small<16, (int) SMALL_CAP>), dim3(nb), dim3(256), 0, stream(), A, R.small_cap);
           }
-        if (R.nmed > 0)
+        if (R.nmed > 0 || R.lane_max > 0)
           { // medium groups: window in LDS, a list with its own ticket counter (ctl[3])
             ChainArgs M = A;
             M.size_lo = 0; M.size_hi = 0xffffffffu;
@@ -1273,7 +1513,8 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
             M.only   = R.medlist.p;
             M.nonly  = R.gcounts.p + 2;
             const int gpbm = 256 / gsmall;
-            const int nbm = (int) std::min<int64_t>(((int64_t) R.nmed + gpbm - 1) / gpbm, 256 * 8);
+            const int nbm = (R.lane_max > 0) ? 256 * 4
+                                             : (int) std::min<int64_t>(((int64_t) R.nmed + gpbm - 1) / gpbm, 256 * 8);
             StageTimer t1("chain_small_groups", 0.0);
             if (gsmall == 32) hipLaunchKernelGGL(k_chain<32>, dim3(nbm), dim3(256), 0, stream(), M);
             else              hipLaunchKernelGGL(k_chain<16>, dim3(nbm), dim3(256), 0, stream(), M);

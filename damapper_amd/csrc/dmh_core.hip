@@ -1270,6 +1270,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "merge_dense") == 0) st.opt_merge_dense = value;
   else if (strcmp(key, "cluster") == 0)     st.opt_cluster = value;
   else if (strcmp(key, "chain_small") == 0) st.opt_chain_small = value;
+  else if (strcmp(key, "chain_lane") == 0)  st.opt_chain_lane = value;
   else return -1;
   return 0;
 }

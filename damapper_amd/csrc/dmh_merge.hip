@@ -76,27 +76,24 @@ __device__ __forceinline__ void b_range(const BLookup &B, uint64_t c, uint32_t &
 constexpr int MG_THREADS = 256;
 constexpr int MG_ITEMS   = 8;
 constexpr int MG_TILE    = MG_THREADS * MG_ITEMS;
-constexpr int SMALLBIN   = 32;
 
 struct MergeEntry { uint32_t a0, ma, b0, mb; };
 
 template <int NK, bool LOW>
 __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__restrict__ akeys, int64_t na,
-                                                            BLookup B, unsigned long long *__restrict__ gram,
+                                                            BLookup B,
                                                             MergeEntry *__restrict__ tile_entries,
                                                             uint32_t *__restrict__ tile_count,
-                                                            uint32_t *__restrict__ tile_hist,
                                                             unsigned long long *__restrict__ tile_hits)
 { __shared__ MergeEntry stage[MG_TILE];        // matched runs of this tile
-  __shared__ uint32_t h[SMALLBIN];
-  __shared__ unsigned long long s_hits[4];
+  __shared__ unsigned long long s_hits[2][4];
   __shared__ uint32_t s_count;
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid < SMALLBIN) h[tid] = 0;
   if (tid == 0) s_count = 0;
   __syncthreads();
 
-  unsigned long long local = 0;
+  // hits of the tile: all of them, and those of the runs below MAXGRAM (what the limit rule can keep at most)
+  unsigned long long local = 0, below = 0;
 
   // The look-ups of a thread's MG_ITEMS codes are independent: issue them phase by phase (codes,
   // bucket bounds, the first two keys of the bucket) so that every thread has MG_ITEMS loads in
@@ -178,9 +175,8 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
             }
         }
       if (hit)
-        { if (ct < SMALLBIN) atomicAdd(&h[(int) ct], 1u);
-          else if (ct < MAXGRAM) atomicAdd(&gram[ct], 1ull);         // rare (repeats)
-          local += ct;
+        { local += ct;
+          if (ct < MAXGRAM) below += ct;
         }
       uint64_t m = __ballot(hit);
       if (m)
@@ -198,19 +194,22 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
             }
         }
     }
-  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
-  if (lane == 0) s_hits[tid >> 6] = local;
+  for (int o = 32; o > 0; o >>= 1)
+    { local += __shfl_down(local, o);
+      below += __shfl_down(below, o);
+    }
+  if (lane == 0) { s_hits[0][tid >> 6] = local; s_hits[1][tid >> 6] = below; }
   __syncthreads();
   // Everything a tile found goes to the tile's OWN slots: its entries (the tile's MG_TILE-entry window
-  // of tile_entries), their number, its small-bin histogram and its hit count.  No global atomic on
-  // the common path: a device-scope atomic is served at the memory side on this multi-die part at a
-  // few ns apiece, and 128 k appends + 300 k histogram updates per pass were most of the run time.
-  // k_merge_gather / k_merge_reduce put the pieces together.
+  // of tile_entries), their number and its two hit counts.  No global atomic: a device-scope atomic is
+  // served at the memory side on this multi-die part at a few ns apiece.  The product histogram of
+  // map.c:881-934 is only needed when the hits do not fit the memory limit, and is then made from the
+  // entry list (k_entry_hist).  k_merge_gather / k_merge_reduce put the pieces together.
   if (tid == 0)
-    { tile_hits[blockIdx.x]  = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3];
+    { tile_hits[2 * (size_t) blockIdx.x]     = s_hits[0][0] + s_hits[0][1] + s_hits[0][2] + s_hits[0][3];
+      tile_hits[2 * (size_t) blockIdx.x + 1] = s_hits[1][0] + s_hits[1][1] + s_hits[1][2] + s_hits[1][3];
       tile_count[blockIdx.x] = s_count;
     }
-  if (tid < SMALLBIN) tile_hist[(size_t) blockIdx.x * SMALLBIN + tid] = h[tid];
   const uint32_t cnt = s_count;
   MergeEntry *dst = tile_entries + (size_t) blockIdx.x * MG_TILE;
   for (uint32_t x = tid; x < cnt; x += MG_THREADS)
@@ -229,32 +228,34 @@ __global__ __launch_bounds__(256) void k_merge_gather(const MergeEntry *__restri
   for (uint32_t x = lane; x < e - b; x += 64) entries[b + x] = src[x];
 }
 
-// sums the tiles' small-bin histograms and hit counts into gram[0..SMALLBIN) and gram[MAXGRAM]
-__global__ __launch_bounds__(256) void k_merge_reduce(const uint32_t *__restrict__ tile_hist,
-                                                      const unsigned long long *__restrict__ tile_hits,
-                                                      int64_t ntiles, unsigned long long *__restrict__ gram)
-{ __shared__ unsigned long long sh[256];
-  const int tid = threadIdx.x, bin = tid & (SMALLBIN - 1), sub = tid / SMALLBIN;      // 8 tiles per step
-  unsigned long long acc = 0, hits = 0;
-  for (int64_t t = (int64_t) blockIdx.x * 8 + sub; t < ntiles; t += (int64_t) gridDim.x * 8)
-    { acc += tile_hist[(size_t) t * SMALLBIN + bin];
-      if (bin == 0) hits += tile_hits[t];
+// sums the tiles' hit counts: sums[0] = all hits, sums[1] = hits of the runs below MAXGRAM
+__global__ __launch_bounds__(256) void k_merge_reduce(const unsigned long long *__restrict__ tile_hits, int64_t ntiles,
+                                                      unsigned long long *__restrict__ sums)
+{ __shared__ unsigned long long sh[2][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned long long a = 0, b = 0;
+  for (int64_t t = (int64_t) blockIdx.x * 256 + tid; t < ntiles; t += (int64_t) gridDim.x * 256)
+    { a += tile_hits[2 * t];
+      b += tile_hits[2 * t + 1];
     }
-  sh[tid] = acc;
-  __syncthreads();
-  if (tid < SMALLBIN)
-    { unsigned long long v = 0;
-      for (int k = 0; k < 8; k++) v += sh[k * SMALLBIN + tid];
-      if (v) atomicAdd(&gram[tid], v);
+  for (int o = 32; o > 0; o >>= 1)
+    { a += __shfl_down(a, o);
+      b += __shfl_down(b, o);
     }
-  __syncthreads();
-  sh[tid] = hits;
+  if (lane == 0) { sh[0][tid >> 6] = a; sh[1][tid >> 6] = b; }
   __syncthreads();
   if (tid == 0)
-    { unsigned long long v = 0;
-      for (int k = 0; k < 8; k++) v += sh[k * SMALLBIN];
-      if (v) atomicAdd(&gram[MAXGRAM], v);
+    { atomicAdd(&sums[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+      atomicAdd(&sums[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
     }
+}
+
+// the product histogram of the matched runs (map.c:926-927), from the entry list -- only when the limit rule needs it
+__global__ void k_entry_hist(const MergeEntry *__restrict__ entries, uint32_t n, unsigned long long *__restrict__ gram)
+{ uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long ct = (unsigned long long) entries[i].ma * entries[i].mb;
+  if (ct < (unsigned long long) MAXGRAM) atomicAdd(&gram[ct], 1ull);
 }
 
 // hits each entry will produce under the limit (map.c:978-979)
@@ -366,35 +367,36 @@ __global__ void k_group_write(const uint64_t *__restrict__ hkeys, int64_t n, int
 //  MAX_GAP.  k_cluster_rekey then gives every hit the key (cluster << pbits) | apos and the value bpos: the
 //  second sort puts each cluster into (apos, bpos) order without moving a hit out of its cluster's range.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t MAX_GAP_B = 1000;      // map.c:36
 
-__global__ void k_cluster_flag(const uint64_t *__restrict__ hkeys, int64_t n, int qbits, uint32_t *__restrict__ flag)
+// The first sort only orders the hits of a pair by bpos >> cb (cb = CLUSTER_CB: buckets of 4096 bases, which saves
+// two radix passes): a cluster is a maximal run of hits whose buckets are equal or adjacent -- a union of the
+// MAX_GAP-connected sets, which is all the chain kernels need.  Inside a bucket the hits keep the order the merge
+// emitted them in, i.e. for equal (aread, apos) ascending bpos (one READ k-mer's partners in REF-index order); the
+// second sort, stable on (cluster, apos), therefore ends in (apos, bpos) order.
+constexpr int CLUSTER_CB = 12;
+
+__device__ __forceinline__ bool cluster_start(uint64_t a, uint64_t b, int qbits, int cb)
+{ const uint64_t qm = (1ull << qbits) - 1ull;
+  return (a >> qbits) != (b >> qbits) || ((b & qm) >> cb) - ((a & qm) >> cb) > 1ull;
+}
+
+__global__ void k_cluster_flag(const uint64_t *__restrict__ hkeys, int64_t n, int qbits, int cb, uint32_t *__restrict__ flag)
 { int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t f = 1;
-  if (i > 0)
-    { const uint64_t a = hkeys[i - 1], b = hkeys[i];
-      const uint64_t qm = (1ull << qbits) - 1ull;
-      f = ((a >> qbits) != (b >> qbits) || (b & qm) - (a & qm) > (uint64_t) MAX_GAP_B) ? 1u : 0u;
-    }
-  flag[i] = f;
+  flag[i] = (i == 0 || cluster_start(hkeys[i - 1], hkeys[i], qbits, cb)) ? 1u : 0u;
 }
 
 // slot[] = exclusive scan of the flags: hit i belongs to cluster slot[i] + flag[i] - 1.  Out of place (the
 // neighbour's key is read): (hkeys, hvals) -> (okeys, ovals).
 __global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32_t *__restrict__ hvals, int64_t n,
-                                int qbits, int pbits, const uint32_t *__restrict__ slot,
+                                int qbits, int cb, int pbits, const uint32_t *__restrict__ slot,
                                 uint64_t *__restrict__ okeys, uint32_t *__restrict__ ovals,
                                 uint32_t *__restrict__ gstart, uint32_t ncl, uint64_t *__restrict__ gkey)
 { int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t k = hkeys[i];
   const uint64_t qm = (1ull << qbits) - 1ull;
-  bool start = (i == 0);
-  if (i > 0)
-    { const uint64_t a = hkeys[i - 1];
-      start = ((a >> qbits) != (k >> qbits) || (k & qm) - (a & qm) > (uint64_t) MAX_GAP_B);
-    }
+  const bool start = (i == 0) || cluster_start(hkeys[i - 1], k, qbits, cb);
   const uint32_t c = slot[i] + (start ? 1u : 0u) - 1u;
   okeys[i] = ((uint64_t) c << pbits) | (uint64_t) hvals[i];
   ovals[i] = (uint32_t) (k & qm);
@@ -521,32 +523,31 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   // --- match + count (map.c:2984-2988)
   static DevBuf<unsigned long long> gram, thits;
   static DevBuf<MergeEntry> entries, tentries;
-  static DevBuf<uint32_t>   tcount, thist;
+  static DevBuf<uint32_t>   tcount;
   static DevBuf<unsigned int> mctl;
   const int64_t ntiles = ceil_div(A.n, MG_TILE);
-  gram.ensure(MAXGRAM + 1, "hit histogram");
+  gram.ensure(MAXGRAM + 4, "hit histogram");
   mctl.ensure(4, "merge counters");
   tentries.ensure((size_t) ntiles * MG_TILE, "matched runs (per tile)");
   tcount.ensure(ntiles + 1, "matched runs per tile");
-  thist.ensure((size_t) ntiles * SMALLBIN, "hit histogram (per tile)");
-  thits.ensure(ntiles, "hits per tile");
-  HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (MAXGRAM + 1), stream()));
+  thits.ensure(2 * (size_t) ntiles, "hits per tile");
+  unsigned long long *sums = gram.p + MAXGRAM + 1;         // [0] all hits, [1] hits of the runs below MAXGRAM
+  HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(unsigned long long) * 2, stream()));
   HIP_CHECK(hipMemsetAsync(mctl.p, 0, 4 * sizeof(unsigned int), stream()));
   { StageTimer tm("merge_match", 16.0 * (A.n + Bx.n));
     if (Bx.probe_keys == 4 && BL.klow != nullptr)
       hipLaunchKernelGGL((k_merge_match<4, true>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                         (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
+                         (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
     else if (Bx.probe_keys == 4)
       hipLaunchKernelGGL((k_merge_match<4, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                         (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
+                         (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
     else if (BL.klow != nullptr)
       hipLaunchKernelGGL((k_merge_match<2, true>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                         (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
+                         (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
     else
       hipLaunchKernelGGL((k_merge_match<2, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                         (const uint64_t *) A.keys, A.n, BL, gram.p, tentries.p, tcount.p, thist.p, thits.p);
-    hipLaunchKernelGGL(k_merge_reduce, dim3(256), dim3(256), 0, stream(), (const uint32_t *) thist.p,
-                       (const unsigned long long *) thits.p, ntiles, gram.p);
+                         (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
+    hipLaunchKernelGGL(k_merge_reduce, dim3(64), dim3(256), 0, stream(), (const unsigned long long *) thits.p, ntiles, sums);
     exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
     HIP_CHECK(hipGetLastError());
   }
@@ -556,8 +557,8 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   if (nent > 0)
     hipLaunchKernelGGL(k_merge_gather, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(),
                        (const MergeEntry *) tentries.p, (const uint32_t *) tcount.p, ntiles, nent, entries.p);
-  std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
-  copy_d2h(histo.data(), gram.p, sizeof(unsigned long long) * (MAXGRAM + 1), 1);   // the limit rule next
+  unsigned long long hsum[2] = {0, 0};
+  copy_d2h(hsum, sums, sizeof(unsigned long long) * 2, 1);                         // the limit rule next
 
   // --- limit (map.c:2992-3055)
   int64_t limit, nhits;
@@ -570,11 +571,26 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
       else
         avail = avail - (alen + blen);
       avail *= .98;
-      int64_t tom = 0;
       int j;
-      for (j = 0; j < MAXGRAM; j++)
-        { tom += j * (int64_t) histo[j];
-          if (tom > avail) break;
+      if ((int64_t) hsum[1] <= avail)
+        { // every run below MAXGRAM fits: the scan over the histogram would run to its end (map.c:3030-3036)
+          j = MAXGRAM;
+          nhits = (int64_t) hsum[1];
+        }
+      else
+        { std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
+          HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (MAXGRAM + 1), stream()));
+          if (nent > 0)
+            hipLaunchKernelGGL(k_entry_hist, dim3(ceil_div(nent, 256)), dim3(256), 0, stream(),
+                               (const MergeEntry *) entries.p, nent, gram.p);
+          copy_d2h(histo.data(), gram.p, sizeof(unsigned long long) * (MAXGRAM + 1));
+          int64_t tom = 0;
+          for (j = 0; j < MAXGRAM; j++)
+            { tom += j * (int64_t) histo[j];
+              if (tom > avail) break;
+            }
+          nhits = 0;
+          for (int x = 1; x < j; x++) nhits += x * (int64_t) histo[x];
         }
       limit = j;
       if (limit <= 1)
@@ -592,12 +608,10 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
         { printf("   Capping mutual k-mer matches over %d (effectively -t%d)\n", (int) limit, (int) sqrt(1. * limit));
           fflush(stdout);
         }
-      nhits = 0;
-      for (j = 1; j < limit; j++) nhits += j * (int64_t) histo[j];
     }
   else
     { limit = INT32_MAX;
-      nhits = (int64_t) histo[MAXGRAM];
+      nhits = (int64_t) hsum[0];
     }
   st.last_limit = (int) limit;
   R.limit = limit;
@@ -658,7 +672,8 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   // --- seed sort (map.c:3110-3126)
   uint64_t *k0 = R.keys.p, *k1 = st.sort.keys_alt.p;
   uint32_t *v0 = R.vals.p, *v1 = st.sort.vals_alt.p;
-  radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, lowbits + R.bbits + R.abits, st.sort, "seed_sort");
+  const int cb = cluster ? std::min(CLUSTER_CB, qbits) : 0;          // (the bits below cb of bpos are not sorted on)
+  radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, cb, lowbits + R.bbits + R.abits - cb, st.sort, "seed_sort");
 
   // --- groups
   static DevBuf<uint32_t> flag;
@@ -680,14 +695,14 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     { uint32_t ncl = 0;
       { StageTimer tm("seed_clusters", 40.0 * nhits);
         int nb = ceil_div(nhits, 256);
-        hipLaunchKernelGGL(k_cluster_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, qbits, flag.p);
+        hipLaunchKernelGGL(k_cluster_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, qbits, cb, flag.p);
         exclusive_scan_u32(flag.p, nhits, st.sort.bsum, flag.p + nhits);
         copy_d2h(&ncl, flag.p + nhits, sizeof(uint32_t), 1);
         R.ngroups = ncl;
         R.gstart.ensure((size_t) ncl + 1, "cluster starts");
         R.gkey.ensure((size_t) ncl + 1, "cluster keys");
         hipLaunchKernelGGL(k_cluster_rekey, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, (const uint32_t *) v0,
-                           nhits, qbits, R.pbits, (const uint32_t *) flag.p, k1, v1, R.gstart.p, ncl, R.gkey.p);
+                           nhits, qbits, cb, R.pbits, (const uint32_t *) flag.p, k1, v1, R.gstart.p, ncl, R.gkey.p);
         std::swap(k0, k1);
         std::swap(v0, v1);
       }
