@@ -49,6 +49,33 @@ __global__ void k_low16(const uint64_t *__restrict__ keys, int64_t n, uint32_t m
 __device__ __forceinline__ void b_range(const BLookup &B, uint64_t c, uint32_t &lo, uint32_t &cnt)
 { uint64_t p = c >> B.shift;
   uint32_t s = B.bstart[p], e = B.bstart[p + 1];
+  if (B.klow != nullptr)
+    { // the entries of a bucket differ in their low `shift` bits only, kept as a 2-byte array: a long bucket (a
+      // repeat's k-mer with its copies) spans a few cache lines of it instead of dozens of the 8-byte keys, so
+      // all but the first steps of the searches below stay in lines already fetched; the end of the run is
+      // looked for by doubling from its start (runs are short next to their buckets' tails only rarely)
+      const uint32_t cq = (uint32_t) (c & (((uint64_t) 1 << B.shift) - 1));
+      uint32_t l = s, h = e;
+      while (l < h)
+        { uint32_t m = (l + h) >> 1;
+          if ((uint32_t) B.klow[m] < cq) l = m + 1; else h = m;
+        }
+      lo = l;
+      if (l >= e || (uint32_t) B.klow[l] != cq) { cnt = 0; return; }
+      uint32_t a = l, step = 1, z;               // klow[a] == cq; find the first z > a with klow[z] != cq (or e)
+      while (true)
+        { uint32_t t = a + step;
+          if (t >= e) { z = e; break; }
+          if ((uint32_t) B.klow[t] == cq) { a = t; step <<= 1; }
+          else { z = t; break; }
+        }
+      while (z - a > 1)
+        { uint32_t m = (a + z) >> 1;
+          if ((uint32_t) B.klow[m] == cq) a = m; else z = m;
+        }
+      cnt = z - l;
+      return;
+    }
   uint32_t l = s, h = e;
   while (l < h)
     { uint32_t m = (l + h) >> 1;
