@@ -539,17 +539,19 @@ __global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_
 //  that is looked up in the background).  A window of more than RW live hits, or more than RT trees with live
 //  members, sends the group to the lane-group kernels (A.retry).  Same rules, same results.
 // ---------------------------------------------------------------------------------------
-constexpr int RW = 16;
-constexpr int RT = 8;
+constexpr int RW = 8;      // window slots of a lane (registers)
+constexpr int RT = 5;      // tree slots of a lane (LDS)
+constexpr int LANE_BLOCK = 64;    // one wavefront per workgroup: 7.5 KB of LDS each, so the registers bound the occupancy
 
-__global__ __launch_bounds__(256) void k_chain_lane(ChainArgs A, uint32_t size_max)
-{ __shared__ int32_t  t_bc[4][RT][64];                       // per tree slot: best score ...
-  __shared__ uint32_t t_oa[4][RT][64], t_ob[4][RT][64];      //   origin (apos, bpos)
-  __shared__ uint32_t t_ea[4][RT][64], t_eb[4][RT][64];      //   best end (apos, bpos)
-  __shared__ uint32_t t_ex[4][RT][64];                       //   best end's position in the group
+__global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t size_max)
+{ constexpr int NW = LANE_BLOCK / 64;
+  __shared__ int32_t  t_bc[NW][RT][64];                       // per tree slot: best score ...
+  __shared__ uint32_t t_oa[NW][RT][64], t_ob[NW][RT][64];      //   origin (apos, bpos)
+  __shared__ uint32_t t_ea[NW][RT][64], t_eb[NW][RT][64];      //   best end (apos, bpos)
+  __shared__ uint32_t t_ex[NW][RT][64];                       //   best end's position in the group
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int K = A.K;
-  const uint32_t nthreads = gridDim.x * 256;
+  const uint32_t nthreads = gridDim.x * LANE_BLOCK;
 
   // the window: slot s holds a live hit iff bit s of vmask
   uint32_t w_ap[RW], w_bp[RW], w_meta[RW];     // meta = position in the group | tree slot << 24
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(256) void k_chain_lane(ChainArgs A, uint32_t size_m
   uint64_t hk = 0;            // the next hit of the group (fetched one iteration ahead)
   uint32_t hv = 0;
   // the group after it: pst 1 = look its bounds up, 2 = bounds on their way, 3 = first hit on its way / there, 9 = none left
-  uint32_t pg = blockIdx.x * 256 + threadIdx.x, q0 = 0, q1 = 0;
+  uint32_t pg = blockIdx.x * LANE_BLOCK + threadIdx.x, q0 = 0, q1 = 0;
   int      pst = 1;
   uint64_t pk = 0;
   uint32_t pv = 0;
@@ -641,57 +643,40 @@ __global__ __launch_bounds__(256) void k_chain_lane(ChainArgs A, uint32_t size_m
         { hk = A.keys[g0 + j + 1];
           hv = A.vals[g0 + j + 1];
         }
-      uint64_t bL = ~0ull, bR = 0;
-      int      Lc = 0, La = 0, Rc = 0, Rb = 0;
-      uint32_t Lm = 0, Rm = 0, Ls = 0, Rs = 0;
-      int      Ld = 0, Rd = 0, Rax = 0, Lbx = 0;
+      // The window scan, written without branches (selects only): the left neighbour is the live hit with the
+      // smallest (diagonal, -apos) among those with a larger diagonal and bpos >= bpos - MAX_GAP, the right one the
+      // largest (diagonal, apos) among those with diagonal <= diag and bpos <= bpos (map.c:1262-1318); keys are
+      // unique inside a group.  Slots no lane of the wavefront uses are skipped as a whole.
+      int      Ldx = 0x7fffffff, Lax = -1, Lc = 0, Rdx = (int) 0x80000000, Rax = -1, Rc = 0;
+      uint32_t Lm = 0, Ls = 0, Rm = 0, Rs = 0, emask = 0;
 #pragma unroll
       for (int s = 0; s < RW; s++)
-        { if (!((vmask >> s) & 1u)) continue;
-          const int ax = (int) w_ap[s];
-          if (ax < old) { vmask &= ~(1u << s); continue; }          // expired (map.c:1787-1796)
-          const int bx = (int) w_bp[s];
-          const int dx = ax - bx;
-          const uint64_t db = (uint64_t) ((uint32_t) dx + 0x80000000u);
-          if (dx > diag)
-            { if (bx >= thresh)
-                { const uint64_t lk = (db << 32) | (uint32_t) (0x7fffffff - ax);
-                  if (lk < bL) { bL = lk; Lc = w_cost[s]; La = ax; Lbx = bx; Lm = w_meta[s]; Ls = (uint32_t) s; Ld = dx; }
-                }
-            }
-          else if (bx <= bpos)
-            { const uint64_t rk = (db << 32) | (uint32_t) ax;
-              if (rk > bR) { bR = rk; Rc = w_cost[s]; Rb = bx; Rax = ax; Rm = w_meta[s]; Rs = (uint32_t) s; Rd = dx; }
-            }
+        { const bool v = (vmask >> s) & 1u;
+          if (__ballot(v) == 0) continue;
+          const int  ax = (int) w_ap[s], bx = (int) w_bp[s], dx = ax - bx;
+          const bool ex = v && ax < old;                            // expired (map.c:1787-1796)
+          emask |= ex ? (1u << s) : 0u;
+          const bool ok  = v && !ex;
+          const bool isL = ok && dx > diag && bx >= thresh;
+          const bool isR = ok && dx <= diag && bx <= bpos;
+          const bool bl  = isL && (dx < Ldx || (dx == Ldx && ax > Lax));
+          const bool br  = isR && (dx > Rdx || (dx == Rdx && ax > Rax));
+          Ldx = bl ? dx : Ldx; Lax = bl ? ax : Lax; Lc = bl ? w_cost[s] : Lc; Lm = bl ? w_meta[s] : Lm; Ls = bl ? (uint32_t) s : Ls;
+          Rdx = br ? dx : Rdx; Rax = br ? ax : Rax; Rc = br ? w_cost[s] : Rc; Rm = br ? w_meta[s] : Rm; Rs = br ? (uint32_t) s : Rs;
         }
-      int lcost = 0, rcost = 0;
-      if (bL != ~0ull) lcost = (apos >= La + K) ? Lc + K : Lc + (apos - La);
-      if (bR != 0)     rcost = (bpos >= Rb + K) ? Rc + K : Rc + (bpos - Rb);
-      if (lcost > rcost) rcost = 0; else lcost = 0;
-      bool     havep = false, overflow = false;
-      uint32_t pm = 0, ps = 0;
-      int      c = K, pa = 0, pd = 0;
-      if (lcost > 0)      { havep = true; pm = Lm; ps = Ls; c = lcost; pa = La;  pd = Ld; }
-      else if (rcost > 0) { havep = true; pm = Rm; ps = Rs; c = rcost; pa = Rax; pd = Rd; }
-      (void) Lbx;
-      uint32_t tj;
-      if (havep)
-        { tj = pm >> 24;
-          A.from[g0 + j] = g0 + (pm & 0xffffffu);
-          const int bcst = t_bc[wv][tj][lane];
-          if (c >= bcst)
-            { int dd = pd - diag;
-              if (dd < 0) dd = -dd;
-              t_bc[wv][tj][lane] = c;
-              t_ea[wv][tj][lane] = (uint32_t) apos;
-              t_eb[wv][tj][lane] = (uint32_t) bpos;
-              t_ex[wv][tj][lane] = j;
-              if ((double) dd <= .2 * (double) (apos - pa)) vmask &= ~(1u << ps);      // map.c:1837,1852
-            }
-        }
-      else
-        { A.from[g0 + j] = NIL;
-          if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
+      vmask &= ~emask;
+      const int  Rbx    = Rax - Rdx;
+      const int  lcost0 = (Lax >= 0) ? ((apos >= Lax + K) ? Lc + K : Lc + (apos - Lax)) : 0;
+      const int  rcost0 = (Rax >= 0) ? ((bpos >= Rbx + K) ? Rc + K : Rc + (bpos - Rbx)) : 0;
+      const bool useL   = lcost0 > rcost0;                        // map.c:1823-1826 (ties go right)
+      const bool havep  = useL || rcost0 > 0;
+      const int      c  = useL ? lcost0 : (havep ? rcost0 : K);
+      const uint32_t pm = useL ? Lm : Rm, ps = useL ? Ls : Rs;
+      const int      pa = useL ? Lax : Rax, pd = useL ? Ldx : Rdx;
+      bool     overflow = false;
+      uint32_t tj = pm >> 24;
+      if (!havep)
+        { if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
             { // no tree slot left: the trees without a live member are complete -- report them and take their slots
               uint32_t used = 0;
 #pragma unroll
@@ -707,26 +692,35 @@ __global__ __launch_bounds__(256) void k_chain_lane(ChainArgs A, uint32_t size_m
           else
             { tj = (uint32_t) __ffs((int) ~tmask) - 1u;
               tmask |= 1u << tj;
-              t_bc[wv][tj][lane] = K;
               t_oa[wv][tj][lane] = (uint32_t) apos;
               t_ob[wv][tj][lane] = (uint32_t) bpos;
-              t_ea[wv][tj][lane] = (uint32_t) apos;
-              t_eb[wv][tj][lane] = (uint32_t) bpos;
-              t_ex[wv][tj][lane] = j;
             }
         }
-      if (!overflow)
-        { const uint32_t fm = ~vmask & ((1u << RW) - 1u);
-          if (fm == 0) overflow = true;
-          else
-            { const int f = __ffs((int) fm) - 1;
+      const int  bcst = havep ? t_bc[wv][tj][lane] : 0;
+      const bool improved = !havep || c >= bcst;                   // (a new origin is its tree's best end)
+      A.from[g0 + j] = havep ? g0 + (pm & 0xffffffu) : NIL;
+      if (improved && !overflow)
+        { t_bc[wv][tj][lane] = c;
+          t_ea[wv][tj][lane] = (uint32_t) apos;
+          t_eb[wv][tj][lane] = (uint32_t) bpos;
+          t_ex[wv][tj][lane] = j;
+        }
+      { int dd = pd - diag;
+        if (dd < 0) dd = -dd;
+        const bool kill = havep && improved && ((double) dd <= .2 * (double) (apos - pa));      // map.c:1837,1852
+        vmask &= ~(kill ? (1u << ps) : 0u);
+      }
+      { const uint32_t fm = ~vmask & ((1u << RW) - 1u);
+        overflow = overflow || fm == 0;
+        const int f = __ffs((int) fm) - 1;             // (-1 when the window is full: no slot matches)
 #pragma unroll
-              for (int s = 0; s < RW; s++)
-                if (s == f)
-                  { w_ap[s] = (uint32_t) apos; w_bp[s] = (uint32_t) bpos; w_cost[s] = c; w_meta[s] = j | (tj << 24); }
-              vmask |= 1u << f;
-            }
-        }
+        for (int s = 0; s < RW; s++)
+          { const bool h = (s == f);
+            w_ap[s] = h ? (uint32_t) apos : w_ap[s]; w_bp[s] = h ? (uint32_t) bpos : w_bp[s];
+            w_cost[s] = h ? c : w_cost[s]; w_meta[s] = h ? (j | (tj << 24)) : w_meta[s];
+          }
+        vmask |= (fm != 0) ? (1u << f) : 0u;
+      }
       j += 1;
       if (overflow)
         { A.retry[atomicAdd(A.nretry, 1u)] = g;          // (the lane-group kernel starts the group afresh)
@@ -1493,11 +1487,12 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
                 hipDeviceProp_t prop;
                 HIP_CHECK(hipGetDevice(&dev));
                 HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_lane, 256, 0));
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_lane, LANE_BLOCK, 0));
                 resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+                if (getenv("DMH_STATS")) fprintf(stderr, "dmh: k_chain_lane: %d workgroups of %d per CU\n", per_cu, LANE_BLOCK);
               }
-            const int nb = (int) std::min<int64_t>((R.ngroups + 255) / 256, resident);
-            hipLaunchKernelGGL(k_chain_lane, dim3(nb), dim3(256), 0, stream(), Q, R.lane_max);
+            const int nb = (int) std::min<int64_t>((R.ngroups + LANE_BLOCK - 1) / LANE_BLOCK, resident);
+            hipLaunchKernelGGL(k_chain_lane, dim3(nb), dim3(LANE_BLOCK), 0, stream(), Q, R.lane_max);
           }
         else if (R.small_cap > 0)
           { // the all-LDS kernel: groups dealt round-robin, as many lane groups as the GPU holds
@@ -1556,6 +1551,11 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     copy_d2h(&nsum, goff.p + ng, sizeof(uint32_t), 1);
   }
   { static const bool stats = getenv("DMH_STATS") != nullptr;
+    if (stats)
+      { uint32_t c3[3] = {0, 0, 0};
+        copy_d2h(c3, R.gcounts.p, 3 * sizeof(uint32_t));
+        fprintf(stderr, "dmh: lists after the chain kernels: big %u piles %u medium %u\n", c3[0], c3[1], c3[2]);
+      }
     if (stats)
       fprintf(stderr, "dmh: pass hits %lld groups %lld (clustered %d) lds<=%u medium %u big %u piles %u chain ends %u\n",
               (long long) nhits, (long long) R.ngroups, (int) R.clustered, R.small_cap, R.nmed, R.nbig, R.npiles, nsum);
