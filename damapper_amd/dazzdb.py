@@ -712,27 +712,36 @@ def pack_block(blk: Block, pinned: bool = True) -> Block:
     return hb
 
 
-def write_db_block(directory: str, root: str, blk: Block, block_size: int = 400_000_000) -> None:
-    """write_db for the reads of an in-memory block (one DB block; native 2-bit packing)."""
+def write_db_blocks(directory: str, root: str, blocks: Sequence[Block], block_size: int = 400_000_000) -> None:
+    """write_db for the reads of several in-memory blocks, one DB block each (native 2-bit packing): the DB that
+    DBsplit would leave if it cut exactly there."""
     os.makedirs(directory, exist_ok=True)
-    hb = pack_block(blk, pinned=False)
-    n = blk.nreads
-    lens = blk.reads["rlen"][1:n + 1].astype(np.int64)
+    n = sum(b.nreads for b in blocks)
     recs = np.zeros(n, dtype=READ_DTYPE)
-    recs["origin"] = np.arange(n)
-    recs["rlen"] = lens
-    recs["boff"] = hb.coff
-    recs["flags"] = DB_BEST
+    firsts, at, off, maxlen, totlen = [0], 0, 0, 0, 0
     with open(os.path.join(directory, "." + root + ".bps"), "wb") as f:
-        f.write(hb.packed.tobytes())
+        for blk in blocks:
+            hb = pack_block(blk, pinned=False)
+            m = blk.nreads
+            lens = blk.reads["rlen"][1:m + 1].astype(np.int64)
+            recs["origin"][at:at + m] = np.arange(at, at + m)
+            recs["rlen"][at:at + m] = lens
+            recs["boff"][at:at + m] = hb.coff + off
+            recs["flags"][at:at + m] = DB_BEST
+            f.write(hb.packed.tobytes())
+            off += len(hb.packed)
+            at += m
+            firsts.append(at)
+            maxlen = max(maxlen, int(lens.max()) if m else 0)
+            totlen += int(lens.sum())
     hdr = DAZZ_DB()
     hdr.ureads = hdr.treads = n
     hdr.cutoff = 0
     hdr.allarr = DB_ALL
     for j in range(4):
-        hdr.freq[j] = blk.db.freq[j]
-    hdr.maxlen = int(lens.max()) if n else 0
-    hdr.totlen = int(lens.sum())
+        hdr.freq[j] = blocks[0].db.freq[j]
+    hdr.maxlen = maxlen
+    hdr.totlen = totlen
     hdr.nreads = n
     hdr.trimmed = 0
     with open(os.path.join(directory, "." + root + ".idx"), "wb") as f:
@@ -741,9 +750,15 @@ def write_db_block(directory: str, root: str, blk: Block, block_size: int = 400_
     with open(os.path.join(directory, root + ".db"), "w") as f:
         f.write("files = %9d\n" % 1)
         f.write("  %9d %s %s\n" % (n, root, root))
-        f.write("blocks = %9d\n" % 1)
+        f.write("blocks = %9d\n" % len(blocks))
         f.write("size = %11d cutoff = %9d all = %1d\n" % (block_size, 0, 1))
-        f.write(" %9d %9d\n %9d %9d\n" % (0, 0, n, n))
+        for b in firsts:
+            f.write(" %9d %9d\n" % (b, b))
+
+
+def write_db_block(directory: str, root: str, blk: Block, block_size: int = 400_000_000) -> None:
+    """write_db for the reads of ONE in-memory block."""
+    write_db_blocks(directory, root, [blk], block_size)
 
 
 def block_reads(blk: Block, lo: int = 0, hi: Optional[int] = None) -> List[np.ndarray]:
