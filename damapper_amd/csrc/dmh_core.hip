@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <thread>
 
 // ---- globals shared with the driver (damapper.c:58-65; map.h:17-24) ----------------------
 extern "C" {
@@ -711,27 +712,37 @@ __global__ void k_mask_flag(const uint32_t *__restrict__ vals, int64_t n, const 
 }
 
 // ---- REF index cache ----------------------------------------------------------------------------
-// Identity of a block's content for the cache: every read length, 4096 samples of 16 bases, the first
-// and last 4 KB, and the parameters the index depends on.  (Sampled, not exhaustive -- which is why
-// the cache is opt-in: two blocks that differ only between the samples would share an index.)
+// Identity of a block's content for the cache: EVERY base and every read boundary go into two independent 64-bit
+// hashes (four host threads, a few GB/s each: ~10 ms for a 375 Mbp block, against the upload and sort it saves),
+// plus the parameters the index depends on.
+static void hash_range(const uint8_t *p, int64_t n, uint64_t out[2])
+{ uint64_t h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull, h3 = 0xc2b2ae3d27d4eb4full, h4 = 0x165667b19e3779f9ull;
+  int64_t i = 0;
+  for (; i + 32 <= n; i += 32)           // four lanes, so that the multiplies overlap
+    { uint64_t a, b, c, d;
+      memcpy(&a, p + i, 8); memcpy(&b, p + i + 8, 8); memcpy(&c, p + i + 16, 8); memcpy(&d, p + i + 24, 8);
+      h1 = (h1 ^ a) * 0x100000001b3ull; h2 = (h2 ^ b) * 0xff51afd7ed558ccdull;
+      h3 = (h3 ^ c) * 0xc4ceb9fe1a85ec53ull; h4 = (h4 ^ d) * 0x9fb21c651e98df25ull;
+      h1 ^= h1 >> 29; h2 ^= h2 >> 31; h3 ^= h3 >> 30; h4 ^= h4 >> 32;
+    }
+  for (; i < n; i++) h1 = (h1 ^ p[i]) * 0x100000001b3ull;
+  out[0] = h1 ^ (h3 * 0x2545f4914f6cdd1dull);
+  out[1] = h2 ^ (h4 * 0xd6e8feb86659fd93ull);
+}
+
 static void content_key(const DAZZ_DB *b, const Params &pm, uint64_t key[4])
 { const uint8_t *p = (const uint8_t *) b->bases;
   const int64_t  L = b->reads[b->nreads].boff;
-  uint64_t h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull;
-  auto mix = [&](uint64_t v) { h1 = (h1 ^ v) * 1099511628211ull; h2 = (h2 + v) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 33; };
+  constexpr int NT = 4;
+  uint64_t part[NT][2];
+  std::vector<std::thread> th;
+  for (int t = 0; t < NT; t++)
+    th.emplace_back([&, t] { int64_t lo = L * t / NT, hi = L * (t + 1) / NT; hash_range(p + lo, hi - lo, part[t]); });
+  for (auto &x : th) x.join();
+  uint64_t h1 = 0x9e3779b97f4a7c15ull, h2 = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { h1 = (h1 ^ v) * 1099511628211ull; h1 ^= h1 >> 32; h2 = (h2 + v) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 33; };
+  for (int t = 0; t < NT; t++) { mix(part[t][0]); mix(part[t][1]); }
   for (int i = 0; i <= b->nreads; i++) mix((uint64_t) b->reads[i].boff);
-  const int64_t step = L / 4096 + 1;
-  for (int64_t i = 0; i + 16 <= L; i += step)
-    { uint64_t a, c;
-      memcpy(&a, p + i, 8); memcpy(&c, p + i + 8, 8);
-      mix(a); mix(c);
-    }
-  const int64_t edge = L < 4096 ? L : 4096;
-  for (int64_t i = 0; i + 8 <= edge; i += 8)
-    { uint64_t a, c;
-      memcpy(&a, p + i, 8); memcpy(&c, p + L - edge + i, 8);
-      mix(a); mix(c);
-    }
   key[0] = h1;
   key[1] = h2;
   key[2] = ((uint64_t) L << 24) ^ (uint64_t) b->nreads;

@@ -704,9 +704,13 @@ static void select_and_write(ReportCtx &C)
       int aend = (ti == NT - 1) ? nreads : (int) (((int64_t) (ti + 1) * nreads) >> C.nshift);
       FILE *afile = nullptr;
       FILE *bfile = nullptr;
+      // every file is written under <name>.tmp and renamed once it is complete (record count patched in, closed):
+      // a name without .tmp is a whole file, whatever happened to the process (the dispatcher resumes by file)
+      std::string aname_, bname_;
       int64_t ahits = 0, bhits = 0;
       if (doB)                                  // map.c:3256-3261
-        { std::string fn = C.sort_path + "/" + C.bname + "." + C.aname + ".R" + std::to_string(ti + 1) + ".las";
+        { bname_ = C.sort_path + "/" + C.bname + "." + C.aname + ".R" + std::to_string(ti + 1) + ".las";
+          const std::string fn = bname_ + ".tmp";
           bfile = fopen(fn.c_str(), "w");
           if (bfile == nullptr)
             { fprintf(stderr, "damapper: Cannot open %s for 'w'\n", fn.c_str());
@@ -717,7 +721,8 @@ static void select_and_write(ReportCtx &C)
           fwrite(&C.spacing, sizeof(int), 1, bfile);
         }
       if (doA)
-        { std::string fn = C.sort_path + "/" + C.aname + "." + C.bname + ".M" + std::to_string(ti + 1) + ".las";
+        { aname_ = C.sort_path + "/" + C.aname + "." + C.bname + ".M" + std::to_string(ti + 1) + ".las";
+          const std::string fn = aname_ + ".tmp";
           afile = fopen(fn.c_str(), "w");
           if (afile == nullptr)
             { fprintf(stderr, "damapper: Cannot open %s for 'w'\n", fn.c_str());
@@ -850,6 +855,15 @@ static void select_and_write(ReportCtx &C)
                             { // map.c:2689-2690 indexes amatch[] with linker[c].link, which may be -1
                               // (the reference then reads the record before the array)
                               int lc = linker[c].link;
+                              if (lc < 0)
+                                { // the reference's value here is whatever precedes its array on the heap, so
+                                  // its choice between the two links cannot be reproduced; 0 is used.  Said once.
+                                  static std::atomic<bool> told{false};
+                                  if (!told.exchange(true))
+                                    fprintf(stderr, "damapper_hip: Warning: read %d ties two chain links where map.c:2689-2690 "
+                                                    "reads amatch[-1] (undefined in the reference); using 0 -- the reference "
+                                                    "may link this read's alignments differently\n", ar + astart);
+                                }
                               gap2 = (lc >= 0 ? am[lc].aepos : 0) - dp.abpos;
                             }
                           else
@@ -957,12 +971,18 @@ static void select_and_write(ReportCtx &C)
       if (doA)
         { rewind(afile);
           fwrite(&ahits, sizeof(int64_t), 1, afile);
-          fclose(afile);
+          if (fclose(afile) != 0 || rename((aname_ + ".tmp").c_str(), aname_.c_str()) != 0)
+            { fprintf(stderr, "damapper: Cannot complete %s\n", aname_.c_str());
+              Clean_Exit(1);
+            }
         }
       if (doB)
         { rewind(bfile);
           fwrite(&bhits, sizeof(int64_t), 1, bfile);
-          fclose(bfile);
+          if (fclose(bfile) != 0 || rename((bname_ + ".tmp").c_str(), bname_.c_str()) != 0)
+            { fprintf(stderr, "damapper: Cannot complete %s\n", bname_.c_str());
+              Clean_Exit(1);
+            }
         }
       return doA ? ahits : bhits;
     }

@@ -51,10 +51,6 @@ def _worker(args) -> None:
     m = driver.Mapper(kmer=args.k, suppress=args.t, threads=args.T, ave_corr=args.e, spacing=args.s,
                       best_tie=args.n, profile=int(args.p), verbose=int(args.v), sort_path=out,
                       retain_ref=retain)
-    if args.N and not args.C:
-        raise SystemExit("damapper_amd.dispatch: Cannot specify N flag without C also")     # damapper.c:716
-    if args.N and args.p:
-        raise SystemExit("damapper_amd.dispatch: Cannot specify both N and p flags together")
     mflag = (capi.FLAG_DOB if args.N else capi.FLAG_DOA | capi.FLAG_DOB) if args.C else capi.FLAG_DOA
     todo = []
     for b in mine:
@@ -111,7 +107,7 @@ def _worker(args) -> None:
         print("[gpu %d] %d blocks in %.2f s" % (args.rank, len(todo), time.time() - t_all), flush=True)
     if args.finish:
         for name in mapped:
-            driver.finish_block(out, name, ref_root, mflag=mflag, map_order=not args.z, outdir=d)
+            driver.finish_block(out, name, ref_root, mflag=mflag, map_order=not args.z, outdir=d, nparts=m.threads_pow2())
 
 
 def main(argv=None) -> int:
@@ -147,6 +143,10 @@ def main(argv=None) -> int:
                     help="rebuild the reference index for every read block (the reference's loop) instead of keeping "
                          "both orientations of every reference block resident in HBM")
     args = ap.parse_args(argv)
+    if args.N and not args.C:
+        raise SystemExit("damapper_amd.dispatch: Cannot specify N flag without C also")     # damapper.c:716
+    if args.N and args.p:
+        raise SystemExit("damapper_amd.dispatch: Cannot specify both N and p flags together")
     if args.rank >= 0:
         _worker(args)
         return 0

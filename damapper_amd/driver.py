@@ -158,7 +158,8 @@ class Mapper:
 
 
 def finish_block(sort_path: str, reads_name: str, ref_name: str, mflag: int = capi.FLAG_DOA,
-                 map_order: bool = True, outdir: str = ".", keep_parts: bool = False) -> Dict[str, str]:
+                 map_order: bool = True, outdir: str = ".", keep_parts: bool = False,
+                 nparts: Optional[int] = None) -> Dict[str, str]:
     """The post-step of main() (damapper.c:887-910) with this package's LAsort/LAcat/LAmerge
     (tools/latools.cpp): per-thread files -> `<reads>.<ref>.las` (and `<ref>.<reads>.las` for -C).
     All queued Reporter output must be on disk: call after dmh_report_wait() when reports are async."""
@@ -173,19 +174,28 @@ def finish_block(sort_path: str, reads_name: str, ref_name: str, mflag: int = ca
             for f in glob.glob(pattern):
                 os.remove(f)
 
+    # the parts M1..M<nparts> / R1..R<nparts> by name (not every numbered file that happens to lie in sort_path: an
+    # earlier run with a larger -T may have left higher-numbered ones), the finals written aside and renamed when whole
+    def parts(stem, suffix):
+        if nparts is None:
+            return [stem + "@" + suffix]
+        return [stem + "%d%s" % (i + 1, suffix) for i in range(nparts)]
+
     if mflag & capi.FLAG_DOA:
         stem = os.path.join(sort_path, "%s.%s.M" % (reads_name, ref_name))
-        subprocess.check_call([las.tool_path("LAsort")] + a + [stem + "@.las"])
+        subprocess.check_call([las.tool_path("LAsort")] + a + parts(stem, ".las"))
         final = os.path.join(outdir, "%s.%s.las" % (reads_name, ref_name))
-        with open(final, "wb") as f:
-            subprocess.check_call([las.tool_path("LAcat"), stem + "@.S"], stdout=f)
+        with open(final + ".tmp", "wb") as f:
+            subprocess.check_call([las.tool_path("LAcat")] + parts(stem, ".S"), stdout=f)
+        os.replace(final + ".tmp", final)
         cleanup(stem + "*.las")
         out["map"] = final
     if mflag & capi.FLAG_DOB:
         stem = os.path.join(sort_path, "%s.%s.R" % (ref_name, reads_name))
-        subprocess.check_call([las.tool_path("LAsort")] + a + [stem + "@.las"])
+        subprocess.check_call([las.tool_path("LAsort")] + a + parts(stem, ".las"))
         final = os.path.join(outdir, "%s.%s" % (ref_name, reads_name))
-        subprocess.check_call([las.tool_path("LAmerge")] + a + [final, stem + "@.S.las"])
+        subprocess.check_call([las.tool_path("LAmerge")] + a + [final + ".tmp"] + parts(stem, ".S.las"))
+        os.replace(final + ".tmp.las", final + ".las")
         cleanup(stem + "*.las")
         out["cover"] = final + ".las"
     return out

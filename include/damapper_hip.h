@@ -127,8 +127,9 @@ void        dmh_reset(void);                 /* drop every cached device buffer 
  * complements and re-indexes every REF block for every READS block): with the cache on, the index
  * Match_Filter has consumed stays in HBM (up to max_gb, least recently used first out; <= 0 keeps the
  * default of 160 GB) and a later Sort_Kmers of a block with the same content returns it without upload
- * or sort.  Content identity is SAMPLED (all read lengths, 4096 x 16 bases, first and last 4 KB), hence
- * opt-in.  Also switched on by the environment variable DMH_REF_CACHE=1 (unmodified driver binary).   */
+ * or sort.  Content identity = two 64-bit hashes over EVERY base and read boundary of the block (hashed on the
+ * host, ~10 ms for a 375 Mbp block) plus k and -t.  Opt-in because it holds HBM; also switched on by the
+ * environment variable DMH_REF_CACHE=1 (unmodified driver binary).                                       */
 void dmh_ref_cache(int on, double max_gb);
 
 /* Sort_Kmers whose radix passes are queued later, in the gaps between the GPU round trips of the

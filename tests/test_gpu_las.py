@@ -344,6 +344,26 @@ def test_dispatcher_maps_every_read_block(tmp_path):
         assert len(rr) > 0 and rr == hr, b
     p2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p2.returncode == 0 and p2.stdout.count("skipped") == nb
+    # a worker that died inside a block leaves <name>.tmp files (parts are renamed only when complete): the block
+    # counts as not done and is mapped again
+    first = os.path.join(d, "las_disp", blocks[0] + ".REF.M2.las")
+    whole = open(first, "rb").read()
+    os.rename(first, first + ".tmp")
+    with open(first + ".tmp", "r+b") as f:
+        f.truncate(len(whole) // 2)
+    p2b = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p2b.returncode == 0 and p2b.stdout.count("skipped") == nb - 1, p2b.stdout[-800:]
+    assert open(first, "rb").read() == whole and not os.path.exists(first + ".tmp")
+    # two workers on "two GPUs" (device numbers are taken modulo the device count, so this runs on a one-GPU box):
+    # the N > 1 partition of the read blocks, b mod N, every worker with its own replica of the reference index
+    cmd2g = cmd[:-3] + ["2", "--out", os.path.join(d, "las_disp_2gpu")]
+    p2g = subprocess.run(cmd2g, env=env, capture_output=True, text=True, timeout=600)
+    assert p2g.returncode == 0, p2g.stdout[-1500:] + p2g.stderr[-1500:]
+    assert "[gpu 0]" in p2g.stdout and "[gpu 1]" in p2g.stdout
+    for b in blocks:
+        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        _, hr = las.read_las_set(os.path.join(d, "las_disp_2gpu"), b + ".REF.M@.las")
+        assert rr == hr, b
     # two workers sharing the GPU: same files
     cmd3 = cmd[:-1] + [os.path.join(d, "las_disp2"), "--workers-per-gpu", "2"]
     p3 = subprocess.run(cmd3, env=env, capture_output=True, text=True, timeout=600)
