@@ -62,12 +62,17 @@ STAGE_KERNEL = {
     "k_radix_scatter": "k_radix_scatter", "k_radix_hist": "k_radix_hist", "radix_scan": "k_scan_*",
     "kmer_emit": "k_kmer_emit", "merge_match": "k_merge_match (+reduce, scan)", "merge_emit": "k_merge_expand (+sizes, scan)",
     "seed_groups": "k_group_flag/write (+scan)", "chain_small_groups": "k_chain<16>", "chain_listed_groups": "k_chain<64>",
-    "chain_piles": "k_chain_pile", "chain_spilled_piles": "k_chain<64> (spilled piles)", "chain_jumps": "k_chain_jumps",
+ "chain_lane_groups": "k_chain_lane", "chain_lds_groups": "k_chain_small",
+    "chain_piles": "k_chain_pile", "chain_dominate": "k_order_summaries + k_dominate (+ scans)", "seed_clusters": "k_cluster_flag/rekey (+scan)",
+    "seed_pairs": "k_pair_flag/write (+scan)", "chain_spilled_piles": "k_chain<64> (spilled piles)", "chain_jumps": "k_chain_jumps",
     "align": "k_align_cands32", "align_wave64": "k_align_cands<128>", "align_global_band": "k_align_cands<8192>",
     "unpack_2bit": "k_unpack_2bit", "pack_bases": "k_pack_fwd", "pack_revcomp": "k_pack_rc", "merge_buckets": "k_bucket_bounds",
 }
 # enclosing stages (their kernels are timed one by one as well): not candidates for "dominant kernel"
-ENCLOSING = {"kmer_sort", "seed_sort", "chain", "sort_pairs"}
+ENCLOSING = {"kmer_sort", "seed_sort", "cluster_sort", "chain", "sort_pairs"}
+# kernel symbols as rocprofv3 names them, for the PMC traffic summary under profiles/
+PMC_SYMBOL = {"k_radix_scatter": "dmh::k_radix_scatter", "k_radix_hist": "dmh::k_radix_hist", "chain_lane_groups": "dmh::k_chain_lane",
+              "kmer_emit": "dmh::k_kmer_emit", "chain_piles": "dmh::k_chain_pile"}
 
 
 def ref_block_ranges(lens):
@@ -338,16 +343,19 @@ def main():
                  "launches": int(v["launches"]), "avg_ms": round(v["ms"] / v["launches"], 4),
                  "alg_bytes_per_launch": v["bytes"] / v["launches"],
                  "share_of_gpu_time": round(v["ms"] / gpu_ms, 3) if gpu_ms > 0 else None}
-            if name == "k_radix_scatter":
-                # HBM bytes per record of this kernel from the PMC passes committed under profiles/
-                # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is)
-                try:
-                    import glob
-                    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.json")))[-1]
-                    pm = json.load(open(latest))
+            # HBM bytes of this kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as
+            # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is): per record for the scatter kernel (whose
+            # launches differ in size), per launch -- of the same workload -- for the others
+            try:
+                import glob
+                latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.json")))[-1]
+                pm = json.load(open(latest))
+                if name == "k_radix_scatter":
                     r["traffic"] = round(pm["derived"]["scatter_traffic_bytes_per_record"] * (v["bytes"] / v["launches"] / 32.0))
-                except Exception:
-                    pass
+                elif pm.get("workload") == args.workload and PMC_SYMBOL.get(name) in pm.get("kernels", {}):
+                    r["traffic"] = round(pm["kernels"][PMC_SYMBOL[name]]["traffic_bytes_per_launch"])
+            except Exception:
+                pass
             return r
 
         dominant = max(kern, key=lambda k: kern[k]["ms"]) if kern else None

@@ -1478,7 +1478,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
             ChainArgs Q = A;
             Q.retry  = R.medlist.p;
             Q.nretry = R.gcounts.p + 2;
-            StageTimer t0("chain_lane_groups", 0.0);
+            StageTimer t0("chain_lane_groups", 16.0 * nhits);        // 16 B per hit, read once by the chain stage
             // persistent lanes: exactly as many workgroups as the GPU holds at once (a second round of them would run
             // on a half-empty GPU)
             static int resident = 0;
