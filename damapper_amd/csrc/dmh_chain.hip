@@ -57,6 +57,7 @@ struct ChainArgs
   uint32_t        size_lo, size_hi;   // this launch takes the groups with size_lo <= hits < size_hi
   const uint32_t *only;               // if set: the launch walks only[0 .. *nonly) instead of all groups
   const uint32_t *nonly;
+  uint32_t        nhits;              // hits in keys / vals
   uint32_t       *retry;              // G < 64: groups whose live window outgrew LDS are appended here
   unsigned int   *nretry;             //         (the 64-lane launch that follows walks this list)
   ChainSummary   *out;
@@ -563,13 +564,31 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
   // the group being walked
   bool     active = false;
   uint32_t g = 0, g0 = 0, n = 0, j = 0, E = 0, obase = 0;
-  uint64_t hk = 0;            // the next hit of the group (fetched one iteration ahead)
-  uint32_t hv = 0;
-  // the group after it: pst 1 = look its bounds up, 2 = bounds on their way, 3 = first hit on its way / there, 9 = none left
+  // Hits are read -- and the `from` links written -- eight at a time per lane: a lane walks its own stretch of the
+  // sorted hits, and a cache line fetched for ONE 8- or 4-byte access of it is long gone when the lane comes back for
+  // the next (10^6 lanes stream at once): 22 GB of HBM traffic per launch against 1.5 GB of data.  A chunk is
+  // the lane's next 64 + 32 bytes, requested together; the chunk after it (or the first one of the lane's next
+  // group) is on its way while this one is walked.
+  constexpr int CH = 8;
+  uint64_t kb[CH], nbk[CH];
+  uint32_t vb[CH], nbv[CH], fb[CH];
+#pragma unroll
+  for (int t = 0; t < CH; t++) { kb[t] = 0; nbk[t] = 0; vb[t] = 0; nbv[t] = 0; fb[t] = 0; }
+  int      nb_for = 0;        // the look-ahead chunk holds: 0 nothing, 1 the next chunk of this group, 2 the first chunk of group pg
+  // the group after it: pst 1 = look its bounds up, 2 = bounds on their way, 4 = bounds there and fine, 3 = and its first
+  // chunk requested, 9 = none left
   uint32_t pg = blockIdx.x * LANE_BLOCK + threadIdx.x, q0 = 0, q1 = 0;
   int      pst = 1;
-  uint64_t pk = 0;
-  uint32_t pv = 0;
+  const uint32_t hlast = A.nhits - 1;
+  auto load_chunk = [&](uint64_t *ck, uint32_t *cv, uint32_t at)
+  {
+#pragma unroll
+    for (int t = 0; t < CH; t++)
+      { const uint32_t x = (at + t < hlast) ? at + t : hlast;
+        ck[t] = A.keys[x];
+        cv[t] = A.vals[x];
+      }
+  };
 
   auto emit = [&](uint32_t t, bool at_end)
   { // the best end of tree slot t, if it scores (map.c:1642-1649)
@@ -602,17 +621,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
   };
 
   while (true)
-    { // ---- look-ahead: bounds and first hit of this lane's next group
+    { // ---- look-ahead: bounds of this lane's next group
       if (pst == 2)
-        { if (q1 - q0 <= size_max)
-            { pk = A.keys[q0];
-              pv = A.vals[q0];
-              pst = 3;
-            }
-          else
-            { pg += nthreads;
-              pst = 1;
-            }
+        { if (q1 - q0 <= size_max) pst = 4;
+          else { pg += nthreads; pst = 1; }
         }
       if (pst == 1)
         { if (pg < A.ngroups)
@@ -624,11 +636,18 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
             pst = 9;
         }
       // ---- a lane without a group takes the one that has been looked up
-      if (!active && pst == 3)
+      if (!active && (pst == 3 || pst == 4))
         { active = true;
           g = pg; g0 = q0; n = q1 - q0; j = 0; E = 0;
           obase = (g0 + HITMIN - 1) / HITMIN;
-          hk = pk; hv = pv;
+          if (pst == 3)
+            {
+#pragma unroll
+              for (int t = 0; t < CH; t++) { kb[t] = nbk[t]; vb[t] = nbv[t]; }
+            }
+          else
+            load_chunk(kb, vb, g0);
+          nb_for = 0;
           vmask = 0; tmask = 0;
           pg += nthreads;
           pst = 1;
@@ -637,12 +656,24 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
       if (!active) continue;
 
       // ---- hit j of the group (map.c:1781-1872)
+      const uint32_t t8 = j & (CH - 1);
+      if (nb_for == 0)
+        { if ((j & ~(uint32_t) (CH - 1)) + CH < n)           // (asked for when the chunk is entered)
+            { load_chunk(nbk, nbv, g0 + (j & ~(uint32_t) (CH - 1)) + CH);
+              nb_for = 1;
+            }
+          else if (pst == 4)                                 // this is the group's last chunk: the next group's first
+            { load_chunk(nbk, nbv, q0);
+              nb_for = 2;
+              pst = 3;
+            }
+        }
+      uint64_t hk = kb[0];
+      uint32_t hv = vb[0];
+#pragma unroll
+      for (int t = 1; t < CH; t++) { hk = (t8 == (uint32_t) t) ? kb[t] : hk; hv = (t8 == (uint32_t) t) ? vb[t] : hv; }
       const int apos = (int) (hk & A.pmask) + 1, bpos = (int) hv + 1;
       const int diag = apos - bpos, thresh = bpos - MAX_GAP, old = apos - MAX_GAP;
-      if (j + 1 < n)                       // the next one, for the next iteration
-        { hk = A.keys[g0 + j + 1];
-          hv = A.vals[g0 + j + 1];
-        }
       // The window scan, written without branches (selects only): the left neighbour is the live hit with the
       // smallest (diagonal, -apos) among those with a larger diagonal and bpos >= bpos - MAX_GAP, the right one the
       // largest (diagonal, apos) among those with diagonal <= diag and bpos <= bpos (map.c:1262-1318); keys are
@@ -698,7 +729,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
         }
       const int  bcst = havep ? t_bc[wv][tj][lane] : 0;
       const bool improved = !havep || c >= bcst;                   // (a new origin is its tree's best end)
-      A.from[g0 + j] = havep ? g0 + (pm & 0xffffffu) : NIL;
+      { const uint32_t fv = havep ? g0 + (pm & 0xffffffu) : NIL;
+#pragma unroll
+        for (int t = 0; t < CH; t++) fb[t] = (t8 == (uint32_t) t) ? fv : fb[t];
+      }
       if (improved && !overflow)
         { t_bc[wv][tj][lane] = c;
           t_ea[wv][tj][lane] = (uint32_t) apos;
@@ -726,12 +760,25 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
         { A.retry[atomicAdd(A.nretry, 1u)] = g;          // (the lane-group kernel starts the group afresh)
           active = false;
         }
-      else if (j == n)
-        { for (uint32_t m = tmask; m != 0; m &= m - 1)
-            emit((uint32_t) __ffs((int) m) - 1u, true);
-          A.gcount[g] = E;
-          A.gbase[g]  = obase;
-          active = false;
+      else if (j == n || t8 == CH - 1)
+        { // the chunk's links go out together
+          uint32_t *fo = A.from + g0 + ((j - 1) & ~(uint32_t) (CH - 1));
+#pragma unroll
+          for (int t = 0; t < CH; t++)
+            if ((uint32_t) t <= t8) fo[t] = fb[t];
+          if (j == n)
+            { for (uint32_t m = tmask; m != 0; m &= m - 1)
+                emit((uint32_t) __ffs((int) m) - 1u, true);
+              A.gcount[g] = E;
+              A.gbase[g]  = obase;
+              active = false;
+            }
+          else
+            {
+#pragma unroll
+              for (int t = 0; t < CH; t++) { kb[t] = nbk[t]; vb[t] = nbv[t]; }
+              nb_for = 0;
+            }
         }
     }
 }
@@ -1411,6 +1458,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
   A.vals = R.svals;
   A.gstart = R.gstart.p;
   A.ngroups = (uint32_t) R.ngroups;
+  A.nhits = (uint32_t) nhits;
   A.pmask = ((uint64_t) 1 << R.pbits) - 1;
   A.K = pm.Kmer;
   A.hithr = HITMIN * pm.Kmer;
