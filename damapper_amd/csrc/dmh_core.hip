@@ -665,6 +665,36 @@ __global__ void k_chunk_table(const int64_t *__restrict__ boff, int nreads, int6
   chunk[c] = (uint32_t) lo;
 }
 
+// The positions of a finished index as (read << posbits) | rpos: the merge then builds a hit from one load per side
+// instead of looking the read up through the chunk table and the offsets for every pair (repeat k-mers: hundreds of
+// pairs per look-up).  Only when both fit 32 bits (read blocks and genome blocks do).
+__global__ void k_pack_positions(uint32_t *__restrict__ vals, int64_t n, const int64_t *__restrict__ boff,
+                                 const uint32_t *__restrict__ chunk, int posbits)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t q = vals[i];
+  uint32_t r = chunk[q >> CHUNK_SHIFT];
+  while (boff[r + 1] <= (int64_t) q) r += 1;
+  vals[i] = (r << posbits) | (uint32_t) ((int64_t) q - boff[r]);
+}
+
+static int ceil_log2_i(int64_t x)
+{ int b = 0;
+  while (((int64_t) 1 << b) < x) b += 1;
+  return b;
+}
+
+// (queued behind the index's last sort / compaction stage, on the main stream)
+void index_pack_positions(IndexDev &ix, int maxlen)
+{ const int pb = ceil_log2_i(maxlen > 1 ? (int64_t) maxlen + 1 : 2), rb = ceil_log2_i(ix.nreads > 1 ? ix.nreads : 1);
+  static const bool off = getenv("DMH_NO_PACKED_POS") != nullptr;
+  if (off || pb + rb > 32 || ix.n <= 0) return;
+  hipLaunchKernelGGL(k_pack_positions, dim3(ceil_div(ix.n, 256)), dim3(256), 0, stream(), ix.vals, ix.n,
+                     (const int64_t *) ix.d_boff, (const uint32_t *) ix.d_chunk, pb);
+  HIP_CHECK(hipGetLastError());
+  ix.posbits = pb;
+}
+
 // Drop every code that occurs >= TooFrequent times (map.c:590-636, compsize/compress_thread).
 __global__ void k_suppress_flag(const uint64_t *__restrict__ keys, int64_t n, int toofreq,
                                 uint32_t *__restrict__ keep)
@@ -821,7 +851,7 @@ struct SortJob
   int       Kshift, npass;
   int       stage;              // index into the stage list (see bg_step)
   const DAZZ_DB *block;         // emit stage: the block whose device copy is read
-  int       Kmer;
+  int       Kmer, maxlen;
 };
 static std::deque<SortJob> g_bg;
 
@@ -906,6 +936,7 @@ static void bg_step()
     { auto it = st.indices.find(J.id);
       if (it == st.indices.end()) fatal("deferred index build lost its index");
       adopt_sorted(it->second, st.sort_aux, J.keys, J.vals, J.k0, J.v0, J.kmers0, J.kmers);
+      index_pack_positions(it->second, J.maxlen);
       it->second.pending = false;
       g_bg.pop_front();
     }
@@ -933,9 +964,12 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
   *len = 0;
   if (kmers <= 0) return nullptr;
   if (kmers > INT32_MAX) fatal("Sort_Kmers: block has %lld k-mers, limit is 2^31-1 (map.c:663)", (long long) kmers);
+  int maxrl = 0;
   for (int i = 0; i < nreads; i++)
-    if (block->reads[i].rlen < pm.Kmer - 1)
-      fatal("Sort_Kmers: read %d is shorter than k-1 (%d < %d)", i, block->reads[i].rlen, pm.Kmer - 1);
+    { if (block->reads[i].rlen < pm.Kmer - 1)
+        fatal("Sort_Kmers: read %d is shorter than k-1 (%d < %d)", i, block->reads[i].rlen, pm.Kmer - 1);
+      maxrl = std::max(maxrl, block->reads[i].rlen);
+    }
 
   const DAZZ_TRACK *mask = (const DAZZ_TRACK *) block->tracks;
   uint64_t ckey[4] = {0, 0, 0, 0};
@@ -1090,6 +1124,7 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
       hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
                          (const int64_t *) ix.d_boff, nreads, ix.nchunk, ix.d_chunk);
       HIP_CHECK(hipGetLastError());
+      if (kmers > 0) index_pack_positions(ix, maxrl);
     }
   // no synchronisation here: every later use of the index is ordered on the same stream, and a
   // driver may queue more work (e.g. the next block's Reporter) behind the sort right away
@@ -1123,6 +1158,7 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
       J.stage = 0;
       J.block = block;
       J.Kmer  = pm.Kmer;
+      J.maxlen = maxrl;
       g_bg.push_back(J);
       if (kmers <= 1) bg_flush();
     }
@@ -1348,11 +1384,17 @@ int dmh_index_download(void *table, void *out)
   KmerPosRec *o = (KmerPosRec *) out;
   const std::vector<int64_t> &boff = ix->h_boff;
   for (int64_t i = 0; i < ix->n; i++)
-    { int64_t q = v[i];
-      int r = (int) (std::upper_bound(boff.begin(), boff.end(), q) - boff.begin()) - 1;
-      o[i].code = k[i];
-      o[i].read = r;
-      o[i].rpos = (int32_t) (q - boff[r]);
+    { o[i].code = k[i];
+      if (ix->posbits > 0)
+        { o[i].read = (int32_t) (v[i] >> ix->posbits);
+          o[i].rpos = (int32_t) (v[i] & ((1u << ix->posbits) - 1u));
+        }
+      else
+        { int64_t q = v[i];
+          int r = (int) (std::upper_bound(boff.begin(), boff.end(), q) - boff.begin()) - 1;
+          o[i].read = r;
+          o[i].rpos = (int32_t) (q - boff[r]);
+        }
     }
   return (int) ix->n;
 }

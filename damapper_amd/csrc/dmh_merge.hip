@@ -298,10 +298,16 @@ __global__ void k_entry_sizes(const MergeEntry *__restrict__ entries, uint32_t n
 struct PosMap
 { const int64_t  *boff;
   const uint32_t *chunk;
+  int             posbits;      // > 0: the index holds (read << posbits) | rpos already
 };
 
 __device__ __forceinline__ void locate(const PosMap &M, uint32_t q, uint32_t &read, uint32_t &rpos)
-{ uint32_t r = M.chunk[q >> CHUNK_SHIFT];
+{ if (M.posbits > 0)
+    { read = q >> M.posbits;
+      rpos = q & ((1u << M.posbits) - 1u);
+      return;
+    }
+  uint32_t r = M.chunk[q >> CHUNK_SHIFT];
   while (M.boff[r + 1] <= (int64_t) q) r += 1;
   read = r;
   rpos = (uint32_t) ((int64_t) q - M.boff[r]);
@@ -680,7 +686,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     hipLaunchKernelGGL(k_entry_sizes, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent, limit, esz.p);
     HIP_CHECK(hipMemcpyAsync(eoff.p, esz.p, sizeof(uint32_t) * nent, hipMemcpyDeviceToDevice, stream()));
     exclusive_scan_u32(eoff.p, nent, st.sort.bsum, eoff.p + nent);
-    PosMap MA{A.d_boff, A.d_chunk}, MB{Bx.d_boff, Bx.d_chunk};
+    PosMap MA{A.d_boff, A.d_chunk, A.posbits}, MB{Bx.d_boff, Bx.d_chunk, Bx.posbits};
     hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                        (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
                        (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, cluster ? 1 : 0, R.keys.p, R.vals.p, ebig.p, mctl.p + 1);

@@ -40,7 +40,9 @@ struct BlockDev
 struct IndexDev
 { int64_t   n      = 0;         // k-mers kept
   uint64_t *keys   = nullptr;   // sorted codes
-  uint32_t *vals   = nullptr;   // base offset q of the k-mer's last base inside the block
+  uint32_t *vals   = nullptr;   // base offset q of the k-mer's last base inside the block -- or, once the index is
+                                //   complete and posbits > 0, (read << posbits) | rpos: what the merge turns into hits
+  int       posbits = 0;
   int64_t  *d_boff = nullptr;   // nreads+1 read offsets (device)
   uint32_t *d_chunk = nullptr;  // read index of position (c << CHUNK_SHIFT), c = 0..nchunk-1
   int64_t   nchunk = 0;
