@@ -637,7 +637,7 @@ def native_genome(seed: int, contig_lens: Sequence[int], kind: str = "repeat", f
     for c in range(n):
         o = int(offs[c])
         layout[o - 1] = 4
-        L.dmh_sim_genome(layout.ctypes.data + o, int(lens[c]), seed * 1000003 + c, fam.ctypes.data, families,
+        L.dmh_sim_genome(layout.ctypes.data + o, int(lens[c]), (seed * 1000003 + c) & 0xffffffffffffffff, fam.ctypes.data, families,
                          family_len if rep else 0, divergence, gap[0], gap[1],
                          tandem_unit if rep else 0, tandem_copies if rep else 0)
     layout[int(offs[-1]) + int(lens[-1]):] = 4

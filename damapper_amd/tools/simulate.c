@@ -16,9 +16,19 @@ static inline uint64_t splitmix(uint64_t *s)
   return z ^ (z >> 31);
 }
 
+/* A seed for one independent stream out of (seed, index): both go through the splitmix finaliser, so that streams of
+ * neighbouring indices (or seeds) are not shifted copies of each other (s + i*G with G the generator's own
+ * increment would be exactly that). */
+static inline uint64_t stream_seed(uint64_t seed, uint64_t index)
+{ uint64_t a = seed, b;
+  a = splitmix(&a);
+  b = a ^ (index * 0xd6e8feb86659fd93ull + 0x2545f4914f6cdd1dull);
+  return splitmix(&b);
+}
+
 /* Generates read i; if out != NULL writes its bases there.  Returns the read length. */
 static int gen_read(const uint8_t *g, int64_t glen, int rl, double err, uint64_t seed, int i, uint8_t *out)
-{ uint64_t s = seed * 0x2545f4914f6cdd1dull + (uint64_t) i * 0x9e3779b97f4a7c15ull + 1;
+{ uint64_t s = stream_seed(seed, (uint64_t) i);
   int64_t  pos = (int64_t) (splitmix(&s) % (uint64_t) (glen - rl + 1));
   int      rev = (int) (splitmix(&s) & 1);
   uint32_t tins = (uint32_t) (err * 0.60 * 4294967296.0);
@@ -105,7 +115,7 @@ void dmh_sim_genome(uint8_t *out, int64_t n, uint64_t seed, const uint8_t *fam, 
   int64_t nch = (n + CH - 1) / CH, c;
 #pragma omp parallel for schedule(static)
   for (c = 0; c < nch; c++)
-    { uint64_t s = seed * 0x9e3779b97f4a7c15ull + (uint64_t) c * 0xd1342543de82ef95ull + 7;
+    { uint64_t s = stream_seed(seed, (uint64_t) c);
       int64_t  e = (c + 1) * CH < n ? (c + 1) * CH : n, i = c * CH;
       while (i < e)
         { uint64_t r = splitmix(&s);
@@ -116,7 +126,7 @@ void dmh_sim_genome(uint8_t *out, int64_t n, uint64_t seed, const uint8_t *fam, 
     }
   if (flen > 0 && gap_hi > gap_lo)
     { /* positions first (sequential, cheap), then the copies in parallel */
-      uint64_t s = seed ^ 0xa0761d6478bd642full;
+      uint64_t s = stream_seed(seed ^ 0xa0761d6478bd642full, 1);
       int64_t  cap = n / (flen + gap_lo) + 2, m = 0, p;
       int64_t *pos = (int64_t *) malloc(sizeof(int64_t) * (size_t) cap);
       p = 500 + (int64_t) (splitmix(&s) % 2500);
@@ -128,7 +138,7 @@ void dmh_sim_genome(uint8_t *out, int64_t n, uint64_t seed, const uint8_t *fam, 
       int64_t  j;
 #pragma omp parallel for schedule(static)
       for (j = 0; j < m; j++)
-        { uint64_t t = seed * 0x2545f4914f6cdd1dull + (uint64_t) j * 0x9e3779b97f4a7c15ull + 11;
+        { uint64_t t = stream_seed(seed ^ 0x94d049bb133111ebull, (uint64_t) j);
           uint64_t r0 = splitmix(&t);
           int      rev = (int) (r0 & 1), x;
           const uint8_t *cons = fam + (size_t) ((r0 >> 8) % (uint64_t) nfam) * (size_t) flen;
@@ -144,7 +154,7 @@ void dmh_sim_genome(uint8_t *out, int64_t n, uint64_t seed, const uint8_t *fam, 
       free(pos);
     }
   if (tunit > 0 && tcopies > 0 && n > 4 * (int64_t) tunit * tcopies)
-    { uint64_t s = seed ^ 0xe7037ed1a0b428dbull;
+    { uint64_t s = stream_seed(seed ^ 0xe7037ed1a0b428dbull, 2);
       int64_t  tl = (int64_t) tunit * tcopies, q = (int64_t) (splitmix(&s) % (uint64_t) (n - tl)), i;
       uint8_t *unit = (uint8_t *) malloc((size_t) tunit);
       for (i = 0; i < tunit; i++) unit[i] = (uint8_t) (splitmix(&s) & 3);
@@ -158,7 +168,7 @@ void dmh_sim_genome(uint8_t *out, int64_t n, uint64_t seed, const uint8_t *fam, 
  * gen_read.  cum[c] = number of valid starts in contigs 0..c-1 (cum[ncontig] = total).                  */
 static int gen_read_multi(const uint8_t *g, const int64_t *coff, const int64_t *cum, int ncontig, int rl, double err,
                           uint64_t seed, int i, uint8_t *out)
-{ uint64_t s = seed * 0x2545f4914f6cdd1dull + (uint64_t) i * 0x9e3779b97f4a7c15ull + 3;
+{ uint64_t s = stream_seed(seed ^ 0x3c6ef372fe94f82bull, (uint64_t) i);
   int64_t  u = (int64_t) (splitmix(&s) % (uint64_t) cum[ncontig]);
   int lo = 0, hi = ncontig - 1;
   while (lo < hi)
