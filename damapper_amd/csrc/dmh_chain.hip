@@ -1390,6 +1390,9 @@ namespace dmh {
 void chain_reset_reads(const DAZZ_DB *ablock)
 { State &st = S();
   CandStore &cs = st.cands;
+  { MergeResult &R = filter_batch();        // hits of a block that never reached Reporter
+    R.open = false; R.nhits = 0; R.npass = 0;
+  }
   const int n = ablock->nreads;
   st.cur_reads = ablock;
   st.reads.clear();
@@ -1426,7 +1429,7 @@ void chain_reset_reads(const DAZZ_DB *ablock)
     ablock->reads[i].coff = -1;
 }
 
-int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock, int comp)
+int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock)
 { State &st = S();
   const Params &pm = st.params;
   if (st.cur_reads != ablock || st.cands.nreads != ablock->nreads)
@@ -1633,7 +1636,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
                        R.clustered ? (const uint32_t *) R.cog.p : (const uint32_t *) nullptr,
                        R.clustered ? (const uint32_t *) R.ocfirst.p : (const uint32_t *) nullptr, ord.p);
     hipLaunchKernelGGL(k_read_groups, dim3(ceil_div((int64_t) ng + 1, 256)), dim3(256), 0, stream(),
-                       (const uint64_t *) R.gkey.p, ng, R.bbits, nreads, rgfirst.p);
+                       (const uint64_t *) R.gkey.p, ng, R.bbits + R.passbits, nreads, rgfirst.p);
     hipLaunchKernelGGL(k_dom_need, dim3(ceil_div(nreads, 256)), dim3(256), 0, stream(),
                        (const uint32_t *) cs.seg_len[cs.cur].p, (const uint32_t *) goff.p, (const uint32_t *) rgfirst.p,
                        nreads, cs.seg_off[nx].p);
@@ -1643,9 +1646,11 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
     D.oldp = cs.pool[cs.cur].p; D.ooff = cs.seg_off[cs.cur].p; D.olen = cs.seg_len[cs.cur].p;
     D.newp = cs.pool[nx].p; D.noff = cs.seg_off[nx].p; D.nlen = cs.seg_len[nx].p;
     D.nreads = nreads;
-    D.bbits = R.bbits; D.passbits = 0;
-    D.pass[0].bbase = bblock->tfirst;
-    D.pass[0].comp  = comp;
+    D.bbits = R.bbits; D.passbits = R.passbits;
+    for (int q = 0; q < R.npass; q++)
+      { D.pass[q].bbase = R.pass[q].bbase;
+        D.pass[q].comp  = R.pass[q].comp;
+      }
     D.cover = PROFILE ? cs.cover.p : nullptr;
     D.cov_off = cs.cov_off.p;
     D.spacing = SPACING;
@@ -1697,6 +1702,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *b
 void cand_mirror(bool with_jumps)
 { State &st = S();
   CandStore &cs = st.cands;
+  st.tfilt += filter_flush();             // (the passes still waiting in the batch)
   if (cs.mirror_valid && (cs.mirror_jumps || !with_jumps)) return;
   const int n = cs.nreads;
   std::vector<DCand>    pool(cs.total_len);

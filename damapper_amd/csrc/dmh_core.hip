@@ -2,6 +2,7 @@
 // and the small stage-level helpers of the C-ABI (see include/damapper_hip.h).
 
 #include "dmh_state.h"
+#include "dmh_merge.h"
 #include <deque>
 #include "dmh_device.h"
 #include <stdarg.h>
@@ -1224,6 +1225,10 @@ void dmh_reset(void)
   st.blocks.clear();
   st.reads.clear();
   st.cur_reads = nullptr;
+  { MergeResult &R = filter_batch();
+    R.open = false; R.nhits = 0; R.npass = 0;
+    R.keys.release(); R.vals.release();
+  }
   { CandStore &cs = st.cands;
     for (int i = 0; i < 2; i++) { cs.pool[i].release(); cs.seg_off[i].release(); cs.seg_len[i].release(); }
     cs.jumps.release(); cs.cover.release(); cs.cov_off.release(); cs.ctl.release();
@@ -1318,6 +1323,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "cluster") == 0)     st.opt_cluster = value;
   else if (strcmp(key, "chain_small") == 0) st.opt_chain_small = value;
   else if (strcmp(key, "chain_lane") == 0)  st.opt_chain_lane = value;
+  else if (strcmp(key, "batch") == 0)       st.opt_batch = value;
   else return -1;
   return 0;
 }

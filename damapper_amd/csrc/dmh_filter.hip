@@ -14,7 +14,7 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
                   int comp, int start)
 { State &st = S();
   Params &pm = st.params;
-  static MergeResult R;
+  MergeResult &R = filter_batch();
 
   int64_t nhits = 0, nfilt = 0;
   if (start)
@@ -31,10 +31,7 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
       index_wait_ready(*A);
       index_wait_ready(*B);
       st.mf_calls += 1;
-      merge_and_sort(R, ablock, bblock, *A, *B, pm.Kshift);
-      nhits = R.nhits;
-      if (nhits > 0)
-        nfilt = chain_and_filter(R, ablock, bblock, comp);
+      nhits = merge_pass(R, ablock, bblock, *A, *B, pm.Kshift, comp, &nfilt);
       st.tfilt += nfilt;
     }
 

@@ -4,8 +4,19 @@
 
 namespace dmh {
 
+constexpr int MAXPASS = 32;        // Match_Filter passes one batch can hold (5 pass bits in the seed key)
+
+// Seed hits on their way from the merge to the chain kernels.  With batching on, consecutive Match_Filter calls of
+// a READS block only APPEND their hits (the pass number becomes part of the sort key, between aread and bread);
+// the batch is sorted, chained and put through the domination rule in one go when it is closed (filter_flush:
+// the hit budget is reached, Reporter starts, or somebody looks at the candidates).  Passes are walked in call
+// order per read, so the result is what the calls would have produced one by one (map.c:2889-3209).
 struct MergeResult
-{ int64_t nhits   = 0;
+{ bool    open    = false;       // a batch is being collected: the key layout below is fixed
+  const DAZZ_DB *ablock = nullptr;
+  int     npass   = 0, passbits = 0, qbits = 0;
+  struct { int bbase, comp; } pass[MAXPASS];
+  int64_t nhits   = 0;
   int64_t limit   = 0;
   int64_t ngroups = 0;
   int     pbits = 0, bbits = 0, abits = 0;     // key = aread | bread | apos (high -> low)
@@ -36,7 +47,14 @@ struct MergeResult
 // classifies the groups of R.gstart on the device and fetches the number of piles
 void chain_classify_groups(MergeResult &R);
 
-void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
-                    IndexDev &A, IndexDev &B, int Kshift);
+// One Match_Filter pass up to the expanded hits (map.c:2984-3099): returns the number of hits it added.  May close the
+// batch first (when the pass does not fit it) and closes it afterwards unless batching is on; *nfilt accumulates the
+// change in the number of candidates of whatever was closed.
+int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &B,
+                   int Kshift, int comp, int64_t *nfilt);
+
+// Sort, group, chain and filter what the batch holds (no-op when it is empty); returns the change in candidates.
+int64_t filter_flush();
+MergeResult &filter_batch();
 
 }  // namespace dmh

@@ -12,6 +12,7 @@
 #include "dmh_state.h"
 #include "dmh_device.h"
 #include "dmh_merge.h"
+#include "dmh_chain.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -320,7 +321,7 @@ constexpr uint32_t BIG_ENTRY = 64;
 __global__ void k_merge_expand(const MergeEntry *__restrict__ entries, uint32_t n,
                                const uint32_t *__restrict__ offs, const uint32_t *__restrict__ sizes,
                                const uint32_t *__restrict__ avals, const uint32_t *__restrict__ bvals,
-                               PosMap MA, PosMap MB, int bshift, int pshift, int swap,
+                               PosMap MA, PosMap MB, int bshift, int pshift, int swap, uint64_t passor,
                                uint64_t *__restrict__ hkeys, uint32_t *__restrict__ hvals,
                                uint32_t *__restrict__ biglist, unsigned int *__restrict__ nbig)
 { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,7 +338,7 @@ __global__ void k_merge_expand(const MergeEntry *__restrict__ entries, uint32_t 
     { uint32_t ar, ap;
       locate(MA, avals[e.a0 + a], ar, ap);
       // key = aread | bread | apos with value bpos -- or, for the cluster sort (swap), bpos in the key and apos as value
-      uint64_t kbase = ((uint64_t) ar << bshift) | (swap ? 0ull : (uint64_t) ap);
+      uint64_t kbase = ((uint64_t) ar << bshift) | passor | (swap ? 0ull : (uint64_t) ap);
       for (uint32_t b = 0; b < e.mb; b++)
         { uint32_t br, bp;
           locate(MB, bvals[e.b0 + b], br, bp);
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
                                                           const uint32_t *__restrict__ avals,
                                                           const uint32_t *__restrict__ bvals,
                                                           PosMap MA, PosMap MB, int bshift, int pshift, int swap,
-                                                          uint64_t *__restrict__ hkeys, uint32_t *__restrict__ hvals)
+                                                          uint64_t passor, uint64_t *__restrict__ hkeys,
+                                                          uint32_t *__restrict__ hvals)
 { const int lane = threadIdx.x & 63;
   uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (w >= nbig) return;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
       uint32_t ar, ap, br, bp;
       locate(MA, avals[e.a0 + a], ar, ap);
       locate(MB, bvals[e.b0 + b], br, bp);
-      hkeys[off + t] = ((uint64_t) ar << bshift) | ((uint64_t) br << pshift) | (uint64_t) (swap ? bp : ap);
+      hkeys[off + t] = ((uint64_t) ar << bshift) | passor | ((uint64_t) br << pshift) | (uint64_t) (swap ? bp : ap);
       hvals[off + t] = swap ? ap : bp;
     }
 }
@@ -502,20 +504,20 @@ static int64_t sizeof_db(const DAZZ_DB *db)
   return s;
 }
 
-void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
-                    IndexDev &A, IndexDev &Bx, int Kshift)
+MergeResult &filter_batch()
+{ static MergeResult R;
+  return R;
+}
+
+// hits a batch may collect before it is closed (68 B of HBM per hit through the sort and the chain kernels)
+constexpr int64_t BATCH_CAP = (int64_t) 160 << 20;
+
+static int64_t close_batch(MergeResult &R);
+
+int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &Bx,
+                   int Kshift, int comp, int64_t *nfilt)
 { State &st = S();
   HostTimer ht("merge_and_sort");
-  R.nhits = 0;
-  R.ngroups = 0;
-
-  // --- key layout (map.c:2911-2937 uses whole bytes; bit-packing keeps the same order)
-  R.pbits = ceil_log2(ablock->maxlen > 1 ? ablock->maxlen : 1);
-  R.bbits = ceil_log2(bblock->nreads);
-  R.abits = ceil_log2(ablock->nreads);
-  if (R.pbits + R.bbits + R.abits > 64)
-    fatal("Match_Filter: seed key needs %d bits", R.pbits + R.bbits + R.abits);
-  int pshift = R.pbits, bshift = R.pbits + R.bbits;        // (revised below for the cluster sort)
 
   // --- bucket table over the REF index: part of the index, built the first time it is merged against
   //     (a retained REF index meets every READS block)
@@ -647,7 +649,6 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
       nhits = (int64_t) hsum[0];
     }
   st.last_limit = (int) limit;
-  R.limit = limit;
   if (VERBOSE)
     { printf("   Hit count = %lld\n", (long long) nhits);
       fflush(stdout);
@@ -655,32 +656,53 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
   if (nhits >= (int64_t) 0xfffffff0ll)
     fatal("Match_Filter: %lld seed hits in one block pair exceed the 32-bit slot range; use smaller blocks or -M",
           (long long) nhits);
-  R.nhits = nhits;
-  if (nhits == 0) return;
+  if (nhits == 0) return 0;
 
-  // --- cluster mode (dmh_merge.h): when a read meets thousands of hits per pass (repeat families), the hits of an
-  //     (aread, bread) pair are cut into B-clusters, which chain independently -- a pair's live window would hold
-  //     hundreds of hits of unrelated loci, a cluster's holds a few dozen.  "cluster" test option: 1 always, 0 never.
+  // --- which batch the pass goes to.  Cluster mode (dmh_merge.h): when a read meets thousands of hits per pass
+  //     (repeat families), the hits of an (aread, bread) pair are cut into B-clusters, which chain independently -- a
+  //     pair's live window would hold hundreds of hits of unrelated loci, a cluster's holds a few dozen; such a pass
+  //     is processed by itself ("cluster" test option: 1 always, 0 never).  Sparse passes are collected: the sort,
+  //     the chain kernels and the domination pass then run once per batch instead of once per pass.
   static const int env_cl = getenv("DMH_CLUSTER") ? atoi(getenv("DMH_CLUSTER")) : -1;
+  static const int env_batch = getenv("DMH_BATCH") ? atoi(getenv("DMH_BATCH")) : 1;
   const int optcl = st.opt_cluster >= 0 ? st.opt_cluster : env_cl;
+  const int pbits = ceil_log2(ablock->maxlen > 1 ? ablock->maxlen : 1);
+  const int abits = ceil_log2(ablock->nreads), bbits = ceil_log2(bblock->nreads);
   const int qbits = ceil_log2(bblock->maxlen > 1 ? (int64_t) bblock->maxlen + 1 : 2);
   bool cluster = (optcl >= 0) ? (optcl != 0) : (nhits >= (int64_t) 1024 * ablock->nreads);
-  if (qbits + R.bbits + R.abits > 64 || nhits >= (int64_t) 0x7fffffff) cluster = false;
-  R.clustered = cluster;
-  const int lowbits = cluster ? qbits : R.pbits;           // bits below (aread | bread) in the first sort's key
-  pshift = lowbits;
-  bshift = lowbits + R.bbits;
+  if (qbits + bbits + abits > 64 || nhits >= (int64_t) 0x7fffffff) cluster = false;
+  const bool batching = !cluster && !VERBOSE && !st.capture_seeds && (st.opt_batch >= 0 ? st.opt_batch != 0 : env_batch != 0);
+  if (R.open && (cluster || !batching || R.ablock != ablock || R.npass >= MAXPASS || R.nhits + nhits > BATCH_CAP ||
+                 bbits > R.bbits || pbits != R.pbits || abits != R.abits))
+    *nfilt += close_batch(R);
+  if (!R.open)
+    { R.open = true;
+      R.ablock = ablock;
+      R.npass = 0;
+      R.nhits = 0;
+      R.clustered = cluster;
+      R.pbits = pbits; R.abits = abits; R.bbits = bbits; R.qbits = qbits;
+      R.passbits = batching ? 5 : 0;
+      if ((cluster ? qbits : pbits) + R.bbits + R.passbits + R.abits > 64)
+        { if (pbits + R.bbits + R.abits > 64) fatal("Match_Filter: seed key needs %d bits", pbits + R.bbits + R.abits);
+          R.passbits = 0;
+        }
+      const int64_t cap = std::max<int64_t>(R.passbits ? BATCH_CAP : 0, nhits);
+      R.keys.ensure(cap, "seed keys");
+      R.vals.ensure(cap, "seed positions");
+    }
+  const int lowbits = R.clustered ? R.qbits : R.pbits;           // bits below bread in the first sort's key
+  const int pshift = lowbits, bshift = lowbits + R.bbits + R.passbits;
+  const uint64_t passor = (uint64_t) R.npass << (lowbits + R.bbits);
 
-  // --- expand the entries under the limit into hits (map.c:3095-3099)
-  R.keys.ensure(nhits, "seed keys");
-  R.vals.ensure(nhits, "seed positions");
-  st.sort.keys_alt.ensure(nhits, "seed sort buffer");
-  st.sort.vals_alt.ensure(nhits, "seed sort buffer");
+  // --- expand the entries under the limit into hits (map.c:3095-3099), behind the batch's earlier passes
   static DevBuf<uint32_t> esz, eoff, ebig;
   esz.ensure((size_t) nent + 1, "entry sizes");
   eoff.ensure((size_t) nent + 2, "entry offsets");
   ebig.ensure((size_t) nent + 1, "big entries");
   uint32_t total = 0, nbig = 0;
+  uint64_t *hk = R.keys.p + R.nhits;
+  uint32_t *hv = R.vals.p + R.nhits;
   { StageTimer tm("merge_emit", 16.0 * nhits);
     int nb = ceil_div(nent, 256);
     hipLaunchKernelGGL(k_entry_sizes, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent, limit, esz.p);
@@ -689,24 +711,51 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
     PosMap MA{A.d_boff, A.d_chunk, A.posbits}, MB{Bx.d_boff, Bx.d_chunk, Bx.posbits};
     hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                        (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
-                       (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, cluster ? 1 : 0, R.keys.p, R.vals.p, ebig.p, mctl.p + 1);
+                       (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0, passor, hk, hv, ebig.p, mctl.p + 1);
     copy_d2h(&total, eoff.p + nent, sizeof(uint32_t));
     copy_d2h(&nbig, mctl.p + 1, sizeof(unsigned int), 1);
     if (nbig > 0)
       hipLaunchKernelGGL(k_merge_expand_big, dim3(ceil_div((int64_t) nbig * 64, 256)), dim3(256), 0, stream(),
                          (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, nbig, (const uint32_t *) eoff.p,
-                         (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, cluster ? 1 : 0,
-                         R.keys.p, R.vals.p);
+                         (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0,
+                         passor, hk, hv);
     HIP_CHECK(hipGetLastError());
   }
   if ((int64_t) total != nhits)
     fatal("Match_Filter: emitted %u hits but the histogram promised %lld", total, (long long) nhits);
+  R.pass[R.npass].bbase = bblock->tfirst;
+  R.pass[R.npass].comp  = comp;
+  R.npass += 1;
+  R.nhits += nhits;
+  if (!R.passbits) *nfilt += close_batch(R);
+  return nhits;
+}
+
+int64_t filter_flush()
+{ MergeResult &R = filter_batch();
+  return R.open ? close_batch(R) : 0;
+}
+
+// sort, groups, chain scoring, domination rule for everything the batch holds
+static int64_t close_batch(MergeResult &R)
+{ State &st = S();
+  const int64_t nhits = R.nhits;
+  const DAZZ_DB *ablock = R.ablock;
+  R.open = false;
+  if (nhits == 0) { R.npass = 0; return 0; }
+  HostTimer ht("filter_close");
+  const bool cluster = R.clustered;
+  const int  qbits = R.qbits;
+  const int  lowbits = cluster ? qbits : R.pbits;
+  const int  pshift = lowbits;
+  st.sort.keys_alt.ensure(nhits, "seed sort buffer");
+  st.sort.vals_alt.ensure(nhits, "seed sort buffer");
 
   // --- seed sort (map.c:3110-3126)
   uint64_t *k0 = R.keys.p, *k1 = st.sort.keys_alt.p;
   uint32_t *v0 = R.vals.p, *v1 = st.sort.vals_alt.p;
   const int cb = cluster ? std::min(CLUSTER_CB, qbits) : 0;          // (the bits below cb of bpos are not sorted on)
-  radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, cb, lowbits + R.bbits + R.abits - cb, st.sort, "seed_sort");
+  radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, cb, lowbits + R.bbits + R.passbits + R.abits - cb, st.sort, "seed_sort");
 
   // --- groups
   static DevBuf<uint32_t> flag;
@@ -768,7 +817,7 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
       if (!cluster)
         for (int64_t i = 0; i < nhits; i++)
           { int apos  = (int) (hk[i] & pm);
-            int bread = (int) ((hk[i] >> R.pbits) & bm);
+            int bread = (int) ((hk[i] >> R.pbits) & bm);            // (capture runs unbatched: no pass bits)
             int aread = (int) (hk[i] >> (R.pbits + R.bbits));
             st.last_seeds[4 * i + 0] = apos - (int) hv[i];
             st.last_seeds[4 * i + 1] = apos;
@@ -797,6 +846,10 @@ void merge_and_sort(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock
             }
         }
     }
+  const int64_t nfilt = chain_and_filter(R, ablock);
+  R.nhits = 0;
+  R.npass = 0;
+  return nfilt;
 }
 
 }  // namespace dmh
