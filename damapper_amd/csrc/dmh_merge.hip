@@ -350,7 +350,8 @@ __global__ void k_merge_expand(const MergeEntry *__restrict__ entries, uint32_t 
 }
 
 __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__restrict__ entries,
-                                                          const uint32_t *__restrict__ biglist, uint32_t nbig,
+                                                          const uint32_t *__restrict__ biglist,
+                                                          const unsigned int *__restrict__ nbig_p,
                                                           const uint32_t *__restrict__ offs,
                                                           const uint32_t *__restrict__ avals,
                                                           const uint32_t *__restrict__ bvals,
@@ -358,19 +359,21 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
                                                           uint64_t passor, uint64_t *__restrict__ hkeys,
                                                           uint32_t *__restrict__ hvals)
 { const int lane = threadIdx.x & 63;
-  uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (w >= nbig) return;
-  uint32_t   i = biglist[w];
-  MergeEntry e = entries[i];
-  uint32_t off = offs[i];
-  uint32_t tot = e.ma * e.mb;
-  for (uint32_t t = lane; t < tot; t += 64)
-    { uint32_t a = t / e.mb, b = t - a * e.mb;
-      uint32_t ar, ap, br, bp;
-      locate(MA, avals[e.a0 + a], ar, ap);
-      locate(MB, bvals[e.b0 + b], br, bp);
-      hkeys[off + t] = ((uint64_t) ar << bshift) | passor | ((uint64_t) br << pshift) | (uint64_t) (swap ? bp : ap);
-      hvals[off + t] = swap ? ap : bp;
+  const uint32_t nbig = *nbig_p;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nbig; w += nwaves)
+    { uint32_t   i = biglist[w];
+      MergeEntry e = entries[i];
+      uint32_t off = offs[i];
+      uint32_t tot = e.ma * e.mb;
+      for (uint32_t t = lane; t < tot; t += 64)
+        { uint32_t a = t / e.mb, b = t - a * e.mb;
+          uint32_t ar, ap, br, bp;
+          locate(MA, avals[e.a0 + a], ar, ap);
+          locate(MB, bvals[e.b0 + b], br, bp);
+          hkeys[off + t] = ((uint64_t) ar << bshift) | passor | ((uint64_t) br << pshift) | (uint64_t) (swap ? bp : ap);
+          hvals[off + t] = swap ? ap : bp;
+        }
     }
 }
 
@@ -561,13 +564,13 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
   static DevBuf<uint32_t>   tcount;
   static DevBuf<unsigned int> mctl;
   const int64_t ntiles = ceil_div(A.n, MG_TILE);
-  gram.ensure(MAXGRAM + 4, "hit histogram");
+  gram.ensure(MAXGRAM + 8, "hit histogram");
   mctl.ensure(4, "merge counters");
   tentries.ensure((size_t) ntiles * MG_TILE, "matched runs (per tile)");
   tcount.ensure(ntiles + 1, "matched runs per tile");
   thits.ensure(2 * (size_t) ntiles, "hits per tile");
   unsigned long long *sums = gram.p + MAXGRAM + 1;         // [0] all hits, [1] hits of the runs below MAXGRAM
-  HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(unsigned long long) * 2, stream()));
+  HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(unsigned long long) * 3, stream()));
   HIP_CHECK(hipMemsetAsync(mctl.p, 0, 4 * sizeof(unsigned int), stream()));
   { StageTimer tm("merge_match", 16.0 * (A.n + Bx.n));
     if (Bx.probe_keys == 4 && BL.klow != nullptr)
@@ -586,14 +589,16 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
     exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
     HIP_CHECK(hipGetLastError());
   }
+  // one round trip for the pass: the number of matched runs and the two hit sums (the count is parked behind the sums)
   unsigned int nent = 0;
-  copy_d2h(&nent, tcount.p + ntiles, sizeof(unsigned int));
+  unsigned long long hsum[3] = {0, 0, 0};
+  HIP_CHECK(hipMemcpyAsync(sums + 2, tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
+  copy_d2h(hsum, sums, sizeof(unsigned long long) * 3, 1);                         // the limit rule next
+  nent = (unsigned int) (hsum[2] & 0xffffffffull);
   entries.ensure((size_t) nent + 64, "matched runs");
   if (nent > 0)
     hipLaunchKernelGGL(k_merge_gather, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(),
                        (const MergeEntry *) tentries.p, (const uint32_t *) tcount.p, ntiles, nent, entries.p);
-  unsigned long long hsum[2] = {0, 0};
-  copy_d2h(hsum, sums, sizeof(unsigned long long) * 2, 1);                         // the limit rule next
 
   // --- limit (map.c:2992-3055)
   int64_t limit, nhits;
@@ -712,17 +717,22 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
     hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                        (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
                        (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0, passor, hk, hv, ebig.p, mctl.p + 1);
-    copy_d2h(&total, eoff.p + nent, sizeof(uint32_t));
-    copy_d2h(&nbig, mctl.p + 1, sizeof(unsigned int), 1);
-    if (nbig > 0)
-      hipLaunchKernelGGL(k_merge_expand_big, dim3(ceil_div((int64_t) nbig * 64, 256)), dim3(256), 0, stream(),
-                         (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, nbig, (const uint32_t *) eoff.p,
-                         (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0,
-                         passor, hk, hv);
+    // the entries of more than BIG_ENTRY pairs, a wavefront each: their number stays on the device (the launch is
+    // sized for the most there can be of them: nhits / BIG_ENTRY)
+    const int64_t maxbig = std::min<int64_t>(nent, nhits / (int64_t) BIG_ENTRY + 1);
+    hipLaunchKernelGGL(k_merge_expand_big, dim3(std::min<int64_t>(ceil_div(maxbig * 64, 256), 65536)), dim3(256), 0, stream(),
+                       (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, (const unsigned int *) (mctl.p + 1),
+                       (const uint32_t *) eoff.p, (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift,
+                       R.clustered ? 1 : 0, passor, hk, hv);
     HIP_CHECK(hipGetLastError());
+    static const bool check = getenv("DMH_CHECK_EMIT") != nullptr;
+    if (check)
+      { copy_d2h(&total, eoff.p + nent, sizeof(uint32_t));
+        if ((int64_t) total != nhits)
+          fatal("Match_Filter: emitted %u hits but the histogram promised %lld", total, (long long) nhits);
+      }
   }
-  if ((int64_t) total != nhits)
-    fatal("Match_Filter: emitted %u hits but the histogram promised %lld", total, (long long) nhits);
+  (void) nbig;
   R.pass[R.npass].bbase = bblock->tfirst;
   R.pass[R.npass].comp  = comp;
   R.npass += 1;

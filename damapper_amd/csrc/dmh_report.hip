@@ -6,6 +6,7 @@
 #include "dmh_spec.h"
 #include "dmh_align.h"
 #include "dmh_chain.h"
+#include "dmh_merge.h"
 #include <algorithm>
 #include <math.h>
 #include <atomic>
@@ -1335,12 +1336,16 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     fatal("Reporter: the Align_Spec was not created by this library's New_Align_Spec");
   if (st.cur_reads != ablock || st.cands.nreads != ablock->nreads)
     fatal("Reporter: called for a READS block that has not been through Match_Filter");
-  // Deferring the alignment kernel pays when the READS block meets a reference of one block (two passes, the
-  // filter about as long as the alignment kernel at half grid).  Against a many-block reference the filter is
-  // several times longer, the kernel would just hold half of the GPU for a part of it and the index stages,
-  // flushed in one go instead of filling the filter's many host gaps, would cost more than is won
-  // (700 Mbp reference: 45.9 ms per block un-deferred, 50.9 deferred).
-  const bool defer = (g_async == 2) && st.mf_calls <= 2;
+  // mode 2: the (VALU-bound) alignment kernel of this block is left running, at a partial grid, next to the filter
+  // of the NEXT block, whose kernels mostly wait for memory.  (Round 1 deferred only for one-block references: the
+  // per-pass host round trips of a many-block filter made the overlap a loss; with the passes batched it wins
+  // there too -- 69.3 -> 65.7 ms per read block against a GRCh38-sized random reference.  DMH_DEFER_MAX_PASSES=2
+  // restores the old rule.)
+  // what is left of this block's filter (the batched passes) comes first: it is the work that runs next to the
+  // previous block's alignment kernel, which is only collected further down
+  st.tfilt += filter_flush();
+  static const int defer_max = getenv("DMH_DEFER_MAX_PASSES") ? atoi(getenv("DMH_DEFER_MAX_PASSES")) : 1 << 30;
+  const bool defer = (g_async == 2) && st.mf_calls <= defer_max;
   st.mf_calls = 0;
   // the index sort of the NEXT block: all of it now, ahead of this block's alignment kernel and while the
   // host collects the previous block's (deferred mode), or a few stages for the GPU to do while the jobs
