@@ -445,6 +445,114 @@ __global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32
   if (i == 0) gstart[ncl] = (uint32_t) n;
 }
 
+// ---------------------------------------------------------------------------------------
+//  Every cluster into (apos, bpos) order without another trip of ALL hits through the global radix sort: the hits
+//  of a cluster are contiguous after the first sort, and clusters are small (some twenty hits; a read's true locus a
+//  few hundred), so each is sorted where it lies -- by rank counting in a 16-lane group (<= CS_SMALL hits), by a
+//  bitonic sort of (apos, position) words in the LDS of a workgroup (<= CS_MEDIUM), and the few larger ones (repeat
+//  piles) by the radix sort on their own range.  Stable in apos, so equal apos keep ascending bpos.
+// ---------------------------------------------------------------------------------------
+constexpr int CS_SMALL  = 64;
+constexpr int CS_MEDIUM = 4096;
+
+__global__ __launch_bounds__(256) void k_csort_small(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                     const uint32_t *__restrict__ gstart, uint32_t ncl, uint64_t pmask,
+                                                     uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
+{ constexpr int G = 16, GPB = 256 / G, PER = CS_SMALL / G;
+  __shared__ uint32_t s_ap[GPB][CS_SMALL];
+  const int lane = threadIdx.x & (G - 1), gi = threadIdx.x / G;
+  uint32_t *ap = s_ap[gi];
+  const uint32_t stride = gridDim.x * GPB;
+  for (uint32_t c = blockIdx.x * GPB + gi; c < ncl; c += stride)
+    { const uint32_t g0 = gstart[c], n = gstart[c + 1] - g0;
+      if (n > (uint32_t) CS_SMALL) continue;
+      uint64_t k[PER];
+      uint32_t v[PER];
+#pragma unroll
+      for (int t = 0; t < PER; t++)
+        { const uint32_t i = lane + G * t;
+          if (i < n)
+            { k[t] = kin[g0 + i];
+              v[t] = vin[g0 + i];
+              ap[i] = (uint32_t) (k[t] & pmask);
+            }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < PER; t++)
+        { const uint32_t i = lane + G * t;
+          if (i < n)
+            { const uint32_t a = ap[i];
+              uint32_t r = 0;
+              for (uint32_t j = 0; j < n; j++)
+                { const uint32_t b = ap[j];
+                  r += (b < a || (b == a && j < i)) ? 1u : 0u;
+                }
+              kout[g0 + r] = k[t];
+              vout[g0 + r] = v[t];
+            }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// clusters of CS_SMALL+1 .. CS_MEDIUM hits -> mlist, larger ones -> blist
+__global__ void k_csort_classify(const uint32_t *__restrict__ gstart, uint32_t ncl, uint32_t *__restrict__ mlist,
+                                 uint32_t *__restrict__ blist, unsigned int *__restrict__ counts)
+{ const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t n = (c < ncl) ? gstart[c + 1] - gstart[c] : 0;
+  const bool ism = n > (uint32_t) CS_SMALL && n <= (uint32_t) CS_MEDIUM, isb = n > (uint32_t) CS_MEDIUM;
+  const uint64_t mm = __ballot(ism), mb = __ballot(isb);
+  uint32_t bm = 0, bb = 0;
+  if (lane == 0)
+    { if (mm) bm = atomicAdd(counts, (uint32_t) __popcll(mm));
+      if (mb) bb = atomicAdd(counts + 1, (uint32_t) __popcll(mb));
+    }
+  bm = __shfl(bm, 0); bb = __shfl(bb, 0);
+  if (ism) mlist[bm + (uint32_t) __popcll(mm & lt)] = c;
+  if (isb) blist[bb + (uint32_t) __popcll(mb & lt)] = c;
+}
+
+// one workgroup per listed cluster: bitonic sort of the words (apos << 12 | position) in LDS (apos < 2^20), then the
+// hits are moved in that order
+__global__ __launch_bounds__(256) void k_csort_medium(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                      const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ list,
+                                                      const unsigned int *__restrict__ nlist_p, uint64_t pmask,
+                                                      uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
+{ __shared__ uint32_t it[CS_MEDIUM];
+  const uint32_t nlist = *nlist_p;
+  for (uint32_t x = blockIdx.x; x < nlist; x += gridDim.x)
+    { const uint32_t c = list[x], g0 = gstart[c], n = gstart[c + 1] - g0;
+      uint32_t m = 1;
+      while (m < n) m <<= 1;
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < m; i += 256)
+        it[i] = (i < n) ? ((((uint32_t) (kin[g0 + i] & pmask)) << 12) | i) : 0xffffffffu;
+      __syncthreads();
+      for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1)
+          { for (uint32_t i = threadIdx.x; i < m; i += 256)
+              { const uint32_t l = i ^ j;
+                if (l > i)
+                  { const uint32_t a = it[i], b = it[l];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { it[i] = b; it[l] = a; }
+                  }
+              }
+            __syncthreads();
+          }
+      for (uint32_t r = threadIdx.x; r < n; r += 256)
+        { const uint32_t i = it[r] & 0xfffu;
+          kout[g0 + r] = kin[g0 + i];
+          vout[g0 + r] = vin[g0 + i];
+        }
+    }
+}
+
 // pairs of the clusters: flag[c] = cluster c opens a new (aread, bread) pair
 __global__ void k_pair_flag(const uint64_t *__restrict__ gkey, uint32_t ncl, uint32_t *__restrict__ flag)
 { uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -798,8 +906,49 @@ static int64_t close_batch(MergeResult &R)
         std::swap(k0, k1);
         std::swap(v0, v1);
       }
-      // every cluster into (apos, bpos) order: stable sort on (cluster, apos); nothing leaves its cluster's range
-      radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, R.pbits + ceil_log2((int64_t) ncl + 1), st.sort, "cluster_sort");
+      // every cluster into (apos, bpos) order; nothing leaves its cluster's range
+      static const bool global_csort = getenv("DMH_GLOBAL_CLUSTER_SORT") != nullptr;
+      if (global_csort || st.opt_cluster_sort == 0 || R.pbits > 20)
+        radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, R.pbits + ceil_log2((int64_t) ncl + 1), st.sort, "cluster_sort");
+      else
+        { StageTimer tm("cluster_sort", 24.0 * nhits);
+          static DevBuf<uint32_t> mlist, blist;
+          static DevBuf<unsigned int> cnt;
+          mlist.ensure((size_t) ncl + 64, "clusters for the workgroup sort");
+          blist.ensure((size_t) ncl + 64, "clusters for the radix sort");
+          cnt.ensure(4, "cluster sort counters");
+          const uint64_t pmask = ((uint64_t) 1 << R.pbits) - 1;
+          const uint32_t smallmax = (st.opt_cluster_sort > 0) ? (uint32_t) st.opt_cluster_sort : 0;   // (test: forces the other paths)
+          (void) smallmax;
+          HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned int), stream()));
+          hipLaunchKernelGGL(k_csort_classify, dim3(ceil_div(ncl, 256)), dim3(256), 0, stream(), (const uint32_t *) R.gstart.p,
+                             ncl, mlist.p, blist.p, cnt.p);
+          hipLaunchKernelGGL(k_csort_small, dim3(std::min<int64_t>(((int64_t) ncl + 15) / 16, 256 * 8)), dim3(256), 0, stream(),
+                             (const uint64_t *) k0, (const uint32_t *) v0, (const uint32_t *) R.gstart.p, ncl, pmask, k1, v1);
+          hipLaunchKernelGGL(k_csort_medium, dim3(2048), dim3(256), 0, stream(), (const uint64_t *) k0, (const uint32_t *) v0,
+                             (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p, pmask, k1, v1);
+          HIP_CHECK(hipGetLastError());
+          unsigned int hc[2] = {0, 0};
+          copy_d2h(hc, cnt.p, 2 * sizeof(unsigned int), 1);
+          if (hc[1] > 0)
+            { // repeat piles: the radix sort on each one's own range (sorted data must end in the k1/v1 side)
+              std::vector<uint32_t> big(hc[1]), gs((size_t) ncl + 1);
+              copy_d2h(big.data(), blist.p, sizeof(uint32_t) * hc[1]);
+              copy_d2h(gs.data(), R.gstart.p, sizeof(uint32_t) * ((size_t) ncl + 1));
+              for (uint32_t c : big)
+                { const int64_t b0 = gs[c], bn = (int64_t) gs[c + 1] - b0;
+                  uint64_t *sk = k0 + b0, *ok = k1 + b0;
+                  uint32_t *sv = v0 + b0, *ov = v1 + b0;
+                  radix_sort_pairs(&sk, &sv, &ok, &ov, bn, 0, R.pbits, st.sort, "pile_sort");
+                  if (sk != k1 + b0)
+                    { HIP_CHECK(hipMemcpyAsync(k1 + b0, sk, sizeof(uint64_t) * bn, hipMemcpyDeviceToDevice, stream()));
+                      HIP_CHECK(hipMemcpyAsync(v1 + b0, sv, sizeof(uint32_t) * bn, hipMemcpyDeviceToDevice, stream()));
+                    }
+                }
+            }
+          std::swap(k0, k1);
+          std::swap(v0, v1);
+        }
       { StageTimer tm("seed_pairs", 0.0);
         R.cog.ensure((size_t) ncl + 2, "pair of cluster");
         R.ocfirst.ensure((size_t) ncl + 2, "first cluster of pair");
