@@ -1324,6 +1324,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "chain_small") == 0) st.opt_chain_small = value;
   else if (strcmp(key, "chain_lane") == 0)  st.opt_chain_lane = value;
   else if (strcmp(key, "batch") == 0)       st.opt_batch = value;
+  else if (strcmp(key, "expand") == 0)      st.opt_expand = value;
   else if (strcmp(key, "cluster_sort") == 0) st.opt_cluster_sort = value;
   else return -1;
   return 0;

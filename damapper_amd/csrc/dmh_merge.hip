@@ -377,6 +377,69 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
     }
 }
 
+// Expansion by OUTPUT tiles: a workgroup writes EX_TILE consecutive hits, consecutive threads consecutive slots
+// (the entry-per-thread kernels above write every entry's pairs from one thread: 3 bytes of HBM traffic per byte of
+// hits).  The tile's entries are found by two searches in the offsets, their offsets go to LDS, every slot then finds
+// its entry there.  Zero-sized entries (runs at or above the limit) simply never contain a slot.
+constexpr int EX_TILE = 2048;
+constexpr int EX_OFFS = 2 * EX_TILE + 2;
+
+__global__ __launch_bounds__(256) void k_merge_expand_tiled(const MergeEntry *__restrict__ entries, uint32_t nent,
+                                                            const uint32_t *__restrict__ eoff,
+                                                            const uint32_t *__restrict__ avals,
+                                                            const uint32_t *__restrict__ bvals,
+                                                            PosMap MA, PosMap MB, int bshift, int pshift, int swap,
+                                                            uint64_t passor, uint64_t *__restrict__ hkeys,
+                                                            uint32_t *__restrict__ hvals)
+{ __shared__ uint32_t s_off[EX_OFFS];
+  __shared__ uint32_t s_e[2];
+  const uint32_t total = eoff[nent];
+  const uint32_t o0 = blockIdx.x * (uint32_t) EX_TILE;
+  if (o0 >= total) return;
+  const uint32_t o1 = (total - o0 < (uint32_t) EX_TILE) ? total : o0 + (uint32_t) EX_TILE;     // one past the tile's last slot
+  if (threadIdx.x < 2)
+    { // last entry whose offset is <= o0 (thread 0) / <= o1 - 1 (thread 1)
+      const uint32_t o = threadIdx.x == 0 ? o0 : o1 - 1;
+      uint32_t lo = 0, hi = nent;              // invariant: eoff[lo] <= o, eoff[hi] > o  (eoff[0] = 0, eoff[nent] = total > o)
+      while (hi - lo > 1)
+        { const uint32_t m = (lo + hi) >> 1;
+          if (eoff[m] <= o) lo = m; else hi = m;
+        }
+      s_e[threadIdx.x] = lo;
+    }
+  __syncthreads();
+  const uint32_t e_lo = s_e[0], ne = s_e[1] - s_e[0] + 1;
+  const bool     inlds = ne + 1 <= (uint32_t) EX_OFFS;
+  if (inlds)
+    for (uint32_t i = threadIdx.x; i <= ne; i += 256) s_off[i] = eoff[e_lo + i];
+  __syncthreads();
+#pragma unroll 2
+  for (int k = 0; k < EX_TILE / 256; k++)
+    { const uint32_t o = o0 + threadIdx.x + 256u * (uint32_t) k;
+      if (o >= o1) break;
+      uint32_t lo = 0, hi = ne;                // last i in [0, ne) with off[i] <= o
+      if (inlds)
+        while (hi - lo > 1)
+          { const uint32_t m = (lo + hi) >> 1;
+            if (s_off[m] <= o) lo = m; else hi = m;
+          }
+      else
+        while (hi - lo > 1)
+          { const uint32_t m = (lo + hi) >> 1;
+            if (eoff[e_lo + m] <= o) lo = m; else hi = m;
+          }
+      const uint32_t   e  = e_lo + lo;
+      const MergeEntry en = entries[e];
+      const uint32_t   t  = o - (inlds ? s_off[lo] : eoff[e]);
+      const uint32_t   a  = t / en.mb, b = t - a * en.mb;
+      uint32_t ar, ap, br, bp;
+      locate(MA, avals[en.a0 + a], ar, ap);
+      locate(MB, bvals[en.b0 + b], br, bp);
+      hkeys[o] = ((uint64_t) ar << bshift) | passor | ((uint64_t) br << pshift) | (uint64_t) (swap ? bp : ap);
+      hvals[o] = swap ? ap : bp;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 //  Group boundaries of the sorted hits: one group per (aread, bread)
 // ---------------------------------------------------------------------------------------
@@ -822,16 +885,23 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
     HIP_CHECK(hipMemcpyAsync(eoff.p, esz.p, sizeof(uint32_t) * nent, hipMemcpyDeviceToDevice, stream()));
     exclusive_scan_u32(eoff.p, nent, st.sort.bsum, eoff.p + nent);
     PosMap MA{A.d_boff, A.d_chunk, A.posbits}, MB{Bx.d_boff, Bx.d_chunk, Bx.posbits};
-    hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
-                       (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
-                       (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0, passor, hk, hv, ebig.p, mctl.p + 1);
-    // the entries of more than BIG_ENTRY pairs, a wavefront each: their number stays on the device (the launch is
-    // sized for the most there can be of them: nhits / BIG_ENTRY)
-    const int64_t maxbig = std::min<int64_t>(nent, nhits / (int64_t) BIG_ENTRY + 1);
-    hipLaunchKernelGGL(k_merge_expand_big, dim3(std::min<int64_t>(ceil_div(maxbig * 64, 256), 65536)), dim3(256), 0, stream(),
-                       (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, (const unsigned int *) (mctl.p + 1),
-                       (const uint32_t *) eoff.p, (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift,
-                       R.clustered ? 1 : 0, passor, hk, hv);
+    static const bool per_entry = getenv("DMH_EXPAND_PER_ENTRY") != nullptr;
+    if (!per_entry && st.opt_expand != 0)
+      hipLaunchKernelGGL(k_merge_expand_tiled, dim3(ceil_div(nhits, EX_TILE)), dim3(256), 0, stream(),
+                         (const MergeEntry *) entries.p, nent, (const uint32_t *) eoff.p, (const uint32_t *) A.vals,
+                         (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0, passor, hk, hv);
+    else
+      { hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
+                           (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
+                           (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0, passor, hk, hv, ebig.p, mctl.p + 1);
+        // the entries of more than BIG_ENTRY pairs, a wavefront each: their number stays on the device (the launch is
+        // sized for the most there can be of them: nhits / BIG_ENTRY)
+        const int64_t maxbig = std::min<int64_t>(nent, nhits / (int64_t) BIG_ENTRY + 1);
+        hipLaunchKernelGGL(k_merge_expand_big, dim3(std::min<int64_t>(ceil_div(maxbig * 64, 256), 65536)), dim3(256), 0, stream(),
+                           (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, (const unsigned int *) (mctl.p + 1),
+                           (const uint32_t *) eoff.p, (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift,
+                           R.clustered ? 1 : 0, passor, hk, hv);
+      }
     HIP_CHECK(hipGetLastError());
     static const bool check = getenv("DMH_CHECK_EMIT") != nullptr;
     if (check)
