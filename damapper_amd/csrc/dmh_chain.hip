@@ -1317,7 +1317,10 @@ __global__ void k_big_groups(const uint32_t *__restrict__ gstart, uint32_t ngrou
       if (mm) bm = atomicAdd(nmlist, (uint32_t) __popcll(mm));
     }
   bp = __shfl(bp, 0); bb = __shfl(bb, 0); bm = __shfl(bm, 0);
-  if (isp) plist[bp + (uint32_t) __popcll(mp & lt)] = g;
+  if (isp)
+    { plist[bp + (uint32_t) __popcll(mp & lt)] = g;
+      atomicAdd(nplist + 2, sz);                 // (counts[3]: hits in piles, for the stage timer's algorithmic bytes)
+    }
   if (isb) list[bb + (uint32_t) __popcll(mb & lt)] = g;
   if (ism) mlist[bm + (uint32_t) __popcll(mm & lt)] = g;
 }
@@ -1363,11 +1366,12 @@ void chain_classify_groups(MergeResult &R)
                      R.pile_min > 0 ? R.pile_min : 0xffffffffu, R.medlist.p, R.gcounts.p + 2, R.biglist.p, R.gcounts.p,
                      R.pilelist.p, R.gcounts.p + 1);
   HIP_CHECK(hipGetLastError());
-  uint32_t cnt[3] = {0, 0, 0};
-  copy_d2h(cnt, R.gcounts.p, 3 * sizeof(uint32_t));
+  uint32_t cnt[4] = {0, 0, 0, 0};
+  copy_d2h(cnt, R.gcounts.p, 4 * sizeof(uint32_t));
   R.nbig   = cnt[0];
   R.npiles = cnt[1];
   R.nmed   = cnt[2];
+  R.pile_hits = cnt[3];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1517,7 +1521,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock)
               }
             HIP_CHECK(hipEventRecord(ev_go, stream()));
             HIP_CHECK(hipStreamWaitEvent(pstream, ev_go, 0));
-            { StageTimer t0("chain_piles", 0.0, pstream);
+            { StageTimer t0("chain_piles", 16.0 * R.pile_hits, pstream);
               hipLaunchKernelGGL(k_chain_pile, dim3(std::min<uint32_t>(R.npiles, 256)), dim3(PILE_THREADS), 0, pstream, P);
             }
             HIP_CHECK(hipEventRecord(ev_done, pstream));

@@ -38,7 +38,7 @@ struct MergeResult
   // (list of the one-wavefront-per-group launch; windows that outgrow LDS are appended later) and repeat
   // piles of >= pile_min hits (one workgroup each)
   DevBuf<uint32_t> biglist, pilelist, medlist, gcounts;  // gcounts[0] = length of biglist, [1] = of pilelist, [2] = of medlist (device)
-  uint32_t small_hi = 0xffffffffu, pile_min = 0, npiles = 0, nbig = 0, nmed = 0;
+  uint32_t small_hi = 0xffffffffu, pile_min = 0, npiles = 0, nbig = 0, nmed = 0, pile_hits = 0;
   uint32_t lane_max = 0;                       // > 0: groups of up to this many hits try the lane-per-group kernel first
   uint32_t small_cap = 0;                      // groups of up to this many hits go to the all-LDS kernel
   bool     classified = false;
