@@ -106,6 +106,7 @@ constexpr int MG_ITEMS   = 8;
 constexpr int MG_TILE    = MG_THREADS * MG_ITEMS;
 
 struct MergeEntry { uint32_t a0, ma, b0, mb; };
+constexpr uint32_t PENDING = 0xffffffffu;     // mb of an entry whose REF run has still to be searched for
 
 template <int NK, bool LOW>
 __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__restrict__ akeys, int64_t na,
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
         { const uint32_t sz = be[j] - bs[j];
           const uint64_t cc = c[j];
           if (sz > (uint32_t) NK && kk[NK - 1][j] <= cq)
-            b_range(B, cc, lo, mb);
+            mb = PENDING;            // a long bucket: searched by k_merge_fixup, where every lane has such a look-up
           else
             {
 #pragma unroll
@@ -196,7 +197,9 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
                     mb += 1;
                   }
             }
-          if (mb != 0)
+          if (mb == PENDING)
+            { e = i; hit = true; }                 // (entry {i, 0, 0, PENDING}: no hits counted yet)
+          else if (mb != 0)
             { e   = (i + 1 < na && akeys[i + 1] == cc) ? run_end(akeys, na, i) : i + 1;
               ct  = (unsigned long long) (e - i) * mb;
               hit = true;
@@ -242,6 +245,53 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
   MergeEntry *dst = tile_entries + (size_t) blockIdx.x * MG_TILE;
   for (uint32_t x = tid; x < cnt; x += MG_THREADS)
     dst[x] = stage[x];
+}
+
+// The look-ups k_merge_match left open: codes that fall into a LONG bucket of the REF index (a repeat's k-mer and its
+// copies, or a neighbour of one).  Searching such a bucket is a chain of dependent loads; inside k_merge_match a
+// wavefront paid for it whenever one of its 64 x 8 look-ups needed it (most wavefronts on a repeat-rich reference,
+// three quarters of the kernel's cycles).  Here the open look-ups of a tile lie side by side in the tile's entry
+// window, so the lanes that search are many.  An entry without partners stays in the list with zero size.
+template <bool LOW>
+__global__ __launch_bounds__(256) void k_merge_fixup(const uint64_t *__restrict__ akeys, int64_t na, BLookup B,
+                                                     MergeEntry *__restrict__ tile_entries,
+                                                     const uint32_t *__restrict__ tile_count,
+                                                     unsigned long long *__restrict__ tile_hits)
+{ __shared__ unsigned long long sh[2][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t cnt = tile_count[blockIdx.x];
+  MergeEntry *ent = tile_entries + (size_t) blockIdx.x * MG_TILE;
+  unsigned long long local = 0, below = 0;
+  for (uint32_t x = tid; x < cnt; x += 256)
+    { MergeEntry en = ent[x];
+      if (en.mb != PENDING) continue;
+      const int64_t  i = en.a0;
+      const uint64_t c = akeys[i];
+      uint32_t lo = 0, mb = 0;
+      b_range(B, c, lo, mb);
+      if (mb != 0)
+        { const int64_t e = (i + 1 < na && akeys[i + 1] == c) ? run_end(akeys, na, i) : i + 1;
+          const unsigned long long ct = (unsigned long long) (e - i) * mb;
+          en.ma = (uint32_t) (e - i); en.b0 = lo; en.mb = mb;
+          local += ct;
+          if (ct < (unsigned long long) MAXGRAM) below += ct;
+        }
+      else
+        { en.ma = 0; en.b0 = 0; en.mb = 0; }
+      ent[x] = en;
+    }
+  for (int o = 32; o > 0; o >>= 1)
+    { local += __shfl_down(local, o);
+      below += __shfl_down(below, o);
+    }
+  if (lane == 0) { sh[0][tid >> 6] = local; sh[1][tid >> 6] = below; }
+  __syncthreads();
+  if (tid == 0)
+    { const unsigned long long a = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+      if (a) tile_hits[2 * (size_t) blockIdx.x]     += a;
+      if (b) tile_hits[2 * (size_t) blockIdx.x + 1] += b;
+    }
+  (void) LOW;
 }
 
 // tile_count has been scanned in place (exclusive): copy every tile's entries to its place in the list
@@ -756,6 +806,8 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
     else
       hipLaunchKernelGGL((k_merge_match<2, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
                          (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
+    hipLaunchKernelGGL((k_merge_fixup<true>), dim3(ntiles), dim3(256), 0, stream(), (const uint64_t *) A.keys, A.n, BL,
+                       tentries.p, (const uint32_t *) tcount.p, thits.p);
     hipLaunchKernelGGL(k_merge_reduce, dim3(64), dim3(256), 0, stream(), (const unsigned long long *) thits.p, ntiles, sums);
     exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
     HIP_CHECK(hipGetLastError());
