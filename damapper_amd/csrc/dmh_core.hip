@@ -685,11 +685,13 @@ static int ceil_log2_i(int64_t x)
   return b;
 }
 
-// (queued behind the index's last sort / compaction stage, on the main stream)
-void index_pack_positions(IndexDev &ix, int maxlen)
-{ const int pb = ceil_log2_i(maxlen > 1 ? (int64_t) maxlen + 1 : 2), rb = ceil_log2_i(ix.nreads > 1 ? ix.nreads : 1);
+// Done by the merge for an index that will be merged against more than a couple of times: a retained or cached REF
+// index, a READS index from its third pass on (the conversion costs about as much as two passes save).
+void index_pack_positions(IndexDev &ix)
+{ const int maxlen = ix.maxlen;
+  const int pb = ceil_log2_i(maxlen > 1 ? (int64_t) maxlen + 1 : 2), rb = ceil_log2_i(ix.nreads > 1 ? ix.nreads : 1);
   static const bool off = getenv("DMH_NO_PACKED_POS") != nullptr;
-  if (off || pb + rb > 32 || ix.n <= 0) return;
+  if (off || ix.posbits > 0 || ix.pending || maxlen <= 0 || pb + rb > 32 || ix.n <= 0) return;
   hipLaunchKernelGGL(k_pack_positions, dim3(ceil_div(ix.n, 256)), dim3(256), 0, stream(), ix.vals, ix.n,
                      (const int64_t *) ix.d_boff, (const uint32_t *) ix.d_chunk, pb);
   HIP_CHECK(hipGetLastError());
@@ -831,6 +833,7 @@ void release_ref_index(IndexDev &ix)
     { free_index(ix);                        // no room (everything else is in use)
       return;
     }
+  index_pack_positions(ix);                  // it will be merged against again
   st.ref_cached.push_front(ix);
   st.ref_cache_bytes += bytes;
   ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr; ix.d_bstart = nullptr;
@@ -852,7 +855,7 @@ struct SortJob
   int       Kshift, npass;
   int       stage;              // index into the stage list (see bg_step)
   const DAZZ_DB *block;         // emit stage: the block whose device copy is read
-  int       Kmer, maxlen;
+  int       Kmer;
 };
 static std::deque<SortJob> g_bg;
 
@@ -937,7 +940,6 @@ static void bg_step()
     { auto it = st.indices.find(J.id);
       if (it == st.indices.end()) fatal("deferred index build lost its index");
       adopt_sorted(it->second, st.sort_aux, J.keys, J.vals, J.k0, J.v0, J.kmers0, J.kmers);
-      index_pack_positions(it->second, J.maxlen);
       it->second.pending = false;
       g_bg.pop_front();
     }
@@ -1020,6 +1022,7 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
   ix.L      = L;
   memcpy(ix.ckey, ckey, sizeof(ckey));
   ix.cacheable = (ckey[3] != 0);
+  ix.maxlen = maxrl;
   ix.h_boff.resize(nreads + 1);
   for (int i = 0; i <= nreads; i++) ix.h_boff[i] = block->reads[i].boff;
 
@@ -1125,7 +1128,6 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
       hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
                          (const int64_t *) ix.d_boff, nreads, ix.nchunk, ix.d_chunk);
       HIP_CHECK(hipGetLastError());
-      if (kmers > 0) index_pack_positions(ix, maxrl);
     }
   // no synchronisation here: every later use of the index is ordered on the same stream, and a
   // driver may queue more work (e.g. the next block's Reporter) behind the sort right away
@@ -1159,7 +1161,6 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
       J.stage = 0;
       J.block = block;
       J.Kmer  = pm.Kmer;
-      J.maxlen = maxrl;
       g_bg.push_back(J);
       if (kmers <= 1) bg_flush();
     }

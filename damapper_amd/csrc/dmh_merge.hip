@@ -923,6 +923,10 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
   const int pshift = lowbits, bshift = lowbits + R.bbits + R.passbits;
   const uint64_t passor = (uint64_t) R.npass << (lowbits + R.bbits);
 
+  // positions as (read, rpos) words for indices that keep being merged against (dmh_core.hip index_pack_positions)
+  if (st.retain_ref && !Bx.borrowed) index_pack_positions(Bx);          // (a cached index is packed when it enters the cache)
+  if (st.mf_calls >= 3) index_pack_positions(A);
+
   // --- expand the entries under the limit into hits (map.c:3095-3099), behind the batch's earlier passes
   static DevBuf<uint32_t> esz, eoff, ebig;
   esz.ensure((size_t) nent + 1, "entry sizes");

@@ -43,6 +43,7 @@ struct IndexDev
   uint32_t *vals   = nullptr;   // base offset q of the k-mer's last base inside the block -- or, once the index is
                                 //   complete and posbits > 0, (read << posbits) | rpos: what the merge turns into hits
   int       posbits = 0;
+  int       maxlen  = 0;        // longest read of the block (for the packing above)
   int64_t  *d_boff = nullptr;   // nreads+1 read offsets (device)
   uint32_t *d_chunk = nullptr;  // read index of position (c << CHUNK_SHIFT), c = 0..nchunk-1
   int64_t   nchunk = 0;
@@ -179,5 +180,6 @@ void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nre
 IndexDev *index_of(void *table, const char *who);
 void      release_ref_index(IndexDev &ix);    // Match_Filter is done with a REF index: cache it or free it
 void      index_wait_ready(IndexDev &ix);     // queue what is left of a deferred build
+void      index_pack_positions(IndexDev &ix); // vals -> (read, rpos) words, when they fit (once per index)
 
 }  // namespace dmh
