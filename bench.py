@@ -338,8 +338,8 @@ def main():
             if not v or v["launches"] <= 0 or v["ms"] <= 0 or v["bytes"] <= 0:
                 return None
             achieved = v["bytes"] / (v["ms"] * 1e-3) / 1e9          # GB/s, algorithmic bytes
-            r = {"bound": "hbm", "kernel": STAGE_KERNEL.get(name, name), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            r = {"bound": "hbm", "kernel": STAGE_KERNEL.get(name, name), "achieved": round(achieved, 4 if achieved < 10 else 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": float("%.3g" % (achieved / HBM_PEAK_GBS)), "traffic": None,
                  "launches": int(v["launches"]), "avg_ms": round(v["ms"] / v["launches"], 4),
                  "alg_bytes_per_launch": v["bytes"] / v["launches"],
                  "share_of_gpu_time": round(v["ms"] / gpu_ms, 3) if gpu_ms > 0 else None}
