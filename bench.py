@@ -36,7 +36,6 @@ import sys
 import tempfile
 import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -252,7 +252,6 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
 // wavefront paid for it whenever one of its 64 x 8 look-ups needed it (most wavefronts on a repeat-rich reference,
 // three quarters of the kernel's cycles).  Here the open look-ups of a tile lie side by side in the tile's entry
 // window, so the lanes that search are many.  An entry without partners stays in the list with zero size.
-template <bool LOW>
 __global__ __launch_bounds__(256) void k_merge_fixup(const uint64_t *__restrict__ akeys, int64_t na, BLookup B,
                                                      MergeEntry *__restrict__ tile_entries,
                                                      const uint32_t *__restrict__ tile_count,
@@ -291,7 +290,6 @@ __global__ __launch_bounds__(256) void k_merge_fixup(const uint64_t *__restrict_
       if (a) tile_hits[2 * (size_t) blockIdx.x]     += a;
       if (b) tile_hits[2 * (size_t) blockIdx.x + 1] += b;
     }
-  (void) LOW;
 }
 
 // tile_count has been scanned in place (exclusive): copy every tile's entries to its place in the list
@@ -806,7 +804,7 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
     else
       hipLaunchKernelGGL((k_merge_match<2, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
                          (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
-    hipLaunchKernelGGL((k_merge_fixup<true>), dim3(ntiles), dim3(256), 0, stream(), (const uint64_t *) A.keys, A.n, BL,
+    hipLaunchKernelGGL(k_merge_fixup, dim3(ntiles), dim3(256), 0, stream(), (const uint64_t *) A.keys, A.n, BL,
                        tentries.p, (const uint32_t *) tcount.p, thits.p);
     hipLaunchKernelGGL(k_merge_reduce, dim3(64), dim3(256), 0, stream(), (const unsigned long long *) thits.p, ntiles, sums);
     exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
