@@ -10,7 +10,13 @@ void chain_reset_reads(const DAZZ_DB *ablock);
 // map.c:1463-1922: score the chains of every (read, contig) group of the sorted hits, apply the
 // per-read domination rule and store the surviving candidates.  Returns the change in the number
 // of candidates (the reference's nfilt).
-int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock);
+//   chain_submit queues the chain kernels of a batch (repeat piles on a stream of their own) and returns;
+//   chain_finish waits for them and does the rest -- reporting order, domination rule, -p deltas, Jump lists.
+// Batches are finished in the order they were submitted (the candidate lists carry over from one to the next), but a
+// few of them may be in flight: a pile is a sequential walk of tens of milliseconds on ONE workgroup, and the
+// merge, sorts and chain kernels of the following passes do not depend on it.
+void    chain_submit(MergeResult &R, const DAZZ_DB *ablock);
+int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock);
 
 // Brings State::reads (the host view of the candidate lists: list order, -p deltas) up to date with the
 // device lists; with_jumps also fetches every candidate's Jump list.

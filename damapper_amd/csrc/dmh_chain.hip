@@ -1394,9 +1394,7 @@ namespace dmh {
 void chain_reset_reads(const DAZZ_DB *ablock)
 { State &st = S();
   CandStore &cs = st.cands;
-  { MergeResult &R = filter_batch();        // hits of a block that never reached Reporter
-    R.open = false; R.nhits = 0; R.npass = 0;
-  }
+  filter_discard();                         // hits of a block that never reached Reporter
   const int n = ablock->nreads;
   st.cur_reads = ablock;
   st.reads.clear();
@@ -1433,17 +1431,31 @@ void chain_reset_reads(const DAZZ_DB *ablock)
     ablock->reads[i].coff = -1;
 }
 
-int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock)
+// Everything the chain stage of one batch keeps between chain_submit and chain_finish
+struct ChainCtx
+{ DevBuf<int32_t>  cost, bestcost;
+  DevBuf<uint32_t> from, rootof, best, state, tmp, ctl, gcnt, gbase, pileretry;
+  DevBuf<uint4>    livebuf;
+  DevBuf<ChainSummary> out;
+  ChainArgs  A;
+  hipEvent_t piles_done = nullptr;
+  bool       has_piles = false, all64 = false;
+};
+
+void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
 { State &st = S();
   const Params &pm = st.params;
   if (st.cur_reads != ablock || st.cands.nreads != ablock->nreads)
     fatal("Match_Filter: first call for a READS block must have start != 0 (map.c:1574)");
+  if (R.cc == nullptr) R.cc = new ChainCtx();
+  ChainCtx &C = *R.cc;
+  DevBuf<int32_t>  &cost = C.cost, &bestcost = C.bestcost;
+  DevBuf<uint32_t> &from = C.from, &rootof = C.rootof, &best = C.best, &state = C.state, &tmp = C.tmp, &ctl = C.ctl;
+  DevBuf<uint32_t> &gcnt = C.gcnt, &gbase = C.gbase, &pileretry = C.pileretry;
+  DevBuf<uint4>    &livebuf = C.livebuf;
+  DevBuf<ChainSummary> &out = C.out;
 
   const int64_t nhits = R.nhits;
-  static DevBuf<int32_t>  cost, bestcost;
-  static DevBuf<uint32_t> from, rootof, best, state, tmp, ctl;
-  static DevBuf<uint4>    livebuf;
-  static DevBuf<ChainSummary> out;
   cost.ensure(nhits, "chain cost");
   from.ensure(nhits, "chain from");
   rootof.ensure(nhits, "chain origin");
@@ -1454,13 +1466,12 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock)
   tmp.ensure(nhits, "chain scratch");
   ctl.ensure(8, "chain counters");
   out.ensure(nhits / HITMIN + 64, "chain summaries");
-  static DevBuf<uint32_t> gcnt, gbase;
   gcnt.ensure((size_t) R.ngroups + 1, "chain ends per group");
   gbase.ensure((size_t) R.ngroups + 1, "first chain end per group");
   HIP_CHECK(hipMemsetAsync(ctl.p, 0, 8 * sizeof(uint32_t), stream()));
   HIP_CHECK(hipMemsetAsync(gcnt.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
 
-  ChainArgs A;
+  ChainArgs &A = C.A;
   A.keys = R.skeys;
   A.vals = R.svals;
   A.gstart = R.gstart.p;
@@ -1498,7 +1509,6 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock)
       { const int gpb = 256 / gsmall;
         (void) gpb;
         hipEvent_t piles_done = nullptr;
-        static DevBuf<uint32_t> pileretry;
         if (R.npiles > 0)
           { // the piles first: they are the longest jobs of the pass.  (Launched only when there are any:
             // a workgroup wants nearly all of a CU's LDS and would wait for whatever else holds some.)
@@ -1513,12 +1523,13 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock)
             // on a stream of their own, next to the other two launches; piles whose window outgrows LDS are
             // listed for a last 64-lane launch behind everything
             static hipStream_t pstream = nullptr;
-            static hipEvent_t  ev_go = nullptr, ev_done = nullptr;
+            static hipEvent_t  ev_go = nullptr;
+            hipEvent_t &ev_done = C.piles_done;
             if (pstream == nullptr)
               { HIP_CHECK(hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking));
                 HIP_CHECK(hipEventCreateWithFlags(&ev_go, hipEventDisableTiming));
-                HIP_CHECK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
               }
+            if (ev_done == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(ev_go, stream()));
             HIP_CHECK(hipStreamWaitEvent(pstream, ev_go, 0));
             { StageTimer t0("chain_piles", 16.0 * R.pile_hits, pstream);
@@ -1579,14 +1590,7 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock)
           StageTimer t2("chain_listed_groups", 0.0);
           hipLaunchKernelGGL(k_chain<64>, dim3(lblocks), dim3(256), 0, stream(), A);
         }
-        if (piles_done != nullptr)
-          { HIP_CHECK(hipStreamWaitEvent(stream(), piles_done, 0));
-            A.ticket = ctl.p + 7;
-            A.only   = pileretry.p;
-            A.nonly  = ctl.p + 6;
-            StageTimer t3("chain_spilled_piles", 0.0);
-            hipLaunchKernelGGL(k_chain<64>, dim3(std::min<uint32_t>((R.npiles + 3) / 4, 256)), dim3(256), 0, stream(), A);
-          }
+        C.has_piles = (piles_done != nullptr);
       }
     else
       { int nblocks = (int) std::min<int64_t>((R.ngroups + 3) / 4, 256 * 8);
@@ -1595,6 +1599,27 @@ int64_t chain_and_filter(MergeResult &R, const DAZZ_DB *ablock)
       }
     HIP_CHECK(hipGetLastError());
   }
+}
+
+int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
+{ State &st = S();
+  ChainCtx &C = *R.cc;
+  ChainArgs A = C.A;
+  DevBuf<uint32_t> &from = C.from, &ctl = C.ctl, &gcnt = C.gcnt, &gbase = C.gbase, &pileretry = C.pileretry;
+  DevBuf<ChainSummary> &out = C.out;
+  const int64_t nhits = R.nhits;
+  if (C.has_piles)
+    { // piles whose window outgrew the workgroup kernel's LDS: a last 64-lane launch (the piles have had the time of
+      // the batches submitted since to finish)
+      HIP_CHECK(hipStreamWaitEvent(stream(), C.piles_done, 0));
+      A.ticket = ctl.p + 7;
+      A.only   = pileretry.p;
+      A.nonly  = ctl.p + 6;
+      StageTimer t3("chain_spilled_piles", 0.0);
+      hipLaunchKernelGGL(k_chain<64>, dim3(std::min<uint32_t>((R.npiles + 3) / 4, 256)), dim3(256), 0, stream(), A);
+      HIP_CHECK(hipGetLastError());
+      C.has_piles = false;
+    }
   // chain ends per group -> first slot of every group's ends in the reference's order, and their number
   const uint32_t ng = (uint32_t) R.ngroups;
   static DevBuf<uint32_t> goff;

@@ -1226,10 +1226,7 @@ void dmh_reset(void)
   st.blocks.clear();
   st.reads.clear();
   st.cur_reads = nullptr;
-  { MergeResult &R = filter_batch();
-    R.open = false; R.nhits = 0; R.npass = 0;
-    R.keys.release(); R.vals.release();
-  }
+  filter_discard();
   { CandStore &cs = st.cands;
     for (int i = 0; i < 2; i++) { cs.pool[i].release(); cs.seg_off[i].release(); cs.seg_len[i].release(); }
     cs.jumps.release(); cs.cover.release(); cs.cov_off.release(); cs.ctl.release();
@@ -1326,6 +1323,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "chain_lane") == 0)  st.opt_chain_lane = value;
   else if (strcmp(key, "batch") == 0)       st.opt_batch = value;
   else if (strcmp(key, "expand") == 0)      st.opt_expand = value;
+  else if (strcmp(key, "in_flight") == 0)   st.opt_in_flight = value;
   else if (strcmp(key, "cluster_sort") == 0) st.opt_cluster_sort = value;
   else return -1;
   return 0;

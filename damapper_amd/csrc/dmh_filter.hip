@@ -14,8 +14,6 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
                   int comp, int start)
 { State &st = S();
   Params &pm = st.params;
-  MergeResult &R = filter_batch();
-
   int64_t nhits = 0, nfilt = 0;
   if (start)
     { HostTimer ht("mf_reset_reads");
@@ -31,7 +29,7 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
       index_wait_ready(*A);
       index_wait_ready(*B);
       st.mf_calls += 1;
-      nhits = merge_pass(R, ablock, bblock, *A, *B, pm.Kshift, comp, &nfilt);
+      nhits = merge_pass(ablock, bblock, *A, *B, pm.Kshift, comp, &nfilt);
       st.tfilt += nfilt;
     }
 

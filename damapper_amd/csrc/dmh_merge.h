@@ -11,8 +11,13 @@ constexpr int MAXPASS = 32;        // Match_Filter passes one batch can hold (5 
 // the batch is sorted, chained and put through the domination rule in one go when it is closed (filter_flush:
 // the hit budget is reached, Reporter starts, or somebody looks at the candidates).  Passes are walked in call
 // order per read, so the result is what the calls would have produced one by one (map.c:2889-3209).
+struct ChainCtx;                   // the chain stage's per-batch buffers (dmh_chain.hip)
+
 struct MergeResult
 { bool    open    = false;       // a batch is being collected: the key layout below is fixed
+  ChainCtx *cc    = nullptr;
+  DevBuf<uint64_t> alt_keys;     // sort partner of keys / vals (the sorted hits may end up here)
+  DevBuf<uint32_t> alt_vals;
   const DAZZ_DB *ablock = nullptr;
   int     npass   = 0, passbits = 0, qbits = 0;
   struct { int bbase, comp; } pass[MAXPASS];
@@ -50,11 +55,13 @@ void chain_classify_groups(MergeResult &R);
 // One Match_Filter pass up to the expanded hits (map.c:2984-3099): returns the number of hits it added.  May close the
 // batch first (when the pass does not fit it) and closes it afterwards unless batching is on; *nfilt accumulates the
 // change in the number of candidates of whatever was closed.
-int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &B,
+int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &B,
                    int Kshift, int comp, int64_t *nfilt);
 
-// Sort, group, chain and filter what the batch holds (no-op when it is empty); returns the change in candidates.
+// Sort, group, chain and filter what the batch holds and everything still in flight (no-op when there is nothing);
+// returns the change in candidates.
 int64_t filter_flush();
+void    filter_discard();          // forget the batches of a READS block that never reached Reporter
 MergeResult &filter_batch();
 
 }  // namespace dmh

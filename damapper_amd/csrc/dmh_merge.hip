@@ -14,6 +14,7 @@
 #include "dmh_merge.h"
 #include "dmh_chain.h"
 #include <algorithm>
+#include <deque>
 #include <type_traits>
 
 namespace dmh {
@@ -726,19 +727,27 @@ static int64_t sizeof_db(const DAZZ_DB *db)
   return s;
 }
 
-MergeResult &filter_batch()
-{ static MergeResult R;
-  return R;
-}
+// The batches: one being collected (ring[cur]) and up to IN_FLIGHT submitted ones whose chain kernels -- repeat piles
+// above all -- are still running while later passes are merged, sorted and chained.  They are finished in order.
+constexpr int IN_FLIGHT = 3;
+constexpr int NRING = IN_FLIGHT + 2;
+static MergeResult g_ring[NRING];
+static int         g_cur = 0;
+static std::deque<int> g_inflight;
+
+MergeResult &filter_batch() { return g_ring[g_cur]; }
 
 // hits a batch may collect before it is closed (68 B of HBM per hit through the sort and the chain kernels)
 constexpr int64_t BATCH_CAP = (int64_t) 160 << 20;
 
-static int64_t close_batch(MergeResult &R);
+static void    close_batch(MergeResult &R);
+static int64_t finish_oldest();
 
-int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &Bx,
+int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &Bx,
                    int Kshift, int comp, int64_t *nfilt)
 { State &st = S();
+  MergeResult *Rp = &filter_batch();
+#define R (*Rp)
   HostTimer ht("merge_and_sort");
 
   // --- bucket table over the REF index: part of the index, built the first time it is merged against
@@ -900,7 +909,9 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
   const bool batching = !cluster && !VERBOSE && !st.capture_seeds && (st.opt_batch >= 0 ? st.opt_batch != 0 : env_batch != 0);
   if (R.open && (cluster || !batching || R.ablock != ablock || R.npass >= MAXPASS || R.nhits + nhits > BATCH_CAP ||
                  bbits > R.bbits || pbits != R.pbits || abits != R.abits))
-    *nfilt += close_batch(R);
+    { close_batch(R);
+      Rp = &filter_batch();                  // (the next slot of the ring)
+    }
   if (!R.open)
     { R.open = true;
       R.ablock = ablock;
@@ -969,33 +980,58 @@ int64_t merge_pass(MergeResult &R, const DAZZ_DB *ablock, const DAZZ_DB *bblock,
   R.pass[R.npass].comp  = comp;
   R.npass += 1;
   R.nhits += nhits;
-  if (!R.passbits) *nfilt += close_batch(R);
+  if (!R.passbits) close_batch(R);
+  // batches in flight: under -v every call reports its own candidate counts, and the stage-level API looks at the
+  // lists after every call -- then nothing stays in flight
+  static const int env_fl = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
+  const int keep = (VERBOSE || st.capture_seeds || st.opt_in_flight == 0) ? 0 : std::min(IN_FLIGHT, std::max(0, env_fl));
+  while ((int) g_inflight.size() > keep) *nfilt += finish_oldest();
   return nhits;
+#undef R
+}
+
+static int64_t finish_oldest()
+{ const int x = g_inflight.front();
+  g_inflight.pop_front();
+  MergeResult &R = g_ring[x];
+  const int64_t nfilt = chain_finish(R, R.ablock);
+  R.nhits = 0;
+  R.npass = 0;
+  return nfilt;
 }
 
 int64_t filter_flush()
 { MergeResult &R = filter_batch();
-  return R.open ? close_batch(R) : 0;
+  if (R.open) close_batch(R);
+  int64_t nfilt = 0;
+  while (!g_inflight.empty()) nfilt += finish_oldest();
+  return nfilt;
 }
 
-// sort, groups, chain scoring, domination rule for everything the batch holds
-static int64_t close_batch(MergeResult &R)
+void filter_discard()
+{ g_inflight.clear();
+  for (int i = 0; i < NRING; i++) { g_ring[i].open = false; g_ring[i].nhits = 0; g_ring[i].npass = 0; }
+}
+
+// sort and groups for everything the batch holds, then its chain kernels are queued (chain_submit) and the batch
+// joins the ones in flight
+static void close_batch(MergeResult &R)
 { State &st = S();
   const int64_t nhits = R.nhits;
   const DAZZ_DB *ablock = R.ablock;
   R.open = false;
-  if (nhits == 0) { R.npass = 0; return 0; }
+  if (nhits == 0) { R.npass = 0; return; }
   HostTimer ht("filter_close");
   const bool cluster = R.clustered;
   const int  qbits = R.qbits;
   const int  lowbits = cluster ? qbits : R.pbits;
   const int  pshift = lowbits;
-  st.sort.keys_alt.ensure(nhits, "seed sort buffer");
-  st.sort.vals_alt.ensure(nhits, "seed sort buffer");
+  R.alt_keys.ensure(nhits, "seed sort buffer");
+  R.alt_vals.ensure(nhits, "seed sort buffer");
 
   // --- seed sort (map.c:3110-3126)
-  uint64_t *k0 = R.keys.p, *k1 = st.sort.keys_alt.p;
-  uint32_t *v0 = R.vals.p, *v1 = st.sort.vals_alt.p;
+  uint64_t *k0 = R.keys.p, *k1 = R.alt_keys.p;
+  uint32_t *v0 = R.vals.p, *v1 = R.alt_vals.p;
   const int cb = cluster ? std::min(CLUSTER_CB, qbits) : 0;          // (the bits below cb of bpos are not sorted on)
   radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, cb, lowbits + R.bbits + R.passbits + R.abits - cb, st.sort, "seed_sort");
 
@@ -1129,10 +1165,18 @@ static int64_t close_batch(MergeResult &R)
             }
         }
     }
-  const int64_t nfilt = chain_and_filter(R, ablock);
-  R.nhits = 0;
-  R.npass = 0;
-  return nfilt;
+  chain_submit(R, ablock);
+  // the batch is in flight; collect the next one in a free slot of the ring
+  int slot = -1;
+  for (int i = 0; i < NRING; i++)
+    if (&g_ring[i] == &R) slot = i;
+  g_inflight.push_back(slot);
+  while ((int) g_inflight.size() > IN_FLIGHT) st.tfilt += finish_oldest();
+  for (int i = 0; i < NRING; i++)
+    { bool busy = false;
+      for (int y : g_inflight) busy = busy || (y == i);
+      if (!busy) { g_cur = i; break; }
+    }
 }
 
 }  // namespace dmh
