@@ -569,7 +569,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
   // the next (10^6 lanes stream at once): 22 GB of HBM traffic per launch against 1.5 GB of data.  A chunk is
   // the lane's next 64 + 32 bytes, requested together; the chunk after it (or the first one of the lane's next
   // group) is on its way while this one is walked.
-  constexpr int CH = 8;
+  constexpr int CH = 4;
   uint64_t kb[CH], nbk[CH];
   uint32_t vb[CH], nbv[CH], fb[CH];
 #pragma unroll
