@@ -139,15 +139,24 @@ void dmh_ref_cache(int on, double max_gb);
 void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
 
 /* Switches between code paths that must give byte-identical results (used by the parity tests to
- * drive every kernel variant): "align_level" 0/1/2 = first rung of the alignment kernel ladder (two
- * candidates per wavefront / one per wavefront with LDS fallback / global-memory band), -1 default;
- * "chain_g" 16/32/64 lanes per chain group, 0 default; "chain_pile" n = groups of >= n hits get a whole
- * workgroup (0 never, -1 default 4096); "pile_cap" n = that kernel may hold n window entries in LDS
- * (forces its spill path; 0 default); "merge_dense" 1/0 = REF bucket table with one bucket per entry
- * and four-key probes / four buckets per entry and two-key probes, 2 = 16 undecided bits per bucket,
- * four-key probes on the 2-byte low-bits array (-1 default: by index size; takes effect for indices
- * built afterwards); "pool_div" n = start with 1/n of the alignment pool (forces the
- * grow-and-retry path).  Returns 0, or -1 for an unknown key.                                          */
+ * drive every kernel variant; -1 / 0 restores the default where not said otherwise):
+ *   "align_level" 0/1/2  first rung of the alignment kernel ladder (two candidates per wavefront / one per
+ *                        wavefront with LDS fallback / global-memory band)
+ *   "chain_g" 16/32/64   lanes per chain group for ALL groups below the pile size (0 default: by group size)
+ *   "chain_lane" 0       no lane-per-group kernel (groups go to the lane-group kernels)
+ *   "chain_small" n      groups of up to n hits take the all-LDS lane-group kernel when chain_lane is off (0 none)
+ *   "chain_pile" n       groups of >= n hits get a whole workgroup (0 never, -1 default 4096); "pile_cap" n = that
+ *                        kernel may hold n window entries in LDS (forces its spill path)
+ *   "cluster" 1/0        chain groups are the B-clusters of an (aread, bread) pair / whole pairs (-1: by hit density)
+ *   "cluster_sort" 0     clusters are ordered by a second global radix sort instead of where they lie
+ *   "batch" 0            every Match_Filter pass is chained by itself (no batches of sparse passes)
+ *   "in_flight" 0        every batch is finished before the next pass starts
+ *   "expand" 0           hits are expanded entry by entry instead of by output tiles
+ *   "merge_dense" 1/0/2  REF bucket table with one bucket per entry and four-key probes / four buckets per entry
+ *                        and two-key probes / 16 undecided bits per bucket, four-key probes on the 2-byte low-bits
+ *                        array (-1: by index size; takes effect for indices built afterwards)
+ *   "pool_div" n         start with 1/n of the alignment pool (forces the grow-and-retry path)
+ * Returns 0, or -1 for an unknown key.                                                                       */
 int dmh_test_option(const char *key, int value);
 
 /* Page-locked host memory for a driver that loads blocks itself: a block whose `bases` live in such
