@@ -39,8 +39,7 @@ struct ChainSummary
 };
 
 struct ChainArgs
-{ const uint64_t *keys;
-  const uint32_t *vals;
+{ const uint64_t *ab;          // the sorted hits, one word each: apos in the low half, bpos in the high half (0-based)
   const uint32_t *gstart;
   uint32_t        ngroups;
   uint64_t        pmask;
@@ -157,8 +156,8 @@ __global__ __launch_bounds__(BLOCK) void k_chain(ChainArgs A)
       bool     spill = false;
 
       for (uint32_t j = g0; j < g1; j++)
-        { const int apos = (int) (A.keys[j] & A.pmask) + 1;       // map.c:1784-1785
-          const int bpos = (int) A.vals[j] + 1;
+        { const int apos = (int) (uint32_t) A.ab[j] + 1;              // map.c:1784-1785
+          const int bpos = (int) (A.ab[j] >> 32) + 1;
           const int diag = apos - bpos;
 
           // ---- expiry (map.c:1787-1796) + neighbour queries (predOf/leftmost/succOf, map.c:1262-1318)
@@ -339,8 +338,8 @@ __global__ __launch_bounds__(BLOCK) void k_chain(ChainArgs A)
 
       for (uint32_t e = lane; e < E; e += G)
         { uint32_t x    = A.tmp[g0 + e];
-          int      ax   = (int) (A.keys[x] & A.pmask) + 1;
-          int      bx   = (int) A.vals[x] + 1;
+          int      ax   = (int) (uint32_t) A.ab[x] + 1;
+          int      bx   = (int) (A.ab[x] >> 32) + 1;
           int      dx   = ax - bx;
           // still in the tree when the PAIR's last hit has been processed (a cluster's own hits may end earlier)
           bool     live_x = (A.state[x] == ST_LIVE) && (A.glast == nullptr || ax >= (int) A.glast[g] - MAX_GAP);
@@ -352,8 +351,8 @@ __global__ __launch_bounds__(BLOCK) void k_chain(ChainArgs A)
           s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax)
                            : (((uint64_t) (uint32_t) ax << 32) | (uint32_t) bx);
           s.cost  = A.cost[x];
-          s.ab    = (int) (A.keys[root] & A.pmask) + 1 - K;
-          s.bb    = (int) A.vals[root] + 1 - K;
+          s.ab    = (int) (uint32_t) A.ab[root] + 1 - K;
+          s.bb    = (int) (A.ab[root] >> 32) + 1 - K;
           s.ae    = ax;
           s.be    = bx;
           s.end   = x;
@@ -396,8 +395,9 @@ __global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_
       const uint32_t n = g1 - g0;
       if (n > size_max) continue;
       for (uint32_t i = lane; i < n; i += G)
-        { ap[i] = (uint32_t) (A.keys[g0 + i] & A.pmask) + 1u;        // map.c:1784-1785
-          bp[i] = A.vals[g0 + i] + 1u;
+        { const uint64_t hb = A.ab[g0 + i];
+          ap[i] = (uint32_t) hb + 1u;        // map.c:1784-1785
+          bp[i] = (uint32_t) (hb >> 32) + 1u;
         }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -571,22 +571,21 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
   // group) is on its way while this one is walked.
   constexpr int CH = 4;
   uint64_t kb[CH], nbk[CH];
-  uint32_t vb[CH], nbv[CH], fb[CH];
+  uint32_t fb[CH];
 #pragma unroll
-  for (int t = 0; t < CH; t++) { kb[t] = 0; nbk[t] = 0; vb[t] = 0; nbv[t] = 0; fb[t] = 0; }
+  for (int t = 0; t < CH; t++) { kb[t] = 0; nbk[t] = 0; fb[t] = 0; }
   int      nb_for = 0;        // the look-ahead chunk holds: 0 nothing, 1 the next chunk of this group, 2 the first chunk of group pg
   // the group after it: pst 1 = look its bounds up, 2 = bounds on their way, 4 = bounds there and fine, 3 = and its first
   // chunk requested, 9 = none left
   uint32_t pg = blockIdx.x * LANE_BLOCK + threadIdx.x, q0 = 0, q1 = 0;
   int      pst = 1;
   const uint32_t hlast = A.nhits - 1;
-  auto load_chunk = [&](uint64_t *ck, uint32_t *cv, uint32_t at)
+  auto load_chunk = [&](uint64_t *ck, uint32_t at)
   {
 #pragma unroll
     for (int t = 0; t < CH; t++)
       { const uint32_t x = (at + t < hlast) ? at + t : hlast;
-        ck[t] = A.keys[x];
-        cv[t] = A.vals[x];
+        ck[t] = A.ab[x];
       }
   };
 
@@ -602,7 +601,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
 #pragma unroll
         for (int s = 0; s < RW; s++)
           if (((vmask >> s) & 1u) && (w_meta[s] & 0xffffffu) == ex) live_x = true;
-        const int last = A.glast ? (int) A.glast[g] : (int) (A.keys[g0 + n - 1] & A.pmask) + 1;
+        const int last = A.glast ? (int) A.glast[g] : (int) (uint32_t) A.ab[g0 + n - 1] + 1;
         live_x = live_x && (int) ea >= last - MAX_GAP;
       }
     ChainSummary sm;
@@ -643,10 +642,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
           if (pst == 3)
             {
 #pragma unroll
-              for (int t = 0; t < CH; t++) { kb[t] = nbk[t]; vb[t] = nbv[t]; }
+              for (int t = 0; t < CH; t++) kb[t] = nbk[t];
             }
           else
-            load_chunk(kb, vb, g0);
+            load_chunk(kb, g0);
           nb_for = 0;
           vmask = 0; tmask = 0;
           pg += nthreads;
@@ -659,20 +658,19 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
       const uint32_t t8 = j & (CH - 1);
       if (nb_for == 0)
         { if ((j & ~(uint32_t) (CH - 1)) + CH < n)           // (asked for when the chunk is entered)
-            { load_chunk(nbk, nbv, g0 + (j & ~(uint32_t) (CH - 1)) + CH);
+            { load_chunk(nbk, g0 + (j & ~(uint32_t) (CH - 1)) + CH);
               nb_for = 1;
             }
           else if (pst == 4)                                 // this is the group's last chunk: the next group's first
-            { load_chunk(nbk, nbv, q0);
+            { load_chunk(nbk, q0);
               nb_for = 2;
               pst = 3;
             }
         }
       uint64_t hk = kb[0];
-      uint32_t hv = vb[0];
 #pragma unroll
-      for (int t = 1; t < CH; t++) { hk = (t8 == (uint32_t) t) ? kb[t] : hk; hv = (t8 == (uint32_t) t) ? vb[t] : hv; }
-      const int apos = (int) (hk & A.pmask) + 1, bpos = (int) hv + 1;
+      for (int t = 1; t < CH; t++) hk = (t8 == (uint32_t) t) ? kb[t] : hk;
+      const int apos = (int) (uint32_t) hk + 1, bpos = (int) (hk >> 32) + 1;
       const int diag = apos - bpos, thresh = bpos - MAX_GAP, old = apos - MAX_GAP;
       // The window scan, written without branches (selects only): the left neighbour is the live hit with the
       // smallest (diagonal, -apos) among those with a larger diagonal and bpos >= bpos - MAX_GAP, the right one the
@@ -776,7 +774,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
           else
             {
 #pragma unroll
-              for (int t = 0; t < CH; t++) { kb[t] = nbk[t]; vb[t] = nbv[t]; }
+              for (int t = 0; t < CH; t++) kb[t] = nbk[t];
               nb_for = 0;
             }
         }
@@ -840,17 +838,15 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
       uint32_t hw = A.pile_cap < 1024u ? A.pile_cap : 1024u;      // compact when the list reaches this length
       bool     spill = false;
       for (int x = tid; x < PILE_BCACHE; x += PILE_THREADS) s_bc[x] = make_uint2(NIL, 0);
-      uint64_t nkey = A.keys[g0];          // the next hit, fetched one round ahead
-      uint32_t nval = A.vals[g0];
+      uint64_t nkey = A.ab[g0];            // the next hit, fetched one round ahead
 
       for (uint32_t j = g0; j < g1; j++)
-        { const int apos = (int) (nkey & A.pmask) + 1;            // map.c:1784-1785
-          const int bpos = (int) nval + 1;
+        { const int apos = (int) (uint32_t) nkey + 1;             // map.c:1784-1785
+          const int bpos = (int) (nkey >> 32) + 1;
           const int diag = apos - bpos;
           const int thresh = bpos - MAX_GAP;
           { const uint32_t jn = (j + 1 < g1) ? j + 1 : j;
-            nkey = A.keys[jn];
-            nval = A.vals[jn];
+            nkey = A.ab[jn];
           }
 
           // ---- expiry (map.c:1787-1796) + neighbour queries (map.c:1262-1318) over the thread's entries
@@ -1027,8 +1023,8 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
                 }
               for (uint32_t e = lane; e < E; e += 64)
                 { uint32_t x    = A.tmp[g0 + e];
-                  int      ax   = (int) (A.keys[x] & A.pmask) + 1;
-                  int      bx   = (int) A.vals[x] + 1;
+                  int      ax   = (int) (uint32_t) A.ab[x] + 1;
+                  int      bx   = (int) (A.ab[x] >> 32) + 1;
                   int      dx   = ax - bx;
                   bool     live_x = (A.state[x] == ST_LIVE) && (A.glast == nullptr || ax >= (int) A.glast[g] - MAX_GAP);
                   uint32_t root = A.rootof[x];
@@ -1038,8 +1034,8 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
                   s.okey  = live_x ? (((uint64_t) ((uint32_t) dx + 0x80000000u) << 32) | (uint32_t) ax)
                                    : (((uint64_t) (uint32_t) ax << 32) | (uint32_t) bx);
                   s.cost  = A.cost[x];
-                  s.ab    = (int) (A.keys[root] & A.pmask) + 1 - K;
-                  s.bb    = (int) A.vals[root] + 1 - K;
+                  s.ab    = (int) (uint32_t) A.ab[root] + 1 - K;
+                  s.bb    = (int) (A.ab[root] >> 32) + 1 - K;
                   s.ae    = ax;
                   s.be    = bx;
                   s.end   = x;
@@ -1255,8 +1251,7 @@ __global__ void k_fresh_list(const DCand *__restrict__ pool, const uint32_t *__r
 // loop map.c:1741-1759): links on one diagonal closer than 100 bp to the last kept point are
 // skipped.  One thread per surviving fresh candidate; pass 0 counts (jlen[c], 0 beyond the list), pass 1
 // writes the pairs at jbase + joff[c] of the jump pool and completes the candidate's record.
-__global__ void k_cand_jumps(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                             uint64_t pmask, const uint32_t *__restrict__ from, DCand *__restrict__ pool,
+__global__ void k_cand_jumps(const uint64_t *__restrict__ ab, const uint32_t *__restrict__ from, DCand *__restrict__ pool,
                              const uint32_t *__restrict__ fresh, const unsigned int *__restrict__ nfresh, uint32_t cap,
                              uint32_t *__restrict__ jlen, const uint32_t *__restrict__ joff, uint16_t *__restrict__ jout,
                              uint32_t jbase, int write)
@@ -1268,16 +1263,15 @@ __global__ void k_cand_jumps(const uint64_t *__restrict__ keys, const uint32_t *
     }
   const uint32_t slot = fresh[c];
   uint32_t x  = pool[slot].end;
-  int      ax = (int) (keys[x] & pmask), bx = (int) vals[x];
+  int      ax = (int) (uint32_t) ab[x], bx = (int) (ab[x] >> 32);
   uint32_t y  = from[x];
   uint32_t cnt = 0;
   uint16_t *o = write ? jout + 2 * ((size_t) jbase + joff[c]) : nullptr;
   while (y != NIL)
     { // the three loads of a step depend on y only: request them together (one round trip per link)
-      const uint64_t ky = keys[y];
-      const uint32_t vy = vals[y];
+      const uint64_t ky = ab[y];
       const uint32_t fy = from[y];
-      int ay = (int) (ky & pmask), by = (int) vy;
+      int ay = (int) (uint32_t) ky, by = (int) (ky >> 32);
       int da = ax - ay, db = bx - by;
       if (!(da == db && da < 100))
         { if (write)
@@ -1472,8 +1466,7 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
   HIP_CHECK(hipMemsetAsync(gcnt.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
 
   ChainArgs &A = C.A;
-  A.keys = R.skeys;
-  A.vals = R.svals;
+  A.ab = R.sab;
   A.gstart = R.gstart.p;
   A.ngroups = (uint32_t) R.ngroups;
   A.nhits = (uint32_t) nhits;
@@ -1690,8 +1683,8 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   { StageTimer tm("chain_jumps", 0.0);
     hipLaunchKernelGGL(k_fresh_list, dim3(ceil_div(nreads, 64)), dim3(64), 0, stream(), (const DCand *) cs.pool[nx].p,
                        (const uint32_t *) cs.seg_off[nx].p, (const uint32_t *) cs.seg_len[nx].p, nreads, fresh.p, cs.ctl.p + 2);
-    hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
-                       (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, cs.pool[nx].p,
+    hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.sab,
+                       (const uint32_t *) from.p, cs.pool[nx].p,
                        (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,
                        (const uint32_t *) nullptr, (uint16_t *) nullptr, 0u, 0);
     HIP_CHECK(hipMemcpyAsync(jl.p + nsum + 1, jl.p, sizeof(uint32_t) * nsum, hipMemcpyDeviceToDevice, stream()));
@@ -1710,8 +1703,8 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
         cs.jumps = nj;
       }
     if (h[2] > 0)
-      hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.skeys,
-                         (const uint32_t *) R.svals, A.pmask, (const uint32_t *) from.p, cs.pool[nx].p,
+      hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.sab,
+                         (const uint32_t *) from.p, cs.pool[nx].p,
                          (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,
                          (const uint32_t *) (jl.p + nsum + 1), cs.jumps.p, (uint32_t) cs.jtop, 1);
     HIP_CHECK(hipGetLastError());

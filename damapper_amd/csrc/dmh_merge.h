@@ -27,8 +27,8 @@ struct MergeResult
   int     pbits = 0, bbits = 0, abits = 0;     // key = aread | bread | apos (high -> low)
   DevBuf<uint64_t> keys;
   DevBuf<uint32_t> vals;
-  uint64_t *skeys = nullptr;                   // sorted hits (either keys/vals or the sort partner)
-  uint32_t *svals = nullptr;                   // value = bpos (0-based last base of the REF k-mer)
+  uint64_t *sab = nullptr;                     // the sorted hits as the chain kernels read them: one word per hit,
+                                               // apos in the low half, bpos (0-based last base of the REF k-mer) in the high
   DevBuf<uint32_t> gstart;                     // ngroups+1 first-hit indices of the groups
   // A group is what one lane group of the chain kernels walks: all hits of an (aread, bread) pair, or -- in
   // cluster mode -- one B-CLUSTER of such a pair: a maximal run of its hits whose bpos values lie at most

@@ -539,7 +539,7 @@ __global__ void k_cluster_flag(const uint64_t *__restrict__ hkeys, int64_t n, in
 // slot[] = exclusive scan of the flags: hit i belongs to cluster slot[i] + flag[i] - 1.  Out of place (the
 // neighbour's key is read): (hkeys, hvals) -> (okeys, ovals).
 __global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32_t *__restrict__ hvals, int64_t n,
-                                int qbits, int cb, int pbits, const uint32_t *__restrict__ slot,
+                                int qbits, int cb, int pbits, int packed, const uint32_t *__restrict__ slot,
                                 uint64_t *__restrict__ okeys, uint32_t *__restrict__ ovals,
                                 uint32_t *__restrict__ gstart, uint32_t ncl, uint64_t *__restrict__ gkey)
 { int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -548,8 +548,12 @@ __global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32
   const uint64_t qm = (1ull << qbits) - 1ull;
   const bool start = (i == 0) || cluster_start(hkeys[i - 1], k, qbits, cb);
   const uint32_t c = slot[i] + (start ? 1u : 0u) - 1u;
-  okeys[i] = ((uint64_t) c << pbits) | (uint64_t) hvals[i];
-  ovals[i] = (uint32_t) (k & qm);
+  if (packed)          // the chain kernels' word: apos | bpos << 32 (the cluster is known from gstart)
+    okeys[i] = (uint64_t) hvals[i] | ((k & qm) << 32);
+  else                 // for the global cluster sort: (cluster, apos) key, bpos value
+    { okeys[i] = ((uint64_t) c << pbits) | (uint64_t) hvals[i];
+      ovals[i] = (uint32_t) (k & qm);
+    }
   if (start)
     { gstart[c] = (uint32_t) i;
       gkey[c]   = k >> qbits;
@@ -567,9 +571,9 @@ __global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32
 constexpr int CS_SMALL  = 64;
 constexpr int CS_MEDIUM = 4096;
 
-__global__ __launch_bounds__(256) void k_csort_small(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
-                                                     const uint32_t *__restrict__ gstart, uint32_t ncl, uint64_t pmask,
-                                                     uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
+__global__ __launch_bounds__(256) void k_csort_small(const uint64_t *__restrict__ kin,
+                                                     const uint32_t *__restrict__ gstart, uint32_t ncl,
+                                                     uint64_t *__restrict__ kout)
 { constexpr int G = 16, GPB = 256 / G, PER = CS_SMALL / G;
   __shared__ uint32_t s_ap[GPB][CS_SMALL];
   const int lane = threadIdx.x & (G - 1), gi = threadIdx.x / G;
@@ -579,14 +583,12 @@ __global__ __launch_bounds__(256) void k_csort_small(const uint64_t *__restrict_
     { const uint32_t g0 = gstart[c], n = gstart[c + 1] - g0;
       if (n > (uint32_t) CS_SMALL) continue;
       uint64_t k[PER];
-      uint32_t v[PER];
 #pragma unroll
       for (int t = 0; t < PER; t++)
         { const uint32_t i = lane + G * t;
           if (i < n)
             { k[t] = kin[g0 + i];
-              v[t] = vin[g0 + i];
-              ap[i] = (uint32_t) (k[t] & pmask);
+              ap[i] = (uint32_t) k[t];           // apos
             }
         }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -602,7 +604,6 @@ __global__ __launch_bounds__(256) void k_csort_small(const uint64_t *__restrict_
                   r += (b < a || (b == a && j < i)) ? 1u : 0u;
                 }
               kout[g0 + r] = k[t];
-              vout[g0 + r] = v[t];
             }
         }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -631,10 +632,10 @@ __global__ void k_csort_classify(const uint32_t *__restrict__ gstart, uint32_t n
 
 // one workgroup per listed cluster: bitonic sort of the words (apos << 12 | position) in LDS (apos < 2^20), then the
 // hits are moved in that order
-__global__ __launch_bounds__(256) void k_csort_medium(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+__global__ __launch_bounds__(256) void k_csort_medium(const uint64_t *__restrict__ kin,
                                                       const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ list,
-                                                      const unsigned int *__restrict__ nlist_p, uint64_t pmask,
-                                                      uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
+                                                      const unsigned int *__restrict__ nlist_p,
+                                                      uint64_t *__restrict__ kout)
 { __shared__ uint32_t it[CS_MEDIUM];
   const uint32_t nlist = *nlist_p;
   for (uint32_t x = blockIdx.x; x < nlist; x += gridDim.x)
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void k_csort_medium(const uint64_t *__restrict
       while (m < n) m <<= 1;
       __syncthreads();
       for (uint32_t i = threadIdx.x; i < m; i += 256)
-        it[i] = (i < n) ? ((((uint32_t) (kin[g0 + i] & pmask)) << 12) | i) : 0xffffffffu;
+        it[i] = (i < n) ? ((((uint32_t) kin[g0 + i]) << 12) | i) : 0xffffffffu;
       __syncthreads();
       for (uint32_t k = 2; k <= m; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1)
@@ -660,9 +661,15 @@ __global__ __launch_bounds__(256) void k_csort_medium(const uint64_t *__restrict
       for (uint32_t r = threadIdx.x; r < n; r += 256)
         { const uint32_t i = it[r] & 0xfffu;
           kout[g0 + r] = kin[g0 + i];
-          vout[g0 + r] = vin[g0 + i];
         }
     }
+}
+
+// (key with apos in its low pbits, value bpos) -> the chain kernels' word
+__global__ void k_pack_ab(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t n, uint64_t pmask,
+                          uint64_t *__restrict__ ab)
+{ int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ab[i] = (keys[i] & pmask) | ((uint64_t) vals[i] << 32);
 }
 
 // pairs of the clusters: flag[c] = cluster c opens a new (aread, bread) pair
@@ -1050,9 +1057,14 @@ static void close_batch(MergeResult &R)
       R.gkey.ensure((size_t) ng + 1, "group keys");
       hipLaunchKernelGGL(k_group_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, pshift,
                          (const uint32_t *) flag.p, R.gstart.p, ng, R.gkey.p);
+      hipLaunchKernelGGL(k_pack_ab, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, (const uint32_t *) v0, nhits,
+                         ((uint64_t) 1 << R.pbits) - 1, k1);
+      std::swap(k0, k1);
     }
   else
     { uint32_t ncl = 0;
+      static const bool global_csort = getenv("DMH_GLOBAL_CLUSTER_SORT") != nullptr;
+      const bool local_sort = !(global_csort || st.opt_cluster_sort == 0 || R.pbits > 20);
       { StageTimer tm("seed_clusters", 40.0 * nhits);
         int nb = ceil_div(nhits, 256);
         hipLaunchKernelGGL(k_cluster_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, qbits, cb, flag.p);
@@ -1062,36 +1074,38 @@ static void close_batch(MergeResult &R)
         R.gstart.ensure((size_t) ncl + 1, "cluster starts");
         R.gkey.ensure((size_t) ncl + 1, "cluster keys");
         hipLaunchKernelGGL(k_cluster_rekey, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, (const uint32_t *) v0,
-                           nhits, qbits, cb, R.pbits, (const uint32_t *) flag.p, k1, v1, R.gstart.p, ncl, R.gkey.p);
+                           nhits, qbits, cb, R.pbits, local_sort ? 1 : 0, (const uint32_t *) flag.p, k1, v1, R.gstart.p, ncl,
+                           R.gkey.p);
         std::swap(k0, k1);
         std::swap(v0, v1);
       }
       // every cluster into (apos, bpos) order; nothing leaves its cluster's range
-      static const bool global_csort = getenv("DMH_GLOBAL_CLUSTER_SORT") != nullptr;
-      if (global_csort || st.opt_cluster_sort == 0 || R.pbits > 20)
-        radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, R.pbits + ceil_log2((int64_t) ncl + 1), st.sort, "cluster_sort");
+      if (!local_sort)
+        { radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, R.pbits + ceil_log2((int64_t) ncl + 1), st.sort, "cluster_sort");
+          hipLaunchKernelGGL(k_pack_ab, dim3(ceil_div(nhits, 256)), dim3(256), 0, stream(), (const uint64_t *) k0,
+                             (const uint32_t *) v0, nhits, ((uint64_t) 1 << R.pbits) - 1, k1);
+          std::swap(k0, k1);
+        }
       else
-        { StageTimer tm("cluster_sort", 24.0 * nhits);
+        { StageTimer tm("cluster_sort", 16.0 * nhits);
           static DevBuf<uint32_t> mlist, blist;
           static DevBuf<unsigned int> cnt;
           mlist.ensure((size_t) ncl + 64, "clusters for the workgroup sort");
           blist.ensure((size_t) ncl + 64, "clusters for the radix sort");
           cnt.ensure(4, "cluster sort counters");
-          const uint64_t pmask = ((uint64_t) 1 << R.pbits) - 1;
-          const uint32_t smallmax = (st.opt_cluster_sort > 0) ? (uint32_t) st.opt_cluster_sort : 0;   // (test: forces the other paths)
-          (void) smallmax;
           HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned int), stream()));
           hipLaunchKernelGGL(k_csort_classify, dim3(ceil_div(ncl, 256)), dim3(256), 0, stream(), (const uint32_t *) R.gstart.p,
                              ncl, mlist.p, blist.p, cnt.p);
           hipLaunchKernelGGL(k_csort_small, dim3(std::min<int64_t>(((int64_t) ncl + 15) / 16, 256 * 8)), dim3(256), 0, stream(),
-                             (const uint64_t *) k0, (const uint32_t *) v0, (const uint32_t *) R.gstart.p, ncl, pmask, k1, v1);
-          hipLaunchKernelGGL(k_csort_medium, dim3(2048), dim3(256), 0, stream(), (const uint64_t *) k0, (const uint32_t *) v0,
-                             (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p, pmask, k1, v1);
+                             (const uint64_t *) k0, (const uint32_t *) R.gstart.p, ncl, k1);
+          hipLaunchKernelGGL(k_csort_medium, dim3(2048), dim3(256), 0, stream(), (const uint64_t *) k0,
+                             (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p, k1);
           HIP_CHECK(hipGetLastError());
           unsigned int hc[2] = {0, 0};
           copy_d2h(hc, cnt.p, 2 * sizeof(unsigned int), 1);
           if (hc[1] > 0)
-            { // repeat piles: the radix sort on each one's own range (sorted data must end in the k1/v1 side)
+            { // repeat piles: the radix sort (on apos, the low bits of the word; the value arrays only ride along) on
+              // each one's own range; sorted data must end in the k1 side
               std::vector<uint32_t> big(hc[1]), gs((size_t) ncl + 1);
               copy_d2h(big.data(), blist.p, sizeof(uint32_t) * hc[1]);
               copy_d2h(gs.data(), R.gstart.p, sizeof(uint32_t) * ((size_t) ncl + 1));
@@ -1101,13 +1115,10 @@ static void close_batch(MergeResult &R)
                   uint32_t *sv = v0 + b0, *ov = v1 + b0;
                   radix_sort_pairs(&sk, &sv, &ok, &ov, bn, 0, R.pbits, st.sort, "pile_sort");
                   if (sk != k1 + b0)
-                    { HIP_CHECK(hipMemcpyAsync(k1 + b0, sk, sizeof(uint64_t) * bn, hipMemcpyDeviceToDevice, stream()));
-                      HIP_CHECK(hipMemcpyAsync(v1 + b0, sv, sizeof(uint32_t) * bn, hipMemcpyDeviceToDevice, stream()));
-                    }
+                    HIP_CHECK(hipMemcpyAsync(k1 + b0, sk, sizeof(uint64_t) * bn, hipMemcpyDeviceToDevice, stream()));
                 }
             }
           std::swap(k0, k1);
-          std::swap(v0, v1);
         }
       { StageTimer tm("seed_pairs", 0.0);
         R.cog.ensure((size_t) ncl + 2, "pair of cluster");
@@ -1118,51 +1129,39 @@ static void close_batch(MergeResult &R)
         exclusive_scan_u32(R.cog.p, ncl, st.sort.bsum, R.cog.p + ncl);
         hipLaunchKernelGGL(k_pair_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p,
                            (const uint32_t *) (R.cog.p + ncl), R.ocfirst.p, (const uint64_t *) k0,
-                           (const uint32_t *) R.gstart.p, ((uint64_t) 1 << R.pbits) - 1, R.glast.p);
+                           (const uint32_t *) R.gstart.p, (uint64_t) 0xffffffffull, R.glast.p);
       }
     }
-  R.skeys = k0;
-  R.svals = v0;
+  R.sab = k0;
   chain_classify_groups(R);          // (its copy of the pile count is the synchronisation point)
   HIP_CHECK(hipGetLastError());
 
   if (st.capture_seeds)
-    { std::vector<uint64_t> hk(nhits);
-      std::vector<uint32_t> hv(nhits);
-      copy_d2h(hk.data(), R.skeys, sizeof(uint64_t) * nhits);
-      copy_d2h(hv.data(), R.svals, sizeof(uint32_t) * nhits);
+    { // stage-level API only: the hits in the reference's (aread, bread, apos, bpos) order
+      std::vector<uint64_t> hk(nhits), gk((size_t) R.ngroups);
+      std::vector<uint32_t> gs((size_t) R.ngroups + 1);
+      copy_d2h(hk.data(), R.sab, sizeof(uint64_t) * nhits);
+      copy_d2h(gk.data(), R.gkey.p, sizeof(uint64_t) * (size_t) R.ngroups);
+      copy_d2h(gs.data(), R.gstart.p, sizeof(uint32_t) * ((size_t) R.ngroups + 1));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      const uint64_t bm = ((uint64_t) 1 << R.bbits) - 1;
+      struct Hit { uint64_t pair; uint32_t apos, bpos; };
+      std::vector<Hit> hs((size_t) nhits);
+      for (int64_t g = 0; g < R.ngroups; g++)
+        for (uint32_t i = gs[g]; i < gs[g + 1]; i++)
+          hs[i] = Hit{gk[g], (uint32_t) hk[i], (uint32_t) (hk[i] >> 32)};
+      if (cluster)
+        std::sort(hs.begin(), hs.end(), [](const Hit &x, const Hit &y)
+                  { if (x.pair != y.pair) return x.pair < y.pair;
+                    if (x.apos != y.apos) return x.apos < y.apos;
+                    return x.bpos < y.bpos;
+                  });
       st.last_seeds.resize((size_t) nhits * 4);
-      const uint64_t pm = ((uint64_t) 1 << R.pbits) - 1, bm = ((uint64_t) 1 << R.bbits) - 1;
-      if (!cluster)
-        for (int64_t i = 0; i < nhits; i++)
-          { int apos  = (int) (hk[i] & pm);
-            int bread = (int) ((hk[i] >> R.pbits) & bm);            // (capture runs unbatched: no pass bits)
-            int aread = (int) (hk[i] >> (R.pbits + R.bbits));
-            st.last_seeds[4 * i + 0] = apos - (int) hv[i];
-            st.last_seeds[4 * i + 1] = apos;
-            st.last_seeds[4 * i + 2] = bread;
-            st.last_seeds[4 * i + 3] = aread;
-          }
-      else
-        { // cluster order -> the reference's (aread, bread, apos, bpos) order, on the host (stage-level API only)
-          std::vector<uint64_t> gk((size_t) R.ngroups);
-          copy_d2h(gk.data(), R.gkey.p, sizeof(uint64_t) * (size_t) R.ngroups);
-          HIP_CHECK(hipStreamSynchronize(stream()));
-          struct Hit { uint64_t pair; uint32_t apos, bpos; };
-          std::vector<Hit> hs((size_t) nhits);
-          for (int64_t i = 0; i < nhits; i++)
-            hs[i] = Hit{gk[(size_t) (hk[i] >> R.pbits)], (uint32_t) (hk[i] & pm), hv[i]};
-          std::sort(hs.begin(), hs.end(), [](const Hit &x, const Hit &y)
-                    { if (x.pair != y.pair) return x.pair < y.pair;
-                      if (x.apos != y.apos) return x.apos < y.apos;
-                      return x.bpos < y.bpos;
-                    });
-          for (int64_t i = 0; i < nhits; i++)
-            { st.last_seeds[4 * i + 0] = (int) hs[i].apos - (int) hs[i].bpos;
-              st.last_seeds[4 * i + 1] = (int) hs[i].apos;
-              st.last_seeds[4 * i + 2] = (int) (hs[i].pair & bm);
-              st.last_seeds[4 * i + 3] = (int) (hs[i].pair >> R.bbits);
-            }
+      for (int64_t i = 0; i < nhits; i++)
+        { st.last_seeds[4 * i + 0] = (int) hs[i].apos - (int) hs[i].bpos;
+          st.last_seeds[4 * i + 1] = (int) hs[i].apos;
+          st.last_seeds[4 * i + 2] = (int) (hs[i].pair & bm);
+          st.last_seeds[4 * i + 3] = (int) (hs[i].pair >> R.bbits);
         }
     }
   chain_submit(R, ablock);
