@@ -39,4 +39,28 @@ __device__ __forceinline__ int64_t run_end(const uint64_t *__restrict__ k, int64
   return hi;
 }
 
+// Inclusive scan across a wavefront.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int lane)
+{
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { uint32_t y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+  return x;
+}
+
+// Exclusive scan across a 256-thread block; *total receives the block sum.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *ws, uint32_t *total)
+{ int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t x = wave_incl_scan(v, lane);
+  if (lane == 63) ws[w] = x;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int i = 0; i < w; i++) wbase += ws[i];
+  *total = ws[0] + ws[1] + ws[2] + ws[3];
+  __syncthreads();
+  return wbase + x - v;
+}
+
 }  // namespace dmh

@@ -36,6 +36,7 @@ struct MergeResult
   // so the clusters of a pair chain independently; the hits are then sorted (cluster, apos, bpos) and the
   // sort key holds the cluster number instead of (aread, bread).
   bool     clustered = false;
+  bool     word = false;                       // cluster mode with one word per hit through the seed sort (no vals)
   DevBuf<uint64_t> gkey;                       // per group: (aread << bbits) | bread
   DevBuf<uint32_t> cog, ocfirst, glast;        // cluster mode: pair number of each cluster, first cluster of each pair
                                                // (+ end), and per cluster its pair's largest apos + 1

@@ -365,6 +365,21 @@ __device__ __forceinline__ void locate(const PosMap &M, uint32_t q, uint32_t &re
 
 constexpr uint32_t BIG_ENTRY = 64;
 
+// One hit into the batch.  mode 0: key aread | pass | bread | apos, value bpos (the reference's seed order);
+// mode 1: bpos in the key and apos as the value (cluster mode, two arrays); mode >= 2: cluster mode with everything in
+// ONE word, aread | bread | bpos | apos with apos in the low mode - 2 bits -- the seed sort then moves 8 bytes per hit.
+__device__ __forceinline__ void put_hit(uint64_t *__restrict__ hkeys, uint32_t *__restrict__ hvals, uint32_t o,
+                                        uint32_t ar, uint32_t ap, uint32_t br, uint32_t bp, int bshift, int pshift,
+                                        int mode, uint64_t passor)
+{ const uint64_t top = ((uint64_t) ar << bshift) | passor | ((uint64_t) br << pshift);
+  if (mode >= 2)
+    hkeys[o] = top | ((uint64_t) bp << (mode - 2)) | (uint64_t) ap;
+  else
+    { hkeys[o] = top | (uint64_t) (mode ? bp : ap);
+      hvals[o] = mode ? ap : bp;
+    }
+}
+
 // Expand entries into hits (map.c:984-994).  Small entries: one thread each; entries with more
 // than BIG_ENTRY pairs are queued for the wavefront-per-entry kernel below.
 __global__ void k_merge_expand(const MergeEntry *__restrict__ entries, uint32_t n,
@@ -386,13 +401,10 @@ __global__ void k_merge_expand(const MergeEntry *__restrict__ entries, uint32_t 
   for (uint32_t a = 0; a < e.ma; a++)
     { uint32_t ar, ap;
       locate(MA, avals[e.a0 + a], ar, ap);
-      // key = aread | bread | apos with value bpos -- or, for the cluster sort (swap), bpos in the key and apos as value
-      uint64_t kbase = ((uint64_t) ar << bshift) | passor | (swap ? 0ull : (uint64_t) ap);
       for (uint32_t b = 0; b < e.mb; b++)
         { uint32_t br, bp;
           locate(MB, bvals[e.b0 + b], br, bp);
-          hkeys[off] = kbase | ((uint64_t) br << pshift) | (swap ? (uint64_t) bp : 0ull);
-          hvals[off] = swap ? ap : bp;
+          put_hit(hkeys, hvals, off, ar, ap, br, bp, bshift, pshift, swap, passor);
           off += 1;
         }
     }
@@ -420,8 +432,7 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
           uint32_t ar, ap, br, bp;
           locate(MA, avals[e.a0 + a], ar, ap);
           locate(MB, bvals[e.b0 + b], br, bp);
-          hkeys[off + t] = ((uint64_t) ar << bshift) | passor | ((uint64_t) br << pshift) | (uint64_t) (swap ? bp : ap);
-          hvals[off + t] = swap ? ap : bp;
+          put_hit(hkeys, hvals, off + t, ar, ap, br, bp, bshift, pshift, swap, passor);
         }
     }
 }
@@ -484,8 +495,7 @@ __global__ __launch_bounds__(256) void k_merge_expand_tiled(const MergeEntry *__
       uint32_t ar, ap, br, bp;
       locate(MA, avals[en.a0 + a], ar, ap);
       locate(MB, bvals[en.b0 + b], br, bp);
-      hkeys[o] = ((uint64_t) ar << bshift) | passor | ((uint64_t) br << pshift) | (uint64_t) (swap ? bp : ap);
-      hvals[o] = swap ? ap : bp;
+      put_hit(hkeys, hvals, o, ar, ap, br, bp, bshift, pshift, swap, passor);
     }
 }
 
@@ -562,6 +572,96 @@ __global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32
 }
 
 // ---------------------------------------------------------------------------------------
+//  One-word hits (put_hit mode >= 2): w = aread | bread | bpos | apos, sorted on the bits from pbits + cb up.  w >> pbits
+//  is the key the kernels above look at.  Two passes over the words instead of flag / scan / rekey over keys, values
+//  and a flag per hit: the cluster starts are counted per tile of WC_TILE hits, the tile counts are scanned (a few ten
+//  thousand numbers), and the second pass numbers the clusters inside its tile and writes the chain kernels' word.
+// ---------------------------------------------------------------------------------------
+constexpr int WC_ITEMS = 8;
+constexpr int WC_TILE  = 256 * WC_ITEMS;
+typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+
+// the tile's words, WC_ITEMS consecutive ones per thread (the arrays start on a 16-byte boundary), and the start flags
+// of the thread's words as a bit mask
+__device__ __forceinline__ uint32_t wc_load(const uint64_t *__restrict__ w, int64_t n, int64_t base, int pbits, int qbits,
+                                            int cb, uint64_t (&x)[WC_ITEMS])
+{ if (base >= n) return 0;
+  if (base + WC_ITEMS <= n)
+    { const ull2 *v = (const ull2 *) (w + base);
+#pragma unroll
+      for (int j = 0; j < WC_ITEMS / 2; j++)
+        { const ull2 t = __builtin_nontemporal_load(v + j);
+          x[2 * j] = t.x; x[2 * j + 1] = t.y;
+        }
+    }
+  else
+    {
+#pragma unroll
+      for (int j = 0; j < WC_ITEMS; j++) x[j] = (base + j < n) ? w[base + j] : 0;
+    }
+  uint64_t prev = (base > 0) ? w[base - 1] : 0;
+  uint32_t f = 0;
+#pragma unroll
+  for (int j = 0; j < WC_ITEMS; j++)
+    { if (base + j < n && (base + j == 0 || cluster_start(prev >> pbits, x[j] >> pbits, qbits, cb))) f |= 1u << j;
+      prev = x[j];
+    }
+  return f;
+}
+
+__global__ __launch_bounds__(256) void k_wcluster_count(const uint64_t *__restrict__ w, int64_t n, int pbits, int qbits,
+                                                        int cb, uint32_t *__restrict__ tcount)
+{ __shared__ uint32_t ws[4];
+  uint64_t x[WC_ITEMS];
+  const int64_t base = (int64_t) blockIdx.x * WC_TILE + (int64_t) threadIdx.x * WC_ITEMS;
+  uint32_t c = (uint32_t) __popc(wc_load(w, n, base, pbits, qbits, cb, x));
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tcount[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// toff = exclusive scan of the tile counts.  sab[i] = apos | bpos << 32; gstart / gkey per cluster.
+__global__ __launch_bounds__(256) void k_wcluster_rekey(const uint64_t *__restrict__ w, int64_t n, int pbits, int qbits,
+                                                        int cb, const uint32_t *__restrict__ toff,
+                                                        uint64_t *__restrict__ sab, uint32_t *__restrict__ gstart,
+                                                        uint32_t ncl, uint64_t *__restrict__ gkey)
+{ __shared__ uint32_t ws[4];
+  uint64_t x[WC_ITEMS];
+  const int64_t base = (int64_t) blockIdx.x * WC_TILE + (int64_t) threadIdx.x * WC_ITEMS;
+  const uint32_t f = wc_load(w, n, base, pbits, qbits, cb, x);
+  uint32_t tot;
+  uint32_t c = toff[blockIdx.x] + block_excl_scan((uint32_t) __popc(f), ws, &tot);
+  if (base >= n) return;
+  const uint64_t pm = (1ull << pbits) - 1ull, qm = (1ull << qbits) - 1ull;
+  const int top = pbits + qbits;
+#pragma unroll
+  for (int j = 0; j < WC_ITEMS; j++)
+    { if ((f >> j) & 1u)
+        { gstart[c] = (uint32_t) (base + j);
+          gkey[c]   = x[j] >> top;
+          c += 1;
+        }
+      x[j] = (x[j] & pm) | (((x[j] >> pbits) & qm) << 32);
+    }
+  if (base + WC_ITEMS <= n)
+    { ull2 *v = (ull2 *) (sab + base);
+#pragma unroll
+      for (int j = 0; j < WC_ITEMS / 2; j++)
+        { ull2 t; t.x = x[2 * j]; t.y = x[2 * j + 1];
+          v[j] = t;
+        }
+    }
+  else
+    {
+#pragma unroll
+      for (int j = 0; j < WC_ITEMS; j++)
+        if (base + j < n) sab[base + j] = x[j];
+    }
+  if (base == 0) gstart[ncl] = (uint32_t) n;
+}
+
+// ---------------------------------------------------------------------------------------
 //  Every cluster into (apos, bpos) order without another trip of ALL hits through the global radix sort: the hits
 //  of a cluster are contiguous after the first sort, and clusters are small (some twenty hits; a read's true locus a
 //  few hundred), so each is sorted where it lies -- by rank counting in a 16-lane group (<= CS_SMALL hits), by a
@@ -571,63 +671,105 @@ __global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32
 constexpr int CS_SMALL  = 64;
 constexpr int CS_MEDIUM = 4096;
 
+// ranks of the group's T x 16 words among the n the group holds: word = apos << 6 | position (distinct), the LDS copy
+// is padded with all-ones words to a multiple of four and read four words at a time
+template <int T>
+__device__ __forceinline__ void csort_ranks(const uint32_t *vv, uint32_t n, const uint32_t (&v)[4], uint32_t (&r)[4])
+{ const uint4 *v4 = (const uint4 *) vv;
+  const uint32_t n4 = (n + 3) >> 2;
+#pragma unroll
+  for (int t = 0; t < 4; t++) r[t] = 0;
+  for (uint32_t jj = 0; jj < n4; jj++)
+    { const uint4 b = v4[jj];
+#pragma unroll
+      for (int t = 0; t < T; t++)
+        r[t] += (b.x < v[t] ? 1u : 0u) + (b.y < v[t] ? 1u : 0u) + (b.z < v[t] ? 1u : 0u) + (b.w < v[t] ? 1u : 0u);
+    }
+}
+
+// A 16-lane group per cluster, four clusters per wavefront, walking the clusters with a fixed stride.  The walk is a
+// software pipeline: while a cluster is ranked, the hits of the group's next cluster and the bounds of the one after
+// are already on their way (a cluster is some 160 bytes: without that every step waits a full memory round trip).
 __global__ __launch_bounds__(256) void k_csort_small(const uint64_t *__restrict__ kin,
                                                      const uint32_t *__restrict__ gstart, uint32_t ncl,
                                                      uint64_t *__restrict__ kout)
 { constexpr int G = 16, GPB = 256 / G, PER = CS_SMALL / G;
-  __shared__ uint32_t s_ap[GPB][CS_SMALL];
-  const int lane = threadIdx.x & (G - 1), gi = threadIdx.x / G;
-  uint32_t *ap = s_ap[gi];
-  const uint32_t stride = gridDim.x * GPB;
-  for (uint32_t c = blockIdx.x * GPB + gi; c < ncl; c += stride)
-    { const uint32_t g0 = gstart[c], n = gstart[c + 1] - g0;
-      if (n > (uint32_t) CS_SMALL) continue;
-      uint64_t k[PER];
+  static_assert(PER == 4, "four words per lane");
+  __shared__ __attribute__((aligned(16))) uint32_t s_v[GPB][CS_SMALL];
+  const uint32_t lane = threadIdx.x & (G - 1);
+  uint32_t *vv = s_v[threadIdx.x / G];
+  const uint64_t stride = (uint64_t) gridDim.x * GPB;
+  uint64_t c = (uint64_t) blockIdx.x * GPB + threadIdx.x / G;
+
+  uint32_t g0 = 0, n = 0, g1 = 0, n1 = 0;          // bounds of cluster c and of c + stride (n = 0: none / not ours)
+  if (c < ncl)          { g0 = gstart[c];          n  = gstart[c + 1] - g0; }
+  if (c + stride < ncl) { g1 = gstart[c + stride]; n1 = gstart[c + stride + 1] - g1; }
+  if (n  > (uint32_t) CS_SMALL) n  = 0;
+  if (n1 > (uint32_t) CS_SMALL) n1 = 0;
+  uint64_t k[PER], kn[PER];
+#pragma unroll
+  for (int t = 0; t < PER; t++) k[t] = (lane + G * t < n) ? kin[g0 + lane + G * t] : 0;
+
+  while (__any(c < ncl))
+    { // bounds two steps ahead, hits one step ahead
+      uint32_t g2 = 0, n2 = 0;
+      if (c + 2 * stride < ncl) { g2 = gstart[c + 2 * stride]; n2 = gstart[c + 2 * stride + 1] - g2; }
+#pragma unroll
+      for (int t = 0; t < PER; t++) kn[t] = (lane + G * t < n1) ? kin[g1 + lane + G * t] : 0;
+
+      uint32_t v[PER], r[PER];
 #pragma unroll
       for (int t = 0; t < PER; t++)
         { const uint32_t i = lane + G * t;
-          if (i < n)
-            { k[t] = kin[g0 + i];
-              ap[i] = (uint32_t) k[t];           // apos
-            }
+          v[t] = (i < n) ? ((((uint32_t) k[t]) << 6) | i) : 0xffffffffu;
+          vv[i] = v[t];
         }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if (!__any(n > 16u))      csort_ranks<1>(vv, n, v, r);
+      else if (!__any(n > 32u)) csort_ranks<2>(vv, n, v, r);
+      else                      csort_ranks<4>(vv, n, v, r);
 #pragma unroll
       for (int t = 0; t < PER; t++)
-        { const uint32_t i = lane + G * t;
-          if (i < n)
-            { const uint32_t a = ap[i];
-              uint32_t r = 0;
-              for (uint32_t j = 0; j < n; j++)
-                { const uint32_t b = ap[j];
-                  r += (b < a || (b == a && j < i)) ? 1u : 0u;
-                }
-              kout[g0 + r] = k[t];
-            }
-        }
+        if (lane + G * t < n) kout[g0 + r[t]] = k[t];
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
+
+      c += stride;
+      g0 = g1; n = n1;
+      g1 = g2; n1 = (n2 > (uint32_t) CS_SMALL) ? 0 : n2;
+#pragma unroll
+      for (int t = 0; t < PER; t++) k[t] = kn[t];
     }
 }
 
 // clusters of CS_SMALL+1 .. CS_MEDIUM hits -> mlist, larger ones -> blist
-__global__ void k_csort_classify(const uint32_t *__restrict__ gstart, uint32_t ncl, uint32_t *__restrict__ mlist,
-                                 uint32_t *__restrict__ blist, unsigned int *__restrict__ counts)
-{ const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int      lane = threadIdx.x & 63;
+__global__ __launch_bounds__(1024) void k_csort_classify(const uint32_t *__restrict__ gstart, uint32_t ncl,
+                                                         uint32_t *__restrict__ mlist, uint32_t *__restrict__ blist,
+                                                         unsigned int *__restrict__ counts)
+{ // one pair of device atomics per 1024 clusters (they are served one after the other, a few ns apiece)
+  __shared__ uint32_t wm[16], wb[16], base[2];
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int      lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t lt = (1ull << lane) - 1ull;
   const uint32_t n = (c < ncl) ? gstart[c + 1] - gstart[c] : 0;
   const bool ism = n > (uint32_t) CS_SMALL && n <= (uint32_t) CS_MEDIUM, isb = n > (uint32_t) CS_MEDIUM;
   const uint64_t mm = __ballot(ism), mb = __ballot(isb);
-  uint32_t bm = 0, bb = 0;
-  if (lane == 0)
-    { if (mm) bm = atomicAdd(counts, (uint32_t) __popcll(mm));
-      if (mb) bb = atomicAdd(counts + 1, (uint32_t) __popcll(mb));
+  if (lane == 0) { wm[wv] = (uint32_t) __popcll(mm); wb[wv] = (uint32_t) __popcll(mb); }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    { uint32_t tm = 0, tb = 0;
+      for (int i = 0; i < 16; i++)
+        { const uint32_t a = wm[i], b2 = wb[i];
+          wm[i] = tm; wb[i] = tb;
+          tm += a; tb += b2;
+        }
+      base[0] = tm ? atomicAdd(counts, tm) : 0;
+      base[1] = tb ? atomicAdd(counts + 1, tb) : 0;
     }
-  bm = __shfl(bm, 0); bb = __shfl(bb, 0);
-  if (ism) mlist[bm + (uint32_t) __popcll(mm & lt)] = c;
-  if (isb) blist[bb + (uint32_t) __popcll(mb & lt)] = c;
+  __syncthreads();
+  if (ism) mlist[base[0] + wm[wv] + (uint32_t) __popcll(mm & lt)] = c;
+  if (isb) blist[base[1] + wb[wv] + (uint32_t) __popcll(mb & lt)] = c;
 }
 
 // one workgroup per listed cluster: bitonic sort of the words (apos << 12 | position) in LDS (apos < 2^20), then the
@@ -673,37 +815,47 @@ __global__ void k_pack_ab(const uint64_t *__restrict__ keys, const uint32_t *__r
 }
 
 // pairs of the clusters: flag[c] = cluster c opens a new (aread, bread) pair
-__global__ void k_pair_flag(const uint64_t *__restrict__ gkey, uint32_t ncl, uint32_t *__restrict__ flag)
+__global__ void k_pair_flag(const uint64_t *__restrict__ gkey, uint32_t ncl, uint32_t *__restrict__ flag,
+                            uint32_t *__restrict__ pmax)
 { uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncl) return;
   flag[c] = (c == 0 || gkey[c] != gkey[c - 1]) ? 1u : 0u;
+  pmax[c] = 0;
 }
 
-// cog[] = exclusive scan of those flags on entry; on exit cog[c] = pair of cluster c, ocfirst[p] = first cluster
-// of pair p (ocfirst[npairs] = ncl), glast[c] = largest apos + 1 among the hits of c's pair (the apos of the pair's
-// last hit in the reference's order) -- the sorted hits' keys are (cluster << pbits) | apos.
-__global__ void k_pair_write(const uint64_t *__restrict__ gkey, uint32_t ncl, uint32_t *__restrict__ cog,
-                             const uint32_t *__restrict__ npairs_p, uint32_t *__restrict__ ocfirst,
-                             const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ gstart, uint64_t pmask,
+// cog[] = exclusive scan of those flags on entry; on exit cog[c] = pair of cluster c, ocfirst[p] = first cluster of
+// pair p (ocfirst[npairs] = ncl), pmax[p] = largest apos + 1 among the hits of pair p (the apos of the pair's last hit
+// in the reference's order; every cluster is in apos order by now, so its last hit holds its largest).  The clusters of
+// a pair are neighbours: their maximum is taken inside the wavefront first, one atomic per pair and wavefront.
+__global__ __launch_bounds__(256) void k_pair_max(const uint64_t *__restrict__ gkey, uint32_t ncl, uint32_t *__restrict__ cog,
+                                                  const uint32_t *__restrict__ npairs_p, uint32_t *__restrict__ ocfirst,
+                                                  const uint64_t *__restrict__ sab, const uint32_t *__restrict__ gstart,
+                                                  uint32_t *__restrict__ pmax)
+{ const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool ok = c < ncl;
+  uint32_t p = 0xffffffffu, a = 0;
+  if (ok)
+    { const bool start = (c == 0 || gkey[c] != gkey[c - 1]);
+      p = cog[c] + (start ? 1u : 0u) - 1u;
+      a = (uint32_t) sab[gstart[c + 1] - 1] + 1u;
+      cog[c] = p;
+      if (start) ocfirst[p] = c;
+      if (c == 0) ocfirst[*npairs_p] = ncl;
+    }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { const uint32_t pa = __shfl_up(a, o), pp = __shfl_up(p, o);
+      if (lane >= o && pp == p && pa > a) a = pa;
+    }
+  const uint32_t pn = __shfl_down(p, 1);
+  if (ok && (lane == 63 || pn != p)) atomicMax(&pmax[p], a);
+}
+
+__global__ void k_pair_glast(const uint32_t *__restrict__ cog, uint32_t ncl, const uint32_t *__restrict__ pmax,
                              uint32_t *__restrict__ glast)
 { uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncl) return;
-  const bool start = (c == 0 || gkey[c] != gkey[c - 1]);
-  if (c == 0) ocfirst[*npairs_p] = ncl;
-  if (!start) return;
-  const uint32_t p = cog[c];               // (exclusive scan: the number of pairs opened before c)
-  ocfirst[p] = c;
-  const uint64_t k = gkey[c];
-  uint32_t e = c, m = 0;
-  while (e < ncl && gkey[e] == k)
-    { uint32_t a = (uint32_t) (skeys[gstart[e + 1] - 1] & pmask) + 1u;
-      m = a > m ? a : m;
-      e += 1;
-    }
-  for (uint32_t x = c; x < e; x++)
-    { if (x != c) cog[x] = p;
-      glast[x] = m;
-    }
+  if (c < ncl) glast[c] = pmax[cog[c]];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -749,6 +901,12 @@ constexpr int64_t BATCH_CAP = (int64_t) 160 << 20;
 
 static void    close_batch(MergeResult &R);
 static int64_t finish_oldest();
+
+// cluster mode: every cluster sorted where it lies (k_csort_*) rather than all hits through the radix sort again
+static bool local_cluster_sort(int pbits)
+{ static const bool global_csort = getenv("DMH_GLOBAL_CLUSTER_SORT") != nullptr;
+  return !(global_csort || S().opt_cluster_sort == 0 || pbits > 20);
+}
 
 int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &Bx,
                    int Kshift, int comp, int64_t *nfilt)
@@ -927,16 +1085,20 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
       R.clustered = cluster;
       R.pbits = pbits; R.abits = abits; R.bbits = bbits; R.qbits = qbits;
       R.passbits = batching ? 5 : 0;
+      // cluster mode: one word per hit through the seed sort when aread | bread | bpos | apos fit it and the clusters
+      // are sorted where they lie ("seed_word" test option: 0 = always keys and values)
+      R.word = cluster && local_cluster_sort(pbits) && st.opt_seed_word != 0 && abits + bbits + qbits + pbits <= 64;
       if ((cluster ? qbits : pbits) + R.bbits + R.passbits + R.abits > 64)
         { if (pbits + R.bbits + R.abits > 64) fatal("Match_Filter: seed key needs %d bits", pbits + R.bbits + R.abits);
           R.passbits = 0;
         }
       const int64_t cap = std::max<int64_t>(R.passbits ? BATCH_CAP : 0, nhits);
       R.keys.ensure(cap, "seed keys");
-      R.vals.ensure(cap, "seed positions");
+      if (!R.word) R.vals.ensure(cap, "seed positions");
     }
-  const int lowbits = R.clustered ? R.qbits : R.pbits;           // bits below bread in the first sort's key
+  const int lowbits = R.word ? R.qbits + R.pbits : (R.clustered ? R.qbits : R.pbits);      // bits below bread in the first sort's key
   const int pshift = lowbits, bshift = lowbits + R.bbits + R.passbits;
+  const int hitmode = R.word ? 2 + R.pbits : (R.clustered ? 1 : 0);                        // (put_hit)
   const uint64_t passor = (uint64_t) R.npass << (lowbits + R.bbits);
 
   // positions as (read, rpos) words for indices that keep being merged against (dmh_core.hip index_pack_positions)
@@ -961,18 +1123,18 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     if (!per_entry && st.opt_expand != 0)
       hipLaunchKernelGGL(k_merge_expand_tiled, dim3(ceil_div(nhits, EX_TILE)), dim3(256), 0, stream(),
                          (const MergeEntry *) entries.p, nent, (const uint32_t *) eoff.p, (const uint32_t *) A.vals,
-                         (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0, passor, hk, hv);
+                         (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, hitmode, passor, hk, hv);
     else
       { hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                            (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
-                           (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, R.clustered ? 1 : 0, passor, hk, hv, ebig.p, mctl.p + 1);
+                           (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, hitmode, passor, hk, hv, ebig.p, mctl.p + 1);
         // the entries of more than BIG_ENTRY pairs, a wavefront each: their number stays on the device (the launch is
         // sized for the most there can be of them: nhits / BIG_ENTRY)
         const int64_t maxbig = std::min<int64_t>(nent, nhits / (int64_t) BIG_ENTRY + 1);
         hipLaunchKernelGGL(k_merge_expand_big, dim3(std::min<int64_t>(ceil_div(maxbig * 64, 256), 65536)), dim3(256), 0, stream(),
                            (const MergeEntry *) entries.p, (const uint32_t *) ebig.p, (const unsigned int *) (mctl.p + 1),
                            (const uint32_t *) eoff.p, (const uint32_t *) A.vals, (const uint32_t *) Bx.vals, MA, MB, bshift, pshift,
-                           R.clustered ? 1 : 0, passor, hk, hv);
+                           hitmode, passor, hk, hv);
       }
     HIP_CHECK(hipGetLastError());
     static const bool check = getenv("DMH_CHECK_EMIT") != nullptr;
@@ -1034,17 +1196,21 @@ static void close_batch(MergeResult &R)
   const int  lowbits = cluster ? qbits : R.pbits;
   const int  pshift = lowbits;
   R.alt_keys.ensure(nhits, "seed sort buffer");
-  R.alt_vals.ensure(nhits, "seed sort buffer");
+  if (!R.word) R.alt_vals.ensure(nhits, "seed sort buffer");
 
   // --- seed sort (map.c:3110-3126)
   uint64_t *k0 = R.keys.p, *k1 = R.alt_keys.p;
   uint32_t *v0 = R.vals.p, *v1 = R.alt_vals.p;
-  const int cb = cluster ? std::min(CLUSTER_CB, qbits) : 0;          // (the bits below cb of bpos are not sorted on)
-  radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, cb, lowbits + R.bbits + R.passbits + R.abits - cb, st.sort, "seed_sort");
+  static const int env_cb = getenv("DMH_CLUSTER_CB") ? atoi(getenv("DMH_CLUSTER_CB")) : CLUSTER_CB;
+  const int cb = cluster ? std::min(env_cb, qbits) : 0;              // (the bits below cb of bpos are not sorted on)
+  if (R.word)
+    radix_sort_pairs(&k0, nullptr, &k1, nullptr, nhits, R.pbits + cb, qbits - cb + R.bbits + R.abits, st.sort, "seed_sort");
+  else
+    radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, cb, lowbits + R.bbits + R.passbits + R.abits - cb, st.sort, "seed_sort");
 
   // --- groups
   static DevBuf<uint32_t> flag;
-  flag.ensure(nhits + 1, "group flags");
+  if (!R.word) flag.ensure(nhits + 1, "group flags");
   if (!cluster)
     { StageTimer tm("seed_groups", 24.0 * nhits);
       int nb = ceil_div(nhits, 256);
@@ -1063,22 +1229,38 @@ static void close_batch(MergeResult &R)
     }
   else
     { uint32_t ncl = 0;
-      static const bool global_csort = getenv("DMH_GLOBAL_CLUSTER_SORT") != nullptr;
-      const bool local_sort = !(global_csort || st.opt_cluster_sort == 0 || R.pbits > 20);
-      { StageTimer tm("seed_clusters", 40.0 * nhits);
-        int nb = ceil_div(nhits, 256);
-        hipLaunchKernelGGL(k_cluster_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, qbits, cb, flag.p);
-        exclusive_scan_u32(flag.p, nhits, st.sort.bsum, flag.p + nhits);
-        copy_d2h(&ncl, flag.p + nhits, sizeof(uint32_t), 1);
-        R.ngroups = ncl;
-        R.gstart.ensure((size_t) ncl + 1, "cluster starts");
-        R.gkey.ensure((size_t) ncl + 1, "cluster keys");
-        hipLaunchKernelGGL(k_cluster_rekey, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, (const uint32_t *) v0,
-                           nhits, qbits, cb, R.pbits, local_sort ? 1 : 0, (const uint32_t *) flag.p, k1, v1, R.gstart.p, ncl,
-                           R.gkey.p);
-        std::swap(k0, k1);
-        std::swap(v0, v1);
-      }
+      const bool local_sort = R.word || local_cluster_sort(R.pbits);
+      if (R.word)
+        { StageTimer tm("seed_clusters", 40.0 * nhits);
+          static DevBuf<uint32_t> tcount;
+          const int nt = ceil_div(nhits, WC_TILE);
+          tcount.ensure((size_t) nt + 1, "cluster starts per tile");
+          hipLaunchKernelGGL(k_wcluster_count, dim3(nt), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, R.pbits, qbits,
+                             cb, tcount.p);
+          exclusive_scan_u32(tcount.p, nt, st.sort.bsum, tcount.p + nt);
+          copy_d2h(&ncl, tcount.p + nt, sizeof(uint32_t), 1);
+          R.ngroups = ncl;
+          R.gstart.ensure((size_t) ncl + 1, "cluster starts");
+          R.gkey.ensure((size_t) ncl + 1, "cluster keys");
+          hipLaunchKernelGGL(k_wcluster_rekey, dim3(nt), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, R.pbits, qbits,
+                             cb, (const uint32_t *) tcount.p, k1, R.gstart.p, ncl, R.gkey.p);
+          std::swap(k0, k1);
+        }
+      else
+        { StageTimer tm("seed_clusters", 40.0 * nhits);
+          int nb = ceil_div(nhits, 256);
+          hipLaunchKernelGGL(k_cluster_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, nhits, qbits, cb, flag.p);
+          exclusive_scan_u32(flag.p, nhits, st.sort.bsum, flag.p + nhits);
+          copy_d2h(&ncl, flag.p + nhits, sizeof(uint32_t), 1);
+          R.ngroups = ncl;
+          R.gstart.ensure((size_t) ncl + 1, "cluster starts");
+          R.gkey.ensure((size_t) ncl + 1, "cluster keys");
+          hipLaunchKernelGGL(k_cluster_rekey, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) k0, (const uint32_t *) v0,
+                             nhits, qbits, cb, R.pbits, local_sort ? 1 : 0, (const uint32_t *) flag.p, k1, v1, R.gstart.p, ncl,
+                             R.gkey.p);
+          std::swap(k0, k1);
+          std::swap(v0, v1);
+        }
       // every cluster into (apos, bpos) order; nothing leaves its cluster's range
       if (!local_sort)
         { radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, 0, R.pbits + ceil_log2((int64_t) ncl + 1), st.sort, "cluster_sort");
@@ -1094,7 +1276,7 @@ static void close_batch(MergeResult &R)
           blist.ensure((size_t) ncl + 64, "clusters for the radix sort");
           cnt.ensure(4, "cluster sort counters");
           HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned int), stream()));
-          hipLaunchKernelGGL(k_csort_classify, dim3(ceil_div(ncl, 256)), dim3(256), 0, stream(), (const uint32_t *) R.gstart.p,
+          hipLaunchKernelGGL(k_csort_classify, dim3(ceil_div(ncl, 1024)), dim3(1024), 0, stream(), (const uint32_t *) R.gstart.p,
                              ncl, mlist.p, blist.p, cnt.p);
           hipLaunchKernelGGL(k_csort_small, dim3(std::min<int64_t>(((int64_t) ncl + 15) / 16, 256 * 8)), dim3(256), 0, stream(),
                              (const uint64_t *) k0, (const uint32_t *) R.gstart.p, ncl, k1);
@@ -1112,8 +1294,7 @@ static void close_batch(MergeResult &R)
               for (uint32_t c : big)
                 { const int64_t b0 = gs[c], bn = (int64_t) gs[c + 1] - b0;
                   uint64_t *sk = k0 + b0, *ok = k1 + b0;
-                  uint32_t *sv = v0 + b0, *ov = v1 + b0;
-                  radix_sort_pairs(&sk, &sv, &ok, &ov, bn, 0, R.pbits, st.sort, "pile_sort");
+                  radix_sort_pairs(&sk, nullptr, &ok, nullptr, bn, 0, R.pbits, st.sort, "pile_sort");
                   if (sk != k1 + b0)
                     HIP_CHECK(hipMemcpyAsync(k1 + b0, sk, sizeof(uint64_t) * bn, hipMemcpyDeviceToDevice, stream()));
                 }
@@ -1124,12 +1305,16 @@ static void close_batch(MergeResult &R)
         R.cog.ensure((size_t) ncl + 2, "pair of cluster");
         R.ocfirst.ensure((size_t) ncl + 2, "first cluster of pair");
         R.glast.ensure((size_t) ncl + 1, "last apos of pair");
+        static DevBuf<uint32_t> pmax;
+        pmax.ensure((size_t) ncl + 2, "largest apos of pair");
         int nb = ceil_div(ncl, 256);
-        hipLaunchKernelGGL(k_pair_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p);
+        hipLaunchKernelGGL(k_pair_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p, pmax.p);
         exclusive_scan_u32(R.cog.p, ncl, st.sort.bsum, R.cog.p + ncl);
-        hipLaunchKernelGGL(k_pair_write, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p,
+        hipLaunchKernelGGL(k_pair_max, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p,
                            (const uint32_t *) (R.cog.p + ncl), R.ocfirst.p, (const uint64_t *) k0,
-                           (const uint32_t *) R.gstart.p, (uint64_t) 0xffffffffull, R.glast.p);
+                           (const uint32_t *) R.gstart.p, pmax.p);
+        hipLaunchKernelGGL(k_pair_glast, dim3(nb), dim3(256), 0, stream(), (const uint32_t *) R.cog.p, ncl,
+                           (const uint32_t *) pmax.p, R.glast.p);
       }
     }
   R.sab = k0;

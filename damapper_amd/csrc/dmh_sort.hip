@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include "dmh_common.h"
+#include "dmh_device.h"
 
 namespace dmh {
 
@@ -19,29 +20,6 @@ namespace dmh {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS   = 8;
 constexpr int SCAN_CHUNK   = SCAN_THREADS * SCAN_ITEMS;
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int lane)
-{
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1)
-    { uint32_t y = __shfl_up(x, o);
-      if (lane >= o) x += y;
-    }
-  return x;
-}
-
-// Exclusive scan across a 256-thread block; *total receives the block sum.
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *ws, uint32_t *total)
-{ int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t x = wave_incl_scan(v, lane);
-  if (lane == 63) ws[w] = x;
-  __syncthreads();
-  uint32_t wbase = 0;
-  for (int i = 0; i < w; i++) wbase += ws[i];
-  *total = ws[0] + ws[1] + ws[2] + ws[3];
-  __syncthreads();
-  return wbase + x - v;
-}
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t *data, int64_t n, uint32_t *bsum)
 { __shared__ uint32_t ws[4];
@@ -153,6 +131,7 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles)
 // through LDS into digit order, so that consecutive threads write consecutive slots of each
 // digit's output run (coalesced 8-byte / 4-byte stores), the run's global start coming from the
 // scanned histogram.
+template <bool VALS>
 __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_t *__restrict__ kin,
                                                                  const uint32_t *__restrict__ vin,
                                                                  uint64_t *__restrict__ kout,
@@ -183,7 +162,7 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_
     { int64_t i = base + j * 64;
       bool ok = i < n;
       key[j] = ok ? __builtin_nontemporal_load(kin + i) : 0;     // read once: keep it out of the caches' way
-      val[j] = ok ? __builtin_nontemporal_load(vin + i) : 0;
+      val[j] = (VALS && ok) ? __builtin_nontemporal_load(vin + i) : 0;
     }
 
   volatile uint32_t *mywh = wh[w];
@@ -245,6 +224,7 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_
           kout[slot[k2]] = k;                   // (plain stores: neighbouring tiles' pieces merge in L2)
         }
     }
+  if (!VALS) return;                            // (keys only: the words of the seed sort carry everything)
   __syncthreads();
   uint32_t *sval = (uint32_t *) skey;
 #pragma unroll
@@ -280,13 +260,18 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
       }
       { // one LSD pass over 16-byte records in the reference: read 16 B + write 16 B per record
         StageTimer tc("k_radix_scatter", 32.0 * (double) n);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
-                           (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,
-                           shift, mask, (const uint32_t *) scr.hist.p, ntiles, 0);
+        if (vals != nullptr)
+          hipLaunchKernelGGL(k_radix_scatter<true>, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+                             (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,
+                             shift, mask, (const uint32_t *) scr.hist.p, ntiles, 0);
+        else
+          hipLaunchKernelGGL(k_radix_scatter<false>, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+                             (const uint64_t *) *keys, (const uint32_t *) nullptr, *okeys, (uint32_t *) nullptr, n,
+                             shift, mask, (const uint32_t *) scr.hist.p, ntiles, 0);
       }
       HIP_CHECK(hipGetLastError());
       uint64_t *tk = *keys; *keys = *okeys; *okeys = tk;
-      uint32_t *tv = *vals; *vals = *ovals; *ovals = tv;
+      if (vals != nullptr) { uint32_t *tv = *vals; *vals = *ovals; *ovals = tv; }
     }
 }
 
@@ -326,7 +311,7 @@ void radix_pass_scatter(const uint64_t *keys, const uint32_t *vals, uint64_t *ok
   if (t1 <= t0) return;
   int64_t recs = std::min<int64_t>(n, (int64_t) t1 * SORT_TILE) - (int64_t) t0 * SORT_TILE;
   StageTimer tc("k_radix_scatter", 32.0 * (double) recs);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(t1 - t0), dim3(SORT_THREADS), 0, stream(), keys, vals, okeys, ovals, n,
+  hipLaunchKernelGGL(k_radix_scatter<true>, dim3(t1 - t0), dim3(SORT_THREADS), 0, stream(), keys, vals, okeys, ovals, n,
                      shift, mask, (const uint32_t *) scr.hist.p, ntiles, t0);
   HIP_CHECK(hipGetLastError());
 }

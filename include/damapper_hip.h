@@ -149,6 +149,7 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  *                        kernel may hold n window entries in LDS (forces its spill path)
  *   "cluster" 1/0        chain groups are the B-clusters of an (aread, bread) pair / whole pairs (-1: by hit density)
  *   "cluster_sort" 0     clusters are ordered by a second global radix sort instead of where they lie
+ *   "seed_word" 0        cluster mode sorts (key, value) pairs even when aread | bread | bpos | apos fit one word
  *   "batch" 0            every Match_Filter pass is chained by itself (no batches of sparse passes)
  *   "in_flight" 0        every batch is finished before the next pass starts
  *   "expand" 0           hits are expanded entry by entry instead of by output tiles

@@ -157,12 +157,14 @@ def test_ragged_and_degenerate_reads(tmp_path):
                                   dict(cluster=1), dict(cluster=1, chain_pile=16), dict(cluster=1, chain_g=64),
                                   dict(chain_small=0), dict(cluster=1, chain_small=0), dict(cluster=1, chain_small=7),
                                   dict(chain_lane=0), dict(cluster=1, chain_lane=0), dict(batch=0),
-                                  dict(cluster=1, cluster_sort=0), dict(expand=0), dict(cluster=1, in_flight=0)],
+                                  dict(cluster=1, cluster_sort=0), dict(expand=0), dict(cluster=1, in_flight=0),
+                                  dict(cluster=1, seed_word=0), dict(cluster=1, seed_word=0, expand=0), dict(cluster=1, expand=0)],
                          ids=["wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
                               "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table", "merge_low16_probes",
                               "clusters", "clusters_piles", "clusters_chain64",
                               "no_lds_groups", "clusters_no_lds_groups", "clusters_lds_groups_7",
-                              "no_lane_groups", "clusters_no_lane_groups", "no_pass_batches", "clusters_global_sort", "expand_per_entry", "clusters_nothing_in_flight"])
+                              "no_lane_groups", "clusters_no_lane_groups", "no_pass_batches", "clusters_global_sort", "expand_per_entry", "clusters_nothing_in_flight",
+                              "clusters_key_value_sort", "clusters_key_value_sort_per_entry", "clusters_expand_per_entry"])
 def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes
     to the same bytes: force each one and compare with the default route (itself checked against the
@@ -199,6 +201,7 @@ def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
         L.dmh_test_option(b"cluster_sort", -1)
         L.dmh_test_option(b"expand", -1)
         L.dmh_test_option(b"in_flight", -1)
+        L.dmh_test_option(b"seed_word", -1)
     assert len(base[0][1]) > 50
     assert base == alt
 
