@@ -1062,45 +1062,53 @@ struct OrdChain
 
 // Reporting order inside a group (map.c:1634-1642): live ends by (diagonal, apos) descending, then expired ends
 // most recent first -- i.e. descending (live, okey).  The keys of a group are unique, so the rank of an end is
-// the number of its siblings that precede it; the ends of group g go to ord[goff[g] ...).
-__global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__restrict__ out, uint32_t ngroups,
-                                                         const uint32_t *__restrict__ gbase,
-                                                         const uint32_t *__restrict__ gcount,
-                                                         const uint32_t *__restrict__ goff,
-                                                         const uint64_t *__restrict__ gkey,
-                                                         const uint32_t *__restrict__ cog,
-                                                         const uint32_t *__restrict__ ocfirst,
-                                                         OrdChain *__restrict__ ord)
+// the number of its siblings that precede it.  The siblings are the ends of all groups of the same (aread, bread)
+// pair -- the group itself, or in cluster mode the pair's clusters c0..c1-1 (their numbers are consecutive), of which
+// only a few hold an end at all.  So the ends are first packed (goff = exclusive scan of the groups' end counts:
+// the ends of group g go to slots goff[g]..., a pair's ends to goff[c0] .. goff[c1]) together with their pair's slot
+// range, and then every end is ranked by its own thread among that short range.
+__global__ __launch_bounds__(256) void k_pack_summaries(const ChainSummary *__restrict__ out, uint32_t ngroups,
+                                                        const uint32_t *__restrict__ gbase,
+                                                        const uint32_t *__restrict__ gcount,
+                                                        const uint32_t *__restrict__ goff,
+                                                        const uint32_t *__restrict__ cog,
+                                                        const uint32_t *__restrict__ ocfirst,
+                                                        ChainSummary *__restrict__ packed, uint2 *__restrict__ range)
 { for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x)
     { const uint32_t En = gcount[g];
       if (En == 0) continue;
-      // the siblings: the ends of all groups of the same (aread, bread) pair -- the group itself, or in cluster
-      // mode the pair's clusters c0..c1-1 (their numbers are consecutive)
       uint32_t c0 = g, c1 = g + 1;
       if (cog != nullptr)
         { const uint32_t p = cog[g];
           c0 = ocfirst[p];
           c1 = ocfirst[p + 1];
         }
-      const uint64_t gk = gkey[g];
-      const uint32_t dst = goff[c0], mb = gbase[g];
+      const uint2 r = make_uint2(goff[c0], goff[c1]);
+      const uint32_t dst = goff[g], mb = gbase[g];
       for (uint32_t e = 0; e < En; e++)
-        { const ChainSummary s = out[mb + e];
-          uint32_t rank = 0;
-          for (uint32_t c = c0; c < c1; c++)
-            { const uint32_t b = gbase[c], E = gcount[c];
-              for (uint32_t f = 0; f < E; f++)
-                { const uint32_t tl = out[b + f].live;
-                  const uint64_t tk = out[b + f].okey;
-                  rank += (tl > s.live || (tl == s.live && tk > s.okey)) ? 1u : 0u;
-                }
-            }
-          OrdChain o;
-          o.cost = s.cost; o.ab = s.ab; o.ae = s.ae; o.bb = s.bb; o.be = s.be; o.end = s.end;
-          o.gkey = gk;
-          ord[dst + rank] = o;
+        { packed[dst + e] = out[mb + e];
+          range[dst + e]  = r;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__restrict__ packed,
+                                                         const uint2 *__restrict__ range, uint32_t nsum,
+                                                         const uint64_t *__restrict__ gkey, OrdChain *__restrict__ ord)
+{ const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsum) return;
+  const ChainSummary s = packed[i];
+  const uint2 r = range[i];
+  uint32_t rank = 0;
+  for (uint32_t j = r.x; j < r.y; j++)
+    { const uint32_t tl = packed[j].live;
+      const uint64_t tk = packed[j].okey;
+      rank += (tl > s.live || (tl == s.live && tk > s.okey)) ? 1u : 0u;
+    }
+  OrdChain o;
+  o.cost = s.cost; o.ab = s.ab; o.ae = s.ae; o.bb = s.bb; o.be = s.be; o.end = s.end;
+  o.gkey = gkey[s.group];
+  ord[r.x + rank] = o;
 }
 
 // rgfirst[r] = first group whose read index is >= r (r = 0..nreads): read r's groups are [rgfirst[r], rgfirst[r+1])
@@ -1640,7 +1648,11 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   const int nreads = ablock->nreads;
   static DevBuf<OrdChain> ord;
   static DevBuf<uint32_t> rgfirst, fresh, jl;
+  static DevBuf<ChainSummary> packed;
+  static DevBuf<uint2> prange;
   ord.ensure(nsum, "ordered chain ends");
+  packed.ensure(nsum, "packed chain ends");
+  prange.ensure(nsum, "sibling ranges of the chain ends");
   rgfirst.ensure((size_t) nreads + 2, "groups per read");
   fresh.ensure(nsum, "fresh candidates");
   jl.ensure(2 * (size_t) nsum + 4, "jump lengths");
@@ -1652,11 +1664,13 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   { StageTimer tm("chain_dominate", 40.0 * nsum);
     HIP_CHECK(hipMemsetAsync(cs.ctl.p, 0, 16 * sizeof(unsigned int), stream()));
-    hipLaunchKernelGGL(k_order_summaries, dim3(std::min<uint32_t>(ceil_div(ng, 256), 8192)), dim3(256), 0, stream(),
+    hipLaunchKernelGGL(k_pack_summaries, dim3(std::min<uint32_t>(ceil_div(ng, 256), 8192)), dim3(256), 0, stream(),
                        (const ChainSummary *) out.p, ng, (const uint32_t *) gbase.p,
-                       (const uint32_t *) gcnt.p, (const uint32_t *) goff.p, (const uint64_t *) R.gkey.p,
+                       (const uint32_t *) gcnt.p, (const uint32_t *) goff.p,
                        R.clustered ? (const uint32_t *) R.cog.p : (const uint32_t *) nullptr,
-                       R.clustered ? (const uint32_t *) R.ocfirst.p : (const uint32_t *) nullptr, ord.p);
+                       R.clustered ? (const uint32_t *) R.ocfirst.p : (const uint32_t *) nullptr, packed.p, prange.p);
+    hipLaunchKernelGGL(k_order_summaries, dim3(ceil_div(nsum, 256)), dim3(256), 0, stream(),
+                       (const ChainSummary *) packed.p, (const uint2 *) prange.p, nsum, (const uint64_t *) R.gkey.p, ord.p);
     hipLaunchKernelGGL(k_read_groups, dim3(ceil_div((int64_t) ng + 1, 256)), dim3(256), 0, stream(),
                        (const uint64_t *) R.gkey.p, ng, R.bbits + R.passbits, nreads, rgfirst.p);
     hipLaunchKernelGGL(k_dom_need, dim3(ceil_div(nreads, 256)), dim3(256), 0, stream(),

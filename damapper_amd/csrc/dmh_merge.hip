@@ -258,13 +258,30 @@ __global__ __launch_bounds__(256) void k_merge_fixup(const uint64_t *__restrict_
                                                      const uint32_t *__restrict__ tile_count,
                                                      unsigned long long *__restrict__ tile_hits)
 { __shared__ unsigned long long sh[2][4];
+  __shared__ uint16_t pend[MG_TILE];
+  __shared__ uint32_t npend;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t cnt = tile_count[blockIdx.x];
   MergeEntry *ent = tile_entries + (size_t) blockIdx.x * MG_TILE;
   unsigned long long local = 0, below = 0;
-  for (uint32_t x = tid; x < cnt; x += 256)
-    { MergeEntry en = ent[x];
-      if (en.mb != PENDING) continue;
+  // the open look-ups are first listed (they are a minority of the tile's entries), so that the searches -- chains of
+  // dependent loads -- run with every lane busy
+  if (tid == 0) npend = 0;
+  __syncthreads();
+  for (uint32_t x0 = 0; x0 < cnt; x0 += 256)
+    { const uint32_t x = x0 + tid;
+      const bool p = x < cnt && ent[x].mb == PENDING;
+      const uint64_t m = __ballot(p);
+      uint32_t base = 0;
+      if (m != 0 && lane == 0) base = atomicAdd(&npend, (uint32_t) __popcll(m));
+      base = __shfl(base, 0);
+      if (p) pend[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) x;
+    }
+  __syncthreads();
+  const uint32_t np = npend;
+  for (uint32_t y = tid; y < np; y += 256)
+    { const uint32_t x = pend[y];
+      MergeEntry en = ent[x];
       const int64_t  i = en.a0;
       const uint64_t c = akeys[i];
       uint32_t lo = 0, mb = 0;
@@ -577,46 +594,56 @@ __global__ void k_cluster_rekey(const uint64_t *__restrict__ hkeys, const uint32
 //  and a flag per hit: the cluster starts are counted per tile of WC_TILE hits, the tile counts are scanned (a few ten
 //  thousand numbers), and the second pass numbers the clusters inside its tile and writes the chain kernels' word.
 // ---------------------------------------------------------------------------------------
-constexpr int WC_ITEMS = 8;
-constexpr int WC_TILE  = 256 * WC_ITEMS;
+constexpr int WC_CHUNKS = 4;                       // a wavefront takes WC_CHUNKS x 128 consecutive words, two per lane and chunk
+constexpr int WC_WAVE   = WC_CHUNKS * 128;
+constexpr int WC_TILE   = 4 * WC_WAVE;
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
-// the tile's words, WC_ITEMS consecutive ones per thread (the arrays start on a 16-byte boundary), and the start flags
-// of the thread's words as a bit mask
-__device__ __forceinline__ uint32_t wc_load(const uint64_t *__restrict__ w, int64_t n, int64_t base, int pbits, int qbits,
-                                            int cb, uint64_t (&x)[WC_ITEMS])
-{ if (base >= n) return 0;
-  if (base + WC_ITEMS <= n)
-    { const ull2 *v = (const ull2 *) (w + base);
+// The wavefront's words (lane l holds words 2l, 2l+1 of each chunk: every load instruction covers 1 KB without gaps;
+// the arrays start on a 16-byte boundary) and the start flags of the lane's two words per chunk (bit 0, bit 1).
+__device__ __forceinline__ void wc_load(const uint64_t *__restrict__ w, int64_t n, int64_t wbase, int lane, int pbits,
+                                        int qbits, int cb, uint64_t (&x)[WC_CHUNKS][2], uint32_t (&f)[WC_CHUNKS])
+{
 #pragma unroll
-      for (int j = 0; j < WC_ITEMS / 2; j++)
-        { const ull2 t = __builtin_nontemporal_load(v + j);
-          x[2 * j] = t.x; x[2 * j + 1] = t.y;
+  for (int c = 0; c < WC_CHUNKS; c++)
+    { const int64_t i = wbase + c * 128 + 2 * lane;
+      if (i + 2 <= n)
+        { const ull2 t = __builtin_nontemporal_load((const ull2 *) (w + i));
+          x[c][0] = t.x; x[c][1] = t.y;
+        }
+      else
+        { x[c][0] = (i < n) ? w[i] : 0;
+          x[c][1] = 0;
         }
     }
-  else
-    {
+  uint64_t carry = (wbase > 0 && wbase < n) ? w[wbase - 1] : 0;        // the word before the chunk's first
 #pragma unroll
-      for (int j = 0; j < WC_ITEMS; j++) x[j] = (base + j < n) ? w[base + j] : 0;
+  for (int c = 0; c < WC_CHUNKS; c++)
+    { const int64_t i = wbase + c * 128 + 2 * lane;
+      uint64_t prev = ((uint64_t) (uint32_t) __shfl_up((int) (uint32_t) (x[c][1] >> 32), 1) << 32)
+                      | (uint64_t) (uint32_t) __shfl_up((int) (uint32_t) x[c][1], 1);
+      if (lane == 0) prev = carry;
+      uint32_t fl = 0;
+      if (i < n && (i == 0 || cluster_start(prev >> pbits, x[c][0] >> pbits, qbits, cb))) fl |= 1u;
+      if (i + 1 < n && cluster_start(x[c][0] >> pbits, x[c][1] >> pbits, qbits, cb)) fl |= 2u;
+      f[c] = fl;
+      carry = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (x[c][1] >> 32), 63) << 32)
+              | (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) x[c][1], 63);
     }
-  uint64_t prev = (base > 0) ? w[base - 1] : 0;
-  uint32_t f = 0;
-#pragma unroll
-  for (int j = 0; j < WC_ITEMS; j++)
-    { if (base + j < n && (base + j == 0 || cluster_start(prev >> pbits, x[j] >> pbits, qbits, cb))) f |= 1u << j;
-      prev = x[j];
-    }
-  return f;
 }
 
 __global__ __launch_bounds__(256) void k_wcluster_count(const uint64_t *__restrict__ w, int64_t n, int pbits, int qbits,
                                                         int cb, uint32_t *__restrict__ tcount)
 { __shared__ uint32_t ws[4];
-  uint64_t x[WC_ITEMS];
-  const int64_t base = (int64_t) blockIdx.x * WC_TILE + (int64_t) threadIdx.x * WC_ITEMS;
-  uint32_t c = (uint32_t) __popc(wc_load(w, n, base, pbits, qbits, cb, x));
+  uint64_t x[WC_CHUNKS][2];
+  uint32_t f[WC_CHUNKS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  wc_load(w, n, (int64_t) blockIdx.x * WC_TILE + (int64_t) wv * WC_WAVE, lane, pbits, qbits, cb, x, f);
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < WC_CHUNKS; k++) c += (uint32_t) __popc(f[k]);
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  if (lane == 0) ws[wv] = c;
   __syncthreads();
   if (threadIdx.x == 0) tcount[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
@@ -627,38 +654,46 @@ __global__ __launch_bounds__(256) void k_wcluster_rekey(const uint64_t *__restri
                                                         uint64_t *__restrict__ sab, uint32_t *__restrict__ gstart,
                                                         uint32_t ncl, uint64_t *__restrict__ gkey)
 { __shared__ uint32_t ws[4];
-  uint64_t x[WC_ITEMS];
-  const int64_t base = (int64_t) blockIdx.x * WC_TILE + (int64_t) threadIdx.x * WC_ITEMS;
-  const uint32_t f = wc_load(w, n, base, pbits, qbits, cb, x);
-  uint32_t tot;
-  uint32_t c = toff[blockIdx.x] + block_excl_scan((uint32_t) __popc(f), ws, &tot);
-  if (base >= n) return;
+  uint64_t x[WC_CHUNKS][2];
+  uint32_t f[WC_CHUNKS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const int64_t wbase = (int64_t) blockIdx.x * WC_TILE + (int64_t) wv * WC_WAVE;
+  wc_load(w, n, wbase, lane, pbits, qbits, cb, x, f);
+  // starts before the lane's first word of each chunk, inside the wavefront
+  uint32_t before[WC_CHUNKS], run = 0;
+#pragma unroll
+  for (int k = 0; k < WC_CHUNKS; k++)
+    { const uint64_t b0 = __ballot(f[k] & 1u), b1 = __ballot(f[k] & 2u);
+      before[k] = run + (uint32_t) __popcll(b0 & lt) + (uint32_t) __popcll(b1 & lt);
+      run += (uint32_t) __popcll(b0) + (uint32_t) __popcll(b1);
+    }
+  if (lane == 0) ws[wv] = run;
+  __syncthreads();
+  uint32_t cbase = toff[blockIdx.x];
+  for (int i = 0; i < wv; i++) cbase += ws[i];
   const uint64_t pm = (1ull << pbits) - 1ull, qm = (1ull << qbits) - 1ull;
   const int top = pbits + qbits;
 #pragma unroll
-  for (int j = 0; j < WC_ITEMS; j++)
-    { if ((f >> j) & 1u)
-        { gstart[c] = (uint32_t) (base + j);
-          gkey[c]   = x[j] >> top;
+  for (int k = 0; k < WC_CHUNKS; k++)
+    { const int64_t i = wbase + k * 128 + 2 * lane;
+      uint32_t c = cbase + before[k];
+      if (f[k] & 1u)
+        { gstart[c] = (uint32_t) i;
+          gkey[c]   = x[k][0] >> top;
           c += 1;
         }
-      x[j] = (x[j] & pm) | (((x[j] >> pbits) & qm) << 32);
-    }
-  if (base + WC_ITEMS <= n)
-    { ull2 *v = (ull2 *) (sab + base);
-#pragma unroll
-      for (int j = 0; j < WC_ITEMS / 2; j++)
-        { ull2 t; t.x = x[2 * j]; t.y = x[2 * j + 1];
-          v[j] = t;
+      if (f[k] & 2u)
+        { gstart[c] = (uint32_t) (i + 1);
+          gkey[c]   = x[k][1] >> top;
         }
+      ull2 t;
+      t.x = (x[k][0] & pm) | (((x[k][0] >> pbits) & qm) << 32);
+      t.y = (x[k][1] & pm) | (((x[k][1] >> pbits) & qm) << 32);
+      if (i + 2 <= n) *(ull2 *) (sab + i) = t;
+      else if (i < n) sab[i] = t.x;
     }
-  else
-    {
-#pragma unroll
-      for (int j = 0; j < WC_ITEMS; j++)
-        if (base + j < n) sab[base + j] = x[j];
-    }
-  if (base == 0) gstart[ncl] = (uint32_t) n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) gstart[ncl] = (uint32_t) n;
 }
 
 // ---------------------------------------------------------------------------------------

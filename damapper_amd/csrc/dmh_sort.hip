@@ -90,6 +90,12 @@ constexpr int SORT_ITEMS   = 16;
 constexpr int SORT_TILE    = SORT_THREADS * SORT_ITEMS;    // 4096 pairs per workgroup
 constexpr int SORT_WTILE   = 64 * SORT_ITEMS;              // 1024 pairs per wavefront
 
+__device__ __forceinline__ int xcd_tile(int b, int ntiles)
+{ const int per = ntiles >> 3;                 // tiles per XCD (the remainder keeps its own index)
+  if (b >= (per << 3)) return b;
+  return (b & 7) * per + (b >> 3);
+}
+
 // Digit histogram of every tile, laid out digit-major (hist[d*ntiles + tile]) so that one
 // exclusive scan over the whole array yields each (digit, tile)'s first output slot.
 __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__restrict__ keys, int64_t n,
@@ -99,7 +105,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
   int tid = threadIdx.x;
   h[tid] = 0;
   __syncthreads();
-  const int tile = tile_base + (int) blockIdx.x;
+  // (XCD-aware like the scatter: sixteen neighbouring tiles share each 64-byte line of hist[], and only tiles that run
+  // on the same XCD merge their 4-byte counts in its L2 before the line is written back)
+  const int tile = tile_base + xcd_tile(blockIdx.x, gridDim.x);
   int64_t base = (int64_t) tile * SORT_TILE;
   // all loads first, from clamped addresses (a guarded load ahead of its LDS atomic compiles to
   // load - wait - atomic, SORT_ITEMS round trips in a row)
@@ -117,12 +125,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
     }
   __syncthreads();
   hist[(size_t) tid * ntiles + tile] = h[tid];
-}
-
-__device__ __forceinline__ int xcd_tile(int b, int ntiles)
-{ const int per = ntiles >> 3;                 // tiles per XCD (the remainder keeps its own index)
-  if (b >= (per << 3)) return b;
-  return (b & 7) * per + (b >> 3);
 }
 
 // Stable scatter.  Each wavefront owns 1024 consecutive pairs (item j of lane l is element
