@@ -253,33 +253,29 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
 // wavefront paid for it whenever one of its 64 x 8 look-ups needed it (most wavefronts on a repeat-rich reference,
 // three quarters of the kernel's cycles).  Here the open look-ups of a tile lie side by side in the tile's entry
 // window, so the lanes that search are many.  An entry without partners stays in the list with zero size.
-__global__ __launch_bounds__(256) void k_merge_fixup(const uint64_t *__restrict__ akeys, int64_t na, BLookup B,
-                                                     MergeEntry *__restrict__ tile_entries,
-                                                     const uint32_t *__restrict__ tile_count,
-                                                     unsigned long long *__restrict__ tile_hits)
-{ __shared__ unsigned long long sh[2][4];
-  __shared__ uint16_t pend[MG_TILE];
-  __shared__ uint32_t npend;
-  const int tid = threadIdx.x, lane = tid & 63;
+constexpr int FX_THREADS = 64;      // one wavefront per tile: what bounds the kernel is how many searches are in flight per CU
+__global__ __launch_bounds__(FX_THREADS) void k_merge_fixup(const uint64_t *__restrict__ akeys, int64_t na, BLookup B,
+                                                            MergeEntry *__restrict__ tile_entries,
+                                                            const uint32_t *__restrict__ tile_count,
+                                                            unsigned long long *__restrict__ tile_hits)
+{ __shared__ uint16_t pend[MG_TILE];
+  const int lane = threadIdx.x;
   const uint32_t cnt = tile_count[blockIdx.x];
   MergeEntry *ent = tile_entries + (size_t) blockIdx.x * MG_TILE;
   unsigned long long local = 0, below = 0;
   // the open look-ups are first listed (they are a minority of the tile's entries), so that the searches -- chains of
   // dependent loads -- run with every lane busy
-  if (tid == 0) npend = 0;
-  __syncthreads();
-  for (uint32_t x0 = 0; x0 < cnt; x0 += 256)
-    { const uint32_t x = x0 + tid;
+  uint32_t np = 0;
+  for (uint32_t x0 = 0; x0 < cnt; x0 += FX_THREADS)
+    { const uint32_t x = x0 + lane;
       const bool p = x < cnt && ent[x].mb == PENDING;
       const uint64_t m = __ballot(p);
-      uint32_t base = 0;
-      if (m != 0 && lane == 0) base = atomicAdd(&npend, (uint32_t) __popcll(m));
-      base = __shfl(base, 0);
-      if (p) pend[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) x;
+      if (p) pend[np + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) x;
+      np += (uint32_t) __popcll(m);
     }
-  __syncthreads();
-  const uint32_t np = npend;
-  for (uint32_t y = tid; y < np; y += 256)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t y = lane; y < np; y += FX_THREADS)
     { const uint32_t x = pend[y];
       MergeEntry en = ent[x];
       const int64_t  i = en.a0;
@@ -301,12 +297,9 @@ __global__ __launch_bounds__(256) void k_merge_fixup(const uint64_t *__restrict_
     { local += __shfl_down(local, o);
       below += __shfl_down(below, o);
     }
-  if (lane == 0) { sh[0][tid >> 6] = local; sh[1][tid >> 6] = below; }
-  __syncthreads();
-  if (tid == 0)
-    { const unsigned long long a = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
-      if (a) tile_hits[2 * (size_t) blockIdx.x]     += a;
-      if (b) tile_hits[2 * (size_t) blockIdx.x + 1] += b;
+  if (lane == 0)
+    { if (local) tile_hits[2 * (size_t) blockIdx.x]     += local;
+      if (below) tile_hits[2 * (size_t) blockIdx.x + 1] += below;
     }
 }
 
@@ -461,8 +454,18 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
 constexpr int EX_TILE = 2048;
 constexpr int EX_OFFS = 2 * EX_TILE + 2;
 
+// tfirst[T] = the entry that holds slot T * EX_TILE (every slot lies in exactly one entry of non-zero size)
+__global__ void k_tile_first(const uint32_t *__restrict__ eoff, uint32_t nent, uint32_t *__restrict__ tfirst)
+{ const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nent) return;
+  const uint32_t o0 = eoff[e], o1 = eoff[e + 1];
+  if (o1 == o0) return;
+  for (uint32_t T = (o0 + (uint32_t) EX_TILE - 1) / (uint32_t) EX_TILE; T <= (o1 - 1) / (uint32_t) EX_TILE; T++) tfirst[T] = e;
+}
+
 __global__ __launch_bounds__(256) void k_merge_expand_tiled(const MergeEntry *__restrict__ entries, uint32_t nent,
                                                             const uint32_t *__restrict__ eoff,
+                                                            const uint32_t *__restrict__ tfirst,
                                                             const uint32_t *__restrict__ avals,
                                                             const uint32_t *__restrict__ bvals,
                                                             PosMap MA, PosMap MB, int bshift, int pshift, int swap,
@@ -475,14 +478,9 @@ __global__ __launch_bounds__(256) void k_merge_expand_tiled(const MergeEntry *__
   if (o0 >= total) return;
   const uint32_t o1 = (total - o0 < (uint32_t) EX_TILE) ? total : o0 + (uint32_t) EX_TILE;     // one past the tile's last slot
   if (threadIdx.x < 2)
-    { // last entry whose offset is <= o0 (thread 0) / <= o1 - 1 (thread 1)
-      const uint32_t o = threadIdx.x == 0 ? o0 : o1 - 1;
-      uint32_t lo = 0, hi = nent;              // invariant: eoff[lo] <= o, eoff[hi] > o  (eoff[0] = 0, eoff[nent] = total > o)
-      while (hi - lo > 1)
-        { const uint32_t m = (lo + hi) >> 1;
-          if (eoff[m] <= o) lo = m; else hi = m;
-        }
-      s_e[threadIdx.x] = lo;
+    { // the entry of the tile's first slot, and an entry at or behind the one of its last slot (the first slot of the
+      // next tile lies in it or in a later one)
+      s_e[threadIdx.x] = (threadIdx.x == 0) ? tfirst[blockIdx.x] : (o1 < total ? tfirst[blockIdx.x + 1] : nent - 1);
     }
   __syncthreads();
   const uint32_t e_lo = s_e[0], ne = s_e[1] - s_e[0] + 1;
@@ -808,24 +806,29 @@ __global__ __launch_bounds__(1024) void k_csort_classify(const uint32_t *__restr
 }
 
 // one workgroup per listed cluster: bitonic sort of the words (apos << 12 | position) in LDS (apos < 2^20), then the
-// hits are moved in that order
+// hits are moved in that order.  Launched twice over the same list: single wavefronts take the clusters of up to
+// CS_WAVE hits (a true locus of a read: a few hundred hits; the barriers of the network then cost nothing), workgroups
+// of 256 the rest.
+constexpr int CS_WAVE = 512;
+
 __global__ __launch_bounds__(256) void k_csort_medium(const uint64_t *__restrict__ kin,
                                                       const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ list,
                                                       const unsigned int *__restrict__ nlist_p,
-                                                      uint64_t *__restrict__ kout)
-{ __shared__ uint32_t it[CS_MEDIUM];
-  const uint32_t nlist = *nlist_p;
+                                                      uint64_t *__restrict__ kout, uint32_t nlo, uint32_t nhi)
+{ extern __shared__ uint32_t it[];              // nhi words (a power of two)
+  const uint32_t nlist = *nlist_p, T = blockDim.x;
   for (uint32_t x = blockIdx.x; x < nlist; x += gridDim.x)
     { const uint32_t c = list[x], g0 = gstart[c], n = gstart[c + 1] - g0;
+      if (n <= nlo || n > nhi) continue;        // (uniform in the workgroup)
       uint32_t m = 1;
       while (m < n) m <<= 1;
       __syncthreads();
-      for (uint32_t i = threadIdx.x; i < m; i += 256)
+      for (uint32_t i = threadIdx.x; i < m; i += T)
         it[i] = (i < n) ? ((((uint32_t) kin[g0 + i]) << 12) | i) : 0xffffffffu;
       __syncthreads();
       for (uint32_t k = 2; k <= m; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1)
-          { for (uint32_t i = threadIdx.x; i < m; i += 256)
+          { for (uint32_t i = threadIdx.x; i < m; i += T)
               { const uint32_t l = i ^ j;
                 if (l > i)
                   { const uint32_t a = it[i], b = it[l];
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(256) void k_csort_medium(const uint64_t *__restrict
               }
             __syncthreads();
           }
-      for (uint32_t r = threadIdx.x; r < n; r += 256)
+      for (uint32_t r = threadIdx.x; r < n; r += T)
         { const uint32_t i = it[r] & 0xfffu;
           kout[g0 + r] = kin[g0 + i];
         }
@@ -1013,7 +1016,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     else
       hipLaunchKernelGGL((k_merge_match<2, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
                          (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
-    hipLaunchKernelGGL(k_merge_fixup, dim3(ntiles), dim3(256), 0, stream(), (const uint64_t *) A.keys, A.n, BL,
+    hipLaunchKernelGGL(k_merge_fixup, dim3(ntiles), dim3(FX_THREADS), 0, stream(), (const uint64_t *) A.keys, A.n, BL,
                        tentries.p, (const uint32_t *) tcount.p, thits.p);
     hipLaunchKernelGGL(k_merge_reduce, dim3(64), dim3(256), 0, stream(), (const unsigned long long *) thits.p, ntiles, sums);
     exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
@@ -1156,9 +1159,14 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     PosMap MA{A.d_boff, A.d_chunk, A.posbits}, MB{Bx.d_boff, Bx.d_chunk, Bx.posbits};
     static const bool per_entry = getenv("DMH_EXPAND_PER_ENTRY") != nullptr;
     if (!per_entry && st.opt_expand != 0)
-      hipLaunchKernelGGL(k_merge_expand_tiled, dim3(ceil_div(nhits, EX_TILE)), dim3(256), 0, stream(),
-                         (const MergeEntry *) entries.p, nent, (const uint32_t *) eoff.p, (const uint32_t *) A.vals,
+      { static DevBuf<uint32_t> tfirst;
+        tfirst.ensure((size_t) ceil_div(nhits, EX_TILE) + 2, "first entry of each hit tile");
+        hipLaunchKernelGGL(k_tile_first, dim3(nb), dim3(256), 0, stream(), (const uint32_t *) eoff.p, nent, tfirst.p);
+        hipLaunchKernelGGL(k_merge_expand_tiled, dim3(ceil_div(nhits, EX_TILE)), dim3(256), 0, stream(),
+                         (const MergeEntry *) entries.p, nent, (const uint32_t *) eoff.p, (const uint32_t *) tfirst.p,
+                         (const uint32_t *) A.vals,
                          (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, hitmode, passor, hk, hv);
+      }
     else
       { hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                            (const uint32_t *) eoff.p, (const uint32_t *) esz.p, (const uint32_t *) A.vals,
@@ -1315,8 +1323,12 @@ static void close_batch(MergeResult &R)
                              ncl, mlist.p, blist.p, cnt.p);
           hipLaunchKernelGGL(k_csort_small, dim3(std::min<int64_t>(((int64_t) ncl + 15) / 16, 256 * 8)), dim3(256), 0, stream(),
                              (const uint64_t *) k0, (const uint32_t *) R.gstart.p, ncl, k1);
-          hipLaunchKernelGGL(k_csort_medium, dim3(2048), dim3(256), 0, stream(), (const uint64_t *) k0,
-                             (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p, k1);
+          hipLaunchKernelGGL(k_csort_medium, dim3(8192), dim3(64), CS_WAVE * sizeof(uint32_t), stream(), (const uint64_t *) k0,
+                             (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p, k1,
+                             (uint32_t) CS_SMALL, (uint32_t) CS_WAVE);
+          hipLaunchKernelGGL(k_csort_medium, dim3(2048), dim3(256), CS_MEDIUM * sizeof(uint32_t), stream(), (const uint64_t *) k0,
+                             (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p, k1,
+                             (uint32_t) CS_WAVE, (uint32_t) CS_MEDIUM);
           HIP_CHECK(hipGetLastError());
           unsigned int hc[2] = {0, 0};
           copy_d2h(hc, cnt.p, 2 * sizeof(unsigned int), 1);
