@@ -115,8 +115,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
                                                             MergeEntry *__restrict__ tile_entries,
                                                             uint32_t *__restrict__ tile_count,
                                                             unsigned long long *__restrict__ tile_hits)
-{ __shared__ MergeEntry stage[MG_TILE];        // matched runs of this tile
-  __shared__ unsigned long long s_hits[2][4];
+{ __shared__ unsigned long long s_hits[2][4];
   __shared__ uint32_t s_count;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) s_count = 0;
@@ -124,6 +123,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
 
   // hits of the tile: all of them, and those of the runs below MAXGRAM (what the limit rule can keep at most)
   unsigned long long local = 0, below = 0;
+  MergeEntry *dst = tile_entries + (size_t) blockIdx.x * MG_TILE;        // the tile's own window of the entry list
 
   // The look-ups of a thread's MG_ITEMS codes are independent: issue them phase by phase (codes,
   // bucket bounds, the first two keys of the bucket) so that every thread has MG_ITEMS loads in
@@ -163,18 +163,32 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
   // exceed the code -- only then the bisection runs
   // LOW: the entries of a bucket share the bits above `shift`, so the probe compares the low bits only, kept
   // in a 2-byte array of their own: a quarter of the REF key traffic of a pass (the bisection uses the keys)
+  // LOW with four keys: the four 2-byte values are ONE (unaligned) 8-byte load -- a quarter of the load instructions and
+  // half the registers of four separate ones; values past the bucket's end are never looked at (every use is
+  // guarded by the bucket's size)
   using KT = typename std::conditional<LOW, uint32_t, uint64_t>::type;      // (registers: NK * MG_ITEMS of these)
-  KT kk[NK][MG_ITEMS];
+  constexpr bool PACK4 = LOW && NK == 4;
+  typedef uint64_t u64a2 __attribute__((aligned(2)));
+  KT       kk[PACK4 ? 1 : NK][MG_ITEMS];
+  uint64_t kq[PACK4 ? MG_ITEMS : 1];
   const uint64_t lowmask = LOW ? (((uint64_t) 1 << B.shift) - 1) : ~0ull;
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
-    {
+    { if (PACK4)
+        kq[j] = (bs[j] < be[j]) ? *(const u64a2 *) (B.klow + bs[j]) : 0;
+      else
+        {
 #pragma unroll
-      for (int t = 0; t < NK; t++)
-        { if (LOW) kk[t][j] = (KT) ((bs[j] + t < be[j]) ? (uint32_t) B.klow[bs[j] + t] : 0xffffffffu);
-          else     kk[t][j] = (KT) ((bs[j] + t < be[j]) ? B.keys[bs[j] + t] : ~0ull);
+          for (int t = 0; t < NK; t++)
+            { if (LOW) kk[t][j] = (KT) ((bs[j] + t < be[j]) ? (uint32_t) B.klow[bs[j] + t] : 0xffffffffu);
+              else     kk[t][j] = (KT) ((bs[j] + t < be[j]) ? B.keys[bs[j] + t] : ~0ull);
+            }
         }
     }
+  auto key_at = [&](int t, int j) -> KT
+  { if (PACK4) return (KT) ((kq[j] >> (16 * t)) & 0xffffull);
+    return kk[PACK4 ? 0 : t][j];
+  };
 
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
@@ -184,16 +198,16 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
       int64_t  e = 0;
       bool     hit = false;
       const KT cq = (KT) (c[j] & lowmask);         // what the fetched keys are compared with
-      if (first[j] && bs[j] < be[j] && kk[0][j] <= cq)
+      if (first[j] && bs[j] < be[j] && key_at(0, j) <= cq)
         { const uint32_t sz = be[j] - bs[j];
           const uint64_t cc = c[j];
-          if (sz > (uint32_t) NK && kk[NK - 1][j] <= cq)
+          if (sz > (uint32_t) NK && key_at(NK - 1, j) <= cq)
             mb = PENDING;            // a long bucket: searched by k_merge_fixup, where every lane has such a look-up
           else
             {
 #pragma unroll
               for (int t = 0; t < NK; t++)
-                if ((uint32_t) t < sz && kk[t][j] == cq)
+                if ((uint32_t) t < sz && key_at(t, j) == cq)
                   { if (mb == 0) lo = bs[j] + (uint32_t) t;
                     mb += 1;
                   }
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
               en.ma = (uint32_t) (e - i);
               en.b0 = lo;
               en.mb = mb;
-              stage[base + __popcll(m & ((1ull << lane) - 1ull))] = en;
+              dst[base + __popcll(m & ((1ull << lane) - 1ull))] = en;    // (a wavefront's entries are neighbours)
             }
         }
     }
@@ -242,10 +256,6 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
       tile_hits[2 * (size_t) blockIdx.x + 1] = s_hits[1][0] + s_hits[1][1] + s_hits[1][2] + s_hits[1][3];
       tile_count[blockIdx.x] = s_count;
     }
-  const uint32_t cnt = s_count;
-  MergeEntry *dst = tile_entries + (size_t) blockIdx.x * MG_TILE;
-  for (uint32_t x = tid; x < cnt; x += MG_THREADS)
-    dst[x] = stage[x];
 }
 
 // The look-ups k_merge_match left open: codes that fall into a LONG bucket of the REF index (a repeat's k-mer and its
@@ -977,7 +987,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
       const bool low16 = Bx.bshift <= 16;
       size_t words = (size_t) (nbucket + 2);
       Bx.low_off = low16 ? words : 0;
-      if (low16) words += ((size_t) Bx.n + 1) / 2 + 1;
+      if (low16) words += ((size_t) Bx.n + 1) / 2 + 3;          // (+ room for the 8-byte probe of the last entry)
       Bx.d_bstart = (uint32_t *) dev_alloc(sizeof(uint32_t) * words, "bucket table");
       Bx.bstart_bytes = sizeof(uint32_t) * words;
       StageTimer tm("merge_buckets", 8.0 * Bx.n);
