@@ -755,7 +755,7 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
   int morea, morey, mored, moreha, morehb, morem, lasta;
   int ncell = 0;
 #ifdef DMH_ALIGN_PROFILE
-  int prof_maxw = 1, prof_sumw = 0;
+  int prof_maxw = 1, prof_sumw = 0, prof_wide = 0, prof_wmode = 0, prof_wsteps = 0;
 #endif
 
   // per-lane state of "my" diagonal
@@ -912,6 +912,9 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
 #ifdef DMH_ALIGN_PROFILE
       if (hgh - low + 1 > prof_maxw) prof_maxw = hgh - low + 1;
       prof_sumw += hgh - low + 1;
+      if (hgh - low + 1 > 14) prof_wide += 1;
+      if (hgh - low + 1 > 14) prof_wmode = 1; else if (hgh - low + 1 <= 10) prof_wmode = 0;
+      prof_wsteps += prof_wmode;
 #endif
 
       const int  k      = low + ((lane - low) & (G - 1));     // the diagonal of this lane in the new band
@@ -1099,6 +1102,8 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
   APROF_ADD(prof_maxw <= 14 ? 8 : (prof_maxw <= 30 ? 9 : (prof_maxw <= 46 ? 10 : 11)), 1);
   APROF_ADD(12, prof_sumw);
   APROF_ADD(13, dif);
+  APROF_ADD(14, prof_wide);
+  APROF_ADD(15, prof_wsteps);
 #endif
   return AL_OK;
 }

@@ -974,7 +974,9 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
       const bool big = (dense >= 0) ? (dense != 0) : (Bx.n >= ((int64_t) 1 << 26));
       int P = ceil_log2(Bx.n) + 2;
       if (P < 8) P = 8;
-      if (big) { if (P > 29) P = 29; } else { if (P > 28) P = 28; }
+      static const int env_p = getenv("DMH_BUCKET_BITS") ? atoi(getenv("DMH_BUCKET_BITS")) : 0;       // (experiments)
+      const int pmax = env_p > 0 ? env_p : 29;
+      if (big) { if (P > pmax) P = pmax; } else { if (P > 28) P = 28; }
       if (dense == 1) P = std::max(4, ceil_log2(Bx.n));
       if (dense == 2) P = std::max(4, Kshift - 16);          // (test: the 2-byte probe array on any index)
       if (P > Kshift) P = Kshift;

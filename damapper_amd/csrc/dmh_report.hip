@@ -1462,7 +1462,15 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
       if (defer)
         { if (g_astream == nullptr)
-            { HIP_CHECK(hipStreamCreateWithFlags(&g_astream, hipStreamNonBlocking));
+            { // (DMH_ASTREAM_PRIO=1: the deferred alignment kernel on a low-priority stream -- experiments)
+              static const int prio = getenv("DMH_ASTREAM_PRIO") ? atoi(getenv("DMH_ASTREAM_PRIO")) : 0;
+              if (prio != 0)
+                { int least = 0, greatest = 0;
+                  HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                  HIP_CHECK(hipStreamCreateWithPriority(&g_astream, hipStreamNonBlocking, prio > 0 ? least : greatest));
+                }
+              else
+                HIP_CHECK(hipStreamCreateWithFlags(&g_astream, hipStreamNonBlocking));
               HIP_CHECK(hipEventCreateWithFlags(&g_ev_ab, hipEventDisableTiming));
               HIP_CHECK(hipEventCreateWithFlags(&g_ev_done, hipEventDisableTiming));
             }
