@@ -756,6 +756,7 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
   int ncell = 0;
 #ifdef DMH_ALIGN_PROFILE
   int prof_maxw = 1, prof_sumw = 0, prof_wide = 0, prof_wmode = 0, prof_wsteps = 0;
+  long long prof_tprev = 0;
 #endif
 
   // per-lane state of "my" diagonal
@@ -910,6 +911,12 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
       if (dif > S.alen + S.blen + 64) return AL_ERR_LOOP;
       dif += 1;
 #ifdef DMH_ALIGN_PROFILE
+      if (G == 32 && (threadIdx.x & 63) == __ffsll((long long) __ballot(true)) - 1)
+        { const long long tnow = clock64();
+          atomicAdd(&g_aprof[10], 1ull);
+          if (prof_tprev != 0) atomicAdd(&g_aprof[15], (unsigned long long) (tnow - prof_tprev));
+        }
+      prof_tprev = clock64();
       if (hgh - low + 1 > prof_maxw) prof_maxw = hgh - low + 1;
       prof_sumw += hgh - low + 1;
       if (hgh - low + 1 > 14) prof_wide += 1;
@@ -1103,8 +1110,438 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
   APROF_ADD(12, prof_sumw);
   APROF_ADD(13, dif);
   APROF_ADD(14, prof_wide);
-  APROF_ADD(15, prof_wsteps);
+  (void) prof_wsteps;
 #endif
+  return AL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+//  FOUR alignments per wavefront: 16 lanes each.  The band of a 10 kb / 15 % read is 7.8 diagonals wide on
+//  average and wider than 14 in 3 % of the wave steps only -- but two passes in three get there at some point,
+//  so a 16-lane ring alone would send most work to the wider kernels.  Here every lane has TWO slots.  While the
+//  band is NARROW (<= 14 diagonals) the ring has 16 positions, diagonal k lives in slot 0 of lane k & 15 and
+//  slot 1 is not even executed (unless another group of the wavefront is wide).  When the band grows past 14 the
+//  ring becomes 32 positions -- position p = k & 31 is slot p >> 4 of lane p & 15 -- and a diagonal moves at most
+//  from slot 0 to slot 1 of its own lane; back to the 16-position ring at <= 10 diagonals.  Neighbour reads are
+//  ds_bpermute on both slots with a select at the seam lanes (0 and 15); masks are 16-bit slices of the wavefront
+//  ballots, joined and rotated into diagonal order with one funnel shift.  Arithmetic and ordered reductions are
+//  those of wave_pass_reg (A view only: the -C runs use the one-per-wavefront kernel).
+//  Measured (configs[1], 26 k candidates): 26 % fewer vector and 21 % fewer scalar instructions than the 32-lane
+//  kernel, but 161 registers = three wavefronts per SIMD instead of four and 200 pebbles of LDS per group instead of
+//  288 (more candidates re-run on the one-per-wavefront kernel): 16.0 ms against 14.1.  Opt-in ("align_g" = 16).
+// ---------------------------------------------------------------------------------------
+template <> struct Grp<16>
+{ static constexpr int BAND   = 30;
+  static constexpr int NARROW = 14;     // widest band of the 16-position ring
+  static constexpr int BACK   = 10;     // back to it at this width
+  static __device__ __forceinline__ int  gl()   { return threadIdx.x & 15; }
+  static __device__ __forceinline__ int  base() { return threadIdx.x & 48; }
+  static __device__ __forceinline__ int  perm(int addr, int v) { return __builtin_amdgcn_ds_bpermute(addr, v); }
+  static __device__ __forceinline__ int  addr_of(int l) { return (base() | (l & 15)) << 2; }
+  static __device__ __forceinline__ uint32_t ballot(bool p)
+  { return (uint32_t) (__ballot(p) >> base()) & 0xffffu; }
+  static __device__ __forceinline__ int  excl_scan(int v, int &total)
+  { const int gl_ = threadIdx.x & 15;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1)
+      { int y = __shfl_up(x, o, 16);
+        if (gl_ >= o) x += y;
+      }
+    total = __shfl(x, 15, 16);
+    return x - v;
+  }
+};
+
+template <int S> struct SlotC { static constexpr int value = S; };
+
+template <int DIR, typename WK>
+__device__ int wave_pass_reg16(const WK &wk, const AlignSpecDev &sp, const SeqView &S,
+                               int k0, int mida, int aoff, WaveEnd &E)
+{ using GR = Grp<16>;
+  const int  lane = GR::gl();
+  const int  TS   = sp.TS;
+  const int  OUTV = (DIR > 0) ? -1 : AL_BIG;
+  const int  soff = (DIR > 0) ? 0 : -1;
+  const int  adl = GR::addr_of(lane - 1), adr = GR::addr_of(lane + 1);     // neighbour lanes on the 16-lane ring
+
+  int low = k0, hgh = k0, dif = 0;
+  int more = 1;
+  int aclip = (DIR > 0) ? AL_BIG : -AL_BIG;
+  int bclip = (DIR > 0) ? -AL_BIG : AL_BIG;
+  int besta, besty, trima, trimy, trimd, trimha;
+  int morea, morey, mored, moreha, morem, lasta;
+  int ncell = 0;
+  bool wide = false;                     // the group's ring has 32 positions
+#ifdef DMH_ALIGN_PROFILE
+  long long prof_tprev = 0;
+#endif
+
+  // per-lane state of the lane's (up to) two diagonals
+  int      V[2] = {OUTV, OUTV}, M[2] = {0, 0}, HA[2] = {0, 0}, HAM[2] = {0, 0}, NA[2] = {0, 0};
+  uint32_t TL[2] = {0, 0}, TH[2] = {0, 0};
+
+  besta = trima = morea = lasta = mida;
+  besty = trimy = morey = (mida - hgh) >> 1;
+  trimd = mored = 0;
+  trimha = moreha = 0;
+  morem = -1;
+
+  // ---- 0-wave on the seed diagonal (uniform on the group's lanes)
+  { const int k = k0;
+    int y = (mida - k) >> 1;
+    int na, ha, ham;
+    if (wk.cellcap < 8) return AL_ERR_PEBBLES;
+    if (DIR > 0)
+      { na = (((y + k) + (TS - aoff)) / TS - 1) * TS + aoff;
+        if (lane == 0) wk.cells[0] = make_int4(-1, k, 0, na);
+        ham = na;
+        na += TS;
+      }
+    else
+      { na = (((y + k) + (TS - aoff) - 1) / TS - 1) * TS + aoff;
+        if (lane == 0) wk.cells[0] = make_int4(-1, k, 0, y + k);
+        ham = y + k;
+      }
+    ha = 0;
+    ncell = 2;
+    { bool end;
+      int  n = (DIR > 0) ? match_fwd(S, k + y, y, end) : match_rev(S, k + y, y, end);
+      y += DIR * n;
+      if (end)
+        { bool bend = (DIR > 0) ? (y == S.blen) : (y == 0);
+          more = 0;
+          if (bend) bclip = k; else aclip = k;
+        }
+    }
+    int c = (y << 1) + k;
+    if (DIR > 0)
+      { while (y + k >= na)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            ha = ncell++; ham = na; na += TS;
+          }
+        if (c > besta)
+          { besta = trima = lasta = c; besty = trimy = y; trimha = ha; }
+      }
+    else
+      { while (y + k <= na)
+          { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
+            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            ha = ncell++; ham = na; na -= TS;
+          }
+        if (c < besta)
+          { besta = trima = lasta = c; besty = trimy = y; trimha = ha; }
+      }
+    if (lane == (k & 15))
+      { V[0] = c; M[0] = AL_PATH_LEN;
+        TL[0] = (uint32_t) (AL_PATH_INT & 0xffffffffu);
+        TH[0] = (uint32_t) (AL_PATH_INT >> 32);
+        HA[0] = ha; HAM[0] = ham; NA[0] = na;
+      }
+  }
+
+  // two 16-bit ballot slices (slot 0, slot 1) -> one mask in diagonal order: bit j <-> diagonal low + j
+  auto dmask = [&](uint32_t b0, uint32_t b1) -> uint32_t
+  { const uint32_t x2 = b0 | ((wide ? b1 : b0) << 16);
+    const uint32_t m  = __builtin_amdgcn_alignbit(x2, x2, (uint32_t) (low & (wide ? 31 : 15)));
+    return wide ? m : (m & 0xffffu);
+  };
+  // the value diagonal kk holds (x0 / x1 = the lanes' slot 0 / slot 1 registers)
+  auto rd = [&](int x0, int x1, int kk, bool anyw) -> int
+  { const int p = kk & (wide ? 31 : 15);
+    const int a = GR::addr_of(p);
+    int v = GR::perm(a, x0);
+    if (anyw)
+      { const int v1 = GR::perm(a, x1);
+        v = (p & 16) ? v1 : v;
+      }
+    return v;
+  };
+
+  auto boundary = [&](bool setd)
+  { if (more != 0) return;
+    { int bi = besty + soff, ai = besta - besty + soff;
+      if (bi >= 0 && bi < S.blen && ai >= 0 && ai < S.alen)
+        more = 1;
+    }
+    const bool anyw = __ballot(wide) != 0;
+    auto clip_at = [&](int kc)
+    { int m = rd(M[0], M[1], kc, anyw);
+      if (morem <= m)
+        { morem = m; morea = rd(V[0], V[1], kc, anyw); morey = (morea - kc) / 2;
+          if (setd) mored = dif;
+          moreha = rd(HA[0], HA[1], kc, anyw);
+        }
+    };
+    if (DIR > 0)
+      { if (hgh >= aclip) { hgh = aclip - 1; clip_at(aclip); }
+        if (low <= bclip) { low = bclip + 1; clip_at(bclip); }
+        aclip = AL_BIG;
+        bclip = -AL_BIG;
+      }
+    else
+      { if (low <= aclip) { low = aclip + 1; clip_at(aclip); }
+        if (hgh >= bclip) { hgh = bclip - 1; clip_at(bclip); }
+        aclip = -AL_BIG;
+        bclip = AL_BIG;
+      }
+  };
+
+  boundary(false);
+
+  while (more && ((DIR > 0) ? (lasta >= besta - AL_TRIM_MLAG) : (lasta <= besta + AL_TRIM_MLAG)))
+    { if (hgh < low) return AL_ERR_BAND;
+      low -= 1;
+      hgh += 1;
+      if (hgh - low + 1 > GR::BAND) return AL_ERR_BAND;
+      if (dif > S.alen + S.blen + 64) return AL_ERR_LOOP;
+      dif += 1;
+
+      if (!wide && hgh - low + 1 > GR::NARROW)
+        { // to the 32-position ring: the diagonals with bit 4 set move to slot 1 of their lanes
+          const int  lo = low + 1;
+          const int  kn = lo + ((lane - lo) & 15);
+          const bool up = (kn & 16) != 0;
+          if (up)
+            { V[1] = V[0]; M[1] = M[0]; HA[1] = HA[0]; HAM[1] = HAM[0]; NA[1] = NA[0]; TL[1] = TL[0]; TH[1] = TH[0];
+              V[0] = OUTV;
+            }
+          else
+            V[1] = OUTV;
+          wide = true;
+        }
+      const bool anyw = __ballot(wide) != 0;          // (some group of the wavefront runs its second slot)
+#ifdef DMH_ALIGN_PROFILE
+      if ((threadIdx.x & 63) == __ffsll((long long) __ballot(true)) - 1)
+        { const long long tnow = clock64();
+          atomicAdd(&g_aprof[13], 1ull);
+          atomicAdd(&g_aprof[12], (unsigned long long) __popcll(__ballot(true)) / 16);
+          if (anyw) atomicAdd(&g_aprof[14], 1ull);
+          if (prof_tprev != 0) atomicAdd(&g_aprof[15], (unsigned long long) (tnow - prof_tprev));
+        }
+      prof_tprev = clock64();
+#endif
+
+      // the lane's diagonals in the new band
+      int  kk[2];
+      bool act[2], inold[2];
+      int  vold[2];
+      kk[0]  = wide ? low + ((lane - low) & 31) : low + ((lane - low) & 15);
+      kk[1]  = low + ((lane + 16 - low) & 31);
+      act[0] = (kk[0] <= hgh);
+      act[1] = wide && (kk[1] <= hgh);
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+        { inold[s] = act[s] && (kk[s] > low) && (kk[s] < hgh);
+          vold[s]  = inold[s] ? V[s] : OUTV;
+        }
+
+      // neighbours' previous-wave state: position p - 1 / p + 1 of the ring
+      int am[2], ap[2], nal[2], nar[2], Ml[2], Mr[2], TLl[2], TLr[2], THl[2], THr[2], HAl[2], HAr[2], HAMl[2], HAMr[2];
+      struct X4 { int l0, l1, r0, r1; };
+      auto xch = [&](int x0, int x1) -> X4
+      { X4 q;
+        const int l0 = GR::perm(adl, x0), r0 = GR::perm(adr, x0);
+        if (anyw)
+          { const int l1 = GR::perm(adl, x1), r1 = GR::perm(adr, x1);
+            q.l0 = (wide && lane == 0) ? l1 : l0;   q.l1 = (lane == 0) ? l0 : l1;
+            q.r0 = (wide && lane == 15) ? r1 : r0;  q.r1 = (lane == 15) ? r0 : r1;
+          }
+        else
+          { q.l0 = l0; q.r0 = r0; q.l1 = l0; q.r1 = r0; }
+        return q;
+      };
+#define DMH_XCH(X0, X1, L, R) { const X4 q_ = xch((int) (X0), (int) (X1)); L[0] = q_.l0; L[1] = q_.l1; R[0] = q_.r0; R[1] = q_.r1; }
+      DMH_XCH(vold[0], vold[1], am, ap)
+      DMH_XCH(NA[0], NA[1], nal, nar)
+      DMH_XCH(M[0], M[1], Ml, Mr)
+      DMH_XCH(TL[0], TL[1], TLl, TLr)
+      DMH_XCH(TH[0], TH[1], THl, THr)
+      DMH_XCH(HA[0], HA[1], HAl, HAr)
+      DMH_XCH(HAM[0], HAM[1], HAMl, HAMr)
+#undef DMH_XCH
+
+      int      c[2] = {0, 0}, m[2] = {0, 0}, ha[2] = {0, 0}, ham[2] = {0, 0}, na[2] = {NA[0], NA[1]}, y[2] = {0, 0};
+      uint64_t b[2] = {0, 0};
+      int      hita[2] = {0, 0}, hitb[2] = {0, 0}, cntA[2] = {0, 0};
+      auto slot_step = [&](auto sc)
+      { constexpr int s = decltype(sc)::value;
+        const int k = kk[s];
+        if (act[s] && k == low && k != hgh) na[s] = nar[s];            // align.c:678-681
+        else if (act[s] && k == hgh && k != low) na[s] = nal[s];
+        if (act[s])
+          { const int ac = vold[s];
+            int sel;      // -1: from k-1, 0: stay, +1: from k+1
+            if (DIR > 0)
+              { if (ac < am[s]) sel = (am[s] < ap[s]) ? 1 : -1;
+                else            sel = (ac < ap[s]) ? 1 : 0;
+                c[s] = (sel == 0) ? ac + 2 : ((sel > 0) ? ap[s] + 1 : am[s] + 1);
+              }
+            else
+              { if (ac > ap[s]) sel = (ap[s] > am[s]) ? -1 : 1;
+                else            sel = (ac > am[s]) ? -1 : 0;
+                c[s] = (sel == 0) ? ac - 2 : ((sel > 0) ? ap[s] - 1 : am[s] - 1);
+              }
+            const bool stay = (sel == 0), fl = (sel < 0);
+            const int  ml_ = Ml[s], mr_ = Mr[s], tll_ = TLl[s], tlr_ = TLr[s], thl_ = THl[s], thr_ = THr[s];
+            const int  hal_ = HAl[s], har_ = HAr[s], haml_ = HAMl[s], hamr_ = HAMr[s];
+            m[s]   = stay ? M[s] : (fl ? ml_ : mr_);
+            ha[s]  = stay ? HA[s] : (fl ? hal_ : har_);
+            ham[s] = stay ? HAM[s] : (fl ? haml_ : hamr_);
+            const uint32_t tl = stay ? TL[s] : (uint32_t) (fl ? tll_ : tlr_);
+            const uint32_t th = stay ? TH[s] : (uint32_t) (fl ? thl_ : thr_);
+            uint64_t bb = ((uint64_t) th << 32) | tl;
+            if ((bb & AL_PATH_TOP) != 0) m[s] -= 1;
+            bb <<= 1;
+
+            int yy = (c[s] - k) >> 1;
+            { bool end;
+              int  n = (DIR > 0) ? match_fwd(S, k + yy, yy, end) : match_rev(S, k + yy, yy, end);
+              yy += DIR * n;
+              push_matches(bb, m[s], n);
+              if (end)
+                { bool bend = (DIR > 0) ? (yy == S.blen) : (yy == 0);
+                  if (bend) hitb[s] = 1; else hita[s] = 1;
+                }
+            }
+            c[s] = (yy << 1) + k;
+            y[s] = yy;
+            b[s] = bb;
+            if (DIR > 0)
+              { int t = na[s]; int h = ham[s];
+                while (yy + k >= t) { if (h < t) { cntA[s] += 1; h = t; } t += TS; }
+              }
+            else
+              { int t = na[s]; int h = ham[s];
+                while (yy + k <= t) { if (h > t) { cntA[s] += 1; h = t; } t -= TS; }
+              }
+          }
+      };
+      slot_step(SlotC<0>());
+      if (anyw) slot_step(SlotC<1>());
+
+      // pebbles: bump allocation in lane order, a lane's slot 0 before its slot 1
+      int tot = 0, off = 0;
+      { const int      t1  = cntA[0] + cntA[1];
+        const uint32_t any = GR::ballot(t1 != 0);
+        if (any != 0)
+          { if (GR::ballot(t1 > 1) == 0)
+              { off = __popc(any & ((1u << lane) - 1u));
+                tot = __popc(any);
+              }
+            else
+              off = GR::excl_scan(t1, tot);
+          }
+      }
+      if (ncell + tot > wk.cellcap) return AL_ERR_PEBBLES;
+      auto slot_commit = [&](auto sc)
+      { constexpr int s = decltype(sc)::value;
+        if (act[s])
+          { const int k = kk[s];
+            int idx = ncell + off + (s ? cntA[0] : 0);
+            if (DIR > 0)
+              { while (y[s] + k >= na[s])
+                  { if (ham[s] < na[s]) { wk.cells[idx] = make_int4(ha[s], k, dif, na[s]); ha[s] = idx++; ham[s] = na[s]; }
+                    na[s] += TS;
+                  }
+              }
+            else
+              { while (y[s] + k <= na[s])
+                  { if (ham[s] > na[s]) { wk.cells[idx] = make_int4(ha[s], k, dif, na[s]); ha[s] = idx++; ham[s] = na[s]; }
+                    na[s] -= TS;
+                  }
+              }
+            V[s] = c[s]; M[s] = m[s]; TL[s] = (uint32_t) (b[s] & 0xffffffffu); TH[s] = (uint32_t) (b[s] >> 32);
+            HA[s] = ha[s]; HAM[s] = ham[s]; NA[s] = na[s];
+          }
+      };
+      slot_commit(SlotC<0>());
+      if (anyw) slot_commit(SlotC<1>());
+      ncell += tot;
+
+      // boundary clips
+      { const uint32_t ma = dmask(GR::ballot(act[0] && hita[0]), GR::ballot(act[1] && hita[1]));
+        const uint32_t mb = dmask(GR::ballot(act[0] && hitb[0]), GR::ballot(act[1] && hitb[1]));
+        if (ma)
+          { more = 0;
+            aclip = (DIR > 0) ? low + (__ffs((int) ma) - 1) : low + (31 - __clz((int) ma));
+          }
+        if (mb)
+          { more = 0;
+            bclip = (DIR > 0) ? low + (31 - __clz((int) mb)) : low + (__ffs((int) mb) - 1);
+          }
+      }
+
+      // record setters of the running best, visited in the reference's loop order
+      { bool beats[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) beats[s] = act[s] && ((DIR > 0) ? (c[s] > besta) : (c[s] < besta));
+        uint32_t rb = dmask(GR::ballot(beats[0]), GR::ballot(beats[1]));
+        if (rb)
+          { bool lflag[2] = {false, false}, tflag[2] = {false, false};
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+              if (beats[s])
+                { lflag[s] = (m[s] >= sp.PATH_AVE);
+                  if (lflag[s]) tflag[s] = trim_ok_tab(wk.trimtab, b[s]);
+                }
+            const uint32_t rL = dmask(GR::ballot(lflag[0]), GR::ballot(lflag[1]));
+            const uint32_t rT = dmask(GR::ballot(tflag[0]), GR::ballot(tflag[1]));
+            while (rb)
+              { const int j = (DIR > 0) ? (31 - __clz((int) rb)) : (__ffs((int) rb) - 1);
+                rb &= ~(1u << j);
+                const int kd = low + j;
+                const int cl = rd(c[0], c[1], kd, anyw);
+                if ((DIR > 0) ? (cl > besta) : (cl < besta))
+                  { besta = cl;
+                    besty = (cl - kd) >> 1;
+                    if ((rL >> j) & 1u)
+                      { lasta = cl;
+                        if ((rT >> j) & 1u)
+                          { trima  = cl;
+                            trimy  = besty;
+                            trimd  = dif;
+                            trimha = rd(ha[0], ha[1], kd, anyw);
+                          }
+                      }
+                  }
+              }
+          }
+      }
+
+      boundary(true);
+
+      // keep the points within WAVE_LAG of the best (align.c:877-885)
+      if (hgh >= low)
+        { const int  k0n = wide ? low + ((lane - low) & 31) : low + ((lane - low) & 15);
+          const int  k1n = low + ((lane + 16 - low) & 31);
+          const int  n   = (DIR > 0) ? besta - AL_WAVE_LAG : besta + AL_WAVE_LAG;
+          const bool p0  = (k0n <= hgh) && ((DIR > 0) ? (V[0] >= n) : (V[0] <= n));
+          const bool p1  = wide && (k1n <= hgh) && ((DIR > 0) ? (V[1] >= n) : (V[1] <= n));
+          const uint32_t keep = dmask(GR::ballot(p0), GR::ballot(p1));
+          if (keep)
+            { const int l0 = __ffs((int) keep) - 1, h0 = 31 - __clz((int) keep);
+              hgh = low + h0;
+              low = low + l0;
+            }
+          else
+            hgh = low - 1;
+        }
+
+      if (wide && hgh >= low && hgh - low + 1 <= GR::BACK)
+        { // back to the 16-position ring: a diagonal kept in slot 1 returns to slot 0 of its lane
+          const int  kn = low + ((lane - low) & 15);
+          if (kn <= hgh && (kn & 16) != 0)
+            { V[0] = V[1]; M[0] = M[1]; HA[0] = HA[1]; HAM[0] = HAM[1]; NA[0] = NA[1]; TL[0] = TL[1]; TH[0] = TH[1]; }
+          wide = false;
+        }
+    }
+
+  E.trima = trima; E.trimy = trimy; E.trimd = trimd; E.trimha = trimha; E.trimhb = 1;
+  E.morea = morea; E.morey = morey; E.mored = mored; E.moreha = moreha; E.morehb = 1;
+  E.morem = morem;
+  E.ncell = ncell;
   return AL_OK;
 }
 
@@ -1356,7 +1793,12 @@ __device__ int run_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Seq
       wf.cellcap = ((F_COUNT * 2 + 2) * W) / 4;
     }
   APROF_T0();
-  st = wave_pass_reg<DIR, WANT_B, WaveWork<W>, G>(wf, sp, S, k0, mida, aoff, boff, E);
+  if constexpr (G == 16)
+    { static_assert(G != 16 || !WANT_B, "the four-per-wavefront pass keeps the A view only");
+      st = wave_pass_reg16<DIR, WaveWork<W>>(wf, sp, S, k0, mida, aoff, E);
+    }
+  else
+    st = wave_pass_reg<DIR, WANT_B, WaveWork<W>, G>(wf, sp, S, k0, mida, aoff, boff, E);
   APROF_LAP(0);
   APROF_ADD(3, 1);
   if (G == 64 && (st == AL_ERR_BAND || st == AL_ERR_PEBBLES))

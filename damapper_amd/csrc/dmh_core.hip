@@ -1325,6 +1325,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "expand") == 0)      st.opt_expand = value;
   else if (strcmp(key, "in_flight") == 0)   st.opt_in_flight = value;
   else if (strcmp(key, "seed_word") == 0)   st.opt_seed_word = value;
+  else if (strcmp(key, "align_g") == 0)     st.opt_align_g = value;
   else if (strcmp(key, "cluster_sort") == 0) st.opt_cluster_sort = value;
   else return -1;
   return 0;

@@ -123,6 +123,60 @@ __global__ __launch_bounds__(256) void k_align_seeds(const uint64_t *apk, const 
     }
 }
 
+// Stage-level API on the lane-group passes (test option "align_g" = 16 / 32): G lanes per Local_Alignment, A view only
+// (the B end points follow from the A view; B trace lengths are reported as 0).  Jobs whose band or pebbles outgrow
+// the group come back with their error status and are re-run by k_align_seeds.
+template <int G, int PEB>
+__global__ __launch_bounds__(256, (G == 16 ? 3 : 4)) void k_align_seeds_g(const uint64_t *apk, const uint64_t *arc,
+                                                                         const uint64_t *bpk, const SeedJob *jobs, int njobs,
+                                                                         AlignSpecDev sp, uint16_t *traces, int tcap,
+                                                                         unsigned int *ticket, int *out, uint16_t *atr_out,
+                                                                         int stride)
+{ constexpr int NG = 256 / G;
+  __shared__ int4 peb[NG * PEB];
+  __shared__ int  mbox[NG * 16];
+  __shared__ int2 trimtab[32];
+  const int lane = threadIdx.x & (G - 1), gid = threadIdx.x / G;
+  const int gg = blockIdx.x * NG + gid;
+  if (threadIdx.x < 64) build_trim_tab(trimtab, sp.mscore, sp.dscore);
+  __syncthreads();
+  WaveWork<LDS_W> wk;
+  wk.band    = nullptr;
+  wk.cells   = peb + gid * PEB;
+  wk.cellcap = PEB;
+  wk.tcap    = tcap;
+  wk.atrace  = traces + (size_t) gg * (4 * (size_t) tcap) + tcap;
+  wk.btrace  = wk.atrace + 2 * (size_t) tcap;
+  wk.mbox    = mbox + 16 * gid;
+  wk.trimtab = trimtab;
+  while (true)
+    { unsigned int t = 0;
+      if (lane == 0) t = atomicAdd(ticket, 1u);
+      t = __shfl(t, 0, G);
+      if (t >= (unsigned int) njobs) break;
+      const int j = (int) t;
+      SeedJob J = jobs[j];
+      SeqView S{J.comp ? arc : apk, bpk, J.aoff, J.boff, J.alen, J.blen, J.comp};
+      PathRes P;
+      int B[4];
+      int st = local_alignment<LDS_W, false, G>(wk, sp, S, J.dg, J.ad, P, B);
+      if (lane == 0)
+        { int *o = out + 16 * (size_t) j;
+          o[0] = P.abpos; o[1] = P.bbpos; o[2] = P.aepos; o[3] = P.bepos; o[4] = P.diffs;
+          o[5] = (st == AL_OK) ? P.atlen : 0;
+          o[6] = 0;
+          o[7] = st;
+          o[8] = B[0]; o[9] = B[1]; o[10] = B[2]; o[11] = B[3];
+          o[12] = P.aorg; o[13] = 0; o[14] = 0; o[15] = 0;
+        }
+      if (st == AL_OK)
+        { int na = P.atlen < stride ? P.atlen : stride;
+          for (int i = lane; i < na; i += G) atr_out[(size_t) j * stride + i] = wk.atrace[P.aorg + i];
+        }
+      wave_sync();
+    }
+}
+
 // Output pool record: 16-int header {cand, seq, abpos, bbpos, aepos, bepos, diffs, atlen,
 // B view: abpos, bbpos, aepos, bepos, btlen, 0, 0, 0} followed by atlen uint16 A-trace values (padded
 // to an even count) and, for -C, btlen B-trace values (padded likewise).
@@ -219,25 +273,29 @@ __global__ __launch_bounds__(256, 4) void k_align_cands(const uint64_t *apk, con
 // orders the tickets by orientation and read length).  A band or pebble overflow ends the job with
 // AL_ERR_BAND / AL_ERR_PEBBLES; the host re-runs it on k_align_cands.
 constexpr int PEB32 = 288;     // pebbles per half-wavefront
+// Four per wavefront (16-lane groups, dmh_align.h wave_pass_reg16): 3 workgroups of 16 groups per CU, so a group's
+// pebbles get 3.2 KB of LDS.
+constexpr int PEB16 = 200;
 
-__global__ __launch_bounds__(256, 4) void k_align_cands32(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
-                                                        const CandJob *jobs, int njobs,
-                                                        const uint16_t *jumps, int hithr, AlignSpecDev sp,
-                                                        uint16_t *traces, int tcap, unsigned int *ticket, int *status,
-                                                        int *pool, unsigned int *pool_used,
-                                                        unsigned int pool_cap, const int *only)
-{ constexpr int G = 32;
-  __shared__ int4 peb[8 * PEB32];
-  __shared__ int  mbox[8 * 16];
+template <int G, int PEB>
+__device__ __forceinline__ void align_cands_groups(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
+                                                   const CandJob *jobs, int njobs,
+                                                   const uint16_t *jumps, int hithr, const AlignSpecDev &sp,
+                                                   uint16_t *traces, int tcap, unsigned int *ticket, int *status,
+                                                   int *pool, unsigned int *pool_used,
+                                                   unsigned int pool_cap, const int *only)
+{ constexpr int NG = 256 / G;
+  __shared__ int4 peb[NG * PEB];
+  __shared__ int  mbox[NG * 16];
   __shared__ int2 trimtab[32];
   const int lane = threadIdx.x & (G - 1), gid = threadIdx.x / G;
-  const int gg = blockIdx.x * (256 / G) + gid;
+  const int gg = blockIdx.x * NG + gid;
   if (threadIdx.x < 64) build_trim_tab(trimtab, sp.mscore, sp.dscore);
   __syncthreads();
   WaveWork<LDS_W> wk;
   wk.band    = nullptr;
-  wk.cells   = peb + gid * PEB32;
-  wk.cellcap = PEB32;
+  wk.cells   = peb + gid * PEB;
+  wk.cellcap = PEB;
   wk.tcap    = tcap;
   wk.atrace  = traces + (size_t) gg * (4 * (size_t) tcap) + tcap;
   wk.btrace  = wk.atrace + 2 * (size_t) tcap;
@@ -295,6 +353,26 @@ __global__ __launch_bounds__(256, 4) void k_align_cands32(const uint64_t *apk, c
       if (lane == 0) status[j] = st;
       wave_sync();
     }
+}
+
+__global__ __launch_bounds__(256, 4) void k_align_cands32(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
+                                                        const CandJob *jobs, int njobs,
+                                                        const uint16_t *jumps, int hithr, AlignSpecDev sp,
+                                                        uint16_t *traces, int tcap, unsigned int *ticket, int *status,
+                                                        int *pool, unsigned int *pool_used,
+                                                        unsigned int pool_cap, const int *only)
+{ align_cands_groups<32, PEB32>(apk, arc, bpk, jobs, njobs, jumps, hithr, sp, traces, tcap, ticket, status, pool, pool_used,
+                                pool_cap, only);
+}
+
+__global__ __launch_bounds__(256, 3) void k_align_cands16(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
+                                                        const CandJob *jobs, int njobs,
+                                                        const uint16_t *jumps, int hithr, AlignSpecDev sp,
+                                                        uint16_t *traces, int tcap, unsigned int *ticket, int *status,
+                                                        int *pool, unsigned int *pool_used,
+                                                        unsigned int pool_cap, const int *only)
+{ align_cands_groups<16, PEB16>(apk, arc, bpk, jobs, njobs, jumps, hithr, sp, traces, tcap, ticket, status, pool, pool_used,
+                                pool_cap, only);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1148,7 +1226,11 @@ static void launch_round(PendingReport &P)
       only = d_only.p;
     }
   const int level = P.level, doB = P.doB;
-  const int per_block = (level == 0) ? 8 : 4;
+  // level 0: two candidates per wavefront (k_align_cands32); four (k_align_cands16) with the "align_g" test option = 16
+  // or DMH_ALIGN_G=16 -- measured slower, see DESIGN.md 3
+  static const int env_g = getenv("DMH_ALIGN_G") ? atoi(getenv("DMH_ALIGN_G")) : 32;
+  const bool g16 = (level == 0) && (S().opt_align_g > 0 ? S().opt_align_g == 16 : env_g == 16);
+  const int per_block = (level == 0) ? (g16 ? 16 : 8) : 4;
   // four workgroups per CU take every SIMD's registers; a deferred kernel leaves about half of them to the next
   // block's merge and chain kernels (ms per block 30.1 at 384 workgroups, 29.7 at 416, 29.0 at 448,
   // 29.4 at 480, 29.5 at 512, 30.8 at 544, 31.2 at 576; 39.7 at the full 1024)
@@ -1163,7 +1245,12 @@ static void launch_round(PendingReport &P)
   HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), ks));
   HIP_CHECK(hipMemsetAsync(d_pool.p, 0xff, sizeof(int) * P.pool_cap, ks));   // cand = -1 ends the parse
   { StageTimer tm(level == 2 ? "align_global_band" : (level == 1 ? "align_wave64" : "align"), 0.0, ks);
-    if (level == 0)
+    if (level == 0 && g16)
+      hipLaunchKernelGGL(k_align_cands16, dim3(nblocks), dim3(256), 0, ks,
+                         P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
+                         (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
+                         d_pool.p, ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
+    else if (level == 0)
       hipLaunchKernelGGL(k_align_cands32, dim3(nblocks), dim3(256), 0, ks,
                          P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
                          (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
@@ -1564,15 +1651,43 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
   std::vector<int> res(16 * (size_t) njobs);
   std::vector<int> todo;
   int *d_only = nullptr;
+  bool listed = false;          // the first wavefront-per-job pass runs a list (what the lane-group pass left over)
+  const int optg = S().opt_align_g;
+  if (optg == 16 || optg == 32)
+    { // A view on 16- or 32-lane groups first; band / pebble overflows go on to the passes below
+      const int per_block = 256 / optg;
+      int nblocks = std::min((njobs + per_block - 1) / per_block, 256 * (optg == 16 ? 3 : 4));
+      Scratch sc = prepare_scratch(nblocks, tcap, false, per_block, false);
+      HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), stream()));
+      HIP_CHECK(hipMemsetAsync(dat, 0, sizeof(uint16_t) * (size_t) njobs * trace_stride, stream()));
+      HIP_CHECK(hipMemsetAsync(dbt, 0, sizeof(uint16_t) * (size_t) njobs * trace_stride, stream()));
+      { StageTimer tm("align_seeds_groups", 0.0);
+        if (optg == 16)
+          hipLaunchKernelGGL((k_align_seeds_g<16, PEB16>), dim3(nblocks), dim3(256), 0, stream(),
+                             (const uint64_t *) (apkraw + 2), (const uint64_t *) (arcraw + 2), (const uint64_t *) (bpkraw + 2),
+                             (const SeedJob *) dj, njobs, spd, sc.traces, sc.tcap, ascr().ctl.p, dout, dat, trace_stride);
+        else
+          hipLaunchKernelGGL((k_align_seeds_g<32, PEB32>), dim3(nblocks), dim3(256), 0, stream(),
+                             (const uint64_t *) (apkraw + 2), (const uint64_t *) (arcraw + 2), (const uint64_t *) (bpkraw + 2),
+                             (const SeedJob *) dj, njobs, spd, sc.traces, sc.tcap, ascr().ctl.p, dout, dat, trace_stride);
+        HIP_CHECK(hipGetLastError());
+      }
+      copy_d2h(res.data(), dout, sizeof(int) * 16 * njobs);
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      for (int i = 0; i < njobs; i++)
+        if (res[16 * (size_t) i + 7] == AL_ERR_BAND || res[16 * (size_t) i + 7] == AL_ERR_PEBBLES) todo.push_back(i);
+      listed = true;
+    }
   for (int pass = 0; pass < 2; pass++)
     { bool global_band = (pass == 1);
-      int  nrun = global_band ? (int) todo.size() : njobs;
+      int  nrun = (global_band || listed) ? (int) todo.size() : njobs;
       if (nrun == 0) break;
       int nblocks = std::min((nrun + 3) / 4, 256 * 4);
       Scratch sc = prepare_scratch(nblocks, tcap, global_band);
       HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), stream()));
-      if (global_band)
-        { d_only = (int *) dev_alloc(sizeof(int) * nrun, "retry list");
+      if (global_band || listed)
+        { if (d_only) dev_free(d_only);
+          d_only = (int *) dev_alloc(sizeof(int) * nrun, "retry list");
           copy_h2d(d_only, todo.data(), sizeof(int) * nrun);
         }
       { StageTimer tm(global_band ? "align_seeds_global_band" : "align_seeds", 0.0);
@@ -1585,12 +1700,13 @@ int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes,
           hipLaunchKernelGGL((k_align_seeds<LDS_W, true>), dim3(nblocks), dim3(256), 0, stream(),
                              (const uint64_t *) (apkraw + 2), (const uint64_t *) (arcraw + 2), (const uint64_t *) (bpkraw + 2),
                              (const SeedJob *) dj, nrun, spd, sc, ascr().ctl.p, dout, dat, dbt, trace_stride,
-                             (const int *) nullptr);
+                             listed ? (const int *) d_only : (const int *) nullptr);
         HIP_CHECK(hipGetLastError());
       }
       copy_d2h(res.data(), dout, sizeof(int) * 16 * njobs);
       HIP_CHECK(hipStreamSynchronize(stream()));
       todo.clear();
+      listed = false;
       for (int i = 0; i < njobs; i++)
         if (res[16 * (size_t) i + 7] == AL_ERR_BAND) todo.push_back(i);
     }

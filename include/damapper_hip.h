@@ -142,6 +142,9 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  * drive every kernel variant; -1 / 0 restores the default where not said otherwise):
  *   "align_level" 0/1/2  first rung of the alignment kernel ladder (two candidates per wavefront / one per
  *                        wavefront with LDS fallback / global-memory band)
+ *   "align_g" 16/32      16: the first rung runs four candidates per wavefront on 16-lane groups with two slots per lane
+ *                        instead of two on 32-lane groups; 16 or 32 also make dmh_local_alignment try that lane-group
+ *                        pass first (A view only)
  *   "chain_g" 16/32/64   lanes per chain group for ALL groups below the pile size (0 default: by group size)
  *   "chain_lane" 0       no lane-per-group kernel (groups go to the lane-group kernels)
  *   "chain_small" n      groups of up to n hits take the all-LDS lane-group kernel when chain_lane is off (0 none)

@@ -150,7 +150,7 @@ def test_ragged_and_degenerate_reads(tmp_path):
     assert 12 not in mapped and 13 not in mapped                               # the noise does not
 
 
-@pytest.mark.parametrize("opts", [dict(align_level=1), dict(align_level=2), dict(pool_div=400),
+@pytest.mark.parametrize("opts", [dict(align_g=16), dict(align_level=1), dict(align_level=2), dict(pool_div=400),
                                   dict(chain_g=64), dict(chain_g=32), dict(chain_g=16),
                                   dict(chain_pile=16), dict(chain_pile=16, pile_cap=128), dict(chain_pile=0),
                                   dict(merge_dense=1), dict(merge_dense=2),
@@ -159,7 +159,7 @@ def test_ragged_and_degenerate_reads(tmp_path):
                                   dict(chain_lane=0), dict(cluster=1, chain_lane=0), dict(batch=0),
                                   dict(cluster=1, cluster_sort=0), dict(expand=0), dict(cluster=1, in_flight=0),
                                   dict(cluster=1, seed_word=0), dict(cluster=1, seed_word=0, expand=0), dict(cluster=1, expand=0)],
-                         ids=["wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
+                         ids=["four_per_wavefront", "wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
                               "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table", "merge_low16_probes",
                               "clusters", "clusters_piles", "clusters_chain64",
                               "no_lds_groups", "clusters_no_lds_groups", "clusters_lds_groups_7",
@@ -189,6 +189,7 @@ def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
         alt = run("las_alt")
     finally:
         L.dmh_test_option(b"align_level", -1)
+        L.dmh_test_option(b"align_g", -1)
         L.dmh_test_option(b"chain_g", 0)
         L.dmh_test_option(b"pool_div", 1)
         L.dmh_test_option(b"chain_pile", -1)
@@ -503,6 +504,7 @@ def test_retained_ref_index_and_pipelining_give_identical_files(ref_block, tmp_p
     finally:
         L.dmh_test_option(b"pool_div", 1)
         L.dmh_test_option(b"align_level", -1)
+        L.dmh_test_option(b"align_g", -1)
     for b in range(nb):
         for t in range(1, 5):
             fn = "READS.%d.REF.M%d.las" % (b + 1, t)
