@@ -18,6 +18,9 @@ void chain_reset_reads(const DAZZ_DB *ablock);
 void    chain_submit(MergeResult &R, const DAZZ_DB *ablock);
 int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock);
 
+// Drops the chain stage's per-batch buffers of a ring slot that is not in use (memory pressure).
+void    chain_release(MergeResult &R);
+
 // Brings State::reads (the host view of the candidate lists: list order, -p deltas) up to date with the
 // device lists; with_jumps also fetches every candidate's Jump list.
 void cand_mirror(bool with_jumps);

@@ -1444,6 +1444,16 @@ struct ChainCtx
   bool       has_piles = false, all64 = false;
 };
 
+void chain_release(MergeResult &R)
+{ if (R.cc == nullptr) return;
+  ChainCtx &C = *R.cc;
+  C.cost.release(); C.bestcost.release();
+  C.from.release(); C.rootof.release(); C.best.release(); C.state.release(); C.tmp.release();
+  C.gcnt.release(); C.gbase.release(); C.pileretry.release();
+  C.livebuf.release();
+  C.out.release();
+}
+
 void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
 { State &st = S();
   const Params &pm = st.params;

@@ -43,6 +43,9 @@ bool report_adopt_block(const DAZZ_DB *block);   // a deferred Reporter takes ov
 // for a failed Malloc, e.g. map.c:689-690).
 void *dev_alloc(size_t bytes, const char *what);
 void  dev_free(void *p);
+// Called when device memory runs out, before giving up: returns true when it has released something (the filter
+// registers one that finishes the batches in flight and drops the buffers of the idle ring slots).
+void  set_reclaim_hook(bool (*fn)());
 
 // Host <-> device transfers go through one persistent pinned staging buffer: handing pageable host
 // memory to hipMemcpyAsync makes the runtime pin and unpin those pages around the copy, and the

@@ -94,9 +94,24 @@ static std::map<void *, size_t>  g_live;
 static size_t                    g_pooled = 0;
 static const size_t              POOL_MAX = (size_t) 96 << 30;
 
+static bool (*g_reclaim)() = nullptr;
+static bool g_reclaiming = false;
+
+static int g_alloc_fail = 0;       // test option "alloc_fail" = n: the n-th allocation from now behaves as if memory had run out
+
 void *dev_alloc(size_t bytes, const char *what)
 { init_device();
   if (bytes == 0) bytes = 16;
+  if (g_alloc_fail > 0 && --g_alloc_fail == 0 && g_reclaim != nullptr && !g_reclaiming)
+    { g_reclaiming = true;
+      S().simulated_oom = true;
+      (void) g_reclaim();
+      S().simulated_oom = false;
+      g_reclaiming = false;
+      for (auto &b : g_free) (void) hipFree(b.p);
+      g_free.clear();
+      g_pooled = 0;
+    }
   // quantise sizes (8 steps per octave above 1 MB) so that near-equal requests -- read blocks
   // differ by a fraction of a percent -- land in the same pool bucket instead of in hipMalloc
   { size_t g = 256;
@@ -121,16 +136,34 @@ void *dev_alloc(size_t bytes, const char *what)
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess)
     { // give the pool back and retry once
+      (void) hipGetLastError();            // (the failure must not surface at some later launch check)
       for (auto &b : g_free) (void) hipFree(b.p);
       g_free.clear();
       g_pooled = 0;
       e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) (void) hipGetLastError();
+    }
+  if (e != hipSuccess && g_reclaim != nullptr && !g_reclaiming)
+    { // last resort: what other stages can do without (batches in flight are finished, their buffers dropped)
+      (void) hipGetLastError();
+      g_reclaiming = true;
+      const bool got = g_reclaim();
+      g_reclaiming = false;
+      if (got)
+        { for (auto &b : g_free) (void) hipFree(b.p);
+          g_free.clear();
+          g_pooled = 0;
+          e = hipMalloc(&p, bytes);
+          if (e != hipSuccess) (void) hipGetLastError();
+        }
     }
   if (e != hipSuccess)
     fatal("out of device memory allocating %zu bytes (%s): %s", bytes, what, hipGetErrorString(e));
   g_live[p] = bytes;
   return p;
 }
+
+void set_reclaim_hook(bool (*fn)()) { g_reclaim = fn; }
 
 void dev_free(void *p)
 { if (p == nullptr) return;
@@ -1325,6 +1358,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "expand") == 0)      st.opt_expand = value;
   else if (strcmp(key, "in_flight") == 0)   st.opt_in_flight = value;
   else if (strcmp(key, "seed_word") == 0)   st.opt_seed_word = value;
+  else if (strcmp(key, "alloc_fail") == 0)  g_alloc_fail = value > 0 ? value : 0;
   else if (strcmp(key, "align_g") == 0)     st.opt_align_g = value;
   else if (strcmp(key, "cluster_sort") == 0) st.opt_cluster_sort = value;
   else return -1;

@@ -949,6 +949,8 @@ constexpr int64_t BATCH_CAP = (int64_t) 160 << 20;
 
 static void    close_batch(MergeResult &R);
 static int64_t finish_oldest();
+static bool    filter_reclaim();
+static int     g_flight_cap = IN_FLIGHT;     // batches that may be in flight: one fewer after every time memory ran out
 
 // cluster mode: every cluster sorted where it lies (k_csort_*) rather than all hits through the radix sort again
 static bool local_cluster_sort(int pbits)
@@ -962,6 +964,8 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   MergeResult *Rp = &filter_batch();
 #define R (*Rp)
   HostTimer ht("merge_and_sort");
+  static const bool hooked = (set_reclaim_hook(filter_reclaim), true);
+  (void) hooked;
 
   // --- bucket table over the REF index: part of the index, built the first time it is merged against
   //     (a retained REF index meets every READS block)
@@ -1208,20 +1212,51 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // batches in flight: under -v every call reports its own candidate counts, and the stage-level API looks at the
   // lists after every call -- then nothing stays in flight
   static const int env_fl = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
-  const int keep = (VERBOSE || st.capture_seeds || st.opt_in_flight == 0) ? 0 : std::min(IN_FLIGHT, std::max(0, env_fl));
+  const int keep = (VERBOSE || st.capture_seeds || st.opt_in_flight == 0) ? 0 : std::min(g_flight_cap, std::max(0, env_fl));
   while ((int) g_inflight.size() > keep) *nfilt += finish_oldest();
   return nhits;
 #undef R
 }
 
+static bool    g_finishing = false;          // inside chain_finish (its own allocations must not finish the next batch)
+
 static int64_t finish_oldest()
 { const int x = g_inflight.front();
   g_inflight.pop_front();
   MergeResult &R = g_ring[x];
+  g_finishing = true;
   const int64_t nfilt = chain_finish(R, R.ablock);
+  g_finishing = false;
   R.nhits = 0;
   R.npass = 0;
   return nfilt;
+}
+
+// Device memory ran out (dev_alloc): the batches in flight are finished -- in order, as always -- and every ring slot
+// that is neither being collected nor in flight gives its buffers back.  A pass of 10^9 hits needs some 80 bytes
+// per hit; three such batches in flight next to 120 GB of indices do not fit 288 GB, one at a time does.
+static bool filter_reclaim()
+{ bool got = false;
+  if (!g_finishing)
+    while (!g_inflight.empty())
+      { S().tfilt += finish_oldest();
+        got = true;
+      }
+  if (g_flight_cap > 0 && !S().simulated_oom) g_flight_cap -= 1;
+  for (int i = 0; i < NRING; i++)
+    { bool busy = (i == g_cur);
+      for (int y : g_inflight) busy = busy || (y == i);
+      if (busy) continue;
+      MergeResult &R = g_ring[i];
+      if (R.keys.p || R.alt_keys.p || R.vals.p || R.alt_vals.p) got = true;
+      R.keys.release(); R.alt_keys.release(); R.vals.release(); R.alt_vals.release();
+      R.gstart.release(); R.gkey.release(); R.cog.release(); R.ocfirst.release(); R.glast.release();
+      R.biglist.release(); R.pilelist.release(); R.medlist.release();
+      chain_release(R);
+    }
+  static const bool stats = getenv("DMH_STATS") != nullptr;
+  if (stats) fprintf(stderr, "dmh: out of device memory: batches in flight finished, idle ring slots released\n");
+  return got;
 }
 
 int64_t filter_flush()
@@ -1414,7 +1449,7 @@ static void close_batch(MergeResult &R)
   for (int i = 0; i < NRING; i++)
     if (&g_ring[i] == &R) slot = i;
   g_inflight.push_back(slot);
-  while ((int) g_inflight.size() > IN_FLIGHT) st.tfilt += finish_oldest();
+  while ((int) g_inflight.size() > g_flight_cap) st.tfilt += finish_oldest();
   for (int i = 0; i < NRING; i++)
     { bool busy = false;
       for (int y : g_inflight) busy = busy || (y == i);

@@ -150,6 +150,7 @@ struct State
   int  opt_cluster_sort = -1;   // 0: clusters ordered by the global radix sort instead of where they lie
   int  opt_in_flight   = -1;    // 0: every batch is finished before the next pass starts
   int  opt_align_g     = -1;    // 16: the first rung of the alignment ladder runs four candidates per wavefront (default two)
+  bool simulated_oom   = false;  // the reclaim hook runs for the "alloc_fail" test option (nothing is learnt from it)
   int  opt_seed_word   = -1;    // 0: cluster mode sorts (key, value) pairs even when a hit fits one word
   int  opt_expand      = -1;    // 0: hits expanded entry by entry (one thread / wavefront per entry) instead of by output tiles
   int  opt_batch       = -1;    // collect sparse Match_Filter passes into batches (0 off, -1 default on)

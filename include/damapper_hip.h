@@ -152,6 +152,8 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  *                        kernel may hold n window entries in LDS (forces its spill path)
  *   "cluster" 1/0        chain groups are the B-clusters of an (aread, bread) pair / whole pairs (-1: by hit density)
  *   "cluster_sort" 0     clusters are ordered by a second global radix sort instead of where they lie
+ *   "alloc_fail" n       the n-th device allocation from now behaves as if memory had run out: the batches in flight
+ *                        are finished and the idle buffers of the filter released (what a pass of 10^9 hits triggers)
  *   "seed_word" 0        cluster mode sorts (key, value) pairs even when aread | bread | bpos | apos fit one word
  *   "batch" 0            every Match_Filter pass is chained by itself (no batches of sparse passes)
  *   "in_flight" 0        every batch is finished before the next pass starts
