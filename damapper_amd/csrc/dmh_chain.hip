@@ -1441,6 +1441,7 @@ struct ChainCtx
   DevBuf<ChainSummary> out;
   ChainArgs  A;
   hipEvent_t piles_done = nullptr;
+  hipEvent_t submitted = nullptr;    // the batch's chain kernels are queued on the main stream up to here
   bool       has_piles = false, all64 = false;
 };
 
@@ -1610,11 +1611,19 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
       }
     HIP_CHECK(hipGetLastError());
   }
+  if (C.submitted == nullptr) HIP_CHECK(hipEventCreateWithFlags(&C.submitted, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(C.submitted, stream()));
 }
 
+// Runs on the FINISH stream (dmh_common.h): a dozen small, latency-bound kernels and two counter round trips per
+// batch that depend on nothing the main stream does meanwhile (the merge, sort and chain kernels of later batches) and
+// on which only the next batch's finish and Reporter depend.  The caller (finish_oldest) makes the main stream wait
+// for its end before the batch's ring slot is used again.
 int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
 { State &st = S();
   ChainCtx &C = *R.cc;
+  StreamScope on_finish(finish_stream());
+  if (stream() != main_stream()) HIP_CHECK(hipStreamWaitEvent(stream(), C.submitted, 0));
   ChainArgs A = C.A;
   DevBuf<uint32_t> &from = C.from, &ctl = C.ctl, &gcnt = C.gcnt, &gbase = C.gbase, &pileretry = C.pileretry;
   DevBuf<ChainSummary> &out = C.out;
@@ -1636,7 +1645,7 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   static DevBuf<uint32_t> goff;
   goff.ensure((size_t) ng + 2, "chain ends per group");
   HIP_CHECK(hipMemcpyAsync(goff.p, gcnt.p, sizeof(uint32_t) * ng, hipMemcpyDeviceToDevice, stream()));
-  exclusive_scan_u32(goff.p, ng, st.sort.bsum, goff.p + ng);
+  exclusive_scan_u32(goff.p, ng, st.sort_fin.bsum, goff.p + ng);
   uint32_t nsum = 0;
   { HostTimer ht("chain_wait");
     copy_d2h(&nsum, goff.p + ng, sizeof(uint32_t), 1);
@@ -1686,7 +1695,7 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
     hipLaunchKernelGGL(k_dom_need, dim3(ceil_div(nreads, 256)), dim3(256), 0, stream(),
                        (const uint32_t *) cs.seg_len[cs.cur].p, (const uint32_t *) goff.p, (const uint32_t *) rgfirst.p,
                        nreads, cs.seg_off[nx].p);
-    exclusive_scan_u32(cs.seg_off[nx].p, nreads, st.sort.bsum, cs.seg_off[nx].p + nreads);
+    exclusive_scan_u32(cs.seg_off[nx].p, nreads, st.sort_fin.bsum, cs.seg_off[nx].p + nreads);
     DomArgs D;
     D.ord = ord.p; D.goff = goff.p; D.rgfirst = rgfirst.p;
     D.oldp = cs.pool[cs.cur].p; D.ooff = cs.seg_off[cs.cur].p; D.olen = cs.seg_len[cs.cur].p;
@@ -1712,7 +1721,7 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
                        (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,
                        (const uint32_t *) nullptr, (uint16_t *) nullptr, 0u, 0);
     HIP_CHECK(hipMemcpyAsync(jl.p + nsum + 1, jl.p, sizeof(uint32_t) * nsum, hipMemcpyDeviceToDevice, stream()));
-    exclusive_scan_u32(jl.p + nsum + 1, nsum, st.sort.bsum, cs.ctl.p + 3);
+    exclusive_scan_u32(jl.p + nsum + 1, nsum, st.sort_fin.bsum, cs.ctl.p + 3);
     HIP_CHECK(hipMemcpyAsync(cs.ctl.p + 4, cs.seg_off[nx].p + nreads, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
     copy_d2h(h, cs.ctl.p, 8 * sizeof(uint32_t), 2);      // added, removed, fresh survivors, jump pairs, records in the new lists
     const size_t need = cs.jtop + h[3];

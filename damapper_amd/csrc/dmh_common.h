@@ -24,7 +24,14 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
                  hipGetErrorString(_e));                                                 \
   } while (0)
 
-hipStream_t stream();
+hipStream_t stream();              // the stream this thread's launches go to: the main stream unless a StreamScope is open
+hipStream_t main_stream();
+hipStream_t finish_stream();       // where the filter finishes its batches (chain_finish); the main stream when switched off
+struct StreamScope                 // stream() = s for the calling thread while the scope lives
+{ explicit StreamScope(hipStream_t s);
+  ~StreamScope();
+  hipStream_t prev;
+};
 
 // Deferred index builds (dmh_sort_kmers_async): the sort of the NEXT READS block is cut into stages
 // (k-mer emit, then per radix pass a histogram stage and a scatter stage) that are queued on the

@@ -75,14 +75,35 @@ static void init_device()
   g_init = true;
 }
 
+static thread_local hipStream_t g_stream_scope = nullptr;
+static hipStream_t g_fstream = nullptr;
+
 hipStream_t stream()
+{ init_device();
+  return g_stream_scope != nullptr ? g_stream_scope : g_stream;
+}
+
+hipStream_t main_stream()
 { init_device();
   return g_stream;
 }
 
+hipStream_t finish_stream()
+{ init_device();
+  static const int env_fs = getenv("DMH_FIN_STREAM") ? atoi(getenv("DMH_FIN_STREAM")) : 1;
+  const int on = S().opt_fin_stream >= 0 ? S().opt_fin_stream : env_fs;
+  if (on == 0) return g_stream;
+  if (g_fstream == nullptr) HIP_CHECK(hipStreamCreateWithFlags(&g_fstream, hipStreamNonBlocking));
+  return g_fstream;
+}
+
+StreamScope::StreamScope(hipStream_t s) : prev(g_stream_scope) { g_stream_scope = (s == g_stream) ? nullptr : s; }
+StreamScope::~StreamScope() { g_stream_scope = prev; }
+
 static void sync_all_streams()
 { init_device();
   HIP_CHECK(hipStreamSynchronize(g_upstream));
+  if (g_fstream != nullptr) HIP_CHECK(hipStreamSynchronize(g_fstream));
   HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 
@@ -979,12 +1000,14 @@ static void bg_step()
 }
 
 void bg_pump(int nstages)
-{ if (g_bg.empty() || report_in_flight()) return;
+{ StreamScope on_main(main_stream());        // (also when called from inside chain_finish: the index build lives on the main stream)
+  if (g_bg.empty() || report_in_flight()) return;
   for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step();
 }
 
 void bg_flush()
-{ g_bg_whole = true;
+{ StreamScope on_main(main_stream());
+  g_bg_whole = true;
   while (!g_bg.empty()) bg_step();
   g_bg_whole = false;
 }
@@ -1358,6 +1381,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "expand") == 0)      st.opt_expand = value;
   else if (strcmp(key, "in_flight") == 0)   st.opt_in_flight = value;
   else if (strcmp(key, "seed_word") == 0)   st.opt_seed_word = value;
+  else if (strcmp(key, "fin_stream") == 0)  st.opt_fin_stream = value;
   else if (strcmp(key, "alloc_fail") == 0)  g_alloc_fail = value > 0 ? value : 0;
   else if (strcmp(key, "align_g") == 0)     st.opt_align_g = value;
   else if (strcmp(key, "cluster_sort") == 0) st.opt_cluster_sort = value;

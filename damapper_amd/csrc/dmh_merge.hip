@@ -1227,6 +1227,14 @@ static int64_t finish_oldest()
   g_finishing = true;
   const int64_t nfilt = chain_finish(R, R.ablock);
   g_finishing = false;
+  if (finish_stream() != main_stream())
+    { // whatever the main stream does from here on (the slot's buffers are about to be used again, Reporter reads the
+      // candidate lists) comes after the finish stream's last kernel
+      static hipEvent_t fin_done = nullptr;
+      if (fin_done == nullptr) HIP_CHECK(hipEventCreateWithFlags(&fin_done, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(fin_done, finish_stream()));
+      HIP_CHECK(hipStreamWaitEvent(main_stream(), fin_done, 0));
+    }
   R.nhits = 0;
   R.npass = 0;
   return nfilt;
@@ -1243,6 +1251,7 @@ static bool filter_reclaim()
         got = true;
       }
   if (g_flight_cap > 0 && !S().simulated_oom) g_flight_cap -= 1;
+  HIP_CHECK(hipDeviceSynchronize());          // (buffers are about to go back to the driver)
   for (int i = 0; i < NRING; i++)
     { bool busy = (i == g_cur);
       for (int y : g_inflight) busy = busy || (y == i);

@@ -151,6 +151,7 @@ struct State
   int  opt_in_flight   = -1;    // 0: every batch is finished before the next pass starts
   int  opt_align_g     = -1;    // 16: the first rung of the alignment ladder runs four candidates per wavefront (default two)
   bool simulated_oom   = false;  // the reclaim hook runs for the "alloc_fail" test option (nothing is learnt from it)
+  int  opt_fin_stream  = -1;    // 0: batches are finished on the main stream (no second stream)
   int  opt_seed_word   = -1;    // 0: cluster mode sorts (key, value) pairs even when a hit fits one word
   int  opt_expand      = -1;    // 0: hits expanded entry by entry (one thread / wavefront per entry) instead of by output tiles
   int  opt_batch       = -1;    // collect sparse Match_Filter passes into batches (0 off, -1 default on)
@@ -166,6 +167,7 @@ struct State
 
   SortScratch sort;
   SortScratch sort_aux;         // scratch of the deferred index build (lives across Match_Filter calls)
+  SortScratch sort_fin;         // scratch of the scans of chain_finish (its own stream)
 };
 
 State &S();

@@ -157,6 +157,7 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  *   "seed_word" 0        cluster mode sorts (key, value) pairs even when aread | bread | bpos | apos fit one word
  *   "batch" 0            every Match_Filter pass is chained by itself (no batches of sparse passes)
  *   "in_flight" 0        every batch is finished before the next pass starts
+ *   "fin_stream" 0       batches are finished on the main stream instead of a stream of their own
  *   "expand" 0           hits are expanded entry by entry instead of by output tiles
  *   "merge_dense" 1/0/2  REF bucket table with one bucket per entry and four-key probes / four buckets per entry
  *                        and two-key probes / 16 undecided bits per bucket, four-key probes on the 2-byte low-bits
