@@ -97,6 +97,15 @@ hipStream_t finish_stream()
   return g_fstream;
 }
 
+void join_side_streams()
+{ static hipEvent_t ev = nullptr;
+  if (ev == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (g_fstream != nullptr)
+    { HIP_CHECK(hipEventRecord(ev, g_fstream));
+      HIP_CHECK(hipStreamWaitEvent(g_stream, ev, 0));
+    }
+}
+
 StreamScope::StreamScope(hipStream_t s) : prev(g_stream_scope) { g_stream_scope = (s == g_stream) ? nullptr : s; }
 StreamScope::~StreamScope() { g_stream_scope = prev; }
 

@@ -1277,7 +1277,8 @@ int64_t filter_flush()
 }
 
 void filter_discard()
-{ g_inflight.clear();
+{ join_side_streams();             // (their kernels may still read the batches that are dropped here)
+  g_inflight.clear();
   for (int i = 0; i < NRING; i++) { g_ring[i].open = false; g_ring[i].nhits = 0; g_ring[i].npass = 0; }
 }
 
