@@ -5,6 +5,7 @@
 #include "dmh_state.h"
 #include "dmh_spec.h"
 #include "dmh_align.h"
+#include <chrono>
 #include "dmh_chain.h"
 #include "dmh_merge.h"
 #include <algorithm>
@@ -1231,10 +1232,43 @@ static void launch_round(PendingReport &P)
   static const int env_g = getenv("DMH_ALIGN_G") ? atoi(getenv("DMH_ALIGN_G")) : 32;
   const bool g16 = (level == 0) && (S().opt_align_g > 0 ? S().opt_align_g == 16 : env_g == 16);
   const int per_block = (level == 0) ? (g16 ? 16 : 8) : 4;
-  // four workgroups per CU take every SIMD's registers; a deferred kernel leaves about half of them to the next
-  // block's merge and chain kernels (ms per block 30.1 at 384 workgroups, 29.7 at 416, 29.0 at 448,
-  // 29.4 at 480, 29.5 at 512, 30.8 at 544, 31.2 at 576; 39.7 at the full 1024)
-  static const int aux_grid = getenv("DMH_DEFER_GRID") ? std::max(64, atoi(getenv("DMH_DEFER_GRID"))) : 448;
+  // Four workgroups per CU take every SIMD's registers; a DEFERRED kernel shares the machine with the next block's
+  // filter, and how many workgroups it should get depends on what that filter is made of: 448 against a random
+  // GRCh38-sized reference (merge-bound: 59.9 ms per block, 65.3 at 704), 576 on configs[1] (34.1 against 35.7 at 448
+  // and 34.9 at 704), all 1024 against the repeat-rich reference (262.8 against 270.3 at 448).  So the grid is tuned
+  // while the process runs: each candidate gets three read blocks (the first one, a mix of two settings, is not
+  // counted), the one with the shortest time between deferred launches is kept.  DMH_DEFER_GRID fixes it.
+  static const int fixed_grid = getenv("DMH_DEFER_GRID") ? std::max(64, atoi(getenv("DMH_DEFER_GRID"))) : 0;
+  int aux_grid = fixed_grid;
+  if (P.on_aux && fixed_grid == 0 && level == 0)
+    { static const int cand[4] = {448, 704, 1024, 576};
+      static int    phase = 0;            // blocks launched while exploring; >= 12: decided
+      static int    best = 448;
+      static double best_t = 1e30, acc = 0.0;
+      static double last = 0.0;
+      const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      if (phase < 12)
+        { const int c = phase / 3, k = phase % 3;
+          if (k > 0) acc += now - last;                 // (two periods per candidate: the kernel launched at k = 0 and
+          if (k == 0 && c > 0)                          //  k = 1 ran next to the filters that end at k = 1 and k = 2)
+            { if (acc < best_t) { best_t = acc; best = cand[c - 1]; }
+              acc = 0.0;
+            }
+          aux_grid = cand[c];
+          phase += 1;
+        }
+      else
+        { if (phase == 12)
+            { if (acc < best_t) { best_t = acc; best = cand[3]; }
+              phase = 13;
+              if (getenv("DMH_STATS")) fprintf(stderr, "dmh: deferred alignment grid: %d workgroups\n", best);
+            }
+          aux_grid = best;
+        }
+      last = now;
+    }
+  else if (aux_grid == 0)
+    aux_grid = 448;
   int nblocks = std::min((nrun + per_block - 1) / per_block, P.on_aux ? aux_grid : 256 * 4);
   Scratch sc = prepare_scratch(nblocks, P.tcap, level == 2, per_block, level != 0);
   if (P.on_aux)
