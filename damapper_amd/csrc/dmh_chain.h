@@ -24,5 +24,8 @@ void    chain_release(MergeResult &R);
 // Brings State::reads (the host view of the candidate lists: list order, -p deltas) up to date with the
 // device lists; with_jumps also fetches every candidate's Jump list.
 void cand_mirror(bool with_jumps);
+// The two halves of it: the lists as they are on the device, and the per-read objects made from them.
+void cand_fetch(CandRaw &raw);
+void cand_build(const CandRaw &raw, std::vector<ReadState> &reads, const std::vector<uint16_t> *jd);
 
 }  // namespace dmh

@@ -1754,51 +1754,72 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
 // ---------------------------------------------------------------------------------------
 //  Host view of the device lists (Reporter, stage-level API)
 // ---------------------------------------------------------------------------------------
-void cand_mirror(bool with_jumps)
+// The candidate lists as they are on the device (no Jump lists: they stay in HBM for the alignment kernel).
+void cand_fetch(CandRaw &raw)
 { State &st = S();
   CandStore &cs = st.cands;
   st.tfilt += filter_flush();             // (the passes still waiting in the batch)
-  if (cs.mirror_valid && (cs.mirror_jumps || !with_jumps)) return;
   const int n = cs.nreads;
-  std::vector<DCand>    pool(cs.total_len);
-  std::vector<uint32_t> off((size_t) n + 1), len((size_t) n + 1);
-  std::vector<uint16_t> jd;
-  std::vector<int16_t>  cov;
+  raw.nreads = n;
+  raw.pool.resize(cs.total_len);
+  raw.off.assign((size_t) n + 1, 0);
+  raw.len.assign((size_t) n + 1, 0);
+  raw.cov.clear();
+  raw.cov_off = cs.h_cov_off;
   if (cs.total_len > 0)
-    { copy_d2h(pool.data(), cs.pool[cs.cur].p, sizeof(DCand) * cs.total_len);
-      copy_d2h(off.data(), cs.seg_off[cs.cur].p, sizeof(uint32_t) * ((size_t) n + 1));
-      copy_d2h(len.data(), cs.seg_len[cs.cur].p, sizeof(uint32_t) * (size_t) n);
-    }
-  if (with_jumps && cs.jtop > 0)
-    { jd.resize(2 * cs.jtop);
-      copy_d2h(jd.data(), cs.jumps.p, sizeof(uint16_t) * 2 * cs.jtop);
+    { copy_d2h(raw.pool.data(), cs.pool[cs.cur].p, sizeof(DCand) * cs.total_len);
+      copy_d2h(raw.off.data(), cs.seg_off[cs.cur].p, sizeof(uint32_t) * ((size_t) n + 1));
+      copy_d2h(raw.len.data(), cs.seg_len[cs.cur].p, sizeof(uint32_t) * (size_t) n);
     }
   if (!cs.h_cov_off.empty())
-    { cov.resize(cs.h_cov_off[n]);
-      if (!cov.empty()) copy_d2h(cov.data(), cs.cover.p, sizeof(int16_t) * cov.size());
+    { raw.cov.resize(cs.h_cov_off[n]);
+      if (!raw.cov.empty()) copy_d2h(raw.cov.data(), cs.cover.p, sizeof(int16_t) * raw.cov.size());
     }
   HIP_CHECK(hipStreamSynchronize(stream()));
-  st.reads.clear();
-  st.reads.resize(n);
+  raw.valid = true;
+}
+
+// Per read: its candidates newest first (the reference's list order), tombstones left out; ids count them in that
+// order over the block.  jd (may be null): the block's Jump pool.
+void cand_build(const CandRaw &raw, std::vector<ReadState> &reads, const std::vector<uint16_t> *jd)
+{ const int n = raw.nreads;
+  reads.clear();
+  reads.resize(n);
   int id = 0;
   for (int r = 0; r < n; r++)
-    { ReadState &rs = st.reads[r];
-      if (cs.total_len > 0)
-        for (uint32_t i = len[r]; i-- > 0;)            // newest first: the reference's list order
-          { const DCand &d = pool[off[r] + i];
+    { ReadState &rs = reads[r];
+      if (!raw.pool.empty())
+        for (uint32_t i = raw.len[r]; i-- > 0;)
+          { const DCand &d = raw.pool[raw.off[r] + i];
             if (d.flags & DC_TOMB) continue;
             std::unique_ptr<Candidate> c(new Candidate());
             c->score = d.score; c->length = (int) d.jlen; c->bread = d.bread; c->comp = (d.flags & DC_COMP) ? 1 : 0;
             c->afirst = d.afirst; c->alast = d.alast; c->bfirst = d.bfirst; c->blast = d.blast;
             c->id = id++;
             c->joff = d.joff;
-            if (with_jumps && d.jlen > 0)
-              c->jumps.assign(jd.begin() + 2 * (size_t) d.joff, jd.begin() + 2 * ((size_t) d.joff + d.jlen));
+            if (jd != nullptr && d.jlen > 0)
+              c->jumps.assign(jd->begin() + 2 * (size_t) d.joff, jd->begin() + 2 * ((size_t) d.joff + d.jlen));
             rs.cands.push_back(std::move(c));
           }
-      if (!cs.h_cov_off.empty())
-        rs.cover.assign(cov.begin() + cs.h_cov_off[r], cov.begin() + cs.h_cov_off[r + 1]);
+      if (!raw.cov_off.empty())
+        rs.cover.assign(raw.cov.begin() + raw.cov_off[r], raw.cov.begin() + raw.cov_off[r + 1]);
     }
+}
+
+void cand_mirror(bool with_jumps)
+{ State &st = S();
+  CandStore &cs = st.cands;
+  st.tfilt += filter_flush();             // (the passes still waiting in the batch)
+  if (cs.mirror_valid && (cs.mirror_jumps || !with_jumps)) return;
+  CandRaw raw;
+  cand_fetch(raw);
+  std::vector<uint16_t> jd;
+  if (with_jumps && cs.jtop > 0)
+    { jd.resize(2 * cs.jtop);
+      copy_d2h(jd.data(), cs.jumps.p, sizeof(uint16_t) * 2 * cs.jtop);
+      HIP_CHECK(hipStreamSynchronize(stream()));
+    }
+  cand_build(raw, st.reads, with_jumps ? &jd : nullptr);
   cs.mirror_valid = true;
   cs.mirror_jumps = with_jumps;
 }

@@ -44,6 +44,10 @@ void bg_flush();
 // true while a deferred Reporter's alignment kernel is running on the alignment stream: background
 // stages are then held back (the HBM-bound sort kernels keep the GPU to themselves, before the alignment)
 bool report_in_flight();
+// Called by the filter at a moment when the GPU has work queued: if the previous READS block's deferred alignment
+// kernel has finished, its records are fetched now and the candidates that need a wider kernel are re-launched --
+// instead of at the next Reporter call, where the GPU would wait for both.
+void report_poll();
 void report_finish_pending();
 bool report_adopt_block(const DAZZ_DB *block);   // a deferred Reporter takes over the resident copy it reads
 

@@ -1459,6 +1459,7 @@ static void close_batch(MergeResult &R)
   for (int i = 0; i < NRING; i++)
     if (&g_ring[i] == &R) slot = i;
   g_inflight.push_back(slot);
+  report_poll();                 // (the chain kernels just queued keep the GPU busy meanwhile)
   while ((int) g_inflight.size() > g_flight_cap) st.tfilt += finish_oldest();
   for (int i = 0; i < NRING; i++)
     { bool busy = false;

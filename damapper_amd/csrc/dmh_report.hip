@@ -6,6 +6,7 @@
 #include "dmh_spec.h"
 #include "dmh_align.h"
 #include <chrono>
+#include <memory>
 #include "dmh_chain.h"
 #include "dmh_merge.h"
 #include <algorithm>
@@ -713,7 +714,8 @@ struct ReportCtx
   double best_tie;
   std::string aname, bname, sort_path;
   std::vector<int> rlen;
-  std::vector<ReadState> reads;
+  std::vector<ReadState> reads;   // built from raw by the report stage itself (select_and_write)
+  CandRaw raw;
   std::vector<int> job_of_first;
   std::vector<std::vector<AlnRec>> recs;
   std::vector<int> pool;
@@ -766,6 +768,10 @@ static void select_and_write(ReportCtx &C)
       fixup_recs(C.pool_base(), C.recs);
     }
   HostTimer ht2("report_select_write");
+  if (C.raw.valid)
+    { cand_build(C.raw, C.reads, nullptr);
+      C.raw = CandRaw();
+    }
   // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
   const bool small = (S_ <= TRACE_XOVR);
   std::vector<std::vector<uint8_t>> prof(C.profile ? nreads : 0);
@@ -1191,6 +1197,7 @@ struct PendingReport
   size_t deferred_got = 0;
   std::vector<int> status, todo;
   int    njobs = 0, doB = 0, hithr = 0, tcap = 0, level = 0, round = 0;
+  bool   polled = false, collected = false;      // report_poll has looked at the first round / everything is in
   size_t pool_cap = 0;
   AlignSpecDev spd;
   const uint64_t *apk = nullptr, *arc = nullptr, *bpk = nullptr;
@@ -1398,7 +1405,8 @@ static bool collect_round(PendingReport &P)
 
 static void finish_report(PendingReport *P)
 { if (P->njobs > 0)
-    { while (!collect_round(*P)) launch_round(*P);
+    { if (!P->collected)
+        while (!collect_round(*P)) launch_round(*P);
       if (P->deferred_got == 0) fixup_recs(P->pool.data(), P->recs);
     }
   delete P->ht;
@@ -1423,6 +1431,18 @@ bool report_adopt_block(const DAZZ_DB *block)
   P->hold[P->nhold++] = it->second;
   st.blocks.erase(it);
   return true;
+}
+
+void report_poll()
+{ PendingReport *P = g_pending;
+  static const bool off = getenv("DMH_NO_REPORT_POLL") != nullptr;
+  if (off || P == nullptr || !P->on_aux || P->polled || P->njobs == 0) return;
+  const hipError_t e = hipEventQuery(g_ev_done);
+  if (e != hipSuccess) { (void) hipGetLastError(); return; }
+  P->polled = true;
+  HostTimer ht("report_poll");
+  if (collect_round(*P)) P->collected = true;
+  else launch_round(*P);                        // (collected by the next Reporter / report_wait)
 }
 
 void report_finish_pending()
@@ -1464,15 +1484,26 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   // restores the old rule.)
   // what is left of this block's filter (the batched passes) comes first: it is the work that runs next to the
   // previous block's alignment kernel, which is only collected further down
-  st.tfilt += filter_flush();
+  { HostTimer hf("report_flush");
+    st.tfilt += filter_flush();
+  }
   static const int defer_max = getenv("DMH_DEFER_MAX_PASSES") ? atoi(getenv("DMH_DEFER_MAX_PASSES")) : 1 << 30;
   const bool defer = (g_async == 2) && st.mf_calls <= defer_max;
   st.mf_calls = 0;
   // the index sort of the NEXT block: all of it now, ahead of this block's alignment kernel and while the
   // host collects the previous block's (deferred mode), or a few stages for the GPU to do while the jobs
   // are put together
-  if (defer) bg_flush();
-  report_finish_pending();                     // the previous block's alignments (deferred mode)
+  // the candidate lists first: their copy would otherwise queue behind the next block's index sort
+  CandRaw raw;
+  { HostTimer hm("report_mirror");
+    cand_fetch(raw);                          // (their Jump lists stay in HBM)
+  }
+  { HostTimer hb("report_bg_flush");
+    if (defer) bg_flush();
+  }
+  { HostTimer hq("report_previous");
+    report_finish_pending();                   // the previous block's alignments (deferred mode)
+  }
   if (!defer) bg_pump(8);
   const int doA = (mflag & FLAG_DOA) != 0;
   const int doB = (mflag & FLAG_DOB) != 0;
@@ -1483,23 +1514,27 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   PendingReport *P = new PendingReport();
   P->ht = new HostTimer("report_align");
-  cand_mirror(false);                         // the candidate lists (without their Jump lists, which stay in HBM)
+  std::unique_ptr<HostTimer> hj(new HostTimer("report_jobs"));
 
-  // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel
+  // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel: per read newest first,
+  //         tombstones left out -- the order in which cand_build numbers the Candidate objects of the report stage
   std::vector<int> job_of_first(nreads + 1, 0);   // first job index of each read
   for (int ar = 0; ar < nreads; ar++)
     { job_of_first[ar] = (int) P->jobs.size();
-      for (auto &c : st.reads[ar].cands)
-        { CandJob J;
+      if (raw.pool.empty()) continue;
+      for (uint32_t i = raw.len[ar]; i-- > 0;)
+        { const DCand &c = raw.pool[raw.off[ar] + i];
+          if (c.flags & DC_TOMB) continue;
+          CandJob J;
           J.aoff  = ablock->reads[ar].boff;
           J.alen  = ablock->reads[ar].rlen;
-          J.boff  = bblock->reads[c->bread].boff;
-          J.blen  = bblock->reads[c->bread].rlen;
-          J.comp  = c->comp;
-          J.alast = c->alast;
-          J.blast = c->blast;
-          J.npts  = c->length;
-          J.joff  = c->joff;
+          J.boff  = bblock->reads[c.bread].boff;
+          J.blen  = bblock->reads[c.bread].rlen;
+          J.comp  = (c.flags & DC_COMP) ? 1 : 0;
+          J.alast = c.alast;
+          J.blast = c.blast;
+          J.npts  = (int) c.jlen;
+          J.joff  = c.joff;
           J.pad   = 0;
           P->jobs.push_back(J);
         }
@@ -1518,7 +1553,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     C->aname = aname; C->bname = bname; C->sort_path = SORT_PATH;
     C->rlen.resize(nreads);
     for (int i = 0; i < nreads; i++) C->rlen[i] = ablock->reads[i].rlen;
-    C->reads = std::move(st.reads);
+    C->raw = std::move(raw);
     st.reads.clear();
     st.cur_reads = nullptr;
     st.cands.block = nullptr;
@@ -1581,6 +1616,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
             }
         }
 
+      hj.reset();
       if (defer)
         { if (g_astream == nullptr)
             { // (DMH_ASTREAM_PRIO=1: the deferred alignment kernel on a low-priority stream -- experiments)

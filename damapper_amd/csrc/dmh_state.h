@@ -121,6 +121,17 @@ struct ReadState
   std::vector<int16_t> cover;                       // -p deltas
 };
 
+// The candidate lists of a READS block as they come off the device (cand_fetch): what Reporter needs to make its
+// alignment jobs; the per-read Candidate objects of the report stage are built from it later (cand_build, on the
+// report stage's own thread).
+struct CandRaw
+{ int nreads = 0;
+  std::vector<DCand>    pool;
+  std::vector<uint32_t> off, len, cov_off;
+  std::vector<int16_t>  cov;
+  bool valid = false;
+};
+
 struct State
 { Params params;
   std::map<int, IndexDev>          indices;
