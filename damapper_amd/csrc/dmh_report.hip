@@ -721,6 +721,8 @@ struct ReportCtx
   std::vector<int> pool;
   PinBuf *pin = nullptr;         // the pool lives here instead when one launch aligned everything
   size_t deferred_got = 0;       // > 0: pool[0..deferred_got) still has to be parsed into recs
+  struct Seg { size_t base, got; std::vector<char> failed; };
+  std::vector<Seg> segs;         // several launches: their stretches of `pool` and the jobs whose records do not count
   int *pool_base() { return pin ? pin->p : pool.data(); }
   ~ReportCtx() { if (pin) pin->busy.store(false); }
 };
@@ -766,6 +768,12 @@ static void select_and_write(ReportCtx &C)
   if (C.deferred_got > 0)
     { parse_pool(C.pool_base(), 0, C.deferred_got, (int) C.recs.size(), std::vector<char>(), C.recs);
       fixup_recs(C.pool_base(), C.recs);
+    }
+  else if (!C.segs.empty())
+    { for (const ReportCtx::Seg &g : C.segs)
+        parse_pool(C.pool.data(), g.base, g.got, (int) C.recs.size(), g.failed, C.recs);
+      fixup_recs(C.pool.data(), C.recs);
+      C.segs.clear();
     }
   HostTimer ht2("report_select_write");
   if (C.raw.valid)
@@ -1197,6 +1205,7 @@ struct PendingReport
   size_t deferred_got = 0;
   std::vector<int> status, todo;
   int    njobs = 0, doB = 0, hithr = 0, tcap = 0, level = 0, round = 0;
+  std::vector<ReportCtx::Seg> segs;
   bool   polled = false, collected = false;      // report_poll has looked at the first round / everything is in
   size_t pool_cap = 0;
   AlignSpecDev spd;
@@ -1391,8 +1400,7 @@ static bool collect_round(PendingReport &P)
   pb->busy.store(false);
   std::vector<char> failed(njobs, 0);
   for (int j : again) failed[j] = 1;
-  parse_pool(P.pool.data(), base, got, njobs, failed, P.recs);
-  for (int j : again) P.recs[j].clear();
+  P.segs.push_back(ReportCtx::Seg{base, got, std::move(failed)});      // parsed by the report stage, on its thread
   if (again.empty()) return true;
   std::sort(again.begin(), again.end());
   P.todo = again;
@@ -1407,7 +1415,6 @@ static void finish_report(PendingReport *P)
 { if (P->njobs > 0)
     { if (!P->collected)
         while (!collect_round(*P)) launch_round(*P);
-      if (P->deferred_got == 0) fixup_recs(P->pool.data(), P->recs);
     }
   delete P->ht;
   HostTimer ht_tail("report_tail");
@@ -1416,6 +1423,7 @@ static void finish_report(PendingReport *P)
   C->pool = std::move(P->pool);
   C->pin = P->pool_pin;
   C->deferred_got = P->deferred_got;
+  C->segs = std::move(P->segs);
   report_submit(C);
   for (int i = 0; i < P->nhold; i++) free_blockdev(P->hold[i]);
   P->jumps.release();
