@@ -1755,27 +1755,57 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
 //  Host view of the device lists (Reporter, stage-level API)
 // ---------------------------------------------------------------------------------------
 // The candidate lists as they are on the device (no Jump lists: they stay in HBM for the alignment kernel).
-void cand_fetch(CandRaw &raw)
+size_t cand_fetch_bytes()
 { State &st = S();
   CandStore &cs = st.cands;
   st.tfilt += filter_flush();             // (the passes still waiting in the batch)
+  const size_t n = (size_t) cs.nreads;
+  size_t b = sizeof(DCand) * (size_t) cs.total_len + 64 + sizeof(uint32_t) * 2 * (n + 1) + 64;
+  if (!cs.h_cov_off.empty()) b += sizeof(int16_t) * (size_t) cs.h_cov_off[n] + 64;
+  return b;
+}
+
+void cand_fetch(CandRaw &raw, void *dst, size_t dst_bytes)
+{ State &st = S();
+  CandStore &cs = st.cands;
+  st.tfilt += filter_flush();
   const int n = cs.nreads;
   raw.nreads = n;
-  raw.pool.resize(cs.total_len);
-  raw.off.assign((size_t) n + 1, 0);
-  raw.len.assign((size_t) n + 1, 0);
-  raw.cov.clear();
+  raw.npool = cs.total_len;
   raw.cov_off = cs.h_cov_off;
-  if (cs.total_len > 0)
-    { copy_d2h(raw.pool.data(), cs.pool[cs.cur].p, sizeof(DCand) * cs.total_len);
-      copy_d2h(raw.off.data(), cs.seg_off[cs.cur].p, sizeof(uint32_t) * ((size_t) n + 1));
-      copy_d2h(raw.len.data(), cs.seg_len[cs.cur].p, sizeof(uint32_t) * (size_t) n);
+  const size_t ncov = cs.h_cov_off.empty() ? 0 : (size_t) cs.h_cov_off[n];
+  if (dst != nullptr && dst_bytes >= cand_fetch_bytes())
+    { // straight into the caller's page-locked memory: one wait, no staging copy
+      uint8_t *q = (uint8_t *) dst;
+      auto take = [&](size_t bytes) { uint8_t *r = q; q += (bytes + 63) & ~(size_t) 63; return r; };
+      DCand    *pp = (DCand *) take(sizeof(DCand) * raw.npool);
+      uint32_t *po = (uint32_t *) take(sizeof(uint32_t) * ((size_t) n + 1));
+      uint32_t *pl = (uint32_t *) take(sizeof(uint32_t) * ((size_t) n + 1));
+      int16_t  *pc = (int16_t *) take(sizeof(int16_t) * ncov);
+      if (raw.npool > 0)
+        { HIP_CHECK(hipMemcpyAsync(pp, cs.pool[cs.cur].p, sizeof(DCand) * raw.npool, hipMemcpyDeviceToHost, stream()));
+          HIP_CHECK(hipMemcpyAsync(po, cs.seg_off[cs.cur].p, sizeof(uint32_t) * ((size_t) n + 1), hipMemcpyDeviceToHost, stream()));
+          HIP_CHECK(hipMemcpyAsync(pl, cs.seg_len[cs.cur].p, sizeof(uint32_t) * (size_t) n, hipMemcpyDeviceToHost, stream()));
+        }
+      if (ncov > 0)
+        HIP_CHECK(hipMemcpyAsync(pc, cs.cover.p, sizeof(int16_t) * ncov, hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      raw.pool = pp; raw.off = po; raw.len = pl; raw.cov = pc;
     }
-  if (!cs.h_cov_off.empty())
-    { raw.cov.resize(cs.h_cov_off[n]);
-      if (!raw.cov.empty()) copy_d2h(raw.cov.data(), cs.cover.p, sizeof(int16_t) * raw.cov.size());
+  else
+    { raw.v_pool.resize(raw.npool);
+      raw.v_off.assign((size_t) n + 1, 0);
+      raw.v_len.assign((size_t) n + 1, 0);
+      raw.v_cov.resize(ncov);
+      if (raw.npool > 0)
+        { copy_d2h(raw.v_pool.data(), cs.pool[cs.cur].p, sizeof(DCand) * raw.npool);
+          copy_d2h(raw.v_off.data(), cs.seg_off[cs.cur].p, sizeof(uint32_t) * ((size_t) n + 1));
+          copy_d2h(raw.v_len.data(), cs.seg_len[cs.cur].p, sizeof(uint32_t) * (size_t) n);
+        }
+      if (ncov > 0) copy_d2h(raw.v_cov.data(), cs.cover.p, sizeof(int16_t) * ncov);
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      raw.pool = raw.v_pool.data(); raw.off = raw.v_off.data(); raw.len = raw.v_len.data(); raw.cov = raw.v_cov.data();
     }
-  HIP_CHECK(hipStreamSynchronize(stream()));
   raw.valid = true;
 }
 
@@ -1788,7 +1818,7 @@ void cand_build(const CandRaw &raw, std::vector<ReadState> &reads, const std::ve
   int id = 0;
   for (int r = 0; r < n; r++)
     { ReadState &rs = reads[r];
-      if (!raw.pool.empty())
+      if (raw.npool > 0)
         for (uint32_t i = raw.len[r]; i-- > 0;)
           { const DCand &d = raw.pool[raw.off[r] + i];
             if (d.flags & DC_TOMB) continue;
@@ -1802,7 +1832,7 @@ void cand_build(const CandRaw &raw, std::vector<ReadState> &reads, const std::ve
             rs.cands.push_back(std::move(c));
           }
       if (!raw.cov_off.empty())
-        rs.cover.assign(raw.cov.begin() + raw.cov_off[r], raw.cov.begin() + raw.cov_off[r + 1]);
+        rs.cover.assign(raw.cov + raw.cov_off[r], raw.cov + raw.cov_off[r + 1]);
     }
 }
 

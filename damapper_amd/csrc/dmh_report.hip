@@ -716,6 +716,7 @@ struct ReportCtx
   std::vector<int> rlen;
   std::vector<ReadState> reads;   // built from raw by the report stage itself (select_and_write)
   CandRaw raw;
+  PinBuf *raw_pin = nullptr;      // page-locked memory raw points into
   std::vector<int> job_of_first;
   std::vector<std::vector<AlnRec>> recs;
   std::vector<int> pool;
@@ -724,7 +725,7 @@ struct ReportCtx
   struct Seg { size_t base, got; std::vector<char> failed; };
   std::vector<Seg> segs;         // several launches: their stretches of `pool` and the jobs whose records do not count
   int *pool_base() { return pin ? pin->p : pool.data(); }
-  ~ReportCtx() { if (pin) pin->busy.store(false); }
+  ~ReportCtx() { if (pin) pin->busy.store(false); if (raw_pin) raw_pin->busy.store(false); }
 };
 
 // Records of the alignment pool: {cand, seq, abpos, bbpos, aepos, bepos, diffs, tlen} + trace
@@ -779,6 +780,7 @@ static void select_and_write(ReportCtx &C)
   if (C.raw.valid)
     { cand_build(C.raw, C.reads, nullptr);
       C.raw = CandRaw();
+      if (C.raw_pin) { C.raw_pin->busy.store(false); C.raw_pin = nullptr; }
     }
   // ---- 2. per read: redundancy removal, chain linking, selection, output (map.c:2449-2846)
   const bool small = (S_ <= TRACE_XOVR);
@@ -1503,8 +1505,11 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   // are put together
   // the candidate lists first: their copy would otherwise queue behind the next block's index sort
   CandRaw raw;
+  PinBuf *raw_pin = nullptr;
   { HostTimer hm("report_mirror");
-    cand_fetch(raw);                          // (their Jump lists stay in HBM)
+    const size_t nb = cand_fetch_bytes();
+    raw_pin = pin_acquire(nb / sizeof(int) + 64);
+    cand_fetch(raw, raw_pin->p, sizeof(int) * raw_pin->cap);      // (their Jump lists stay in HBM)
   }
   { HostTimer hb("report_bg_flush");
     if (defer) bg_flush();
@@ -1529,7 +1534,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   std::vector<int> job_of_first(nreads + 1, 0);   // first job index of each read
   for (int ar = 0; ar < nreads; ar++)
     { job_of_first[ar] = (int) P->jobs.size();
-      if (raw.pool.empty()) continue;
+      if (raw.npool == 0) continue;
       for (uint32_t i = raw.len[ar]; i-- > 0;)
         { const DCand &c = raw.pool[raw.off[ar] + i];
           if (c.flags & DC_TOMB) continue;
@@ -1562,6 +1567,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     C->rlen.resize(nreads);
     for (int i = 0; i < nreads; i++) C->rlen[i] = ablock->reads[i].rlen;
     C->raw = std::move(raw);
+    C->raw_pin = raw_pin;
     st.reads.clear();
     st.cur_reads = nullptr;
     st.cands.block = nullptr;

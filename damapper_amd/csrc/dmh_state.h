@@ -126,9 +126,15 @@ struct ReadState
 // report stage's own thread).
 struct CandRaw
 { int nreads = 0;
-  std::vector<DCand>    pool;
-  std::vector<uint32_t> off, len, cov_off;
-  std::vector<int16_t>  cov;
+  // views (into the vectors below, or into page-locked memory the caller lent to cand_fetch)
+  const DCand    *pool = nullptr;
+  size_t          npool = 0;
+  const uint32_t *off = nullptr, *len = nullptr;
+  const int16_t  *cov = nullptr;
+  std::vector<uint32_t> cov_off;
+  std::vector<DCand>    v_pool;
+  std::vector<uint32_t> v_off, v_len;
+  std::vector<int16_t>  v_cov;
   bool valid = false;
 };
 
