@@ -722,15 +722,20 @@ struct ReportCtx
   std::vector<int> pool;
   PinBuf *pin = nullptr;         // the pool lives here instead when one launch aligned everything
   size_t deferred_got = 0;       // > 0: pool[0..deferred_got) still has to be parsed into recs
-  struct Seg { size_t base, got; std::vector<char> failed; };
-  std::vector<Seg> segs;         // several launches: their stretches of `pool` and the jobs whose records do not count
+  struct Seg { PinBuf *pin; size_t got; std::vector<char> failed; };
+  std::vector<Seg> segs;         // several launches: the page-locked copy of each one's records and the jobs whose
+                                 // records do not count
   int *pool_base() { return pin ? pin->p : pool.data(); }
-  ~ReportCtx() { if (pin) pin->busy.store(false); if (raw_pin) raw_pin->busy.store(false); }
+  ~ReportCtx()
+  { if (pin) pin->busy.store(false);
+    if (raw_pin) raw_pin->busy.store(false);
+    for (Seg &g : segs) if (g.pin) g.pin->busy.store(false);
+  }
 };
 
 // Records of the alignment pool: {cand, seq, abpos, bbpos, aepos, bepos, diffs, tlen} + trace
 static void parse_pool(int *pool, size_t base, size_t got, int njobs, const std::vector<char> &failed,
-                       std::vector<std::vector<AlnRec>> &recs)
+                       std::vector<std::vector<AlnRec>> &recs, bool absolute = false)
 { size_t p = base;
   while (p + REC_HDR <= base + got)
     { int *r = pool + p;
@@ -744,8 +749,14 @@ static void parse_pool(int *pool, size_t base, size_t got, int njobs, const std:
           a.seq = r[1]; a.abpos = r[2]; a.bbpos = r[3]; a.aepos = r[4]; a.bepos = r[5];
           a.diffs = r[6]; a.tlen = tlen;
           a.babpos = r[8]; a.bbbpos = r[9]; a.baepos = r[10]; a.bbepos = r[11]; a.btlen = btl;
-          a.trace  = (const uint16_t *) (size_t) (p + REC_HDR);      // offsets, fixed up later
-          a.btrace = (const uint16_t *) (size_t) (p + REC_HDR + ((size_t) tlen + 1) / 2);
+          if (absolute)
+            { a.trace  = (const uint16_t *) (pool + p + REC_HDR);
+              a.btrace = (const uint16_t *) (pool + p + REC_HDR + ((size_t) tlen + 1) / 2);
+            }
+          else
+            { a.trace  = (const uint16_t *) (size_t) (p + REC_HDR);      // offsets, fixed up later
+              a.btrace = (const uint16_t *) (size_t) (p + REC_HDR + ((size_t) tlen + 1) / 2);
+            }
           recs[cand].push_back(a);
         }
       p += need;
@@ -772,9 +783,10 @@ static void select_and_write(ReportCtx &C)
     }
   else if (!C.segs.empty())
     { for (const ReportCtx::Seg &g : C.segs)
-        parse_pool(C.pool.data(), g.base, g.got, (int) C.recs.size(), g.failed, C.recs);
-      fixup_recs(C.pool.data(), C.recs);
-      C.segs.clear();
+        parse_pool(g.pin->p, 0, g.got, (int) C.recs.size(), g.failed, C.recs, true);
+      for (auto &v : C.recs)
+        if (v.size() > 1)
+          std::sort(v.begin(), v.end(), [](const AlnRec &x, const AlnRec &y) { return x.seq < y.seq; });
     }
   HostTimer ht2("report_select_write");
   if (C.raw.valid)
@@ -1151,7 +1163,11 @@ static void worker_main()
         g_rqueue.pop_front();
       }
       select_and_write(*C);
-      { // the context was allocated piece by piece on the main thread: hand it back for disposal
+      // what this thread allocated (the per-read candidate objects, the parsed records) it frees itself
+      { std::vector<ReadState>().swap(C->reads);
+        for (auto &v : C->recs) std::vector<AlnRec>().swap(v);
+      }
+      { // the rest of the context was allocated piece by piece on the main thread: hand it back for disposal
         // there (freeing it here would fight the main thread for its malloc arena)
         std::unique_lock<std::mutex> lk(g_rmu);
         g_rdone.push_back(C);
@@ -1396,13 +1412,9 @@ static bool collect_round(PendingReport &P)
       P.pool_pin = pb;
       return true;
     }
-  size_t base = P.pool.size();
-  P.pool.resize(base + got);
-  if (got > 0) memcpy(P.pool.data() + base, pb->p, sizeof(int) * got);
-  pb->busy.store(false);
   std::vector<char> failed(njobs, 0);
   for (int j : again) failed[j] = 1;
-  P.segs.push_back(ReportCtx::Seg{base, got, std::move(failed)});      // parsed by the report stage, on its thread
+  P.segs.push_back(ReportCtx::Seg{pb, got, std::move(failed)});        // parsed by the report stage, on its thread
   if (again.empty()) return true;
   std::sort(again.begin(), again.end());
   P.todo = again;
