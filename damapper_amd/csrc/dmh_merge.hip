@@ -936,7 +936,7 @@ static int64_t sizeof_db(const DAZZ_DB *db)
 
 // The batches: one being collected (ring[cur]) and up to IN_FLIGHT submitted ones whose chain kernels -- repeat piles
 // above all -- are still running while later passes are merged, sorted and chained.  They are finished in order.
-constexpr int IN_FLIGHT = 3;
+constexpr int IN_FLIGHT = 4;
 constexpr int NRING = IN_FLIGHT + 2;
 static MergeResult g_ring[NRING];
 static int         g_cur = 0;
