@@ -118,7 +118,11 @@ static void sync_all_streams()
 
 // Device memory comes from a small caching pool: hipMalloc/hipFree of multi-GB buffers cost
 // milliseconds each and the block loops allocate the same sizes over and over.
-struct PoolBlock { void *p; size_t cap; };
+// A block goes back to the pool while kernels queued earlier on the stream of the code that frees it may still use it:
+// harmless when the next user queues its work on the same stream, not when it is the filter's finish stream (or the
+// main stream, the other way round).  Every free block therefore remembers the stream it was freed under, blocks of the
+// asking stream are preferred, and a block that changes streams is only handed out once its old stream has drained.
+struct PoolBlock { void *p; size_t cap; hipStream_t owner; };
 static std::vector<PoolBlock>    g_free;
 static std::map<void *, size_t>  g_live;
 static size_t                    g_pooled = 0;
@@ -152,14 +156,17 @@ void *dev_alloc(size_t bytes, const char *what)
     bytes = (bytes + g - 1) / g * g;
   }
   int best = -1;
-  for (size_t i = 0; i < g_free.size(); i++)
-    if (g_free[i].cap >= bytes && g_free[i].cap <= 2 * bytes + (1 << 20))
-      if (best < 0 || g_free[i].cap < g_free[best].cap) best = (int) i;
+  const hipStream_t me = stream();
+  for (int pass = 0; pass < 2 && best < 0; pass++)          // first the blocks this stream freed itself
+    for (size_t i = 0; i < g_free.size(); i++)
+      if ((pass == 1 || g_free[i].owner == me) && g_free[i].cap >= bytes && g_free[i].cap <= 2 * bytes + (1 << 20))
+        if (best < 0 || g_free[i].cap < g_free[best].cap) best = (int) i;
   if (best >= 0)
     { PoolBlock b = g_free[best];
       g_free.erase(g_free.begin() + best);
       g_pooled -= b.cap;
       g_live[b.p] = b.cap;
+      if (b.owner != me) HIP_CHECK(hipStreamSynchronize(b.owner));
       return b.p;
     }
   void *p = nullptr;
@@ -209,7 +216,7 @@ void dev_free(void *p)
       HIP_CHECK(hipFree(p));
       return;
     }
-  g_free.push_back({p, cap});
+  g_free.push_back({p, cap, stream()});
   g_pooled += cap;
 }
 

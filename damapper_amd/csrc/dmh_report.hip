@@ -1224,7 +1224,8 @@ struct PendingReport
   std::vector<int> status, todo;
   int    njobs = 0, doB = 0, hithr = 0, tcap = 0, level = 0, round = 0;
   std::vector<ReportCtx::Seg> segs;
-  bool   polled = false, collected = false;      // report_poll has looked at the first round / everything is in
+  std::vector<PinBuf *> uploads;  // page-locked copies of job / retry lists on their way to the device (freed with P)
+  bool   polled = false, collected = false, jobs_up = false;      // report_poll has looked at the first round / everything is in
   size_t pool_cap = 0;
   AlignSpecDev spd;
   const uint64_t *apk = nullptr, *arc = nullptr, *bpk = nullptr;
@@ -1248,6 +1249,16 @@ bool report_in_flight()
   return false;
 }
 
+// host -> device on the stream the kernel will run on, from a page-locked buffer that lives as long as P: no wait
+// (copy_h2d would wait for everything queued on the MAIN stream -- the next block's index sort, or the chain kernels
+// the filter has just queued when report_poll gets here)
+static void upload_for(PendingReport &P, hipStream_t ks, void *dev, const void *host, size_t bytes)
+{ PinBuf *b = pin_acquire(bytes / sizeof(int) + 16);
+  memcpy(b->p, host, bytes);
+  HIP_CHECK(hipMemcpyAsync(dev, b->p, bytes, hipMemcpyHostToDevice, ks));
+  P.uploads.push_back(b);
+}
+
 static void launch_round(PendingReport &P)
 { hipStream_t ks = P.on_aux ? g_astream : stream();
   const int njobs = P.njobs;
@@ -1255,9 +1266,13 @@ static void launch_round(PendingReport &P)
   d_pool.ensure(P.pool_cap, "alignment pool");
   int nrun = P.todo.empty() ? njobs : (int) P.todo.size();
   const int *only = nullptr;
+  if (!P.jobs_up)
+    { upload_for(P, ks, d_jobs.p, P.jobs.data(), sizeof(CandJob) * (size_t) njobs);
+      P.jobs_up = true;
+    }
   if (!P.todo.empty())
     { d_only.ensure(P.todo.size(), "retry list");
-      copy_h2d(d_only.p, P.todo.data(), sizeof(int) * P.todo.size());
+      upload_for(P, ks, d_only.p, P.todo.data(), sizeof(int) * P.todo.size());
       only = d_only.p;
     }
   const int level = P.level, doB = P.doB;
@@ -1441,6 +1456,7 @@ static void finish_report(PendingReport *P)
   report_submit(C);
   for (int i = 0; i < P->nhold; i++) free_blockdev(P->hold[i]);
   P->jumps.release();
+  for (PinBuf *b : P->uploads) b->busy.store(false);      // (every launch that read them has been collected)
   delete P;
 }
 
@@ -1606,7 +1622,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
       d_jobs.ensure(njobs, "candidate jobs");
       if (P->jumps.p == nullptr) P->jumps.ensure(16, "candidate jumps");
       d_status.ensure(njobs, "candidate status");
-      copy_h2d(d_jobs.p, P->jobs.data(), sizeof(CandJob) * njobs);
+      // (the jobs go to the device with the first launch, on its stream)
 
       // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
       P->pool_cap = (size_t) njobs * 2 * (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8)) + 4096;
