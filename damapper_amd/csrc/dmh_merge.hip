@@ -1225,7 +1225,10 @@ static int64_t finish_oldest()
   g_inflight.pop_front();
   MergeResult &R = g_ring[x];
   g_finishing = true;
-  const int64_t nfilt = chain_finish(R, R.ablock);
+  int64_t nfilt;
+  { HostTimer hf("filter_finish");
+    nfilt = chain_finish(R, R.ablock);
+  }
   g_finishing = false;
   if (finish_stream() != main_stream())
     { // whatever the main stream does from here on (the slot's buffers are about to be used again, Reporter reads the
