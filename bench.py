@@ -172,7 +172,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="grch38")
     ap.add_argument("--genome-mbp", type=float, default=None, help="override the reference size (contig count scales)")
     ap.add_argument("--families", type=int, default=None, help="override the number of repeat families")
