@@ -1522,25 +1522,29 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   // restores the old rule.)
   // what is left of this block's filter (the batched passes) comes first: it is the work that runs next to the
   // previous block's alignment kernel, which is only collected further down
-  { HostTimer hf("report_flush");
-    st.tfilt += filter_flush();
-  }
   static const int defer_max = getenv("DMH_DEFER_MAX_PASSES") ? atoi(getenv("DMH_DEFER_MAX_PASSES")) : 1 << 30;
   const bool defer = (g_async == 2) && st.mf_calls <= defer_max;
   st.mf_calls = 0;
-  // the index sort of the NEXT block: all of it now, ahead of this block's alignment kernel and while the
-  // host collects the previous block's (deferred mode), or a few stages for the GPU to do while the jobs
-  // are put together
-  // the candidate lists first: their copy would otherwise queue behind the next block's index sort
+  // the index sort of the NEXT block: all of it now (deferred mode) -- ahead of this block's alignment kernel, and on
+  // the main stream while the finish stream drains this block's last batches (a dozen small kernels and two round
+  // trips each, which leave the machine nearly empty) -- or a few stages for the GPU to do while the jobs are put together
+  // (not ahead of a batch of sparse passes that is still open: its sort and chain kernels are this block's work)
+  const bool index_first = defer && !filter_batch().open;
+  { HostTimer hb("report_bg_flush");
+    if (index_first) bg_flush();
+  }
+  { HostTimer hf("report_flush");
+    st.tfilt += filter_flush();
+  }
+  if (defer && !index_first) bg_flush();
+  // the candidate lists: copied on the finish stream (the main stream is busy with the index sort)
   CandRaw raw;
   PinBuf *raw_pin = nullptr;
   { HostTimer hm("report_mirror");
+    StreamScope on_finish(index_first ? finish_stream() : main_stream());
     const size_t nb = cand_fetch_bytes();
     raw_pin = pin_acquire(nb / sizeof(int) + 64);
     cand_fetch(raw, raw_pin->p, sizeof(int) * raw_pin->cap);      // (their Jump lists stay in HBM)
-  }
-  { HostTimer hb("report_bg_flush");
-    if (defer) bg_flush();
   }
   { HostTimer hq("report_previous");
     report_finish_pending();                   // the previous block's alignments (deferred mode)
