@@ -93,7 +93,17 @@ hipStream_t finish_stream()
   static const int env_fs = getenv("DMH_FIN_STREAM") ? atoi(getenv("DMH_FIN_STREAM")) : 1;
   const int on = S().opt_fin_stream >= 0 ? S().opt_fin_stream : env_fs;
   if (on == 0) return g_stream;
-  if (g_fstream == nullptr) HIP_CHECK(hipStreamCreateWithFlags(&g_fstream, hipStreamNonBlocking));
+  if (g_fstream == nullptr)
+    { // (DMH_FIN_PRIO=1: high priority -- experiments)
+      static const int prio = getenv("DMH_FIN_PRIO") ? atoi(getenv("DMH_FIN_PRIO")) : 0;
+      if (prio != 0)
+        { int least = 0, greatest = 0;
+          HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+          HIP_CHECK(hipStreamCreateWithPriority(&g_fstream, hipStreamNonBlocking, prio > 0 ? greatest : least));
+        }
+      else
+        HIP_CHECK(hipStreamCreateWithFlags(&g_fstream, hipStreamNonBlocking));
+    }
   return g_fstream;
 }
 
