@@ -12,7 +12,7 @@ import numpy as np
 from .dazzdb import DAZZ_DB, Block
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdamapper_hip.so")
+LIB_PATH = os.environ.get("DMH_LIB") or os.path.join(_HERE, "libdamapper_hip.so")      # (DMH_LIB: an instrumented build)
 
 KMERPOS = np.dtype([("code", "<u8"), ("rpos", "<i4"), ("read", "<i4")])               # map.c:78-82
 SEEDPAIR = np.dtype([("diag", "<i4"), ("apos", "<i4"), ("bread", "<i4"), ("aread", "<i4")])  # map.c:84-89

@@ -11,6 +11,18 @@
 
 #include "../../include/damapper_hip.h"
 
+// -DDMH_DEBUG_LAUNCH (make debug): every kernel launch prints its name and waits for the device, so that a device
+// fault is reported right behind the kernel that caused it (never part of the library build).
+#ifdef DMH_DEBUG_LAUNCH
+#include <stdio.h>
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                                          \
+  do { fprintf(stderr, "dmh: launch %s\n", #kernelName); fflush(stderr);                            \
+       hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                                        \
+       (void) hipDeviceSynchronize();                                                                \
+  } while (0)
+#endif
+
 namespace dmh {
 
 void fatal(const char *fmt, ...) __attribute__((format(printf, 1, 2), noreturn));
@@ -87,6 +99,7 @@ struct StageTimer
   ~StageTimer();
   int    idx;
   bool   active;
+  const char *tname;
   hipStream_t s;
   hipEvent_t e0, e1;
 };

@@ -141,6 +141,11 @@ static const size_t              POOL_MAX = (size_t) 96 << 30;
 static bool (*g_reclaim)() = nullptr;
 static bool g_reclaiming = false;
 
+// Every block handed out starts as zeros: what a kernel reads before anybody wrote it is
+// then the same on every box and in every run -- device memory comes back from the driver, and from this pool, with
+// whatever its last user left in it.  (A device fault seen only on some boxes, and only with such leftovers or with
+// DMH_POISON, is still being looked for: DESIGN.md 8.)  DMH_NO_ZERO_FILL=1 switches it off.
+static const bool g_zero_fill = getenv("DMH_NO_ZERO_FILL") == nullptr;
 static int g_alloc_fail = 0;       // test option "alloc_fail" = n: the n-th allocation from now behaves as if memory had run out
 
 void *dev_alloc(size_t bytes, const char *what)
@@ -171,12 +176,24 @@ void *dev_alloc(size_t bytes, const char *what)
     for (size_t i = 0; i < g_free.size(); i++)
       if ((pass == 1 || g_free[i].owner == me) && g_free[i].cap >= bytes && g_free[i].cap <= 2 * bytes + (1 << 20))
         if (best < 0 || g_free[i].cap < g_free[best].cap) best = (int) i;
+  // DMH_POISON=<byte> (debugging): every allocation starts out filled with that byte, so that a kernel that reads what nobody wrote
+  // misbehaves every time and not only when the memory happens to hold another process's leftovers
+  static const bool poison = getenv("DMH_POISON") != nullptr;
+  static const int  pbyte = poison ? (int) strtol(getenv("DMH_POISON"), nullptr, 0) & 0xff : 0;      // (the byte to fill with)
   if (best >= 0)
     { PoolBlock b = g_free[best];
       g_free.erase(g_free.begin() + best);
       g_pooled -= b.cap;
       g_live[b.p] = b.cap;
       if (b.owner != me) HIP_CHECK(hipStreamSynchronize(b.owner));
+      if (poison)
+        { HIP_CHECK(hipMemsetAsync(b.p, pbyte, b.cap, me));
+          HIP_CHECK(hipStreamSynchronize(me));
+        }
+      else if (g_zero_fill)
+        { HIP_CHECK(hipMemsetAsync(b.p, 0, b.cap, me));          // (finished before the block is handed out: its first
+          HIP_CHECK(hipStreamSynchronize(me));                   //  writer may well be another stream, e.g. an upload)
+        }
       return b.p;
     }
   void *p = nullptr;
@@ -207,6 +224,14 @@ void *dev_alloc(size_t bytes, const char *what)
   if (e != hipSuccess)
     fatal("out of device memory allocating %zu bytes (%s): %s", bytes, what, hipGetErrorString(e));
   g_live[p] = bytes;
+  if (poison)
+    { HIP_CHECK(hipMemsetAsync(p, pbyte, bytes, me));
+      HIP_CHECK(hipStreamSynchronize(me));
+    }
+  else if (g_zero_fill)
+    { HIP_CHECK(hipMemsetAsync(p, 0, bytes, me));
+      HIP_CHECK(hipStreamSynchronize(me));
+    }
   return p;
 }
 
@@ -331,10 +356,16 @@ static int slot_of(const char *name)
   return (int) g_slots.size() - 1;
 }
 
+// DMH_TRACE_STAGES (debugging a device fault): every stage prints its name and waits for its stream at its end
+static const bool g_trace_stages = getenv("DMH_TRACE_STAGES") != nullptr;
+static const char *g_trace_prefix = getenv("DMH_TRACE_PREFIX");        // only the stages whose names start like this wait
+
 StageTimer::StageTimer(const char *name, double bytes, hipStream_t on)
 { active = g_timing && (!g_timing_roofline_only || strcmp(name, "k_radix_scatter") == 0);
   idx = -1;
   s = on ? on : stream();
+  tname = name;
+  if (g_trace_stages && g_trace_prefix == nullptr) { fprintf(stderr, "dmh: stage %s ...\n", name); fflush(stderr); }
   if (!active) return;
   { std::lock_guard<std::mutex> lk(g_tmu);
     idx = slot_of(name);
@@ -347,7 +378,11 @@ StageTimer::StageTimer(const char *name, double bytes, hipStream_t on)
 }
 
 StageTimer::~StageTimer()
-{ if (!active) return;
+{ if (g_trace_stages && (g_trace_prefix == nullptr || strncmp(tname, g_trace_prefix, strlen(g_trace_prefix)) == 0))
+    { HIP_CHECK(hipStreamSynchronize(s));
+      if (g_trace_prefix == nullptr) { fprintf(stderr, "dmh: stage %s done\n", tname); fflush(stderr); }
+    }
+  if (!active) return;
   HIP_CHECK(hipEventRecord(e1, s));
   std::lock_guard<std::mutex> lk(g_tmu);
   g_pending.push_back({idx, e0, e1});
