@@ -178,8 +178,23 @@ void *dev_alloc(size_t bytes, const char *what)
         if (best < 0 || g_free[i].cap < g_free[best].cap) best = (int) i;
   // DMH_POISON=<byte> (debugging): every allocation starts out filled with that byte, so that a kernel that reads what nobody wrote
   // misbehaves every time and not only when the memory happens to hold another process's leftovers
-  static const bool poison = getenv("DMH_POISON") != nullptr;
-  static const int  pbyte = poison ? (int) strtol(getenv("DMH_POISON"), nullptr, 0) & 0xff : 0;      // (the byte to fill with)
+  // DMH_POISON_WHAT=a|b|c: only the allocations whose label contains one of these; DMH_POISON_LOG: print every label
+  static const char *pwhat = getenv("DMH_POISON_WHAT");
+  static const bool  plog  = getenv("DMH_POISON_LOG") != nullptr;
+  bool poison = getenv("DMH_POISON") != nullptr;
+  if (poison && pwhat != nullptr)
+    { poison = false;
+      std::string list(pwhat);
+      size_t a = 0;
+      while (a <= list.size())
+        { size_t b = list.find('|', a);
+          if (b == std::string::npos) b = list.size();
+          if (b > a && strstr(what, list.substr(a, b - a).c_str()) != nullptr) poison = true;
+          a = b + 1;
+        }
+    }
+  if (plog) { fprintf(stderr, "dmh: alloc [%s]\n", what); fflush(stderr); }
+  static const int  pbyte = getenv("DMH_POISON") ? (int) strtol(getenv("DMH_POISON"), nullptr, 0) & 0xff : 0;      // (the byte to fill with)
   if (best >= 0)
     { PoolBlock b = g_free[best];
       g_free.erase(g_free.begin() + best);
