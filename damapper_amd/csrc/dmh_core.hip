@@ -194,6 +194,20 @@ void *dev_alloc(size_t bytes, const char *what)
         }
     }
   if (plog) { fprintf(stderr, "dmh: alloc [%s]\n", what); fflush(stderr); }
+  // DMH_ZERO_WHAT=a|b|c: these allocations are zero-filled whatever else is set (who READS the leftovers?)
+  static const char *zwhat = getenv("DMH_ZERO_WHAT");
+  bool zero_this = false;
+  if (zwhat != nullptr)
+    { std::string list(zwhat);
+      size_t a = 0;
+      while (a <= list.size())
+        { size_t b = list.find('|', a);
+          if (b == std::string::npos) b = list.size();
+          if (b > a && strstr(what, list.substr(a, b - a).c_str()) != nullptr) zero_this = true;
+          a = b + 1;
+        }
+      if (zero_this) poison = false;
+    }
   static const int  pbyte = getenv("DMH_POISON") ? (int) strtol(getenv("DMH_POISON"), nullptr, 0) & 0xff : 0;      // (the byte to fill with)
   if (best >= 0)
     { PoolBlock b = g_free[best];
@@ -205,7 +219,7 @@ void *dev_alloc(size_t bytes, const char *what)
         { HIP_CHECK(hipMemsetAsync(b.p, pbyte, b.cap, me));
           HIP_CHECK(hipStreamSynchronize(me));
         }
-      else if (g_zero_fill)
+      else if (g_zero_fill || zero_this)
         { HIP_CHECK(hipMemsetAsync(b.p, 0, b.cap, me));          // (finished before the block is handed out: its first
           HIP_CHECK(hipStreamSynchronize(me));                   //  writer may well be another stream, e.g. an upload)
         }
@@ -243,7 +257,7 @@ void *dev_alloc(size_t bytes, const char *what)
     { HIP_CHECK(hipMemsetAsync(p, pbyte, bytes, me));
       HIP_CHECK(hipStreamSynchronize(me));
     }
-  else if (g_zero_fill)
+  else if (g_zero_fill || zero_this)
     { HIP_CHECK(hipMemsetAsync(p, 0, bytes, me));
       HIP_CHECK(hipStreamSynchronize(me));
     }
