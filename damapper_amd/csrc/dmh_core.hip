@@ -141,11 +141,10 @@ static const size_t              POOL_MAX = (size_t) 96 << 30;
 static bool (*g_reclaim)() = nullptr;
 static bool g_reclaiming = false;
 
-// Every block handed out starts as zeros: what a kernel reads before anybody wrote it is
-// then the same on every box and in every run -- device memory comes back from the driver, and from this pool, with
-// whatever its last user left in it.  (A device fault seen only on some boxes, and only with such leftovers or with
-// DMH_POISON, is still being looked for: DESIGN.md 8.)  DMH_NO_ZERO_FILL=1 switches it off.
-static const bool g_zero_fill = getenv("DMH_NO_ZERO_FILL") == nullptr;
+// DMH_ZERO_FILL=1 (debugging): every block handed out starts as zeros -- device memory comes back from the driver, and
+// from this pool, with whatever its last user left in it.  (Was the default for a few hours while a device fault that
+// looked like a read of uninitialised memory was hunted; the cause was an over-read in k_kmer_emit)
+static const bool g_zero_fill = getenv("DMH_ZERO_FILL") != nullptr && getenv("DMH_NO_ZERO_FILL") == nullptr;
 static int g_alloc_fail = 0;       // test option "alloc_fail" = n: the n-th allocation from now behaves as if memory had run out
 
 void *dev_alloc(size_t bytes, const char *what)

@@ -354,9 +354,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__res
   const int64_t  a0  = (r0 >> 4) << 4;
   const int      sh  = (int) (r0 - a0);
   const int      nvec = (sh + EMIT_TILE + halo + 15) >> 4;
+  // The copy holds raw[0 .. L] and 64 bytes of padding: a 16-byte line that would reach past them is NOT fetched -- it
+  // belongs to positions behind the block, which are turned into separators below anyway.  (The last tile used to
+  // fetch up to EMIT_TILE + K bytes past the end of the allocation: harmless wherever the next page happened to be
+  // mapped, a device fault where it was not -- seen on one box in five, with the smallest blocks of the test suite.)
   if (tid < nvec)
     { int64_t off = a0 + 16 * (int64_t) tid;
-      sraw[tid] = (off >= 0) ? *(const uint4 *) (raw + off) : make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
+      sraw[tid] = (off >= 0 && off + 16 <= L + 1 + 64) ? *(const uint4 *) (raw + off)
+                                                       : make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
     }
   uint8_t *sb = (uint8_t *) sraw + sh;                     // sb[x] = bases[tile - halo + x]
   if (tile + EMIT_TILE > L)                                // the last tile: whatever lies behind the block is a separator
