@@ -1067,13 +1067,19 @@ struct OrdChain
 // only a few hold an end at all.  So the ends are first packed (goff = exclusive scan of the groups' end counts:
 // the ends of group g go to slots goff[g]..., a pair's ends to goff[c0] .. goff[c1]) together with their pair's slot
 // range, and then every end is ranked by its own thread among that short range.
+// The order of two sibling ends in one word: live before expired, then okey.  A live okey is (diagonal + 2^31, apos)
+// and an expired one (apos, bpos), with positions below 2^31, so the low half gives up its top bit to make room.
+__device__ __forceinline__ uint64_t order_word(uint32_t live, uint64_t okey)
+{ return ((uint64_t) (live & 1u) << 63) | ((okey >> 32) << 31) | (okey & 0x7fffffffull); }
+
 __global__ __launch_bounds__(256) void k_pack_summaries(const ChainSummary *__restrict__ out, uint32_t ngroups,
                                                         const uint32_t *__restrict__ gbase,
                                                         const uint32_t *__restrict__ gcount,
                                                         const uint32_t *__restrict__ goff,
                                                         const uint32_t *__restrict__ cog,
                                                         const uint32_t *__restrict__ ocfirst,
-                                                        ChainSummary *__restrict__ packed, uint2 *__restrict__ range)
+                                                        ChainSummary *__restrict__ packed, uint2 *__restrict__ range,
+                                                        uint64_t *__restrict__ oword)
 { for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x)
     { const uint32_t En = gcount[g];
       if (En == 0) continue;
@@ -1086,25 +1092,31 @@ __global__ __launch_bounds__(256) void k_pack_summaries(const ChainSummary *__re
       const uint2 r = make_uint2(goff[c0], goff[c1]);
       const uint32_t dst = goff[g], mb = gbase[g];
       for (uint32_t e = 0; e < En; e++)
-        { packed[dst + e] = out[mb + e];
+        { const ChainSummary s = out[mb + e];
+          packed[dst + e] = s;
           range[dst + e]  = r;
+          oword[dst + e]  = order_word(s.live, s.okey);
         }
     }
 }
 
+// The sibling ranges are short and the ends of a pair sit next to each other, so neighbouring lanes walk the same
+// order words (one 8-byte load per sibling, mostly the same address across the wavefront).
 __global__ __launch_bounds__(256) void k_order_summaries(const ChainSummary *__restrict__ packed,
-                                                         const uint2 *__restrict__ range, uint32_t nsum,
+                                                         const uint2 *__restrict__ range,
+                                                         const uint64_t *__restrict__ oword, uint32_t nsum,
                                                          const uint64_t *__restrict__ gkey, OrdChain *__restrict__ ord)
 { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nsum) return;
-  const ChainSummary s = packed[i];
   const uint2 r = range[i];
-  uint32_t rank = 0;
-  for (uint32_t j = r.x; j < r.y; j++)
-    { const uint32_t tl = packed[j].live;
-      const uint64_t tk = packed[j].okey;
-      rank += (tl > s.live || (tl == s.live && tk > s.okey)) ? 1u : 0u;
+  const uint64_t mine = oword[i];
+  uint32_t rank = 0, j = r.x;
+  for (; j + 4 <= r.y; j += 4)
+    { const uint64_t t0 = oword[j], t1 = oword[j + 1], t2 = oword[j + 2], t3 = oword[j + 3];
+      rank += (t0 > mine ? 1u : 0u) + (t1 > mine ? 1u : 0u) + (t2 > mine ? 1u : 0u) + (t3 > mine ? 1u : 0u);
     }
+  for (; j < r.y; j++) rank += (oword[j] > mine) ? 1u : 0u;
+  const ChainSummary s = packed[i];
   OrdChain o;
   o.cost = s.cost; o.ab = s.ab; o.ae = s.ae; o.bb = s.bb; o.be = s.be; o.end = s.end;
   o.gkey = gkey[s.group];
@@ -1669,9 +1681,11 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   static DevBuf<uint32_t> rgfirst, fresh, jl;
   static DevBuf<ChainSummary> packed;
   static DevBuf<uint2> prange;
+  static DevBuf<uint64_t> oword;
   ord.ensure(nsum, "ordered chain ends");
   packed.ensure(nsum, "packed chain ends");
   prange.ensure(nsum, "sibling ranges of the chain ends");
+  oword.ensure(nsum, "order words of the chain ends");
   rgfirst.ensure((size_t) nreads + 2, "groups per read");
   fresh.ensure(nsum, "fresh candidates");
   jl.ensure(2 * (size_t) nsum + 4, "jump lengths");
@@ -1687,9 +1701,11 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
                        (const ChainSummary *) out.p, ng, (const uint32_t *) gbase.p,
                        (const uint32_t *) gcnt.p, (const uint32_t *) goff.p,
                        R.clustered ? (const uint32_t *) R.cog.p : (const uint32_t *) nullptr,
-                       R.clustered ? (const uint32_t *) R.ocfirst.p : (const uint32_t *) nullptr, packed.p, prange.p);
+                       R.clustered ? (const uint32_t *) R.ocfirst.p : (const uint32_t *) nullptr, packed.p, prange.p,
+                       oword.p);
     hipLaunchKernelGGL(k_order_summaries, dim3(ceil_div(nsum, 256)), dim3(256), 0, stream(),
-                       (const ChainSummary *) packed.p, (const uint2 *) prange.p, nsum, (const uint64_t *) R.gkey.p, ord.p);
+                       (const ChainSummary *) packed.p, (const uint2 *) prange.p, (const uint64_t *) oword.p, nsum,
+                       (const uint64_t *) R.gkey.p, ord.p);
     hipLaunchKernelGGL(k_read_groups, dim3(ceil_div((int64_t) ng + 1, 256)), dim3(256), 0, stream(),
                        (const uint64_t *) R.gkey.p, ng, R.bbits + R.passbits, nreads, rgfirst.p);
     hipLaunchKernelGGL(k_dom_need, dim3(ceil_div(nreads, 256)), dim3(256), 0, stream(),
