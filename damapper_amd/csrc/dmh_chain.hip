@@ -574,6 +574,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
   uint32_t fb[CH];
 #pragma unroll
   for (int t = 0; t < CH; t++) { kb[t] = 0; nbk[t] = 0; fb[t] = 0; }
+  bool     copy_nb = false;   // the chunk was finished in the last step: its successor is waiting in nbk
+  bool     flush = false, ending = false;    // ... its links are to be written; ... and it was the group's last
+  uint32_t last_r = 0;        // apos of the group's last hit (live test of its ends), asked for when the group is taken
+  uint32_t lq0 = 0, lq1 = 0;  // bounds of group pg on their way (pst 2)
   int      nb_for = 0;        // the look-ahead chunk holds: 0 nothing, 1 the next chunk of this group, 2 the first chunk of group pg
   // the group after it: pst 1 = look its bounds up, 2 = bounds on their way, 4 = bounds there and fine, 3 = and its first
   // chunk requested, 9 = none left
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
       }
   };
 
-  auto emit = [&](uint32_t t, bool at_end)
+  auto emit = [&](uint32_t t, bool at_end, int lastv)
   { // the best end of tree slot t, if it scores (map.c:1642-1649)
     const int bcst = t_bc[wv][t][lane];
     if (bcst < A.hithr) return;
@@ -601,8 +605,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
 #pragma unroll
         for (int s = 0; s < RW; s++)
           if (((vmask >> s) & 1u) && (w_meta[s] & 0xffffffu) == ex) live_x = true;
-        const int last = A.glast ? (int) A.glast[g] : (int) (uint32_t) A.ab[g0 + n - 1] + 1;
-        live_x = live_x && (int) ea >= last - MAX_GAP;
+        live_x = live_x && (int) ea >= lastv - MAX_GAP;
       }
     ChainSummary sm;
     sm.group = g;
@@ -619,54 +622,85 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
     E += 1;
   };
 
+  // A wavefront waits for ALL its outstanding loads at once, whichever lane asked for them: a load whose result is used
+  // a few instructions later costs every lane a memory round trip.  So a step of the walk first takes in whatever
+  // earlier steps have asked for (the chunk after the one just finished, the bounds and the first chunk of the next
+  // group), then issues this step's loads, and only then walks its hit: the loads have the whole walk to arrive.
   while (true)
-    { // ---- look-ahead: bounds of this lane's next group
+    { // ---- take in (a lane that is about to leave its group, or has none, and whose next group's first chunk has
+      //      been asked for takes that chunk now: nothing below reads kb before the walk)
+      if (copy_nb || ((!active || ending) && pst == 3))
+        {
+#pragma unroll
+          for (int t = 0; t < CH; t++) kb[t] = nbk[t];
+          nb_for = 0;
+          copy_nb = false;
+        }
       if (pst == 2)
-        { if (q1 - q0 <= size_max) pst = 4;
+        { q0 = lq0; q1 = lq1;            // (the registers a load is on its way to are read nowhere else)
+          if (q1 - q0 <= size_max) pst = 4;
           else { pg += nthreads; pst = 1; }
         }
+      // ---- what the last step left to be written: its group's ends (they read last_r: before any store, or the
+      //      wait for it would wait for the stores too), its chunk's links
+      const bool was_flush = flush;
+      const uint32_t jl = j - 1;
+      uint32_t *fo = A.from + g0 + (jl & ~(uint32_t) (CH - 1));
+      if (ending)
+        { const int lastv = (int) last_r + (A.glast ? 0 : 1);
+          for (uint32_t m = tmask; m != 0; m &= m - 1)
+            emit((uint32_t) __ffs((int) m) - 1u, true, lastv);
+          A.gcount[g] = E;
+          A.gbase[g]  = obase;
+          active = false;
+          ending = false;
+        }
+      if (was_flush)
+        {
+#pragma unroll
+          for (int t = 0; t < CH; t++)
+            if ((uint32_t) t <= (jl & (CH - 1))) fo[t] = fb[t];
+          flush = false;
+        }
+      bool taken = false;
+      if (!active && pst == 3)
+        { active = true; taken = true;
+          g = pg; g0 = q0; n = q1 - q0; j = 0; E = 0;
+          obase = (g0 + HITMIN - 1) / HITMIN;
+          vmask = 0; tmask = 0;
+          pg += nthreads;
+          pst = 1;
+        }
+      // ---- ask for: the group's last apos, the bounds of the lane's next group, the next chunk (of this group, or the
+      //      first one of the next group once its bounds are known)
+      if (taken)
+        last_r = A.glast ? A.glast[g] : (uint32_t) A.ab[g0 + n - 1];      // (0-based there: see emit)
       if (pst == 1)
         { if (pg < A.ngroups)
-            { q0 = A.gstart[pg];
-              q1 = A.gstart[pg + 1];
+            { lq0 = A.gstart[pg];
+              lq1 = A.gstart[pg + 1];
               pst = 2;
             }
           else
             pst = 9;
         }
-      // ---- a lane without a group takes the one that has been looked up
-      if (!active && (pst == 3 || pst == 4))
-        { active = true;
-          g = pg; g0 = q0; n = q1 - q0; j = 0; E = 0;
-          obase = (g0 + HITMIN - 1) / HITMIN;
-          if (pst == 3)
-            {
-#pragma unroll
-              for (int t = 0; t < CH; t++) kb[t] = nbk[t];
+      if (nb_for == 0)
+        { uint32_t at = 0;
+          int      what = 0;
+          const uint32_t nxt = (j & ~(uint32_t) (CH - 1)) + CH;
+          if (active && nxt < n) { at = g0 + nxt; what = 1; }
+          else if (pst == 4)     { at = q0; what = 2; }
+          if (what != 0)
+            { load_chunk(nbk, at);
+              nb_for = what;
+              if (what == 2) pst = 3;
             }
-          else
-            load_chunk(kb, g0);
-          nb_for = 0;
-          vmask = 0; tmask = 0;
-          pg += nthreads;
-          pst = 1;
         }
       if (__ballot(active || pst != 9) == 0) break;
       if (!active) continue;
 
       // ---- hit j of the group (map.c:1781-1872)
       const uint32_t t8 = j & (CH - 1);
-      if (nb_for == 0)
-        { if ((j & ~(uint32_t) (CH - 1)) + CH < n)           // (asked for when the chunk is entered)
-            { load_chunk(nbk, g0 + (j & ~(uint32_t) (CH - 1)) + CH);
-              nb_for = 1;
-            }
-          else if (pst == 4)                                 // this is the group's last chunk: the next group's first
-            { load_chunk(nbk, q0);
-              nb_for = 2;
-              pst = 3;
-            }
-        }
       uint64_t hk = kb[0];
 #pragma unroll
       for (int t = 1; t < CH; t++) hk = (t8 == (uint32_t) t) ? kb[t] : hk;
@@ -713,7 +747,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
                 if ((vmask >> s) & 1u) used |= 1u << (w_meta[s] >> 24);
               const uint32_t dead = tmask & ~used;
               for (uint32_t m = dead; m != 0; m &= m - 1)
-                emit((uint32_t) __ffs((int) m) - 1u, false);
+                emit((uint32_t) __ffs((int) m) - 1u, false, 0);
               tmask &= ~dead;
             }
           if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
@@ -757,26 +791,14 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
       if (overflow)
         { A.retry[atomicAdd(A.nretry, 1u)] = g;          // (the lane-group kernel starts the group afresh)
           active = false;
+          if (nb_for == 1) nb_for = 0;                   // (nbk holds the abandoned group's next chunk)
         }
       else if (j == n || t8 == CH - 1)
-        { // the chunk's links go out together
-          uint32_t *fo = A.from + g0 + ((j - 1) & ~(uint32_t) (CH - 1));
-#pragma unroll
-          for (int t = 0; t < CH; t++)
-            if ((uint32_t) t <= t8) fo[t] = fb[t];
-          if (j == n)
-            { for (uint32_t m = tmask; m != 0; m &= m - 1)
-                emit((uint32_t) __ffs((int) m) - 1u, true);
-              A.gcount[g] = E;
-              A.gbase[g]  = obase;
-              active = false;
-            }
-          else
-            {
-#pragma unroll
-              for (int t = 0; t < CH; t++) kb[t] = nbk[t];
-              nb_for = 0;
-            }
+        { // the chunk's links go out together -- at the head of the next step, like the group's ends when this was
+          // its last hit (stores count as outstanding memory operations too)
+          flush = true;
+          if (j == n) ending = true;
+          else        copy_nb = true;
         }
     }
 }
