@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_
 // ---------------------------------------------------------------------------------------
 constexpr int RW = 8;      // window slots of a lane (registers)
 constexpr int RT = 5;      // tree slots of a lane (LDS)
+constexpr int LANE_WALKS = 2;    // hits a lane walks per step of the wavefront (divides the chunk)
 constexpr int LANE_BLOCK = 64;    // one wavefront per workgroup: 7.5 KB of LDS each, so the registers bound the occupancy
 
 __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t size_max)
@@ -696,109 +697,115 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
               if (what == 2) pst = 3;
             }
         }
+      asm volatile("" ::: "memory");        // (no store of the above is to be moved behind the walk)
       if (__ballot(active || pst != 9) == 0) break;
-      if (!active) continue;
+      // ---- LANE_WALKS hits per step: the memory operations above have that much longer to complete, and their
+      //      bookkeeping is shared (a chunk is a whole number of steps; a lane whose group ends inside one idles)
+#pragma unroll 1
+      for (int u = 0; u < LANE_WALKS; u++)
+        { if (!active || ending || copy_nb) continue;
 
-      // ---- hit j of the group (map.c:1781-1872)
-      const uint32_t t8 = j & (CH - 1);
-      uint64_t hk = kb[0];
+          // ---- hit j of the group (map.c:1781-1872)
+          const uint32_t t8 = j & (CH - 1);
+          uint64_t hk = kb[0];
 #pragma unroll
-      for (int t = 1; t < CH; t++) hk = (t8 == (uint32_t) t) ? kb[t] : hk;
-      const int apos = (int) (uint32_t) hk + 1, bpos = (int) (hk >> 32) + 1;
-      const int diag = apos - bpos, thresh = bpos - MAX_GAP, old = apos - MAX_GAP;
-      // The window scan, written without branches (selects only): the left neighbour is the live hit with the
-      // smallest (diagonal, -apos) among those with a larger diagonal and bpos >= bpos - MAX_GAP, the right one the
-      // largest (diagonal, apos) among those with diagonal <= diag and bpos <= bpos (map.c:1262-1318); keys are
-      // unique inside a group.  Slots no lane of the wavefront uses are skipped as a whole.
-      int      Ldx = 0x7fffffff, Lax = -1, Lc = 0, Rdx = (int) 0x80000000, Rax = -1, Rc = 0;
-      uint32_t Lm = 0, Ls = 0, Rm = 0, Rs = 0, emask = 0;
+          for (int t = 1; t < CH; t++) hk = (t8 == (uint32_t) t) ? kb[t] : hk;
+          const int apos = (int) (uint32_t) hk + 1, bpos = (int) (hk >> 32) + 1;
+          const int diag = apos - bpos, thresh = bpos - MAX_GAP, old = apos - MAX_GAP;
+          // The window scan, written without branches (selects only): the left neighbour is the live hit with the
+          // smallest (diagonal, -apos) among those with a larger diagonal and bpos >= bpos - MAX_GAP, the right one the
+          // largest (diagonal, apos) among those with diagonal <= diag and bpos <= bpos (map.c:1262-1318); keys are
+          // unique inside a group.  Slots no lane of the wavefront uses are skipped as a whole.
+          int      Ldx = 0x7fffffff, Lax = -1, Lc = 0, Rdx = (int) 0x80000000, Rax = -1, Rc = 0;
+          uint32_t Lm = 0, Ls = 0, Rm = 0, Rs = 0, emask = 0;
 #pragma unroll
-      for (int s = 0; s < RW; s++)
-        { const bool v = (vmask >> s) & 1u;
-          if (__ballot(v) == 0) continue;
-          const int  ax = (int) w_ap[s], bx = (int) w_bp[s], dx = ax - bx;
-          const bool ex = v && ax < old;                            // expired (map.c:1787-1796)
-          emask |= ex ? (1u << s) : 0u;
-          const bool ok  = v && !ex;
-          const bool isL = ok && dx > diag && bx >= thresh;
-          const bool isR = ok && dx <= diag && bx <= bpos;
-          const bool bl  = isL && (dx < Ldx || (dx == Ldx && ax > Lax));
-          const bool br  = isR && (dx > Rdx || (dx == Rdx && ax > Rax));
-          Ldx = bl ? dx : Ldx; Lax = bl ? ax : Lax; Lc = bl ? w_cost[s] : Lc; Lm = bl ? w_meta[s] : Lm; Ls = bl ? (uint32_t) s : Ls;
-          Rdx = br ? dx : Rdx; Rax = br ? ax : Rax; Rc = br ? w_cost[s] : Rc; Rm = br ? w_meta[s] : Rm; Rs = br ? (uint32_t) s : Rs;
-        }
-      vmask &= ~emask;
-      const int  Rbx    = Rax - Rdx;
-      const int  lcost0 = (Lax >= 0) ? ((apos >= Lax + K) ? Lc + K : Lc + (apos - Lax)) : 0;
-      const int  rcost0 = (Rax >= 0) ? ((bpos >= Rbx + K) ? Rc + K : Rc + (bpos - Rbx)) : 0;
-      const bool useL   = lcost0 > rcost0;                        // map.c:1823-1826 (ties go right)
-      const bool havep  = useL || rcost0 > 0;
-      const int      c  = useL ? lcost0 : (havep ? rcost0 : K);
-      const uint32_t pm = useL ? Lm : Rm, ps = useL ? Ls : Rs;
-      const int      pa = useL ? Lax : Rax, pd = useL ? Ldx : Rdx;
-      bool     overflow = false;
-      uint32_t tj = pm >> 24;
-      if (!havep)
-        { if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
-            { // no tree slot left: the trees without a live member are complete -- report them and take their slots
-              uint32_t used = 0;
-#pragma unroll
-              for (int s = 0; s < RW; s++)
-                if ((vmask >> s) & 1u) used |= 1u << (w_meta[s] >> 24);
-              const uint32_t dead = tmask & ~used;
-              for (uint32_t m = dead; m != 0; m &= m - 1)
-                emit((uint32_t) __ffs((int) m) - 1u, false, 0);
-              tmask &= ~dead;
+          for (int s = 0; s < RW; s++)
+            { const bool v = (vmask >> s) & 1u;
+              if (__ballot(v) == 0) continue;
+              const int  ax = (int) w_ap[s], bx = (int) w_bp[s], dx = ax - bx;
+              const bool ex = v && ax < old;                            // expired (map.c:1787-1796)
+              emask |= ex ? (1u << s) : 0u;
+              const bool ok  = v && !ex;
+              const bool isL = ok && dx > diag && bx >= thresh;
+              const bool isR = ok && dx <= diag && bx <= bpos;
+              const bool bl  = isL && (dx < Ldx || (dx == Ldx && ax > Lax));
+              const bool br  = isR && (dx > Rdx || (dx == Rdx && ax > Rax));
+              Ldx = bl ? dx : Ldx; Lax = bl ? ax : Lax; Lc = bl ? w_cost[s] : Lc; Lm = bl ? w_meta[s] : Lm; Ls = bl ? (uint32_t) s : Ls;
+              Rdx = br ? dx : Rdx; Rax = br ? ax : Rax; Rc = br ? w_cost[s] : Rc; Rm = br ? w_meta[s] : Rm; Rs = br ? (uint32_t) s : Rs;
             }
-          if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
-            { overflow = true; tj = 0; }
-          else
-            { tj = (uint32_t) __ffs((int) ~tmask) - 1u;
-              tmask |= 1u << tj;
-              t_oa[wv][tj][lane] = (uint32_t) apos;
-              t_ob[wv][tj][lane] = (uint32_t) bpos;
+          vmask &= ~emask;
+          const int  Rbx    = Rax - Rdx;
+          const int  lcost0 = (Lax >= 0) ? ((apos >= Lax + K) ? Lc + K : Lc + (apos - Lax)) : 0;
+          const int  rcost0 = (Rax >= 0) ? ((bpos >= Rbx + K) ? Rc + K : Rc + (bpos - Rbx)) : 0;
+          const bool useL   = lcost0 > rcost0;                        // map.c:1823-1826 (ties go right)
+          const bool havep  = useL || rcost0 > 0;
+          const int      c  = useL ? lcost0 : (havep ? rcost0 : K);
+          const uint32_t pm = useL ? Lm : Rm, ps = useL ? Ls : Rs;
+          const int      pa = useL ? Lax : Rax, pd = useL ? Ldx : Rdx;
+          bool     overflow = false;
+          uint32_t tj = pm >> 24;
+          if (!havep)
+            { if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
+                { // no tree slot left: the trees without a live member are complete -- report them and take their slots
+                  uint32_t used = 0;
+#pragma unroll
+                  for (int s = 0; s < RW; s++)
+                    if ((vmask >> s) & 1u) used |= 1u << (w_meta[s] >> 24);
+                  const uint32_t dead = tmask & ~used;
+                  for (uint32_t m = dead; m != 0; m &= m - 1)
+                    emit((uint32_t) __ffs((int) m) - 1u, false, 0);
+                  tmask &= ~dead;
+                }
+              if ((tmask & ((1u << RT) - 1u)) == ((1u << RT) - 1u))
+                { overflow = true; tj = 0; }
+              else
+                { tj = (uint32_t) __ffs((int) ~tmask) - 1u;
+                  tmask |= 1u << tj;
+                  t_oa[wv][tj][lane] = (uint32_t) apos;
+                  t_ob[wv][tj][lane] = (uint32_t) bpos;
+                }
             }
-        }
-      const int  bcst = havep ? t_bc[wv][tj][lane] : 0;
-      const bool improved = !havep || c >= bcst;                   // (a new origin is its tree's best end)
-      { const uint32_t fv = havep ? g0 + (pm & 0xffffffu) : NIL;
+          const int  bcst = havep ? t_bc[wv][tj][lane] : 0;
+          const bool improved = !havep || c >= bcst;                   // (a new origin is its tree's best end)
+          { const uint32_t fv = havep ? g0 + (pm & 0xffffffu) : NIL;
 #pragma unroll
-        for (int t = 0; t < CH; t++) fb[t] = (t8 == (uint32_t) t) ? fv : fb[t];
-      }
-      if (improved && !overflow)
-        { t_bc[wv][tj][lane] = c;
-          t_ea[wv][tj][lane] = (uint32_t) apos;
-          t_eb[wv][tj][lane] = (uint32_t) bpos;
-          t_ex[wv][tj][lane] = j;
-        }
-      { int dd = pd - diag;
-        if (dd < 0) dd = -dd;
-        const bool kill = havep && improved && ((double) dd <= .2 * (double) (apos - pa));      // map.c:1837,1852
-        vmask &= ~(kill ? (1u << ps) : 0u);
-      }
-      { const uint32_t fm = ~vmask & ((1u << RW) - 1u);
-        overflow = overflow || fm == 0;
-        const int f = __ffs((int) fm) - 1;             // (-1 when the window is full: no slot matches)
-#pragma unroll
-        for (int s = 0; s < RW; s++)
-          { const bool h = (s == f);
-            w_ap[s] = h ? (uint32_t) apos : w_ap[s]; w_bp[s] = h ? (uint32_t) bpos : w_bp[s];
-            w_cost[s] = h ? c : w_cost[s]; w_meta[s] = h ? (j | (tj << 24)) : w_meta[s];
+            for (int t = 0; t < CH; t++) fb[t] = (t8 == (uint32_t) t) ? fv : fb[t];
           }
-        vmask |= (fm != 0) ? (1u << f) : 0u;
-      }
-      j += 1;
-      if (overflow)
-        { A.retry[atomicAdd(A.nretry, 1u)] = g;          // (the lane-group kernel starts the group afresh)
-          active = false;
-          if (nb_for == 1) nb_for = 0;                   // (nbk holds the abandoned group's next chunk)
-        }
-      else if (j == n || t8 == CH - 1)
-        { // the chunk's links go out together -- at the head of the next step, like the group's ends when this was
-          // its last hit (stores count as outstanding memory operations too)
-          flush = true;
-          if (j == n) ending = true;
-          else        copy_nb = true;
+          if (improved && !overflow)
+            { t_bc[wv][tj][lane] = c;
+              t_ea[wv][tj][lane] = (uint32_t) apos;
+              t_eb[wv][tj][lane] = (uint32_t) bpos;
+              t_ex[wv][tj][lane] = j;
+            }
+          { int dd = pd - diag;
+            if (dd < 0) dd = -dd;
+            const bool kill = havep && improved && ((double) dd <= .2 * (double) (apos - pa));      // map.c:1837,1852
+            vmask &= ~(kill ? (1u << ps) : 0u);
+          }
+          { const uint32_t fm = ~vmask & ((1u << RW) - 1u);
+            overflow = overflow || fm == 0;
+            const int f = __ffs((int) fm) - 1;             // (-1 when the window is full: no slot matches)
+#pragma unroll
+            for (int s = 0; s < RW; s++)
+              { const bool h = (s == f);
+                w_ap[s] = h ? (uint32_t) apos : w_ap[s]; w_bp[s] = h ? (uint32_t) bpos : w_bp[s];
+                w_cost[s] = h ? c : w_cost[s]; w_meta[s] = h ? (j | (tj << 24)) : w_meta[s];
+              }
+            vmask |= (fm != 0) ? (1u << f) : 0u;
+          }
+          j += 1;
+          if (overflow)
+            { A.retry[atomicAdd(A.nretry, 1u)] = g;          // (the lane-group kernel starts the group afresh)
+              active = false;
+              if (nb_for == 1) nb_for = 0;                   // (nbk holds the abandoned group's next chunk)
+            }
+          else if (j == n || t8 == CH - 1)
+            { // the chunk's links go out together -- at the head of the next step, like the group's ends when this was
+              // its last hit (stores count as outstanding memory operations too)
+              flush = true;
+              if (j == n) ending = true;
+              else        copy_nb = true;
+            }
         }
     }
 }
