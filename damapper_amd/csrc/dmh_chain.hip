@@ -542,7 +542,13 @@ __global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_
 // ---------------------------------------------------------------------------------------
 constexpr int RW = 8;      // window slots of a lane (registers)
 constexpr int RT = 5;      // tree slots of a lane (LDS)
-constexpr int LANE_WALKS = 2;    // hits a lane walks per step of the wavefront (divides the chunk)
+#ifndef DMH_LANE_WALKS
+#define DMH_LANE_WALKS 4
+#endif
+#ifndef DMH_LANE_CH
+#define DMH_LANE_CH 8
+#endif
+constexpr int LANE_WALKS = DMH_LANE_WALKS;    // hits a lane walks per step of the wavefront (divides the chunk)
 constexpr int LANE_BLOCK = 64;    // one wavefront per workgroup: 7.5 KB of LDS each, so the registers bound the occupancy
 
 __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t size_max)
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
   // the next (10^6 lanes stream at once): 22 GB of HBM traffic per launch against 1.5 GB of data.  A chunk is
   // the lane's next 64 + 32 bytes, requested together; the chunk after it (or the first one of the lane's next
   // group) is on its way while this one is walked.
-  constexpr int CH = 4;
+  constexpr int CH = DMH_LANE_CH;
   uint64_t kb[CH], nbk[CH];
   uint32_t fb[CH];
 #pragma unroll
