@@ -753,12 +753,27 @@ __global__ __launch_bounds__(256) void k_csort_small(const uint64_t *__restrict_
 #pragma unroll
   for (int t = 0; t < PER; t++) k[t] = (lane + G * t < n) ? kin[g0 + lane + G * t] : 0;
 
+  // (a wavefront waits for ALL its outstanding memory operations at once, stores included: the sorted hits of a cluster
+  // are written at the head of the NEXT step, ahead of that step's loads, so that the wait for those loads at the
+  // step's end finds everything a whole ranking old)
+  uint64_t pk[PER];
+  uint32_t pr[PER], pg0 = 0, pn = 0;
+#pragma unroll
+  for (int t = 0; t < PER; t++) { pk[t] = 0; pr[t] = 0; }
+  // (the loads above have arrived before the loop is entered: left pending, they would make the compiler wait at the
+  // first use of k, g1 and n1 INSIDE the loop, i.e. behind the loads of every step)
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
   while (__any(c < ncl))
-    { // bounds two steps ahead, hits one step ahead
-      uint32_t g2 = 0, n2 = 0;
-      if (c + 2 * stride < ncl) { g2 = gstart[c + 2 * stride]; n2 = gstart[c + 2 * stride + 1] - g2; }
+    {
+#pragma unroll
+      for (int t = 0; t < PER; t++)
+        if (lane + G * t < pn) kout[pg0 + pr[t]] = pk[t];
+      // hits one step ahead, bounds two steps ahead (their difference is taken at the step's end: here it would wait)
 #pragma unroll
       for (int t = 0; t < PER; t++) kn[t] = (lane + G * t < n1) ? kin[g1 + lane + G * t] : 0;
+      uint32_t g2 = 0, e2 = 0;
+      if (c + 2 * stride < ncl) { g2 = gstart[c + 2 * stride]; e2 = gstart[c + 2 * stride + 1]; }
+      asm volatile("" ::: "memory");
 
       uint32_t v[PER], r[PER];
 #pragma unroll
@@ -772,18 +787,21 @@ __global__ __launch_bounds__(256) void k_csort_small(const uint64_t *__restrict_
       if (!__any(n > 16u))      csort_ranks<1>(vv, n, v, r);
       else if (!__any(n > 32u)) csort_ranks<2>(vv, n, v, r);
       else                      csort_ranks<4>(vv, n, v, r);
-#pragma unroll
-      for (int t = 0; t < PER; t++)
-        if (lane + G * t < n) kout[g0 + r[t]] = k[t];
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < PER; t++) { pk[t] = k[t]; pr[t] = r[t]; }
+      pg0 = g0; pn = n;
 
       c += stride;
       g0 = g1; n = n1;
-      g1 = g2; n1 = (n2 > (uint32_t) CS_SMALL) ? 0 : n2;
+      g1 = g2; n1 = (e2 - g2 > (uint32_t) CS_SMALL) ? 0 : e2 - g2;
 #pragma unroll
       for (int t = 0; t < PER; t++) k[t] = kn[t];
     }
+#pragma unroll
+  for (int t = 0; t < PER; t++)
+    if (lane + G * t < pn) kout[pg0 + pr[t]] = pk[t];
 }
 
 // clusters of CS_SMALL+1 .. CS_MEDIUM hits -> mlist, larger ones -> blist
