@@ -873,7 +873,12 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
       uint32_t hw = A.pile_cap < 1024u ? A.pile_cap : 1024u;      // compact when the list reaches this length
       bool     spill = false;
       for (int x = tid; x < PILE_BCACHE; x += PILE_THREADS) s_bc[x] = make_uint2(NIL, 0);
-      uint64_t nkey = A.ab[g0];            // the next hit, fetched one round ahead
+      // The next hit, fetched one round ahead -- through the scalar cache (the address is the workgroup's, and nothing
+      // writes the hits here): a vector load would share the wavefront's one in-order counter with thread 0's
+      // stores of the round before, and waiting for the hit would wait for their acknowledgement, every round.
+      typedef const __attribute__((address_space(4))) uint64_t *const_hits;
+      const const_hits cab = (const_hits) (uintptr_t) A.ab;
+      uint64_t nkey = cab[g0];
 
       for (uint32_t j = g0; j < g1; j++)
         { const int apos = (int) (uint32_t) nkey + 1;             // map.c:1784-1785
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
           const int diag = apos - bpos;
           const int thresh = bpos - MAX_GAP;
           { const uint32_t jn = (j + 1 < g1) ? j + 1 : j;
-            nkey = A.ab[jn];
+            nkey = cab[jn];
           }
 
           // ---- expiry (map.c:1787-1796) + neighbour queries (map.c:1262-1318) over the thread's entries
@@ -947,8 +952,16 @@ __global__ __launch_bounds__(PILE_THREADS) void k_chain_pile(ChainArgs A)
               uint32_t jroot = j;
               if (pe.x != NIL)
                 { const uint32_t root = s_root[ppos];
-                  const uint2    cb   = s_bc[root & (PILE_BCACHE - 1)];
-                  const int      bc   = (cb.x == root) ? (int) cb.y : A.bestcost[root];
+                  // (one 8-byte read and a branch: as two 4-byte reads the compiler turns "cached score or the one in
+                  // global memory" into a flat load from a selected address, waited for -- together with every store
+                  // before it -- at every hit)
+                  const uint64_t cbw  = *(const uint64_t *) &s_bc[root & (PILE_BCACHE - 1)];
+                  const uint2    cb   = make_uint2((uint32_t) cbw, (uint32_t) (cbw >> 32));
+                  int            bc   = (int) cb.y;
+                  if (cb.x != root)
+                    { bc = A.bestcost[root];
+                      asm volatile("" : "+v"(bc));        // (the wait for it here, not behind the join at every hit)
+                    }
                   jroot = root;
                   A.from[j]   = pe.x;
                   A.cost[j]   = c;
