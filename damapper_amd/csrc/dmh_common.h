@@ -56,6 +56,7 @@ void bg_flush();
 // true while a deferred Reporter's alignment kernel is running on the alignment stream: background
 // stages are then held back (the HBM-bound sort kernels keep the GPU to themselves, before the alignment)
 bool report_in_flight();
+bool report_deferred_mode();          // dmh_async_report(2): the alignment kernel of a block runs next to the following block's filter
 // Called by the filter at a moment when the GPU has work queued: if the previous READS block's deferred alignment
 // kernel has finished, its records are fetched now and the candidates that need a wider kernel are re-launched --
 // instead of at the next Reporter call, where the GPU would wait for both.

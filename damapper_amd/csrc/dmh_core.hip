@@ -94,8 +94,9 @@ hipStream_t finish_stream()
   const int on = S().opt_fin_stream >= 0 ? S().opt_fin_stream : env_fs;
   if (on == 0) return g_stream;
   if (g_fstream == nullptr)
-    { // (DMH_FIN_PRIO=1: high priority -- experiments)
-      static const int prio = getenv("DMH_FIN_PRIO") ? atoi(getenv("DMH_FIN_PRIO")) : 0;
+    { // High priority: its kernels are small and the host waits for them (three round trips per batch); behind the
+      // workgroups of a sort or a chain kernel they took a third longer (DMH_FIN_PRIO=0: default priority, -1: lowest)
+      static const int prio = getenv("DMH_FIN_PRIO") ? atoi(getenv("DMH_FIN_PRIO")) : 1;
       if (prio != 0)
         { int least = 0, greatest = 0;
           HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -1090,6 +1091,11 @@ static void bg_step()
 
 void bg_pump(int nstages)
 { StreamScope on_main(main_stream());        // (also when called from inside chain_finish: the index build lives on the main stream)
+  // With the alignment kernel deferred (dmh_async_report(2)) nothing is pumped: Reporter queues the whole build
+  // at the block boundary, where the main stream is idle for some 35 ms (the last batches finish one after the
+  // other, then Reporter's host work); between the passes it has no gaps to fill (DMH_PUMP=1: as before).
+  static const bool pump_anyway = getenv("DMH_PUMP") != nullptr;
+  if (report_deferred_mode() && !pump_anyway) return;
   if (g_bg.empty() || report_in_flight()) return;
   for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step();
 }

@@ -1242,6 +1242,8 @@ static hipEvent_t     g_ev_ab = nullptr, g_ev_done = nullptr;
 static DevBuf<CandJob>  d_jobs;
 static DevBuf<int>      d_status, d_pool, d_only;
 
+bool report_deferred_mode() { return g_async == 2; }
+
 bool report_in_flight()
 { if (g_pending == nullptr || !g_pending->on_aux) return false;
   hipError_t e = hipEventQuery(g_ev_done);
