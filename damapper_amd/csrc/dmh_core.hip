@@ -1094,6 +1094,7 @@ void bg_pump(int nstages)
   // With the alignment kernel deferred (dmh_async_report(2)) nothing is pumped: Reporter queues the whole build
   // at the block boundary, where the main stream is idle for some 35 ms (the last batches finish one after the
   // other, then Reporter's host work); between the passes it has no gaps to fill (DMH_PUMP=1: as before).
+  // Default workload 214.7 -> 211 ms per read block, one-REF-block chr1 674 -> 641 ms per step, ecoli unchanged.
   static const bool pump_anyway = getenv("DMH_PUMP") != nullptr;
   if (report_deferred_mode() && !pump_anyway) return;
   if (g_bg.empty() || report_in_flight()) return;
