@@ -535,9 +535,9 @@ __global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_
 //  the parallelism a GPU wants without any inside a group.  Here every lane walks groups of its own: the live
 //  window sits in registers (RW slots, scanned by an unrolled loop; a hit takes the first free slot), the chain
 //  trees with a live member in a small LDS table private to the lane (best score, origin, best end: all a
-//  summary needs, so nothing is read back from global memory), hits are fetched one ahead, and a lane that
-//  finishes a group starts its next one in the same iteration while the other lanes carry on (the group after
-//  that is looked up in the background).  A window of more than RW live hits, or more than RT trees with live
+//  summary needs, so nothing is read back from global memory), hits are fetched a chunk ahead, and a lane that
+//  finishes a group starts its next one at the wavefront's following step while the other lanes carry on (the group
+//  after that is looked up in the background).  A window of more than RW live hits, or more than RT trees with live
 //  members, sends the group to the lane-group kernels (A.retry).  Same rules, same results.
 // ---------------------------------------------------------------------------------------
 constexpr int RW = 8;      // window slots of a lane (registers)
@@ -574,8 +574,8 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
   // Hits are read -- and the `from` links written -- eight at a time per lane: a lane walks its own stretch of the
   // sorted hits, and a cache line fetched for ONE 8- or 4-byte access of it is long gone when the lane comes back for
   // the next (10^6 lanes stream at once): 22 GB of HBM traffic per launch against 1.5 GB of data.  A chunk is
-  // the lane's next 64 + 32 bytes, requested together; the chunk after it (or the first one of the lane's next
-  // group) is on its way while this one is walked.
+  // the lane's next 64 bytes (and the 32 bytes of links that go with them), requested together; the chunk after it
+  // (or the first one of the lane's next group) is on its way while this one is walked.
   constexpr int CH = DMH_LANE_CH;
   uint64_t kb[CH], nbk[CH];
   uint32_t fb[CH];
