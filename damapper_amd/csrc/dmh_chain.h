@@ -20,6 +20,8 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock);
 
 // Drops the chain stage's per-batch buffers of a ring slot that is not in use (memory pressure).
 void    chain_release(MergeResult &R);
+// A submitted batch is dropped unfinished: later work on the main and finish streams waits for its pile kernel.
+void    chain_abandon(MergeResult &R);
 
 // Brings State::reads (the host view of the candidate lists: list order, -p deltas) up to date with the
 // device lists; with_jumps also fetches every candidate's Jump list.

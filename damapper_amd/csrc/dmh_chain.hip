@@ -1515,6 +1515,15 @@ void chain_release(MergeResult &R)
   C.out.release();
 }
 
+// A batch in flight is dropped (filter_discard): its pile kernel may still be writing the chain arrays on the pile
+// stream, which join_side_streams does not cover -- whatever the main stream does next comes after it
+void chain_abandon(MergeResult &R)
+{ if (R.cc == nullptr || !R.cc->has_piles) return;
+  HIP_CHECK(hipStreamWaitEvent(main_stream(), R.cc->piles_done, 0));
+  if (finish_stream() != main_stream()) HIP_CHECK(hipStreamWaitEvent(finish_stream(), R.cc->piles_done, 0));
+  R.cc->has_piles = false;
+}
+
 void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
 { State &st = S();
   const Params &pm = st.params;
@@ -1730,6 +1739,8 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   static DevBuf<ChainSummary> packed;
   static DevBuf<uint2> prange;
   static DevBuf<uint64_t> oword;
+  if (st.opt_oom_finish > 0 && --st.opt_oom_finish == 0)
+    simulate_out_of_memory();            // (test: the batch being finished must survive the reclaim, dmh_merge.hip)
   ord.ensure(nsum, "ordered chain ends");
   packed.ensure(nsum, "packed chain ends");
   prange.ensure(nsum, "sibling ranges of the chain ends");

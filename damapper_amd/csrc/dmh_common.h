@@ -71,6 +71,7 @@ void  dev_free(void *p);
 // Called when device memory runs out, before giving up: returns true when it has released something (the filter
 // registers one that finishes the batches in flight and drops the buffers of the idle ring slots).
 void  set_reclaim_hook(bool (*fn)());
+void  simulate_out_of_memory();       // runs the hook as a failed allocation would (test options)
 
 // Host <-> device transfers go through one persistent pinned staging buffer: handing pageable host
 // memory to hipMemcpyAsync makes the runtime pin and unpin those pages around the copy, and the

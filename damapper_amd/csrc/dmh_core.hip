@@ -148,19 +148,23 @@ static bool g_reclaiming = false;
 static const bool g_zero_fill = getenv("DMH_ZERO_FILL") != nullptr && getenv("DMH_NO_ZERO_FILL") == nullptr;
 static int g_alloc_fail = 0;       // test option "alloc_fail" = n: the n-th allocation from now behaves as if memory had run out
 
+// what an allocation that fails does before it retries, without the failure (tests: "alloc_fail", "oom_finish")
+void simulate_out_of_memory()
+{ if (g_reclaim == nullptr || g_reclaiming) return;
+  g_reclaiming = true;
+  S().simulated_oom = true;
+  (void) g_reclaim();
+  S().simulated_oom = false;
+  g_reclaiming = false;
+  for (auto &b : g_free) (void) hipFree(b.p);
+  g_free.clear();
+  g_pooled = 0;
+}
+
 void *dev_alloc(size_t bytes, const char *what)
 { init_device();
   if (bytes == 0) bytes = 16;
-  if (g_alloc_fail > 0 && --g_alloc_fail == 0 && g_reclaim != nullptr && !g_reclaiming)
-    { g_reclaiming = true;
-      S().simulated_oom = true;
-      (void) g_reclaim();
-      S().simulated_oom = false;
-      g_reclaiming = false;
-      for (auto &b : g_free) (void) hipFree(b.p);
-      g_free.clear();
-      g_pooled = 0;
-    }
+  if (g_alloc_fail > 0 && --g_alloc_fail == 0) simulate_out_of_memory();
   // quantise sizes (8 steps per octave above 1 MB) so that near-equal requests -- read blocks
   // differ by a fraction of a percent -- land in the same pool bucket instead of in hipMalloc
   { size_t g = 256;
@@ -1481,6 +1485,8 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "alloc_fail") == 0)  g_alloc_fail = value > 0 ? value : 0;
   else if (strcmp(key, "align_g") == 0)     st.opt_align_g = value;
   else if (strcmp(key, "cluster_sort") == 0) st.opt_cluster_sort = value;
+  else if (strcmp(key, "oom_finish") == 0)  st.opt_oom_finish = value > 0 ? value : 0;
+  else if (strcmp(key, "read_sort") == 0)   st.opt_read_sort = value;
   else return -1;
   return 0;
 }

@@ -1237,17 +1237,20 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
 }
 
 static bool    g_finishing = false;          // inside chain_finish (its own allocations must not finish the next batch)
+static int     g_finishing_slot = -1;        // ... and the ring slot it works on: busy for filter_reclaim although it has left g_inflight
 
 static int64_t finish_oldest()
 { const int x = g_inflight.front();
   g_inflight.pop_front();
   MergeResult &R = g_ring[x];
   g_finishing = true;
+  g_finishing_slot = x;
   int64_t nfilt;
   { HostTimer hf("filter_finish");
     nfilt = chain_finish(R, R.ablock);
   }
   g_finishing = false;
+  g_finishing_slot = -1;
   if (finish_stream() != main_stream())
     { // whatever the main stream does from here on (the slot's buffers are about to be used again, Reporter reads the
       // candidate lists) comes after the finish stream's last kernel
@@ -1274,7 +1277,7 @@ static bool filter_reclaim()
   if (g_flight_cap > 0 && !S().simulated_oom) g_flight_cap -= 1;
   HIP_CHECK(hipDeviceSynchronize());          // (buffers are about to go back to the driver)
   for (int i = 0; i < NRING; i++)
-    { bool busy = (i == g_cur);
+    { bool busy = (i == g_cur) || (i == g_finishing_slot);       // (chain_finish still reads the slot it is finishing)
       for (int y : g_inflight) busy = busy || (y == i);
       if (busy) continue;
       MergeResult &R = g_ring[i];
@@ -1299,6 +1302,7 @@ int64_t filter_flush()
 
 void filter_discard()
 { join_side_streams();             // (their kernels may still read the batches that are dropped here)
+  for (int y : g_inflight) chain_abandon(g_ring[y]);       // ... and the pile stream's, which the join does not cover
   g_inflight.clear();
   for (int i = 0; i < NRING; i++) { g_ring[i].open = false; g_ring[i].nhits = 0; g_ring[i].npass = 0; }
 }

@@ -1268,6 +1268,13 @@ static void launch_round(PendingReport &P)
   d_pool.ensure(P.pool_cap, "alignment pool");
   int nrun = P.todo.empty() ? njobs : (int) P.todo.size();
   const int *only = nullptr;
+  if (P.on_aux)
+    { // everything queued on the main stream so far (packing, the flushed index sort -- and whatever main-stream kernel
+      // may still be using a pool block that d_jobs / d_only have just been given) comes first: the uploads below and
+      // the kernel run on the alignment stream
+      HIP_CHECK(hipEventRecord(g_ev_ab, stream()));
+      HIP_CHECK(hipStreamWaitEvent(ks, g_ev_ab, 0));
+    }
   if (!P.jobs_up)
     { upload_for(P, ks, d_jobs.p, P.jobs.data(), sizeof(CandJob) * (size_t) njobs);
       P.jobs_up = true;
@@ -1323,7 +1330,7 @@ static void launch_round(PendingReport &P)
   int nblocks = std::min((nrun + per_block - 1) / per_block, P.on_aux ? aux_grid : 256 * 4);
   Scratch sc = prepare_scratch(nblocks, P.tcap, level == 2, per_block, level != 0);
   if (P.on_aux)
-    { // everything queued on the main stream so far (packing, uploads, the flushed index sort) comes first
+    { // (prepare_scratch may have grown its buffers under the main stream's scope since the event above)
       HIP_CHECK(hipEventRecord(g_ev_ab, stream()));
       HIP_CHECK(hipStreamWaitEvent(ks, g_ev_ab, 0));
     }

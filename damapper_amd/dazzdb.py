@@ -545,9 +545,9 @@ def _sim_lib():
         L.dmh_sim_genome.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_double,
                                      C.c_int, C.c_int, C.c_int, C.c_int]
         L.dmh_sim_lengths_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
-                                            C.c_uint64, C.c_void_p]
+                                            C.c_uint64, C.c_void_p, C.c_double]
         L.dmh_sim_fill_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
-                                         C.c_uint64, C.c_void_p, C.c_void_p]
+                                         C.c_uint64, C.c_void_p, C.c_void_p, C.c_double]
         L.dmh_pack_bps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _sim = L
     return _sim
@@ -669,25 +669,29 @@ def genome_block(G: Genome, first: int = 0, last: Optional[int] = None, part: in
 
 
 def simulate_block_genome(seed: int, G: Genome, nreads: int, read_len: int = 10000, err: float = 0.15,
-                          tfirst: int = 0, part: int = 0, path: bytes = b"./.mem", pinned: bool = False) -> Block:
-    """simulate_block with the template start uniform over ALL contigs of a Genome (a read never spans two)."""
+                          tfirst: int = 0, part: int = 0, path: bytes = b"./.mem", pinned: bool = False,
+                          lengths: str = "fixed") -> Block:
+    """simulate_block with the template start uniform over ALL contigs of a Genome (a read never spans two).
+    lengths = "lognormal": CLR-like template lengths, log-normal with mean `read_len` (sigma 0.4, clipped to
+    read_len / 10 .. 4 read_len) instead of the fixed `read_len`."""
     L = _sim_lib()
     nc = len(G)
     coff = np.ascontiguousarray(np.concatenate((G.offs, [int(G.offs[-1]) + int(G.lens[-1])])), dtype=np.int64)
-    valid = np.maximum(G.lens - read_len + 1, 0)
+    sigma = 0.4 if lengths == "lognormal" else 0.0
+    valid = np.maximum(G.lens - (4 * read_len if sigma > 0 else read_len) + 1, 0)
     cum = np.ascontiguousarray(np.concatenate(([0], np.cumsum(valid))), dtype=np.int64)
     if cum[-1] <= 0:
         raise ValueError("no contig is as long as a read")
     rlen = np.zeros(nreads, dtype=np.int32)
     g = G.layout
-    L.dmh_sim_lengths_multi(g.ctypes.data, coff.ctypes.data, cum.ctypes.data, nc, nreads, read_len, err, seed, rlen.ctypes.data)
+    L.dmh_sim_lengths_multi(g.ctypes.data, coff.ctypes.data, cum.ctypes.data, nc, nreads, read_len, err, seed, rlen.ctypes.data, sigma)
     boff = np.zeros(nreads + 1, dtype=np.int64)
     np.cumsum(rlen.astype(np.int64) + 1, out=boff[1:])
     tot = int(rlen.sum())
     bases = host_bytes(tot + nreads + 4, pinned)
     bases[-4:] = 4
     L.dmh_sim_fill_multi(g.ctypes.data, coff.ctypes.data, cum.ctypes.data, nc, nreads, read_len, err, seed,
-                         boff.ctypes.data, bases.ctypes.data)
+                         boff.ctypes.data, bases.ctypes.data, sigma)
     cnt = np.bincount(bases[:1 << 24], minlength=5)[:4].astype(np.float64)
     blk = make_block([], tfirst=tfirst, part=part, path=path, freq=cnt / max(1.0, cnt.sum()), lens=rlen)
     blk.bases = bases

@@ -7,6 +7,7 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <omp.h>
 
 static inline uint64_t splitmix(uint64_t *s)
@@ -166,6 +167,21 @@ void dmh_sim_genome(uint8_t *out, int64_t n, uint64_t seed, const uint8_t *fam, 
 /* Reads sampled from SEVERAL contigs laid out one after the other in `g` (contig c = g[coff[c] .. coff[c+1])):
  * the template start is uniform over all positions that leave `rl` bases inside one contig.  Otherwise as
  * gen_read.  cum[c] = number of valid starts in contigs 0..c-1 (cum[ncontig] = total).                  */
+/* Template length of read i: `rl` when sigma = 0, else log-normal with mean rl (mu = ln rl - sigma^2 / 2; "CLR-like",
+ * SURVEY 8d) clipped to [rl / 10, 4 rl], from a stream of its own (so that the fixed-length reads do not change).
+ * cum[] is then made for templates of 4 rl bases: every start leaves room for the longest one. */
+static int template_length(int rl, double sigma, uint64_t seed, int i)
+{ if (sigma <= 0.) return rl;
+  uint64_t s = stream_seed(seed ^ 0x1f83d9abfb41bd6bull, (uint64_t) i);
+  double u1 = ((double) (splitmix(&s) >> 11) + 1.) / 9007199254740993.;
+  double u2 = (double) (splitmix(&s) >> 11) / 9007199254740992.;
+  double z  = sqrt(-2. * log(u1)) * cos(6.283185307179586 * u2);
+  double t  = exp(log((double) rl) - .5 * sigma * sigma + sigma * z);
+  if (t < rl / 10.) t = rl / 10.;
+  if (t > 4. * rl)  t = 4. * rl;
+  return (int) t;
+}
+
 static int gen_read_multi(const uint8_t *g, const int64_t *coff, const int64_t *cum, int ncontig, int rl, double err,
                           uint64_t seed, int i, uint8_t *out)
 { uint64_t s = stream_seed(seed ^ 0x3c6ef372fe94f82bull, (uint64_t) i);
@@ -207,20 +223,20 @@ static int gen_read_multi(const uint8_t *g, const int64_t *coff, const int64_t *
 }
 
 void dmh_sim_lengths_multi(const uint8_t *g, const int64_t *coff, const int64_t *cum, int ncontig, int nreads, int rl,
-                           double err, uint64_t seed, int *rlen)
+                           double err, uint64_t seed, int *rlen, double sigma)
 { int i;
 #pragma omp parallel for schedule(static)
   for (i = 0; i < nreads; i++)
-    rlen[i] = gen_read_multi(g, coff, cum, ncontig, rl, err, seed, i, NULL);
+    rlen[i] = gen_read_multi(g, coff, cum, ncontig, template_length(rl, sigma, seed, i), err, seed, i, NULL);
 }
 
 void dmh_sim_fill_multi(const uint8_t *g, const int64_t *coff, const int64_t *cum, int ncontig, int nreads, int rl,
-                        double err, uint64_t seed, const int64_t *boff, uint8_t *bases)
+                        double err, uint64_t seed, const int64_t *boff, uint8_t *bases, double sigma)
 { int i;
   bases[0] = 4;
 #pragma omp parallel for schedule(static)
   for (i = 0; i < nreads; i++)
-    { int n = gen_read_multi(g, coff, cum, ncontig, rl, err, seed, i, bases + 1 + boff[i]);
+    { int n = gen_read_multi(g, coff, cum, ncontig, template_length(rl, sigma, seed, i), err, seed, i, bases + 1 + boff[i]);
       bases[1 + boff[i] + n] = 4;
     }
 }

@@ -159,56 +159,80 @@ def test_ragged_and_degenerate_reads(tmp_path):
                                   dict(chain_lane=0), dict(cluster=1, chain_lane=0), dict(batch=0),
                                   dict(cluster=1, cluster_sort=0), dict(expand=0), dict(cluster=1, in_flight=0),
                                   dict(cluster=1, seed_word=0), dict(cluster=1, seed_word=0, expand=0), dict(cluster=1, expand=0),
-                                  dict(cluster=1, fin_stream=0), dict(fin_stream=0), dict(cluster=1, alloc_fail=30), dict(cluster=1, alloc_fail=90), dict(alloc_fail=150)],
+                                  dict(cluster=1, fin_stream=0), dict(fin_stream=0), dict(cluster=1, alloc_fail=30), dict(cluster=1, alloc_fail=90), dict(alloc_fail=150),
+                                  dict(cluster=1, oom_finish=2), dict(oom_finish=1), dict(cluster=1, read_sort=0)],
                          ids=["four_per_wavefront", "wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
                               "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table", "merge_low16_probes",
                               "clusters", "clusters_piles", "clusters_chain64",
                               "no_lds_groups", "clusters_no_lds_groups", "clusters_lds_groups_7",
                               "no_lane_groups", "clusters_no_lane_groups", "no_pass_batches", "clusters_global_sort", "expand_per_entry", "clusters_nothing_in_flight",
                               "clusters_key_value_sort", "clusters_key_value_sort_per_entry", "clusters_expand_per_entry",
-                              "clusters_finish_on_main_stream", "finish_on_main_stream", "clusters_memory_runs_out_30", "clusters_memory_runs_out_90", "memory_runs_out_150"])
+                              "clusters_finish_on_main_stream", "finish_on_main_stream", "clusters_memory_runs_out_30", "clusters_memory_runs_out_90", "memory_runs_out_150",
+                              "clusters_memory_runs_out_inside_finish", "memory_runs_out_inside_finish", "clusters_global_seed_sort"])
 def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes
-    to the same bytes: force each one and compare with the default route (itself checked against the
-    reference by the tests above) on data that has repeats, dropouts and low-complexity reads."""
+    to the same bytes: force each one and compare with the default route on data that has repeats, dropouts and
+    low-complexity reads; the default route on this data is compared with the reference by
+    test_variant_dataset_matches_reference below."""
     from damapper_amd import capi
-    g, reads = make_dataset("repeat", 97, [150000, 120000], 70, dropouts=2)
-    reads = list(reads) + [np.zeros(3000, dtype=np.uint8), np.tile(np.array([0, 1, 1], dtype=np.uint8), 1200)]
     d = str(tmp_path)
-    dazzdb.write_db(d, "REF", g, block_size=400000)
-    dazzdb.write_db(d, "READS", reads)
-
-    def run(out):
-        driver.map_db(d, "REF", "READS", threads=4, mem_limit=8 << 30, sort_path=os.path.join(d, out), profile=1)
-        return (las.read_las_set(os.path.join(d, out), "READS.REF.M@.las"),
-                open(os.path.join(d, ".READS.prof.data"), "rb").read())
-
-    base = run("las_default")
+    base = _variant_base()
+    _variant_dbs(d)
     L = capi.lib()
     try:
         for k, v in opts.items():
             assert L.dmh_test_option(k.encode(), v) == 0
-        alt = run("las_alt")
+        alt = _variant_run(d, "las_alt")
     finally:
-        L.dmh_test_option(b"align_level", -1)
-        L.dmh_test_option(b"align_g", -1)
-        L.dmh_test_option(b"chain_g", 0)
-        L.dmh_test_option(b"pool_div", 1)
-        L.dmh_test_option(b"chain_pile", -1)
-        L.dmh_test_option(b"pile_cap", 0)
-        L.dmh_test_option(b"merge_dense", -1)
-        L.dmh_test_option(b"cluster", -1)
-        L.dmh_test_option(b"chain_small", -1)
-        L.dmh_test_option(b"chain_lane", -1)
-        L.dmh_test_option(b"batch", -1)
-        L.dmh_test_option(b"cluster_sort", -1)
-        L.dmh_test_option(b"expand", -1)
-        L.dmh_test_option(b"in_flight", -1)
-        L.dmh_test_option(b"seed_word", -1)
-        L.dmh_test_option(b"alloc_fail", 0)
-        L.dmh_test_option(b"fin_stream", -1)
+        for k, v in VARIANT_DEFAULTS.items():
+            L.dmh_test_option(k.encode(), v)
     assert len(base[0][1]) > 50
     assert base == alt
+
+
+VARIANT_DEFAULTS = dict(align_level=-1, align_g=-1, chain_g=0, pool_div=1, chain_pile=-1, pile_cap=0, merge_dense=-1,
+                        cluster=-1, chain_small=-1, chain_lane=-1, batch=-1, cluster_sort=-1, expand=-1, in_flight=-1,
+                        seed_word=-1, alloc_fail=0, fin_stream=-1, read_sort=-1, oom_finish=0)
+_VARIANT = {}
+
+
+def _variant_dbs(d):
+    g, reads = make_dataset("repeat", 97, [150000, 120000], 70, dropouts=2)
+    reads = list(reads) + [np.zeros(3000, dtype=np.uint8), np.tile(np.array([0, 1, 1], dtype=np.uint8), 1200)]
+    dazzdb.write_db(d, "REF", g, block_size=400000)
+    dazzdb.write_db(d, "READS", reads)
+
+
+def _variant_run(d, out):
+    driver.map_db(d, "REF", "READS", threads=4, mem_limit=8 << 30, sort_path=os.path.join(d, out), profile=1)
+    return (las.read_las_set(os.path.join(d, out), "READS.REF.M@.las"),
+            open(os.path.join(d, ".READS.prof.data"), "rb").read())
+
+
+def _variant_base():
+    """The default route's files on the variant data set (made once per session)."""
+    if "base" not in _VARIANT:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            _variant_dbs(d)
+            _VARIANT["base"] = _variant_run(d, "las_default")
+    return _VARIANT["base"]
+
+
+def test_variant_dataset_matches_reference(tmp_path):
+    """Pins the 30-odd forced routes above: the default route's record stream and -p track on THEIR data set
+    (repeat-rich genome, dropout reads, a poly-A and a trinucleotide read) against the compiled reference."""
+    run_ref = _run_ref()
+    d = str(tmp_path)
+    _variant_dbs(d)
+    run_ref.run_reference(d, "REF", ["READS"], flags=["-p", "-M8"], threads=4)
+    # (the track from a single-threaded run: special_log() races with more than one report thread, DESIGN.md 4)
+    run_ref.run_reference(d, "REF", ["READS"], flags=["-p", "-M8"], threads=1, keep="las_ref_T1")
+    want_prof = open(os.path.join(d, ".READS.prof.data"), "rb").read()
+    want = las.read_las_set(os.path.join(d, "las_ref"), "READS.REF.M@.las")
+    base = _variant_base()
+    assert base[0] == want
+    assert base[1] == want_prof
 
 
 def test_trimmed_db_view_identical_to_reference(tmp_path):
