@@ -65,14 +65,15 @@ STAGE_KERNEL = {
     "chain_piles": "k_chain_pile", "chain_dominate": "k_order_summaries + k_dominate (+ scans)", "seed_clusters": "k_cluster_flag/rekey (+scan)",
     "seed_pairs": "k_pair_flag/write (+scan)", "chain_spilled_piles": "k_chain<64> (spilled piles)", "chain_jumps": "k_chain_jumps",
     "align": "k_align_cands32", "align_wave64": "k_align_cands<128>", "align_global_band": "k_align_cands<8192>",
-    "unpack_2bit": "k_unpack_2bit", "pack_bases": "k_pack_fwd", "pack_revcomp": "k_pack_rc", "merge_buckets": "k_bucket_bounds",
+    "read_sort": "k_read_sort", "unpack_2bit": "k_unpack_2bit", "pack_bases": "k_pack_fwd", "pack_revcomp": "k_pack_rc", "merge_buckets": "k_bucket_bounds",
 }
 # enclosing stages (their kernels are timed one by one as well): not candidates for "dominant kernel"
 ENCLOSING = {"kmer_sort", "seed_sort", "cluster_sort", "chain", "sort_pairs"}
 SIDE_STREAM = {"chain_piles"}
 # kernel symbols as rocprofv3 names them, for the PMC traffic summary under profiles/
 PMC_SYMBOL = {"k_radix_scatter": "dmh::k_radix_scatter", "k_radix_hist": "dmh::k_radix_hist", "chain_lane_groups": "dmh::k_chain_lane",
-              "kmer_emit": "dmh::k_kmer_emit", "chain_piles": "dmh::k_chain_pile"}
+              "kmer_emit": "dmh::k_kmer_emit", "chain_piles": "dmh::k_chain_pile", "read_sort": "dmh::k_read_sort",
+              "merge_match": "dmh::k_merge_match", "align": "dmh::k_align_cands32"}
 
 
 def ref_block_ranges(lens):

@@ -37,6 +37,7 @@ struct MergeResult
   // sort key holds the cluster number instead of (aread, bread).
   bool     clustered = false;
   bool     word = false;                       // cluster mode with one word per hit through the seed sort (no vals)
+  bool     read_sorted = false;                // ... and the hits written read by read, to be ordered per read in LDS
   DevBuf<uint64_t> gkey;                       // per group: (aread << bbits) | bread
   DevBuf<uint32_t> cog, ocfirst, glast;        // cluster mode: pair number of each cluster, first cluster of each pair
                                                // (+ end), and per cluster its pair's largest apos + 1

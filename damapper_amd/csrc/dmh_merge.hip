@@ -473,6 +473,8 @@ __global__ void k_tile_first(const uint32_t *__restrict__ eoff, uint32_t nent, u
   for (uint32_t T = (o0 + (uint32_t) EX_TILE - 1) / (uint32_t) EX_TILE; T <= (o1 - 1) / (uint32_t) EX_TILE; T++) tfirst[T] = e;
 }
 
+// rstart != nullptr: the hits go to their READ's segment instead of slot o -- row (entry, a) of the merge owns the
+// mb slots from rstart[aread] + rowdst[first slot of the row] (k_row_place)
 __global__ __launch_bounds__(256) void k_merge_expand_tiled(const MergeEntry *__restrict__ entries, uint32_t nent,
                                                             const uint32_t *__restrict__ eoff,
                                                             const uint32_t *__restrict__ tfirst,
@@ -480,7 +482,9 @@ __global__ __launch_bounds__(256) void k_merge_expand_tiled(const MergeEntry *__
                                                             const uint32_t *__restrict__ bvals,
                                                             PosMap MA, PosMap MB, int bshift, int pshift, int swap,
                                                             uint64_t passor, uint64_t *__restrict__ hkeys,
-                                                            uint32_t *__restrict__ hvals)
+                                                            uint32_t *__restrict__ hvals,
+                                                            const uint32_t *__restrict__ rstart,
+                                                            const uint32_t *__restrict__ rowdst)
 { __shared__ uint32_t s_off[EX_OFFS];
   __shared__ uint32_t s_e[2];
   const uint32_t total = eoff[nent];
@@ -520,8 +524,35 @@ __global__ __launch_bounds__(256) void k_merge_expand_tiled(const MergeEntry *__
       uint32_t ar, ap, br, bp;
       locate(MA, avals[en.a0 + a], ar, ap);
       locate(MB, bvals[en.b0 + b], br, bp);
-      put_hit(hkeys, hvals, o, ar, ap, br, bp, bshift, pshift, swap, passor);
+      const uint32_t dst = (rstart != nullptr) ? rstart[ar] + rowdst[o - b] + b : o;
+      put_hit(hkeys, hvals, dst, ar, ap, br, bp, bshift, pshift, swap, passor);
     }
+}
+
+// Rows of the merge: READ k-mer a of an entry with its mb partners.  Every row takes mb consecutive slots of its
+// read's segment: rcount[aread] counts the hits of the read, the value before the add is the row's place inside the
+// segment, kept at the row's first slot in expansion order (rowdst is as long as the hit list, one word per row used).
+// The order of the rows inside a segment is whatever the atomics make it -- the per-read sort does not care.
+__global__ void k_row_place(const MergeEntry *__restrict__ entries, uint32_t n, const uint32_t *__restrict__ esz,
+                            const uint32_t *__restrict__ eoff, const uint32_t *__restrict__ avals, PosMap MA,
+                            uint32_t *__restrict__ rcount, uint32_t *__restrict__ rowdst)
+{ const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || esz[i] == 0) return;
+  const MergeEntry e = entries[i];
+  const uint32_t o = eoff[i];
+  for (uint32_t a = 0; a < e.ma; a++)
+    { uint32_t ar, ap;
+      locate(MA, avals[e.a0 + a], ar, ap);
+      rowdst[o + a * e.mb] = atomicAdd(&rcount[ar], e.mb);
+    }
+}
+
+// the largest segment of the pass (-> stats[0])
+__global__ void k_read_max(const uint32_t *__restrict__ rcount, int nreads, uint32_t *__restrict__ stats)
+{ const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = (r < nreads) ? rcount[r] : 0;
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t) __shfl_down(v, o));
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(stats, v);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -564,6 +595,10 @@ __device__ __forceinline__ bool cluster_start(uint64_t a, uint64_t b, int qbits,
 { const uint64_t qm = (1ull << qbits) - 1ull;
   return (a >> qbits) != (b >> qbits) || ((b & qm) >> cb) - ((a & qm) >> cb) > 1ull;
 }
+
+}  // namespace dmh
+#include "dmh_readsort.h"
+namespace dmh {
 
 __global__ void k_cluster_flag(const uint64_t *__restrict__ hkeys, int64_t n, int qbits, int cb, uint32_t *__restrict__ flag)
 { int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -873,6 +908,45 @@ __global__ __launch_bounds__(256) void k_csort_medium(const uint64_t *__restrict
     }
 }
 
+// The read-sorted route (dmh_readsort.h) leaves the clusters of more than RS_IN hits in the order of their coarse
+// buckets: here each is put into (apos, bpos) order where it lies -- a bitonic sort of the words with their halves
+// swapped (apos << 32 | bpos) in LDS, in place.  Launched like k_csort_medium: wavefronts for the clusters of up to
+// CS_WAVE hits, workgroups for the rest up to CS_MEDIUM.
+__global__ __launch_bounds__(256) void k_csort_wide(uint64_t *__restrict__ ab, const uint32_t *__restrict__ gstart,
+                                                    const uint32_t *__restrict__ list, const unsigned int *__restrict__ nlist_p,
+                                                    uint32_t nlo, uint32_t nhi)
+{ extern __shared__ __attribute__((aligned(16))) uint64_t wit[];       // nhi words (a power of two)
+  const uint32_t nlist = *nlist_p, T = blockDim.x;
+  for (uint32_t x = blockIdx.x; x < nlist; x += gridDim.x)
+    { const uint32_t c = list[x], g0 = gstart[c], n = gstart[c + 1] - g0;
+      if (n <= nlo || n > nhi) continue;        // (uniform in the workgroup)
+      uint32_t m = 1;
+      while (m < n) m <<= 1;
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < m; i += T)
+        { const uint64_t v = (i < n) ? ab[g0 + i] : 0;
+          wit[i] = (i < n) ? ((v << 32) | (v >> 32)) : ~0ull;
+        }
+      __syncthreads();
+      for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1)
+          { for (uint32_t i = threadIdx.x; i < m; i += T)
+              { const uint32_t l = i ^ j;
+                if (l > i)
+                  { const uint64_t a = wit[i], b = wit[l];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { wit[i] = b; wit[l] = a; }
+                  }
+              }
+            __syncthreads();
+          }
+      for (uint32_t r = threadIdx.x; r < n; r += T)
+        { const uint64_t v = wit[r];
+          ab[g0 + r] = (v << 32) | (v >> 32);
+        }
+    }
+}
+
 // (key with apos in its low pbits, value bpos) -> the chain kernels' word
 __global__ void k_pack_ab(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t n, uint64_t pmask,
                           uint64_t *__restrict__ ab)
@@ -961,6 +1035,10 @@ static int         g_cur = 0;
 static std::deque<int> g_inflight;
 
 MergeResult &filter_batch() { return g_ring[g_cur]; }
+
+// per-read route: segment starts of the pass being collected (main stream only; a dense pass is closed at once)
+static DevBuf<uint32_t> g_rstart, g_rowdst, g_rstats;
+constexpr int RS_SMALL_T = 256, RS_BIG_T = 1024;      // k_read_sort workgroups: segments of up to 4,096 / 16,384 hits
 
 // hits a batch may collect before it is closed (68 B of HBM per hit through the sort and the chain kernels)
 constexpr int64_t BATCH_CAP = (int64_t) 160 << 20;
@@ -1177,6 +1255,13 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   if (st.retain_ref && !Bx.borrowed) index_pack_positions(Bx);          // (a cached index is packed when it enters the cache)
   if (st.mf_calls >= 3) index_pack_positions(A);
 
+  // --- the per-read route (dmh_readsort.h): a dense pass in one-word mode writes its hits read by read
+  static const int env_rs = getenv("DMH_READ_SORT") ? atoi(getenv("DMH_READ_SORT")) : 1;
+  static const bool env_per_entry = getenv("DMH_EXPAND_PER_ENTRY") != nullptr;
+  const bool by_read = R.word && R.npass == 0 && !env_per_entry && st.opt_expand != 0 &&
+                       (st.opt_read_sort >= 0 ? st.opt_read_sort != 0 : env_rs != 0);
+  R.read_sorted = false;
+
   // --- expand the entries under the limit into hits (map.c:3095-3099), behind the batch's earlier passes
   static DevBuf<uint32_t> esz, eoff, ebig;
   esz.ensure((size_t) nent + 1, "entry sizes");
@@ -1191,15 +1276,40 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     HIP_CHECK(hipMemcpyAsync(eoff.p, esz.p, sizeof(uint32_t) * nent, hipMemcpyDeviceToDevice, stream()));
     exclusive_scan_u32(eoff.p, nent, st.sort.bsum, eoff.p + nent);
     PosMap MA{A.d_boff, A.d_chunk, A.posbits}, MB{Bx.d_boff, Bx.d_chunk, Bx.posbits};
-    static const bool per_entry = getenv("DMH_EXPAND_PER_ENTRY") != nullptr;
+    const bool per_entry = env_per_entry;
     if (!per_entry && st.opt_expand != 0)
       { static DevBuf<uint32_t> tfirst;
         tfirst.ensure((size_t) ceil_div(nhits, EX_TILE) + 2, "first entry of each hit tile");
         hipLaunchKernelGGL(k_tile_first, dim3(nb), dim3(256), 0, stream(), (const uint32_t *) eoff.p, nent, tfirst.p);
+        const uint32_t *rstart = nullptr, *rowdst = nullptr;
+        if (by_read)
+          { // segment of every read: hits per read counted row by row, then scanned over the reads
+            const int nr = ablock->nreads;
+            g_rstart.ensure((size_t) nr + 2, "first hit of each read");
+            g_rowdst.ensure((size_t) nhits + 1, "place of each merge row in its read's segment");
+            g_rstats.ensure(4, "read segment statistics");
+            HIP_CHECK(hipMemsetAsync(g_rstart.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
+            HIP_CHECK(hipMemsetAsync(g_rstats.p, 0, sizeof(uint32_t) * 4, stream()));
+            hipLaunchKernelGGL(k_row_place, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
+                               (const uint32_t *) esz.p, (const uint32_t *) eoff.p, (const uint32_t *) A.vals, MA,
+                               g_rstart.p, g_rowdst.p);
+            hipLaunchKernelGGL(k_read_max, dim3(ceil_div(nr, 256)), dim3(256), 0, stream(), (const uint32_t *) g_rstart.p, nr,
+                               g_rstats.p);
+            exclusive_scan_u32(g_rstart.p, nr, st.sort.bsum, g_rstart.p + nr);
+            rstart = g_rstart.p; rowdst = g_rowdst.p;
+          }
         hipLaunchKernelGGL(k_merge_expand_tiled, dim3(ceil_div(nhits, EX_TILE)), dim3(256), 0, stream(),
                          (const MergeEntry *) entries.p, nent, (const uint32_t *) eoff.p, (const uint32_t *) tfirst.p,
                          (const uint32_t *) A.vals,
-                         (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, hitmode, passor, hk, hv);
+                         (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, hitmode, passor, hk, hv, rstart, rowdst);
+        if (by_read)
+          { // a read with more hits than the LDS of a workgroup takes (a tandem array: a pile) sends the whole pass
+            // through the global sort, which takes the words in any order
+            uint32_t mx = 0;
+            copy_d2h(&mx, g_rstats.p, sizeof(uint32_t), 1);
+            // ("read_sort" test option = 3: segments of more than 512 hits count as too large)
+            R.read_sorted = mx <= (st.opt_read_sort == 3 ? 512u : (uint32_t) RS_BIG_T * RS_E);
+          }
       }
     else
       { hipLaunchKernelGGL(k_merge_expand, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
@@ -1328,7 +1438,10 @@ static void close_batch(MergeResult &R)
   uint32_t *v0 = R.vals.p, *v1 = R.alt_vals.p;
   static const int env_cb = getenv("DMH_CLUSTER_CB") ? atoi(getenv("DMH_CLUSTER_CB")) : CLUSTER_CB;
   const int cb = cluster ? std::min(env_cb, qbits) : 0;              // (the bits below cb of bpos are not sorted on)
-  if (R.word)
+  const bool rs = R.word && R.read_sorted;             // hits lie read by read: ordered per read in LDS (dmh_readsort.h)
+  if (rs)
+    ;
+  else if (R.word)
     radix_sort_pairs(&k0, nullptr, &k1, nullptr, nhits, R.pbits + cb, qbits - cb + R.bbits + R.abits, st.sort, "seed_sort");
   else
     radix_sort_pairs(&k0, &v0, &k1, &v1, nhits, cb, lowbits + R.bbits + R.passbits + R.abits - cb, st.sort, "seed_sort");
@@ -1355,7 +1468,48 @@ static void close_batch(MergeResult &R)
   else
     { uint32_t ncl = 0;
       const bool local_sort = R.word || local_cluster_sort(R.pbits);
-      if (R.word)
+      if (rs)
+        { const int nr = ablock->nreads;
+          static DevBuf<uint64_t> lcl;
+          static DevBuf<uint32_t> rncl;
+          lcl.ensure((size_t) nhits + 1, "cluster records per read");
+          rncl.ensure((size_t) nr + 2, "clusters per read");
+          HIP_CHECK(hipMemsetAsync(rncl.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
+          ReadSortArgs RA;
+          RA.in = k0; RA.out = k1; RA.rstart = g_rstart.p;
+          RA.pbits = R.pbits; RA.qbits = qbits; RA.bbits = R.bbits; RA.cb = cb;
+          RA.kbits = qbits - cb + R.bbits;
+          RA.npass = (RA.kbits + RS_DB - 1) / RS_DB;
+          RA.dbits = RA.npass > 0 ? (RA.kbits + RA.npass - 1) / RA.npass : 0;
+          RA.lcl = lcl.p; RA.rncl = rncl.p;
+          static bool attr = false;
+          if (!attr)
+            { attr = true;
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_BIG_T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_BIG_T>()));
+            }
+          { // (8 B read + 8 B written per hit)
+            StageTimer tm("read_sort", 16.0 * nhits);
+            // ("read_sort" test option = 2: the large workgroups take everything above 128 hits)
+            const uint32_t cut = (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_SMALL_T * RS_E;
+            RA.nlo = 0; RA.nhi = cut;
+            hipLaunchKernelGGL(k_read_sort<RS_SMALL_T>, dim3(nr), dim3(RS_SMALL_T), read_sort_lds<RS_SMALL_T>(), stream(), RA);
+            RA.nlo = cut; RA.nhi = RS_BIG_T * RS_E;
+            hipLaunchKernelGGL(k_read_sort<RS_BIG_T>, dim3(nr), dim3(RS_BIG_T), read_sort_lds<RS_BIG_T>(), stream(), RA);
+            HIP_CHECK(hipGetLastError());
+          }
+          StageTimer tm("seed_clusters", 0.0);
+          exclusive_scan_u32(rncl.p, nr, st.sort.bsum, rncl.p + nr);
+          copy_d2h(&ncl, rncl.p + nr, sizeof(uint32_t), 1);
+          R.ngroups = ncl;
+          R.gstart.ensure((size_t) ncl + 1, "cluster starts");
+          R.gkey.ensure((size_t) ncl + 1, "cluster keys");
+          hipLaunchKernelGGL(k_cluster_compact, dim3(ceil_div((int64_t) nr * 64, 256)), dim3(256), 0, stream(),
+                             (const uint64_t *) lcl.p, (const uint32_t *) g_rstart.p, (const uint32_t *) rncl.p, nr, R.bbits,
+                             (uint32_t) nhits, R.gstart.p, R.gkey.p);
+          std::swap(k0, k1);
+        }
+      else if (R.word)
         { StageTimer tm("seed_clusters", 40.0 * nhits);
           static DevBuf<uint32_t> tcount;
           const int nt = ceil_div(nhits, WC_TILE);
@@ -1403,6 +1557,35 @@ static void close_batch(MergeResult &R)
           HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned int), stream()));
           hipLaunchKernelGGL(k_csort_classify, dim3(ceil_div(ncl, 1024)), dim3(1024), 0, stream(), (const uint32_t *) R.gstart.p,
                              ncl, mlist.p, blist.p, cnt.p);
+          if (rs)
+            { // the small clusters are in order already; the others are sorted where they lie, on both positions
+              hipLaunchKernelGGL(k_csort_wide, dim3(8192), dim3(64), CS_WAVE * sizeof(uint64_t), stream(), k0,
+                                 (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p,
+                                 (uint32_t) CS_SMALL, (uint32_t) CS_WAVE);
+              hipLaunchKernelGGL(k_csort_wide, dim3(2048), dim3(256), CS_MEDIUM * sizeof(uint64_t), stream(), k0,
+                                 (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p,
+                                 (uint32_t) CS_WAVE, (uint32_t) CS_MEDIUM);
+              HIP_CHECK(hipGetLastError());
+              unsigned int hc[2] = {0, 0};
+              copy_d2h(hc, cnt.p, 2 * sizeof(unsigned int), 1);
+              if (hc[1] > 0)
+                { // repeat piles: stable radix passes on bpos (the high half of the word), then on apos
+                  std::vector<uint32_t> big(hc[1]), gs((size_t) ncl + 1);
+                  copy_d2h(big.data(), blist.p, sizeof(uint32_t) * hc[1]);
+                  copy_d2h(gs.data(), R.gstart.p, sizeof(uint32_t) * ((size_t) ncl + 1));
+                  for (uint32_t c : big)
+                    { const int64_t b0 = gs[c], bn = (int64_t) gs[c + 1] - b0;
+                      uint64_t *sk = k0 + b0, *ok = k1 + b0;
+                      radix_sort_pairs(&sk, nullptr, &ok, nullptr, bn, 32, qbits, st.sort, "pile_sort");
+                      radix_sort_pairs(&sk, nullptr, &ok, nullptr, bn, 0, R.pbits, st.sort, "pile_sort");
+                      if (sk != k0 + b0)
+                        HIP_CHECK(hipMemcpyAsync(k0 + b0, sk, sizeof(uint64_t) * bn, hipMemcpyDeviceToDevice, stream()));
+                    }
+                }
+              std::swap(k0, k1);             // (undone below: the sorted hits are on the k0 side on this route)
+            }
+          else
+            {
           hipLaunchKernelGGL(k_csort_small, dim3(std::min<int64_t>(((int64_t) ncl + 15) / 16, 256 * 8)), dim3(256), 0, stream(),
                              (const uint64_t *) k0, (const uint32_t *) R.gstart.p, ncl, k1);
           hipLaunchKernelGGL(k_csort_medium, dim3(8192), dim3(64), CS_WAVE * sizeof(uint32_t), stream(), (const uint64_t *) k0,
@@ -1427,6 +1610,7 @@ static void close_batch(MergeResult &R)
                   if (sk != k1 + b0)
                     HIP_CHECK(hipMemcpyAsync(k1 + b0, sk, sizeof(uint64_t) * bn, hipMemcpyDeviceToDevice, stream()));
                 }
+            }
             }
           std::swap(k0, k1);
         }

@@ -248,7 +248,7 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
   scr.hist.ensure((size_t) 256 * ntiles, "radix histogram");
   int npass = (nbits + 7) / 8;
   // algorithmic traffic of one pass with the reference's 16-byte records: read + write
-  StageTimer tm(stage, (double) npass * 32.0 * (double) n);
+  StageTimer tm(stage, (double) npass * (vals != nullptr ? 32.0 : 16.0) * (double) n);
   for (int p = 0; p < npass; p++)
     { int      shift = lo_bit + 8 * p;
       int      w     = nbits - 8 * p;
@@ -260,8 +260,9 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
       { StageTimer ts("radix_scan", 0.0);
         exclusive_scan_u32(scr.hist.p, (int64_t) 256 * ntiles, scr.bsum, nullptr);
       }
-      { // one LSD pass over 16-byte records in the reference: read 16 B + write 16 B per record
-        StageTimer tc("k_radix_scatter", 32.0 * (double) n);
+      { // one LSD pass over 16-byte records in the reference: read 16 B + write 16 B per record; a keys-only pass
+        // (the one-word hits of cluster mode) is charged what it moves, 8 B + 8 B
+        StageTimer tc("k_radix_scatter", (vals != nullptr ? 32.0 : 16.0) * (double) n);
         if (vals != nullptr)
           hipLaunchKernelGGL(k_radix_scatter<true>, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
                              (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,

@@ -15,7 +15,8 @@ import sys
 def per_kernel(path):
     out = collections.defaultdict(lambda: {"launches": 0, "sum_KB": 0.0, "threads": 0})
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        # (templated kernels -- k_radix_scatter<true>, k_merge_match<4, true> -- are summed under their plain name)
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         out[k]["launches"] += 1
         out[k]["sum_KB"] += float(r["Counter_Value"])
         out[k]["threads"] += int(r["Grid_Size"])
@@ -33,6 +34,8 @@ for k in sorted(set(f) | set(w)):
 sc_f, sc_w = f["dmh::k_radix_scatter"], w["dmh::k_radix_scatter"]
 hist = f["dmh::k_radix_hist"]
 recs = sc_f["threads"] * 16            # 16 records per thread (upper bound: the last tile of a launch is partial)
+# (keys-and-values launches move 12 + 12 B per record, keys-only launches 8 + 8: the figure below is the mean over
+#  the launches of the profiled run)
 fetch = 2.0 * sc_f["sum_KB"] * 1024
 write = sc_w["sum_KB"] * 1024
 print(json.dumps({

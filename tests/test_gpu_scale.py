@@ -150,8 +150,9 @@ def test_configs4_resident_multi_block_reference_n95_p(tmp_path):
         assert want.max() >= 10                      # repeat coverage shows
 
 
-@pytest.mark.parametrize("cluster", [-1, 0], ids=["auto", "pairs"])
-def test_one_family_repeat_stress(cluster, tmp_path):
+@pytest.mark.parametrize("cluster,read_sort", [(-1, -1), (0, -1), (-1, 0), (-1, 2)],
+                         ids=["auto", "pairs", "auto_global_seed_sort", "auto_large_workgroups"])
+def test_one_family_repeat_stress(cluster, read_sort, tmp_path):
     run_ref = _run_ref()
     d = str(tmp_path)
     G = dazzdb.native_genome(23, [4_000_000, 4_000_000], "repeat", families=1)
@@ -159,10 +160,12 @@ def test_one_family_repeat_stress(cluster, tmp_path):
     dazzdb.write_db_block(d, "READS", dazzdb.simulate_block_genome(4000, G, 1500))
     run_ref.run_reference(d, "REF", ["READS.1"], flags=["-k20", "-e.85", "-M64"], threads=_threads())
     capi.lib().dmh_test_option(b"cluster", cluster)
+    capi.lib().dmh_test_option(b"read_sort", read_sort)
     try:
         _map_blocks_like_bench(d, "REF", "READS", "las_hip", mem_limit=64 << 30)
     finally:
         capi.lib().dmh_test_option(b"cluster", -1)
+        capi.lib().dmh_test_option(b"read_sort", -1)
     _compare(d, "las_ref", "las_hip", ["READS.1"], 1500)
 
 
