@@ -1713,8 +1713,7 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   const uint32_t ng = (uint32_t) R.ngroups;
   static DevBuf<uint32_t> goff;
   goff.ensure((size_t) ng + 2, "chain ends per group");
-  HIP_CHECK(hipMemcpyAsync(goff.p, gcnt.p, sizeof(uint32_t) * ng, hipMemcpyDeviceToDevice, stream()));
-  exclusive_scan_u32(goff.p, ng, st.sort_fin.bsum, goff.p + ng);
+  exclusive_scan_u32((const uint32_t *) gcnt.p, goff.p, ng, st.sort_fin.bsum, goff.p + ng);
   uint32_t nsum = 0;
   { HostTimer ht("chain_wait");
     copy_d2h(&nsum, goff.p + ng, sizeof(uint32_t), 1);
@@ -1795,8 +1794,7 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
                        (const uint32_t *) from.p, cs.pool[nx].p,
                        (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,
                        (const uint32_t *) nullptr, (uint16_t *) nullptr, 0u, 0);
-    HIP_CHECK(hipMemcpyAsync(jl.p + nsum + 1, jl.p, sizeof(uint32_t) * nsum, hipMemcpyDeviceToDevice, stream()));
-    exclusive_scan_u32(jl.p + nsum + 1, nsum, st.sort_fin.bsum, cs.ctl.p + 3);
+    exclusive_scan_u32((const uint32_t *) jl.p, jl.p + nsum + 1, nsum, st.sort_fin.bsum, cs.ctl.p + 3);
     HIP_CHECK(hipMemcpyAsync(cs.ctl.p + 4, cs.seg_off[nx].p + nreads, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
     copy_d2h(h, cs.ctl.p, 8 * sizeof(uint32_t), 2);      // added, removed, fresh survivors, jump pairs, records in the new lists
     const size_t need = cs.jtop + h[3];

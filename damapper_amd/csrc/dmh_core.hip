@@ -1398,6 +1398,7 @@ void dmh_reset(void)
   st.sort_aux.bsum.release();
   st.sort_aux.keys_alt.release();
   st.sort_aux.vals_alt.release();
+  scan_state_reset();
   pool_release();
 }
 

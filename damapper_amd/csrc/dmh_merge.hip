@@ -547,14 +547,6 @@ __global__ void k_row_place(const MergeEntry *__restrict__ entries, uint32_t n, 
     }
 }
 
-// the largest segment of the pass (-> stats[0])
-__global__ void k_read_max(const uint32_t *__restrict__ rcount, int nreads, uint32_t *__restrict__ stats)
-{ const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t v = (r < nreads) ? rcount[r] : 0;
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t) __shfl_down(v, o));
-  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(stats, v);
-}
-
 // ---------------------------------------------------------------------------------------
 //  Group boundaries of the sorted hits: one group per (aread, bread)
 // ---------------------------------------------------------------------------------------
@@ -1037,8 +1029,9 @@ static std::deque<int> g_inflight;
 MergeResult &filter_batch() { return g_ring[g_cur]; }
 
 // per-read route: segment starts of the pass being collected (main stream only; a dense pass is closed at once)
-static DevBuf<uint32_t> g_rstart, g_rowdst, g_rstats;
-constexpr int RS_SMALL_T = 256, RS_BIG_T = 1024;      // k_read_sort workgroups: segments of up to 4,096 / 16,384 hits
+static DevBuf<uint32_t> g_rstart, g_rowdst, g_rstats, g_rlists;
+static uint32_t g_rcnt[4] = {0, 0, 0, 0}, g_rlim = 0;      // reads per k_read_sort workgroup size, largest segment; its limit
+constexpr int RS_T0 = 256, RS_T1 = 512, RS_T2 = 1024;      // k_read_sort workgroups: segments of up to 4,096 / 8,192 / 16,384 hits
 
 // hits a batch may collect before it is closed (68 B of HBM per hit through the sort and the chain kernels)
 constexpr int64_t BATCH_CAP = (int64_t) 160 << 20;
@@ -1273,8 +1266,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   { StageTimer tm("merge_emit", 16.0 * nhits);
     int nb = ceil_div(nent, 256);
     hipLaunchKernelGGL(k_entry_sizes, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent, limit, esz.p);
-    HIP_CHECK(hipMemcpyAsync(eoff.p, esz.p, sizeof(uint32_t) * nent, hipMemcpyDeviceToDevice, stream()));
-    exclusive_scan_u32(eoff.p, nent, st.sort.bsum, eoff.p + nent);
+    exclusive_scan_u32((const uint32_t *) esz.p, eoff.p, nent, st.sort.bsum, eoff.p + nent);
     PosMap MA{A.d_boff, A.d_chunk, A.posbits}, MB{Bx.d_boff, Bx.d_chunk, Bx.posbits};
     const bool per_entry = env_per_entry;
     if (!per_entry && st.opt_expand != 0)
@@ -1293,9 +1285,16 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
             hipLaunchKernelGGL(k_row_place, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                                (const uint32_t *) esz.p, (const uint32_t *) eoff.p, (const uint32_t *) A.vals, MA,
                                g_rstart.p, g_rowdst.p);
-            hipLaunchKernelGGL(k_read_max, dim3(ceil_div(nr, 256)), dim3(256), 0, stream(), (const uint32_t *) g_rstart.p, nr,
-                               g_rstats.p);
             exclusive_scan_u32(g_rstart.p, nr, st.sort.bsum, g_rstart.p + nr);
+            // the reads by segment size: one list per workgroup size of k_read_sort ("read_sort" test option = 2: the
+            // largest workgroups take everything above 128 hits; = 3: segments above 512 hits count as too large)
+            g_rlists.ensure(3 * (size_t) nr + 16, "reads by segment size");
+            const uint32_t lim2 = (st.opt_read_sort == 3) ? 512u : (uint32_t) RS_T2 * RS_E;
+            const uint32_t lim0 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T0 * RS_E);
+            const uint32_t lim1 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T1 * RS_E);
+            hipLaunchKernelGGL(k_read_classes, dim3(ceil_div(nr, 256)), dim3(256), 0, stream(), (const uint32_t *) g_rstart.p, nr,
+                               lim0, lim1, lim2, g_rlists.p, g_rstats.p);
+            g_rlim = lim2;
             rstart = g_rstart.p; rowdst = g_rowdst.p;
           }
         hipLaunchKernelGGL(k_merge_expand_tiled, dim3(ceil_div(nhits, EX_TILE)), dim3(256), 0, stream(),
@@ -1305,10 +1304,8 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
         if (by_read)
           { // a read with more hits than the LDS of a workgroup takes (a tandem array: a pile) sends the whole pass
             // through the global sort, which takes the words in any order
-            uint32_t mx = 0;
-            copy_d2h(&mx, g_rstats.p, sizeof(uint32_t), 1);
-            // ("read_sort" test option = 3: segments of more than 512 hits count as too large)
-            R.read_sorted = mx <= (st.opt_read_sort == 3 ? 512u : (uint32_t) RS_BIG_T * RS_E);
+            copy_d2h(g_rcnt, g_rstats.p, 4 * sizeof(uint32_t), 1);
+            R.read_sorted = g_rcnt[3] <= g_rlim;
           }
       }
     else
@@ -1479,23 +1476,38 @@ static void close_batch(MergeResult &R)
           RA.in = k0; RA.out = k1; RA.rstart = g_rstart.p;
           RA.pbits = R.pbits; RA.qbits = qbits; RA.bbits = R.bbits; RA.cb = cb;
           RA.kbits = qbits - cb + R.bbits;
-          RA.npass = (RA.kbits + RS_DB - 1) / RS_DB;
-          RA.dbits = RA.npass > 0 ? (RA.kbits + RA.npass - 1) / RA.npass : 0;
           RA.lcl = lcl.p; RA.rncl = rncl.p;
           static bool attr = false;
           if (!attr)
             { attr = true;
-              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_BIG_T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int) read_sort_lds<RS_BIG_T>()));
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_T1>()));
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_T1>()));
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T2, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_T2>()));
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_T2>()));
             }
-          { // (8 B read + 8 B written per hit)
+          // clusters ordered on 32-bit words when apos leaves the room ("read_sort" test option = 4: on 64-bit words)
+          const bool k32 = R.pbits + cb + 6 <= 32 && st.opt_read_sort != 4;
+          { // (8 B read + 8 B written per hit); the largest segments first: they are the longest jobs
             StageTimer tm("read_sort", 16.0 * nhits);
-            // ("read_sort" test option = 2: the large workgroups take everything above 128 hits)
-            const uint32_t cut = (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_SMALL_T * RS_E;
-            RA.nlo = 0; RA.nhi = cut;
-            hipLaunchKernelGGL(k_read_sort<RS_SMALL_T>, dim3(nr), dim3(RS_SMALL_T), read_sort_lds<RS_SMALL_T>(), stream(), RA);
-            RA.nlo = cut; RA.nhi = RS_BIG_T * RS_E;
-            hipLaunchKernelGGL(k_read_sort<RS_BIG_T>, dim3(nr), dim3(RS_BIG_T), read_sort_lds<RS_BIG_T>(), stream(), RA);
+            if (g_rcnt[2] > 0)
+              { RA.list = g_rlists.p + 2 * (size_t) nr;
+                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), stream(), RA);
+                else     hipLaunchKernelGGL((k_read_sort<RS_T2, false>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), stream(), RA);
+              }
+            if (g_rcnt[1] > 0)
+              { RA.list = g_rlists.p + (size_t) nr;
+                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), stream(), RA);
+                else     hipLaunchKernelGGL((k_read_sort<RS_T1, false>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), stream(), RA);
+              }
+            if (g_rcnt[0] > 0)
+              { RA.list = g_rlists.p;
+                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
+                else     hipLaunchKernelGGL((k_read_sort<RS_T0, false>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
+              }
             HIP_CHECK(hipGetLastError());
           }
           StageTimer tm("seed_clusters", 0.0);
@@ -1676,5 +1688,18 @@ static void close_batch(MergeResult &R)
       if (!busy) { g_cur = i; break; }
     }
 }
+
+#ifdef DMH_RS_PROFILE
+}  // namespace dmh
+extern "C" void dmh_rs_profile(unsigned long long *out, int reset)
+{ HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dmh::g_rsprof), sizeof(unsigned long long) * 16));
+  if (reset)
+    { unsigned long long z[16] = {0};
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(dmh::g_rsprof), z, sizeof(z)));
+    }
+}
+namespace dmh {
+#endif
 
 }  // namespace dmh

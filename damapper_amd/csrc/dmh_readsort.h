@@ -31,9 +31,9 @@ struct ReadSortArgs
 { const uint64_t *in;            // the pass's words, read by read (w = aread | bread | bpos | apos)
   uint64_t       *out;           // the chain kernels' words, same positions
   const uint32_t *rstart;        // first word of every read (+ end)
-  uint32_t        nlo, nhi;      // this launch takes the reads with nlo < hits <= nhi
+  const uint32_t *list;          // the reads this launch takes, one per workgroup (k_read_classes)
   int             pbits, qbits, bbits, cb;
-  int             npass, dbits, kbits;       // radix passes of dbits over the kbits of the coarse key
+  int             kbits;         // bits of the coarse key (bread, bpos >> cb)
   uint64_t       *lcl;           // per cluster, at rstart[r] + j: contig << 32 | first word
   uint32_t       *rncl;          // clusters per read
 };
@@ -57,22 +57,40 @@ __device__ __forceinline__ uint32_t block_excl_scan_t(uint32_t v, uint32_t *ws, 
   return wbase + x - v;
 }
 
-template <int T>
-__global__ __launch_bounds__(T) void k_read_sort(ReadSortArgs A)
-{ constexpr int W = T / 64, D = 1 << RS_DB, E = RS_E;
+// -DDMH_RS_PROFILE (make profile): cycles per phase, summed over the workgroups (thread 0's clock)
+#ifdef DMH_RS_PROFILE
+__device__ unsigned long long g_rsprof[16];
+#define RSPROF_T0() long long _t0 = clock64()
+#define RSPROF_LAP(i) do { long long _t1 = clock64(); if (threadIdx.x == 0) atomicAdd(&g_rsprof[i], (unsigned long long) (_t1 - _t0)); _t0 = _t1; } while (0)
+#define RSPROF_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_rsprof[i], (unsigned long long) (v)); } while (0)
+#else
+#define RSPROF_T0()
+#define RSPROF_LAP(i)
+#define RSPROF_ADD(i, v)
+#endif
+
+// LDS of a workgroup: the words, the first pass's counters (one set for the whole workgroup, 2^RS_B1 digits, two
+// 16-bit counters per word), the later passes' counters (one set per wavefront), the cluster-start bits.
+constexpr int RS_B1 = 11;        // most bits of the first (unstable) pass's digit
+
+template <int T, bool K32>
+__global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
+{ constexpr int W = T / 64, D = 1 << RS_DB, D1 = 1 << RS_B1, E = RS_E;
   extern __shared__ __attribute__((aligned(16))) uint64_t rs_lds[];
   uint64_t *buf   = rs_lds;                                   // T * E words
-  uint16_t *wh    = (uint16_t *) (buf + (size_t) T * E);      // W x D digit counters, then offsets
-  uint64_t *flagw = (uint64_t *) (wh + (size_t) W * D);       // cluster-start bits, one word per 64 hits (+ sentinel)
+  uint32_t *c1    = (uint32_t *) (buf + (size_t) T * E);      // D1 / 2 words: the first pass's counters, then offsets
+  uint16_t *wh    = (uint16_t *) c1;                          // W x D counters of the stable passes (the same LDS, later)
+  uint64_t *flagw = (uint64_t *) (c1 + (W * D > D1 ? W * D : D1) / 2);      // cluster-start bits, one word per 64 hits (+ sentinel)
   uint16_t *wpref = (uint16_t *) (flagw + (T * E / 64 + 2));  // starts before each flag word
   __shared__ uint32_t ws[W];
 
-  const uint32_t r  = blockIdx.x;
+  const uint32_t r  = A.list[blockIdx.x];
   const uint32_t s0 = A.rstart[r];
-  const uint32_t n  = A.rstart[r + 1] - s0;
-  if (n <= A.nlo || n > A.nhi) return;                        // (uniform: another launch's read, or none)
+  const uint32_t n  = A.rstart[r + 1] - s0;                   // 0 < n <= T * E (k_read_classes)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  RSPROF_T0();
+  RSPROF_ADD(8, 1); RSPROF_ADD(9, n);
   const uint32_t rounds = (n + 64 * W - 1) / (64 * W);        // <= E
   const uint32_t wbase  = (uint32_t) w * rounds * 64;         // the wavefront's words: [wbase, wbase + 64 rounds)
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -81,14 +99,81 @@ __global__ __launch_bounds__(T) void k_read_sort(ReadSortArgs A)
 #pragma unroll
   for (int j = 0; j < E; j++)
     { const uint32_t i = wbase + 64u * j + lane;
-      key[j] = ((uint32_t) j < rounds && i < n) ? __builtin_nontemporal_load(A.in + s0 + i) : ~0ull;
+      const uint64_t v = __builtin_nontemporal_load(A.in + s0 + (i < n ? i : n - 1));
+      key[j] = (i < n) ? v : ~0ull;
+    }
+#ifdef DMH_RS_PROFILE
+  __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+#endif
+  RSPROF_LAP(0);
+
+  // ---- 1a. the lowest b1 bits of the coarse key.  The words arrive in no particular order, so this pass need not be
+  // stable: a word's place among those with its digit is whatever its add to the workgroup's counter of the digit
+  // returns -- one LDS instruction per word where a stable pass pays nine ballots.
+  const int b1 = A.kbits < RS_B1 ? A.kbits : RS_B1;
+  if (b1 > 0)
+    { const int sh = A.pbits + A.cb;
+      const uint32_t dmask = (1u << b1) - 1u;
+      for (int x = tid; x < D1 / 2; x += T) c1[x] = 0;
+      __syncthreads();
+      uint32_t rk[E];
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        { rk[j] = 0;
+          if ((uint32_t) j < rounds)
+            { const uint32_t i = wbase + 64u * j + lane;
+              const uint32_t d = (uint32_t) (key[j] >> sh) & dmask;
+              if (i < n) rk[j] = atomicAdd(&c1[d >> 1], 1u << ((d & 1u) * 16u));
+            }
+        }
+      __syncthreads();
+      RSPROF_LAP(1);
+      // exclusive scan of the D1 counters (digit order), in place
+      { constexpr int PER = (D1 / 2 + T - 1) / T;              // counter words per thread (consecutive)
+        uint32_t c[PER], tot = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+          { const int x = tid * PER + q;
+            c[q] = (x < D1 / 2) ? c1[x] : 0u;
+            tot += (c[q] & 0xffffu) + (c[q] >> 16);
+          }
+        uint32_t all;
+        uint32_t run = block_excl_scan_t<T>(tot, ws, &all);
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+          { const int x = tid * PER + q;
+            const uint32_t lo = run, hi = run + (c[q] & 0xffffu);
+            run = hi + (c[q] >> 16);
+            if (x < D1 / 2) c1[x] = lo | (hi << 16);
+          }
+      }
+      __syncthreads();
+      RSPROF_LAP(2);
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        if ((uint32_t) j < rounds)
+          { const uint32_t i = wbase + 64u * j + lane;
+            if (i < n)
+              { const uint32_t d = (uint32_t) (key[j] >> sh) & dmask, hs = (d & 1u) * 16u;
+                buf[((c1[d >> 1] >> hs) & 0xffffu) + ((rk[j] >> hs) & 0xffffu)] = key[j];
+              }
+          }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        if ((uint32_t) j < rounds)
+          { const uint32_t i = wbase + 64u * j + lane;
+            key[j] = (i < n) ? buf[i] : ~0ull;
+          }
+      __syncthreads();
+      RSPROF_LAP(3);
     }
 
-  // ---- 1. stable LSD passes over the coarse key
+  // ---- 1b. the remaining bits: stable LSD passes of up to RS_DB bits, ranks inside a wavefront from ballots
   uint16_t *mywh = wh + (size_t) w * D;
-  for (int p = 0; p < A.npass; p++)
-    { const int sh = A.pbits + A.cb + p * A.dbits;
-      const int wd = (A.kbits - p * A.dbits < A.dbits) ? A.kbits - p * A.dbits : A.dbits;
+  for (int done = b1; done < A.kbits; done += RS_DB)
+    { const int sh = A.pbits + A.cb + done;
+      const int wd = (A.kbits - done < RS_DB) ? A.kbits - done : RS_DB;
       const uint32_t dmask = (1u << wd) - 1u;
       for (int x = tid; x < W * D; x += T) wh[x] = 0;
       __syncthreads();
@@ -100,8 +185,7 @@ __global__ __launch_bounds__(T) void k_read_sort(ReadSortArgs A)
               const bool     ok = i < n;
               const uint32_t d  = (uint32_t) (key[j] >> sh) & dmask;
               uint64_t peers = __ballot(ok);
-#pragma unroll
-              for (int b = 0; b < RS_DB; b++)
+              for (int b = 0; b < wd; b++)
                 { const bool     bit = (d >> b) & 1u;
                   const uint64_t bal = __ballot(bit);
                   peers &= bit ? bal : ~bal;
@@ -116,8 +200,10 @@ __global__ __launch_bounds__(T) void k_read_sort(ReadSortArgs A)
               __builtin_amdgcn_wave_barrier();
               rk[j] = b0 + below;
             }
+          __builtin_amdgcn_sched_barrier(0);                   // (one item at a time: interleaved, their ballots spill)
         }
       __syncthreads();
+      RSPROF_LAP(1);
       // digit d: counts per wavefront -> first slot of (d, wavefront) in the order digit, wavefront, position
       { constexpr int PER = (D + T - 1) / T;                   // digits per thread (consecutive)
         uint32_t c[PER][W], tot = 0;
@@ -143,6 +229,7 @@ __global__ __launch_bounds__(T) void k_read_sort(ReadSortArgs A)
           }
       }
       __syncthreads();
+      RSPROF_LAP(2);
 #pragma unroll
       for (int j = 0; j < E; j++)
         if ((uint32_t) j < rounds)
@@ -160,8 +247,9 @@ __global__ __launch_bounds__(T) void k_read_sort(ReadSortArgs A)
             key[j] = (i < n) ? buf[i] : ~0ull;
           }
       __syncthreads();                                         // (everybody has its words: buf and wh are free again)
+      RSPROF_LAP(3);
     }
-  if (A.npass == 0)
+  if (A.kbits == 0)
     { // (a key of no bits: one contig and one bucket -- the words only have to be in LDS)
 #pragma unroll
       for (int j = 0; j < E; j++)
@@ -200,68 +288,145 @@ __global__ __launch_bounds__(T) void k_read_sort(ReadSortArgs A)
     if ((uint32_t) tid < nw) wpref[tid] = (uint16_t) e;
   }
   __syncthreads();
-  // the words become (apos << 32 | bpos): what the clusters are ordered by, and the chain kernels' word with its
-  // halves swapped; every start leaves its cluster's record
-  const uint64_t pm = (1ull << A.pbits) - 1ull, qm = (1ull << A.qbits) - 1ull, bm = (1ull << A.bbits) - 1ull;
-#pragma unroll
-  for (int j = 0; j < E; j++)
-    if ((uint32_t) j < rounds)
-      { const uint32_t i = wbase + 64u * j + lane;
-        if (i < n)
-          { const uint64_t x = key[j];
-            key[j] = ((x & pm) << 32) | ((x >> A.pbits) & qm);
-            buf[i] = key[j];
-            const uint64_t fw = flagw[i >> 6];
-            if ((fw >> (i & 63)) & 1ull)
-              { const uint32_t c = (uint32_t) wpref[i >> 6] + (uint32_t) __popcll(fw & ((1ull << (i & 63)) - 1ull));
-                A.lcl[s0 + c] = (((x >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
-              }
-          }
-      }
-  if (tid == 0) A.rncl[r] = ncl;
-  __syncthreads();
+  RSPROF_LAP(4);
 
-  // ---- 3. clusters of up to RS_IN hits: rank by counting; the others keep the order they have
+  // A round is 64 consecutive, aligned positions, i.e. ONE flag word.  The start of a lane's cluster is the highest flag
+  // at or below its position (in this word or the one before: a cluster that begins earlier is longer than RS_IN anyway),
+  // its end the lowest flag above (this word or the next).  Every start leaves its cluster's record.
+  // What a cluster is ordered by: (apos, bpos).  K32: as ONE 32-bit word, apos above bpos minus the first base of the
+  // cluster's first coarse bucket -- a cluster of up to RS_IN hits spans at most RS_IN adjacent buckets, so the difference
+  // fits the bits apos leaves free (pbits + cb + 6 <= 32: reads of up to 16 kb); else as apos << 32 | bpos.
+  const uint64_t pm = (1ull << A.pbits) - 1ull, qm = (1ull << A.qbits) - 1ull, bm = (1ull << A.bbits) - 1ull;
+  uint32_t se[E];                                              // start | length << 16 (length 0: the hit keeps its position)
+  uint32_t k32[K32 ? E : 1];
+#pragma unroll
+  for (int j = 0; j < E; j++)
+    { se[j] = 0;
+      if (K32) k32[j] = 0;
+      if ((uint32_t) j < rounds)
+        { const uint32_t i = wbase + 64u * j + lane, wi = i >> 6, bi = i & 63;
+          const uint64_t f0 = flagw[wi > 0 ? wi - 1 : 0], f1 = flagw[wi < nw ? wi : 0], f2 = flagw[wi + 1 < nw ? wi + 1 : 0];
+          if (i < n)
+            { const uint64_t x = key[j];
+              if ((f1 >> bi) & 1ull)
+                { const uint32_t c = (uint32_t) wpref[wi] + (uint32_t) __popcll(f1 & ((1ull << bi) - 1ull));
+                  A.lcl[s0 + c] = (((x >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
+                }
+              uint32_t s = 0xffffffffu, e = 0xffffffffu;
+              const uint64_t ms = f1 & (~0ull >> (63 - bi));
+              if (ms) s = wi * 64 + 63 - (uint32_t) __clzll((long long) ms);
+              else if (wi > 0 && f0) s = (wi - 1) * 64 + 63 - (uint32_t) __clzll((long long) f0);
+              const uint64_t me = (bi == 63) ? 0ull : (f1 & (~0ull << (bi + 1)));
+              if (me) e = wi * 64 + (uint32_t) __ffsll((long long) me) - 1;
+              else if (wi + 1 < nw && f2) e = (wi + 1) * 64 + (uint32_t) __ffsll((long long) f2) - 1;
+              if (s != 0xffffffffu && e != 0xffffffffu && e - s <= (uint32_t) RS_IN)
+                { se[j] = s | ((e - s) << 16);
+                  if (K32)
+                    { const uint32_t base = (uint32_t) ((buf[s] >> A.pbits) & qm) >> A.cb << A.cb;
+                      k32[j] = ((uint32_t) (x & pm) << (32 - A.pbits)) | ((uint32_t) ((x >> A.pbits) & qm) - base);
+                    }
+                }
+            }
+        }
+      if (j & 1) __builtin_amdgcn_sched_barrier(0);            // (two rounds' loads in flight, not sixteen: registers)
+    }
+  if (tid == 0) A.rncl[r] = ncl;
+  __syncthreads();                                             // (nobody reads the sorted words any more)
+  uint32_t *b32 = (uint32_t *) buf;
 #pragma unroll
   for (int j = 0; j < E; j++)
     if ((uint32_t) j < rounds)
       { const uint32_t i = wbase + 64u * j + lane;
+        const uint64_t x = key[j];
+        key[j] = (x & pm) | (((x >> A.pbits) & qm) << 32);     // the chain kernels' word: apos | bpos << 32
         if (i < n)
-          { const uint64_t k = key[j];
-            const uint32_t wi = i >> 6, bi = i & 63;
-            // start of my cluster: the highest flag at or below i (in this flag word or the one before -- a cluster
-            // that begins earlier is longer than RS_IN anyway); its end: the lowest flag above i (this word or the
-            // next, the same way)
-            uint32_t s = 0xffffffffu, e = 0xffffffffu;
-            { const uint64_t m = flagw[wi] & (~0ull >> (63 - bi));
-              if (m) s = wi * 64 + 63 - (uint32_t) __clzll((long long) m);
-              else if (wi > 0)
-                { const uint64_t m2 = flagw[wi - 1];
-                  if (m2) s = (wi - 1) * 64 + 63 - (uint32_t) __clzll((long long) m2);
-                }
-            }
-            { const uint64_t m = (bi == 63) ? 0ull : (flagw[wi] & (~0ull << (bi + 1)));
-              if (m) e = wi * 64 + (uint32_t) __ffsll((long long) m) - 1;
-              else if (wi + 1 < nw)
-                { const uint64_t m2 = flagw[wi + 1];
-                  if (m2) e = (wi + 1) * 64 + (uint32_t) __ffsll((long long) m2) - 1;
-                }
-            }
-            uint32_t dst = i;
-            if (s != 0xffffffffu && e != 0xffffffffu && e - s <= (uint32_t) RS_IN)
-              { uint32_t rank = 0;
-                for (uint32_t q = s; q < e; q++) rank += (buf[q] < k) ? 1u : 0u;
-                dst = s + rank;
-              }
-            A.out[s0 + dst] = (k << 32) | (k >> 32);
+          { if (K32) b32[i] = k32[j];
+            else     buf[i] = (key[j] << 32) | (key[j] >> 32);
           }
       }
+  __syncthreads();
+  RSPROF_LAP(5);
+
+  // ---- 3. clusters of up to RS_IN hits: rank by counting; the others keep the order they have.  Two rounds at a
+  // time, four words of each per turn: the LDS round trips of a turn overlap instead of following one another.
+#pragma unroll
+  for (int j = 0; j < E; j += 2)
+    if ((uint32_t) j < rounds)
+      { const uint32_t sa = se[j] & 0xffffu, ma = se[j] >> 16, sb = se[j + 1] & 0xffffu, mb = se[j + 1] >> 16;
+        uint32_t ra = 0, rb = 0;
+        const uint32_t mm = ma > mb ? ma : mb;
+        if (K32)
+          { const uint32_t ka = k32[j], kb = k32[j + 1];
+            for (uint32_t t = 0; t < mm; t += 4)
+              { uint32_t va[4], vb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                  { va[u] = b32[sa + (t + u < ma ? t + u : 0)];
+                    vb[u] = b32[sb + (t + u < mb ? t + u : 0)];
+                  }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                  { ra += (t + u < ma && va[u] < ka) ? 1u : 0u;
+                    rb += (t + u < mb && vb[u] < kb) ? 1u : 0u;
+                  }
+              }
+          }
+        else
+          { const uint64_t ka = (key[j] << 32) | (key[j] >> 32), kb = (key[j + 1] << 32) | (key[j + 1] >> 32);
+            for (uint32_t t = 0; t < mm; t += 4)
+              { uint64_t va[4], vb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                  { va[u] = buf[sa + (t + u < ma ? t + u : 0)];
+                    vb[u] = buf[sb + (t + u < mb ? t + u : 0)];
+                  }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                  { ra += (t + u < ma && va[u] < ka) ? 1u : 0u;
+                    rb += (t + u < mb && vb[u] < kb) ? 1u : 0u;
+                  }
+              }
+          }
+        const uint32_t ia = wbase + 64u * j + lane, ib = ia + 64u;
+        if (ia < n) A.out[s0 + (ma ? sa + ra : ia)] = key[j];
+        if ((uint32_t) (j + 1) < rounds && ib < n) A.out[s0 + (mb ? sb + rb : ib)] = key[j + 1];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#ifdef DMH_RS_PROFILE
+  __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+#endif
+  RSPROF_LAP(6);
 }
 
 // dynamic LDS of k_read_sort<T>
 template <int T> constexpr size_t read_sort_lds()
-{ return sizeof(uint64_t) * (size_t) T * RS_E + sizeof(uint16_t) * (size_t) (T / 64) * (1 << RS_DB)
+{ return sizeof(uint64_t) * (size_t) T * RS_E + sizeof(uint32_t) * ((1 << RS_B1) / 2)
+         + sizeof(uint16_t) * (size_t) (T / 64) * (1 << RS_DB)
          + sizeof(uint64_t) * (T * RS_E / 64 + 2) + sizeof(uint16_t) * (T * RS_E / 64 + 2) + 64;
+}
+
+// The reads by segment size, one list per workgroup size of k_read_sort (lists[c] at c * nreads): class 0 up to lim[0]
+// hits, class 1 up to lim[1], class 2 up to lim[2]; reads without hits are in no list; stats[0..2] = list lengths,
+// stats[3] = the largest segment (larger than lim[2]: the pass takes the global sort).
+__global__ __launch_bounds__(256) void k_read_classes(const uint32_t *__restrict__ rstart, int nreads, uint32_t lim0,
+                                                      uint32_t lim1, uint32_t lim2, uint32_t *__restrict__ lists,
+                                                      uint32_t *__restrict__ stats)
+{ const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t n = (r < nreads) ? rstart[r + 1] - rstart[r] : 0;
+  const int c = (n == 0) ? -1 : (n <= lim0 ? 0 : (n <= lim1 ? 1 : (n <= lim2 ? 2 : -1)));
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    { const uint64_t m = __ballot(c == k);
+      if (m == 0) continue;
+      uint32_t base = 0;
+      if (lane == __ffsll((long long) m) - 1) base = atomicAdd(stats + k, (uint32_t) __popcll(m));
+      base = __shfl(base, __ffsll((long long) m) - 1);
+      if (c == k) lists[(size_t) k * nreads + base + (uint32_t) __popcll(m & lt)] = (uint32_t) r;
+    }
+  uint32_t v = n;
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t) __shfl_down(v, o));
+  if (lane == 0 && v > 0) atomicMax(stats + 3, v);
 }
 
 // cbase = exclusive scan of rncl: the clusters of read r become clusters cbase[r] ... of the pass.  One wavefront per read.

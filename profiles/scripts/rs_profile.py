@@ -1,0 +1,38 @@
+"""Phase clock of k_read_sort (make -C damapper_amd/csrc profile; DMH_RS_PROFILE): runs a few read blocks of the bench
+workload against ONE REF block (both orientations) with the instrumented library and prints cycles per phase."""
+import ctypes as C
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from damapper_amd import capi
+capi.LIB_PATH = os.path.join(ROOT, "build", "libdamapper_hip_prof.so")
+from damapper_amd import dazzdb, driver
+import bench
+
+clen, ncontig, kind, _ = bench.WORKLOADS["grch38"]
+ncontig = 3
+G = dazzdb.native_genome(20, [clen] * ncontig, kind, families=496)
+L = capi.lib()
+m = driver.Mapper(threads=4, mem_limit=64 << 30, sort_path="/tmp/rsprof", retain_ref=True)
+ref_whole = dazzdb.genome_block(G, path=b"./.REF")
+m.make_spec([ref_whole.db.freq[j] for j in range(4)])
+blk = dazzdb.genome_block(G, 0, ncontig, part=1, path=b"./.REF", copy=True)
+m.add_ref_block(blk, 0, drop_bases=True)
+L.dmh_timing_enable(1)
+out = (C.c_ulonglong * 16)()
+L.dmh_rs_profile.argtypes = [C.c_void_p, C.c_int]
+for b in range(3):
+    reads = dazzdb.simulate_block_genome(1000 + b, G, 25000, tfirst=0, part=1, path=b"./.READS")
+    if b == 1:
+        L.dmh_rs_profile(out, 1)
+        L.dmh_timing_reset()
+    m.map_block(reads, "READS.1", [blk], ref_whole, "REF")
+L.dmh_rs_profile(out, 0)
+v = list(out)
+names = ["load", "rank (ballots)", "digit scan", "scatter + reload", "flags + scan", "convert + records", "cluster ranks + store"]
+tot = sum(v[:7])
+print("workgroups %d, hits %d (%.0f per workgroup)" % (v[8], v[9], v[9] / max(1, v[8])))
+for i, nm in enumerate(names):
+    print("%-24s %6.1f %%  %8.0f cycles per workgroup" % (nm, 100.0 * v[i] / max(1, tot), v[i] / max(1, v[8])))
+print({k: round(x["ms"], 1) for k, x in sorted(capi.timings().items(), key=lambda kv: -kv[1]["ms"])[:10]})
