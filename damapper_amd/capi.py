@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
     L.dmh_read_cover.restype = C.c_int
     L.dmh_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
     L.dmh_sort_pairs.restype = C.c_int
+    L.dmh_exclusive_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.dmh_exclusive_scan.restype = C.c_int
     L.dmh_local_alignment.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -103,7 +105,7 @@ def exported_symbols() -> List[str]:
             "dmh_device_count", "dmh_last_error", "dmh_reset", "dmh_preload_block", "dmh_release_block",
             "dmh_retain_ref_index", "dmh_free_index", "dmh_index_download", "dmh_capture_seeds",
             "dmh_last_seed_count", "dmh_last_seeds", "dmh_last_limit", "dmh_read_candidates",
-            "dmh_candidate_jumps", "dmh_read_cover", "dmh_sort_pairs", "dmh_local_alignment",
+            "dmh_candidate_jumps", "dmh_read_cover", "dmh_sort_pairs", "dmh_exclusive_scan", "dmh_local_alignment",
             "dmh_timing_enable", "dmh_timing_reset", "dmh_timing_count", "dmh_timing_get", "dmh_sync",
             "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free", "dmh_test_option", "dmh_ref_cache",
             "dmh_preload_block_2bit", "dmh_download_block", "dmh_prepare_block", "dmh_device_memory"]

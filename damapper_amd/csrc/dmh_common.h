@@ -82,11 +82,13 @@ void copy_h2d(void *dev, const void *host, size_t bytes);
 template <typename T> struct DevBuf
 { T     *p   = nullptr;
   size_t cap = 0;      // elements
+  unsigned gen = 0;    // allocations so far (whoever keeps state INSIDE the buffer between calls checks this)
   void ensure(size_t n, const char *what)
   { if (n > cap)
       { if (p) dev_free(p);
         cap = n + n / 8 + 256;
         p   = (T *) dev_alloc(cap * sizeof(T), what);
+        gen += 1;
       }
   }
   void release()

@@ -1589,4 +1589,34 @@ int dmh_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbits)
   return 0;
 }
 
+// Stage-level: exclusive scan of n uint32 in place (the device-wide scan the sorts and the filter use), repeated `reps`
+// times on the device copy of the input; *total = the sum; *ms (may be null) = mean time of one scan.
+int dmh_exclusive_scan(uint32_t *data, int64_t n, int reps, uint32_t *total, double *ms)
+{ if (n <= 0) return 0;
+  State &st = S();
+  uint32_t *din = (uint32_t *) dev_alloc(sizeof(uint32_t) * n, "scan input");
+  uint32_t *dout = (uint32_t *) dev_alloc(sizeof(uint32_t) * (n + 1), "scan output");
+  copy_h2d(din, data, sizeof(uint32_t) * n);
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  exclusive_scan_u32((const uint32_t *) din, dout, n, st.sort.bsum, dout + n);         // (allocations, first-use set-up)
+  HIP_CHECK(hipEventRecord(e0, stream()));
+  for (int r = 0; r < (reps > 0 ? reps : 1); r++)
+    exclusive_scan_u32((const uint32_t *) din, dout, n, st.sort.bsum, dout + n);
+  HIP_CHECK(hipEventRecord(e1, stream()));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float t = 0;
+  HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+  if (ms != nullptr) *ms = (double) t / (reps > 0 ? reps : 1);
+  copy_d2h(data, dout, sizeof(uint32_t) * n);
+  if (total != nullptr) copy_d2h(total, dout + n, sizeof(uint32_t));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  HIP_CHECK(hipEventDestroy(e0));
+  HIP_CHECK(hipEventDestroy(e1));
+  dev_free(din);
+  dev_free(dout);
+  return 0;
+}
+
 }  // extern "C"

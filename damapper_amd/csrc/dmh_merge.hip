@@ -1028,8 +1028,32 @@ static std::deque<int> g_inflight;
 
 MergeResult &filter_batch() { return g_ring[g_cur]; }
 
+// k_read_sort ranks by the values LDS atomic adds return: true when this device serves them in lane order (it does on
+// gfx950; checked once, some 200,000 adds over conflict patterns from one to 127 counters in play)
+static bool lds_atomics_ordered()
+{ static int known = -1;
+  if (known < 0)
+    { static const bool off = getenv("DMH_NO_LDS_ORDER") != nullptr;
+      unsigned int bad = 1;
+      if (!off)
+        { DevBuf<uint32_t> d;
+          d.ensure(4, "LDS order test");
+          HIP_CHECK(hipMemsetAsync(d.p, 0, 4 * sizeof(uint32_t), stream()));
+          for (uint32_t seed = 1; seed <= 3; seed++)
+            hipLaunchKernelGGL(k_lds_order_test, dim3(28), dim3(256), 0, stream(), seed, d.p);
+          HIP_CHECK(hipGetLastError());
+          copy_d2h(&bad, d.p, sizeof(unsigned int));
+          d.release();
+        }
+      known = (bad == 0) ? 1 : 0;
+      if (getenv("DMH_STATS")) fprintf(stderr, "dmh: LDS atomics served in lane order: %s\n", known ? "yes" : "no (ballot ranks)");
+    }
+  return known == 1;
+}
+
 // per-read route: segment starts of the pass being collected (main stream only; a dense pass is closed at once)
-static DevBuf<uint32_t> g_rstart, g_rowdst, g_rstats, g_rlists;
+static DevBuf<uint32_t> g_rstart, g_rowdst, g_rstats, g_rlists, g_wlist[2];
+static DevBuf<unsigned int> g_wcnt;
 static uint32_t g_rcnt[4] = {0, 0, 0, 0}, g_rlim = 0;      // reads per k_read_sort workgroup size, largest segment; its limit
 constexpr int RS_T0 = 256, RS_T1 = 512, RS_T2 = 1024;      // k_read_sort workgroups: segments of up to 4,096 / 8,192 / 16,384 hits
 
@@ -1251,8 +1275,10 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // --- the per-read route (dmh_readsort.h): a dense pass in one-word mode writes its hits read by read
   static const int env_rs = getenv("DMH_READ_SORT") ? atoi(getenv("DMH_READ_SORT")) : 1;
   static const bool env_per_entry = getenv("DMH_EXPAND_PER_ENTRY") != nullptr;
+  const int  rs_cb = std::min(RS_CB, R.qbits);
   const bool by_read = R.word && R.npass == 0 && !env_per_entry && st.opt_expand != 0 &&
-                       (st.opt_read_sort >= 0 ? st.opt_read_sort != 0 : env_rs != 0);
+                       (st.opt_read_sort >= 0 ? st.opt_read_sort != 0 : env_rs != 0) &&
+                       (R.pbits + RS_DB - 1) / RS_DB + (R.qbits - rs_cb + R.bbits + RS_DB - 1) / RS_DB <= RS_MAXPASS;
   R.read_sorted = false;
 
   // --- expand the entries under the limit into hits (map.c:3095-3099), behind the batch's earlier passes
@@ -1474,8 +1500,22 @@ static void close_batch(MergeResult &R)
           HIP_CHECK(hipMemsetAsync(rncl.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
           ReadSortArgs RA;
           RA.in = k0; RA.out = k1; RA.rstart = g_rstart.p;
-          RA.pbits = R.pbits; RA.qbits = qbits; RA.bbits = R.bbits; RA.cb = cb;
-          RA.kbits = qbits - cb + R.bbits;
+          // the coarse buckets of this route (32 kb: a locus rarely lies across two) and its radix passes: the digits
+          // of apos, then those of the coarse key, each field cut into equal digits of at most RS_DB bits
+          const int rcb = std::min(RS_CB, qbits), kbits = qbits - rcb + R.bbits;
+          RA.pbits = R.pbits; RA.qbits = qbits; RA.bbits = R.bbits; RA.cb = rcb;
+          RA.npass = 0;
+          for (int f = 0; f < 2; f++)
+            { const int bits = f ? kbits : R.pbits, first = f ? R.pbits + rcb : 0;
+              const int nd = (bits + RS_DB - 1) / RS_DB;
+              for (int k = 0, at = 0; k < nd; k++)
+                { const int wdt = (bits - at + (nd - k) - 1) / (nd - k);
+                  RA.sh[RA.npass] = (uint8_t) (first + at); RA.wd[RA.npass] = (uint8_t) wdt;
+                  RA.npass += 1; at += wdt;
+                }
+            }
+          // ("read_sort" test option = 5: ranks from ballots, as on a device whose LDS does not serve atomics in lane order)
+          RA.ordered = (lds_atomics_ordered() && st.opt_read_sort != 5) ? 1 : 0;
           RA.lcl = lcl.p; RA.rncl = rncl.p;
           static bool attr = false;
           if (!attr)
@@ -1490,7 +1530,7 @@ static void close_batch(MergeResult &R)
                                             (int) read_sort_lds<RS_T2>()));
             }
           // clusters ordered on 32-bit words when apos leaves the room ("read_sort" test option = 4: on 64-bit words)
-          const bool k32 = R.pbits + cb + 6 <= 32 && st.opt_read_sort != 4;
+          const bool k32 = R.pbits + rcb + 6 <= 32 && st.opt_read_sort != 4;
           { // (8 B read + 8 B written per hit); the largest segments first: they are the longest jobs
             StageTimer tm("read_sort", 16.0 * nhits);
             if (g_rcnt[2] > 0)
@@ -1516,9 +1556,14 @@ static void close_batch(MergeResult &R)
           R.ngroups = ncl;
           R.gstart.ensure((size_t) ncl + 1, "cluster starts");
           R.gkey.ensure((size_t) ncl + 1, "cluster keys");
+          g_wlist[0].ensure((size_t) ncl + 64, "clusters for the workgroup sort");
+          g_wlist[1].ensure((size_t) ncl + 64, "clusters for the radix sort");
+          g_wcnt.ensure(4, "cluster sort counters");
+          HIP_CHECK(hipMemsetAsync(g_wcnt.p, 0, 4 * sizeof(unsigned int), stream()));
           hipLaunchKernelGGL(k_cluster_compact, dim3(ceil_div((int64_t) nr * 64, 256)), dim3(256), 0, stream(),
                              (const uint64_t *) lcl.p, (const uint32_t *) g_rstart.p, (const uint32_t *) rncl.p, nr, R.bbits,
-                             (uint32_t) nhits, R.gstart.p, R.gkey.p);
+                             (uint32_t) nhits, R.gstart.p, R.gkey.p, (uint32_t) RS_IN, (uint32_t) CS_MEDIUM,
+                             g_wlist[0].p, g_wlist[1].p, g_wcnt.p);
           std::swap(k0, k1);
         }
       else if (R.word)
@@ -1567,23 +1612,25 @@ static void close_batch(MergeResult &R)
           blist.ensure((size_t) ncl + 64, "clusters for the radix sort");
           cnt.ensure(4, "cluster sort counters");
           HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned int), stream()));
-          hipLaunchKernelGGL(k_csort_classify, dim3(ceil_div(ncl, 1024)), dim3(1024), 0, stream(), (const uint32_t *) R.gstart.p,
-                             ncl, mlist.p, blist.p, cnt.p);
+          if (!rs)
+            hipLaunchKernelGGL(k_csort_classify, dim3(ceil_div(ncl, 1024)), dim3(1024), 0, stream(), (const uint32_t *) R.gstart.p,
+                               ncl, mlist.p, blist.p, cnt.p);
           if (rs)
-            { // the small clusters are in order already; the others are sorted where they lie, on both positions
-              hipLaunchKernelGGL(k_csort_wide, dim3(8192), dim3(64), CS_WAVE * sizeof(uint64_t), stream(), k0,
-                                 (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p,
+            { // only the clusters that span coarse buckets and were too large for k_read_sort are left (k_cluster_compact
+              // has listed them): sorted where they lie, on both positions
+              hipLaunchKernelGGL(k_csort_wide, dim3(4096), dim3(64), CS_WAVE * sizeof(uint64_t), stream(), k0,
+                                 (const uint32_t *) R.gstart.p, (const uint32_t *) g_wlist[0].p, (const unsigned int *) g_wcnt.p,
                                  (uint32_t) CS_SMALL, (uint32_t) CS_WAVE);
-              hipLaunchKernelGGL(k_csort_wide, dim3(2048), dim3(256), CS_MEDIUM * sizeof(uint64_t), stream(), k0,
-                                 (const uint32_t *) R.gstart.p, (const uint32_t *) mlist.p, (const unsigned int *) cnt.p,
+              hipLaunchKernelGGL(k_csort_wide, dim3(1024), dim3(256), CS_MEDIUM * sizeof(uint64_t), stream(), k0,
+                                 (const uint32_t *) R.gstart.p, (const uint32_t *) g_wlist[0].p, (const unsigned int *) g_wcnt.p,
                                  (uint32_t) CS_WAVE, (uint32_t) CS_MEDIUM);
               HIP_CHECK(hipGetLastError());
               unsigned int hc[2] = {0, 0};
-              copy_d2h(hc, cnt.p, 2 * sizeof(unsigned int), 1);
+              copy_d2h(hc, g_wcnt.p, 2 * sizeof(unsigned int), 1);
               if (hc[1] > 0)
-                { // repeat piles: stable radix passes on bpos (the high half of the word), then on apos
+                { // repeat piles across buckets: stable radix passes on bpos (the high half of the word), then on apos
                   std::vector<uint32_t> big(hc[1]), gs((size_t) ncl + 1);
-                  copy_d2h(big.data(), blist.p, sizeof(uint32_t) * hc[1]);
+                  copy_d2h(big.data(), g_wlist[1].p, sizeof(uint32_t) * hc[1]);
                   copy_d2h(gs.data(), R.gstart.p, sizeof(uint32_t) * ((size_t) ncl + 1));
                   for (uint32_t c : big)
                     { const int64_t b0 = gs[c], bn = (int64_t) gs[c + 1] - b0;

@@ -7,18 +7,24 @@
 // fits the LDS of one workgroup.  So the merge writes every hit straight into its READ's segment (the segments are
 // laid out by an atomic count per row of the merge and a scan over the reads: dmh_merge.hip k_row_place), and one
 // workgroup per read
-//   1. sorts the segment by the coarse key (bread, bpos >> cb) -- stable LSD radix passes of up to 9 bits, ranks from
-//      wavefront ballots, the words held in registers between reading and re-writing the one LDS copy;
-//   2. cuts it into B-clusters (pair changes, or a gap of more than one coarse bucket: the definition of round 2's
-//      k_wcluster_count, so both routes give the same clusters);
-//   3. puts every cluster of up to RS_IN hits into (apos, bpos) order by rank counting in LDS and writes the chain
-//      kernels' words (apos | bpos << 32) to their final places; larger clusters are written as they are and finished
-//      by k_csort_wide (dmh_merge.hip), the rare repeat piles by the radix sort;
-//   4. leaves one record per cluster (first hit, contig) for k_cluster_compact, which numbers the clusters of all
-//      reads (scan over the reads' counts) into gstart / gkey.
-// The order inside a segment as the merge leaves it is arbitrary (atomic placement), which is harmless: the hits of a
-// read are distinct in (bread, bpos, apos), and every step above ends in a total order on those.
-// HBM traffic per hit: 8 B written by the merge, 8 B read and 8 B written here.
+//   1. sorts the segment by (coarse key, apos), the coarse key being (bread, bpos >> cb): stable LSD radix passes,
+//      the words held in registers between reading and re-writing the one LDS copy.  A word's rank among the words of
+//      its wavefront with the same digit is what its add to the wavefront's LDS counter of the digit RETURNS: the LDS
+//      serves the lanes of one ds_add_rtn in ascending lane order and a wavefront's instructions in program order
+//      (checked when the library starts, lds_atomics_ordered(); wavefront ballots -- nine per word and pass instead of
+//      one instruction -- take over where that should not hold).  A row of the merge (one READ k-mer and its
+//      partners) lies in the segment in bpos order, so equal (bucket, apos) end in bpos order too;
+//   2. cuts it into B-clusters: a pair change, or a gap of more than one coarse bucket (a union of gap-connected
+//      sets, which is all the chain kernels need);
+//   3. a cluster inside ONE bucket is in (apos, bpos) order by now.  The others (a locus across a bucket boundary;
+//      marked in a bit per cluster) are put into that order by rank counting in LDS (up to RS_IN hits), or left to
+//      k_csort_wide / the radix sort (dmh_merge.hip), for which k_cluster_compact lists them;
+//   4. writes the chain kernels' words (apos | bpos << 32) to their final places and leaves one record per cluster
+//      (first hit, contig, "spans buckets") for k_cluster_compact, which numbers the clusters of all reads (scan
+//      over the reads' counts) into gstart / gkey.
+// The order of the rows inside a segment as the merge leaves it is arbitrary (atomic placement), which is harmless:
+// the hits of a read are distinct in (bread, bpos, apos).  HBM traffic per hit: 8 B written by the merge, 8 B read and
+// 8 B written here.
 #pragma once
 
 namespace dmh {
@@ -26,6 +32,8 @@ namespace dmh {
 constexpr int RS_E  = 16;        // words per thread: a workgroup of T threads takes segments of up to 16 T hits
 constexpr int RS_IN = 64;        // clusters of up to this many hits are ordered inside k_read_sort (= CS_SMALL)
 constexpr int RS_DB = 9;         // most bits of a radix digit
+constexpr int RS_MAXPASS = 8;
+constexpr int RS_CB = 15;        // coarse buckets of 32 kb: one locus in fifteen lies across a boundary
 
 struct ReadSortArgs
 { const uint64_t *in;            // the pass's words, read by read (w = aread | bread | bpos | apos)
@@ -33,8 +41,10 @@ struct ReadSortArgs
   const uint32_t *rstart;        // first word of every read (+ end)
   const uint32_t *list;          // the reads this launch takes, one per workgroup (k_read_classes)
   int             pbits, qbits, bbits, cb;
-  int             kbits;         // bits of the coarse key (bread, bpos >> cb)
-  uint64_t       *lcl;           // per cluster, at rstart[r] + j: contig << 32 | first word
+  int             npass;         // radix passes, least significant digit first: apos, then the coarse key
+  uint8_t         sh[RS_MAXPASS], wd[RS_MAXPASS];        // first bit and width of each digit
+  int             ordered;       // the LDS serves atomics in lane order (else: ballots)
+  uint64_t       *lcl;           // per cluster, at rstart[r] + j: spans buckets << 63 | contig << 32 | first word
   uint32_t       *rncl;          // clusters per read
 };
 
@@ -69,19 +79,49 @@ __device__ unsigned long long g_rsprof[16];
 #define RSPROF_ADD(i, v)
 #endif
 
-// LDS of a workgroup: the words, the first pass's counters (one set for the whole workgroup, 2^RS_B1 digits, two
-// 16-bit counters per word), the later passes' counters (one set per wavefront), the cluster-start bits.
-constexpr int RS_B1 = 11;        // most bits of the first (unstable) pass's digit
+// What the ranks of k_read_sort rest on: 64 lanes add to a handful of LDS words (two 16-bit counters each) in several
+// rounds; every add must return the number of earlier adds to its counter -- lower lanes of its round, all lanes of
+// earlier rounds -- as counted with ballots.  bad[0] = number of adds for which it did not.
+__global__ __launch_bounds__(256) void k_lds_order_test(uint32_t seed, uint32_t *bad)
+{ __shared__ uint32_t cnt[4][64];
+  __shared__ uint32_t ref[4][128];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int x = threadIdx.x; x < 4 * 64; x += 256) (&cnt[0][0])[x] = 0;
+  for (int x = threadIdx.x; x < 4 * 128; x += 256) (&ref[0][0])[x] = 0;
+  __syncthreads();
+  uint32_t s = seed * 2654435761u + (blockIdx.x * 256u + threadIdx.x) * 40503u + 1u, nbad = 0;
+  const int distinct = 1 + (int) (blockIdx.x % 7) * 21;          // 1 .. 127 different digits in play
+  for (int r = 0; r < 12; r++)
+    { s = s * 1664525u + 1013904223u;
+      const uint32_t d = ((s >> 11) % (uint32_t) distinct) & 127u, hs = (d & 1u) * 16u;
+      const uint32_t got = (atomicAdd(&cnt[w][d >> 1], 1u << hs) >> hs) & 0xffffu;
+      uint64_t peers = ~0ull;
+      for (int b = 0; b < 7; b++)
+        { const bool bit = (d >> b) & 1u;
+          const uint64_t bal = __ballot(bit);
+          peers &= bit ? bal : ~bal;
+        }
+      const uint32_t below = (uint32_t) __popcll(peers & ((1ull << lane) - 1ull));
+      const uint32_t before = ref[w][d];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (below == 0) ref[w][d] = before + (uint32_t) __popcll(peers);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (got != before + below) nbad += 1;
+    }
+  if (nbad) atomicAdd(bad, nbad);
+}
 
 template <int T, bool K32>
 __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
-{ constexpr int W = T / 64, D = 1 << RS_DB, D1 = 1 << RS_B1, E = RS_E;
+{ constexpr int W = T / 64, D = 1 << RS_DB, E = RS_E;
   extern __shared__ __attribute__((aligned(16))) uint64_t rs_lds[];
   uint64_t *buf   = rs_lds;                                   // T * E words
-  uint32_t *c1    = (uint32_t *) (buf + (size_t) T * E);      // D1 / 2 words: the first pass's counters, then offsets
-  uint16_t *wh    = (uint16_t *) c1;                          // W x D counters of the stable passes (the same LDS, later)
-  uint64_t *flagw = (uint64_t *) (c1 + (W * D > D1 ? W * D : D1) / 2);      // cluster-start bits, one word per 64 hits (+ sentinel)
-  uint16_t *wpref = (uint16_t *) (flagw + (T * E / 64 + 2));  // starts before each flag word
+  uint16_t *wh    = (uint16_t *) (buf + (size_t) T * E);      // W x D digit counters, then offsets
+  uint64_t *flagw = (uint64_t *) (wh + (size_t) W * D);       // cluster-start bits, one word per 64 hits (+ sentinel)
+  uint32_t *mbits = (uint32_t *) (flagw + (T * E / 64 + 2));  // per cluster: spans buckets (T * E / 32 + 2 words)
+  uint16_t *wpref = (uint16_t *) (mbits + (T * E / 32 + 2));  // starts before each flag word
   __shared__ uint32_t ws[W];
 
   const uint32_t r  = A.list[blockIdx.x];
@@ -107,100 +147,58 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
 #endif
   RSPROF_LAP(0);
 
-  // ---- 1a. the lowest b1 bits of the coarse key.  The words arrive in no particular order, so this pass need not be
-  // stable: a word's place among those with its digit is whatever its add to the workgroup's counter of the digit
-  // returns -- one LDS instruction per word where a stable pass pays nine ballots.
-  const int b1 = A.kbits < RS_B1 ? A.kbits : RS_B1;
-  if (b1 > 0)
-    { const int sh = A.pbits + A.cb;
-      const uint32_t dmask = (1u << b1) - 1u;
-      for (int x = tid; x < D1 / 2; x += T) c1[x] = 0;
-      __syncthreads();
-      uint32_t rk[E];
-#pragma unroll
-      for (int j = 0; j < E; j++)
-        { rk[j] = 0;
-          if ((uint32_t) j < rounds)
-            { const uint32_t i = wbase + 64u * j + lane;
-              const uint32_t d = (uint32_t) (key[j] >> sh) & dmask;
-              if (i < n) rk[j] = atomicAdd(&c1[d >> 1], 1u << ((d & 1u) * 16u));
-            }
-        }
-      __syncthreads();
-      RSPROF_LAP(1);
-      // exclusive scan of the D1 counters (digit order), in place
-      { constexpr int PER = (D1 / 2 + T - 1) / T;              // counter words per thread (consecutive)
-        uint32_t c[PER], tot = 0;
-#pragma unroll
-        for (int q = 0; q < PER; q++)
-          { const int x = tid * PER + q;
-            c[q] = (x < D1 / 2) ? c1[x] : 0u;
-            tot += (c[q] & 0xffffu) + (c[q] >> 16);
-          }
-        uint32_t all;
-        uint32_t run = block_excl_scan_t<T>(tot, ws, &all);
-#pragma unroll
-        for (int q = 0; q < PER; q++)
-          { const int x = tid * PER + q;
-            const uint32_t lo = run, hi = run + (c[q] & 0xffffu);
-            run = hi + (c[q] >> 16);
-            if (x < D1 / 2) c1[x] = lo | (hi << 16);
-          }
-      }
-      __syncthreads();
-      RSPROF_LAP(2);
-#pragma unroll
-      for (int j = 0; j < E; j++)
-        if ((uint32_t) j < rounds)
-          { const uint32_t i = wbase + 64u * j + lane;
-            if (i < n)
-              { const uint32_t d = (uint32_t) (key[j] >> sh) & dmask, hs = (d & 1u) * 16u;
-                buf[((c1[d >> 1] >> hs) & 0xffffu) + ((rk[j] >> hs) & 0xffffu)] = key[j];
-              }
-          }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < E; j++)
-        if ((uint32_t) j < rounds)
-          { const uint32_t i = wbase + 64u * j + lane;
-            key[j] = (i < n) ? buf[i] : ~0ull;
-          }
-      __syncthreads();
-      RSPROF_LAP(3);
-    }
-
-  // ---- 1b. the remaining bits: stable LSD passes of up to RS_DB bits, ranks inside a wavefront from ballots
+  // ---- 1. stable LSD passes: apos, then the coarse key
   uint16_t *mywh = wh + (size_t) w * D;
-  for (int done = b1; done < A.kbits; done += RS_DB)
-    { const int sh = A.pbits + A.cb + done;
-      const int wd = (A.kbits - done < RS_DB) ? A.kbits - done : RS_DB;
+  uint32_t *my32 = (uint32_t *) mywh;
+  for (int p = 0; p < A.npass; p++)
+    { const int sh = A.sh[p], wd = A.wd[p];
       const uint32_t dmask = (1u << wd) - 1u;
-      for (int x = tid; x < W * D; x += T) wh[x] = 0;
+      for (int x = tid; x < W * D / 2; x += T) ((uint32_t *) wh)[x] = 0;
       __syncthreads();
       uint32_t rk[E];
+      if (A.ordered)
+        { // the counter before the add = words of this wavefront with the digit in earlier rounds and lower lanes
 #pragma unroll
-      for (int j = 0; j < E; j++)
-        { if ((uint32_t) j < rounds)                           // (uniform)
-            { const uint32_t i  = wbase + 64u * j + lane;
-              const bool     ok = i < n;
-              const uint32_t d  = (uint32_t) (key[j] >> sh) & dmask;
-              uint64_t peers = __ballot(ok);
-              for (int b = 0; b < wd; b++)
-                { const bool     bit = (d >> b) & 1u;
-                  const uint64_t bal = __ballot(bit);
-                  peers &= bit ? bal : ~bal;
+          for (int j = 0; j < E; j++)
+            { rk[j] = 0;
+              if ((uint32_t) j < rounds)
+                { const uint32_t i = wbase + 64u * j + lane;
+                  const uint32_t d = (uint32_t) (key[j] >> sh) & dmask;
+                  if (i < n) rk[j] = atomicAdd(&my32[d >> 1], 1u << ((d & 1u) * 16u));
                 }
-              const uint32_t below = (uint32_t) __popcll(peers & lt);
-              const uint32_t cnt   = (uint32_t) __popcll(peers);
-              const uint32_t b0    = ok ? (uint32_t) mywh[d] : 0u;
-              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              if (ok && below == 0) mywh[d] = (uint16_t) (b0 + cnt);
-              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              rk[j] = b0 + below;
             }
-          __builtin_amdgcn_sched_barrier(0);                   // (one item at a time: interleaved, their ballots spill)
+#pragma unroll
+          for (int j = 0; j < E; j++)
+            if ((uint32_t) j < rounds)
+              rk[j] = (rk[j] >> ((((uint32_t) (key[j] >> sh) & dmask) & 1u) * 16u)) & 0xffffu;
+        }
+      else
+        {
+#pragma unroll
+          for (int j = 0; j < E; j++)
+            { rk[j] = 0;
+              if ((uint32_t) j < rounds)                       // (uniform)
+                { const uint32_t i  = wbase + 64u * j + lane;
+                  const bool     ok = i < n;
+                  const uint32_t d  = (uint32_t) (key[j] >> sh) & dmask;
+                  uint64_t peers = __ballot(ok);
+                  for (int b = 0; b < wd; b++)
+                    { const bool     bit = (d >> b) & 1u;
+                      const uint64_t bal = __ballot(bit);
+                      peers &= bit ? bal : ~bal;
+                    }
+                  const uint32_t below = (uint32_t) __popcll(peers & lt);
+                  const uint32_t cnt   = (uint32_t) __popcll(peers);
+                  const uint32_t b0    = ok ? (uint32_t) mywh[d] : 0u;
+                  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  if (ok && below == 0) mywh[d] = (uint16_t) (b0 + cnt);
+                  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  rk[j] = b0 + below;
+                }
+              __builtin_amdgcn_sched_barrier(0);               // (one item at a time: interleaved, their ballots spill)
+            }
         }
       __syncthreads();
       RSPROF_LAP(1);
@@ -249,8 +247,8 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
       __syncthreads();                                         // (everybody has its words: buf and wh are free again)
       RSPROF_LAP(3);
     }
-  if (A.kbits == 0)
-    { // (a key of no bits: one contig and one bucket -- the words only have to be in LDS)
+  if (A.npass == 0)
+    {
 #pragma unroll
       for (int j = 0; j < E; j++)
         if ((uint32_t) j < rounds)
@@ -260,15 +258,21 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
       __syncthreads();
     }
 
-  // ---- 2. cluster starts: bit i of the flag words; the words of a wavefront are consecutive, so a ballot is a flag word
+  // ---- 2. cluster starts: bit i of the flag words (the words of a round are consecutive, so a ballot is a flag word),
+  // and the positions inside a cluster at which the bucket changes
   const uint32_t nw = n / 64 + 1;                              // flag words, the sentinel bit n included
+  uint32_t chg = 0;                                            // bit j: my word of round j opens a new bucket inside its cluster
+  for (int x = tid; x < (int) (n / 32 + 1); x += T) mbits[x] = 0;
 #pragma unroll
   for (int j = 0; j < E; j++)
     if ((uint32_t) j < rounds)
       { const uint32_t i = wbase + 64u * j + lane;
         bool f = false;
         if (i < n)
-          f = (i == 0) || cluster_start(buf[i - 1] >> A.pbits, key[j] >> A.pbits, A.qbits, A.cb);
+          { const uint64_t pv = (i > 0) ? buf[i - 1] >> A.pbits : 0, cv = key[j] >> A.pbits;
+            f = (i == 0) || cluster_start(pv, cv, A.qbits, A.cb);
+            if (!f && (pv >> A.cb) != (cv >> A.cb)) chg |= 1u << j;
+          }
         else if (i == n)
           f = true;                                            // sentinel: the end of the last cluster
         const uint64_t m = __ballot(f);
@@ -288,49 +292,71 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
     if ((uint32_t) tid < nw) wpref[tid] = (uint16_t) e;
   }
   __syncthreads();
+  // the cluster of every word (starts at or below it, minus one); a bucket change marks its cluster
+  uint16_t cid[E];
+#pragma unroll
+  for (int j = 0; j < E; j++)
+    { cid[j] = 0;
+      if ((uint32_t) j < rounds)
+        { const uint32_t i = wbase + 64u * j + lane, wi = i >> 6, bi = i & 63;
+          if (i < n)
+            { const uint32_t c = (uint32_t) wpref[wi] + (uint32_t) __popcll(flagw[wi] & (~0ull >> (63 - bi))) - 1u;
+              cid[j] = (uint16_t) c;
+              if ((chg >> j) & 1u) atomicOr(&mbits[c >> 5], 1u << (c & 31u));
+            }
+        }
+    }
+  if (tid == 0) A.rncl[r] = ncl;
+  __syncthreads();
   RSPROF_LAP(4);
 
-  // A round is 64 consecutive, aligned positions, i.e. ONE flag word.  The start of a lane's cluster is the highest flag
-  // at or below its position (in this word or the one before: a cluster that begins earlier is longer than RS_IN anyway),
-  // its end the lowest flag above (this word or the next).  Every start leaves its cluster's record.
-  // What a cluster is ordered by: (apos, bpos).  K32: as ONE 32-bit word, apos above bpos minus the first base of the
-  // cluster's first coarse bucket -- a cluster of up to RS_IN hits spans at most RS_IN adjacent buckets, so the difference
-  // fits the bits apos leaves free (pbits + cb + 6 <= 32: reads of up to 16 kb); else as apos << 32 | bpos.
+  // ---- 3. every start leaves its cluster's record; the words of clusters that span buckets look for their cluster's
+  // bounds: a round is 64 consecutive, aligned positions, i.e. ONE flag word; the start of a lane's cluster is the highest
+  // flag at or below its position (in this word or the one before: a cluster that begins earlier is longer than RS_IN
+  // anyway), its end the lowest flag above (this word or the next).
+  // What such a cluster is ordered by: (apos, bpos).  K32: as ONE 32-bit word, apos above bpos minus the first base of the
+  // cluster's first coarse bucket -- RS_IN hits or fewer, so RS_IN adjacent buckets at most, and the difference fits the
+  // bits apos leaves free (pbits + cb + 6 <= 32); else as apos << 32 | bpos.
   const uint64_t pm = (1ull << A.pbits) - 1ull, qm = (1ull << A.qbits) - 1ull, bm = (1ull << A.bbits) - 1ull;
   uint32_t se[E];                                              // start | length << 16 (length 0: the hit keeps its position)
   uint32_t k32[K32 ? E : 1];
+  uint32_t anym = 0;                                           // bit j: some lane of round j has a cluster to sort within
 #pragma unroll
   for (int j = 0; j < E; j++)
     { se[j] = 0;
       if (K32) k32[j] = 0;
       if ((uint32_t) j < rounds)
         { const uint32_t i = wbase + 64u * j + lane, wi = i >> 6, bi = i & 63;
-          const uint64_t f0 = flagw[wi > 0 ? wi - 1 : 0], f1 = flagw[wi < nw ? wi : 0], f2 = flagw[wi + 1 < nw ? wi + 1 : 0];
+          bool multi = false;
           if (i < n)
-            { const uint64_t x = key[j];
-              if ((f1 >> bi) & 1ull)
-                { const uint32_t c = (uint32_t) wpref[wi] + (uint32_t) __popcll(f1 & ((1ull << bi) - 1ull));
-                  A.lcl[s0 + c] = (((x >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
-                }
-              uint32_t s = 0xffffffffu, e = 0xffffffffu;
-              const uint64_t ms = f1 & (~0ull >> (63 - bi));
-              if (ms) s = wi * 64 + 63 - (uint32_t) __clzll((long long) ms);
-              else if (wi > 0 && f0) s = (wi - 1) * 64 + 63 - (uint32_t) __clzll((long long) f0);
-              const uint64_t me = (bi == 63) ? 0ull : (f1 & (~0ull << (bi + 1)));
-              if (me) e = wi * 64 + (uint32_t) __ffsll((long long) me) - 1;
-              else if (wi + 1 < nw && f2) e = (wi + 1) * 64 + (uint32_t) __ffsll((long long) f2) - 1;
-              if (s != 0xffffffffu && e != 0xffffffffu && e - s <= (uint32_t) RS_IN)
-                { se[j] = s | ((e - s) << 16);
-                  if (K32)
-                    { const uint32_t base = (uint32_t) ((buf[s] >> A.pbits) & qm) >> A.cb << A.cb;
-                      k32[j] = ((uint32_t) (x & pm) << (32 - A.pbits)) | ((uint32_t) ((x >> A.pbits) & qm) - base);
+            { const uint32_t c = cid[j];
+              multi = (mbits[c >> 5] >> (c & 31u)) & 1u;
+              if ((flagw[wi] >> bi) & 1ull)
+                A.lcl[s0 + c] = ((uint64_t) multi << 63) | (((key[j] >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
+            }
+          if (__any(multi))                                    // (one locus in fifteen: most rounds skip this)
+            { const uint64_t f0 = flagw[wi > 0 ? wi - 1 : 0], f1 = flagw[wi < nw ? wi : 0], f2 = flagw[wi + 1 < nw ? wi + 1 : 0];
+              if (multi)
+                { const uint64_t x = key[j];
+                  uint32_t s = 0xffffffffu, e = 0xffffffffu;
+                  const uint64_t ms = f1 & (~0ull >> (63 - bi));
+                  if (ms) s = wi * 64 + 63 - (uint32_t) __clzll((long long) ms);
+                  else if (wi > 0 && f0) s = (wi - 1) * 64 + 63 - (uint32_t) __clzll((long long) f0);
+                  const uint64_t me = (bi == 63) ? 0ull : (f1 & (~0ull << (bi + 1)));
+                  if (me) e = wi * 64 + (uint32_t) __ffsll((long long) me) - 1;
+                  else if (wi + 1 < nw && f2) e = (wi + 1) * 64 + (uint32_t) __ffsll((long long) f2) - 1;
+                  if (s != 0xffffffffu && e != 0xffffffffu && e - s <= (uint32_t) RS_IN)
+                    { se[j] = s | ((e - s) << 16);
+                      if (K32)
+                        { const uint32_t base = (uint32_t) ((buf[s] >> A.pbits) & qm) >> A.cb << A.cb;
+                          k32[j] = ((uint32_t) (x & pm) << (32 - A.pbits)) | ((uint32_t) ((x >> A.pbits) & qm) - base);
+                        }
                     }
                 }
+              if (__any(se[j] != 0)) anym |= 1u << j;
             }
         }
-      if (j & 1) __builtin_amdgcn_sched_barrier(0);            // (two rounds' loads in flight, not sixteen: registers)
     }
-  if (tid == 0) A.rncl[r] = ncl;
   __syncthreads();                                             // (nobody reads the sorted words any more)
   uint32_t *b32 = (uint32_t *) buf;
 #pragma unroll
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
       { const uint32_t i = wbase + 64u * j + lane;
         const uint64_t x = key[j];
         key[j] = (x & pm) | (((x >> A.pbits) & qm) << 32);     // the chain kernels' word: apos | bpos << 32
-        if (i < n)
+        if (se[j] != 0)                                        // (only the words of clusters that are ranked are read back)
           { if (K32) b32[i] = k32[j];
             else     buf[i] = (key[j] << 32) | (key[j] >> 32);
           }
@@ -347,50 +373,38 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   __syncthreads();
   RSPROF_LAP(5);
 
-  // ---- 3. clusters of up to RS_IN hits: rank by counting; the others keep the order they have.  Two rounds at a
-  // time, four words of each per turn: the LDS round trips of a turn overlap instead of following one another.
+  // ---- 4. clusters across buckets of up to RS_IN hits: rank by counting; everything else keeps its position
 #pragma unroll
-  for (int j = 0; j < E; j += 2)
+  for (int j = 0; j < E; j++)
     if ((uint32_t) j < rounds)
-      { const uint32_t sa = se[j] & 0xffffu, ma = se[j] >> 16, sb = se[j + 1] & 0xffffu, mb = se[j + 1] >> 16;
-        uint32_t ra = 0, rb = 0;
-        const uint32_t mm = ma > mb ? ma : mb;
-        if (K32)
-          { const uint32_t ka = k32[j], kb = k32[j + 1];
-            for (uint32_t t = 0; t < mm; t += 4)
-              { uint32_t va[4], vb[4];
+      { const uint32_t i = wbase + 64u * j + lane;
+        uint32_t dst = i;
+        if ((anym >> j) & 1u)                                  // (uniform)
+          { const uint32_t s = se[j] & 0xffffu, m = se[j] >> 16;
+            uint32_t rank = 0;
+            if (K32)
+              { const uint32_t kk = k32[j];
+                for (uint32_t t = 0; t < m; t += 4)
+                  { uint32_t v[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                  { va[u] = b32[sa + (t + u < ma ? t + u : 0)];
-                    vb[u] = b32[sb + (t + u < mb ? t + u : 0)];
-                  }
+                    for (int u = 0; u < 4; u++) v[u] = b32[s + (t + u < m ? t + u : 0)];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                  { ra += (t + u < ma && va[u] < ka) ? 1u : 0u;
-                    rb += (t + u < mb && vb[u] < kb) ? 1u : 0u;
+                    for (int u = 0; u < 4; u++) rank += (t + u < m && v[u] < kk) ? 1u : 0u;
                   }
               }
-          }
-        else
-          { const uint64_t ka = (key[j] << 32) | (key[j] >> 32), kb = (key[j + 1] << 32) | (key[j + 1] >> 32);
-            for (uint32_t t = 0; t < mm; t += 4)
-              { uint64_t va[4], vb[4];
+            else
+              { const uint64_t kk = (key[j] << 32) | (key[j] >> 32);
+                for (uint32_t t = 0; t < m; t += 4)
+                  { uint64_t v[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                  { va[u] = buf[sa + (t + u < ma ? t + u : 0)];
-                    vb[u] = buf[sb + (t + u < mb ? t + u : 0)];
-                  }
+                    for (int u = 0; u < 4; u++) v[u] = buf[s + (t + u < m ? t + u : 0)];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                  { ra += (t + u < ma && va[u] < ka) ? 1u : 0u;
-                    rb += (t + u < mb && vb[u] < kb) ? 1u : 0u;
+                    for (int u = 0; u < 4; u++) rank += (t + u < m && v[u] < kk) ? 1u : 0u;
                   }
               }
+            if (m) dst = s + rank;
           }
-        const uint32_t ia = wbase + 64u * j + lane, ib = ia + 64u;
-        if (ia < n) A.out[s0 + (ma ? sa + ra : ia)] = key[j];
-        if ((uint32_t) (j + 1) < rounds && ib < n) A.out[s0 + (mb ? sb + rb : ib)] = key[j + 1];
-        __builtin_amdgcn_sched_barrier(0);
+        if (i < n) A.out[s0 + dst] = key[j];
       }
 #ifdef DMH_RS_PROFILE
   __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
@@ -400,9 +414,9 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
 
 // dynamic LDS of k_read_sort<T>
 template <int T> constexpr size_t read_sort_lds()
-{ return sizeof(uint64_t) * (size_t) T * RS_E + sizeof(uint32_t) * ((1 << RS_B1) / 2)
-         + sizeof(uint16_t) * (size_t) (T / 64) * (1 << RS_DB)
-         + sizeof(uint64_t) * (T * RS_E / 64 + 2) + sizeof(uint16_t) * (T * RS_E / 64 + 2) + 64;
+{ return sizeof(uint64_t) * (size_t) T * RS_E + sizeof(uint16_t) * (size_t) (T / 64) * (1 << RS_DB)
+         + sizeof(uint64_t) * (T * RS_E / 64 + 2) + sizeof(uint32_t) * (T * RS_E / 32 + 2)
+         + sizeof(uint16_t) * (T * RS_E / 64 + 2) + 64;
 }
 
 // The reads by segment size, one list per workgroup size of k_read_sort (lists[c] at c * nreads): class 0 up to lim[0]
@@ -430,17 +444,45 @@ __global__ __launch_bounds__(256) void k_read_classes(const uint32_t *__restrict
 }
 
 // cbase = exclusive scan of rncl: the clusters of read r become clusters cbase[r] ... of the pass.  One wavefront per read.
+// Clusters that span coarse buckets and were too large for k_read_sort are listed for the sorts that finish them:
+// mlist (up to `medium` hits, k_csort_wide) and blist (larger: the radix sort); counts[0], counts[1] = list lengths.
 __global__ __launch_bounds__(256) void k_cluster_compact(const uint64_t *__restrict__ lcl, const uint32_t *__restrict__ rstart,
                                                          const uint32_t *__restrict__ cbase, int nreads, int bbits,
                                                          uint32_t nhits, uint32_t *__restrict__ gstart,
-                                                         uint64_t *__restrict__ gkey)
+                                                         uint64_t *__restrict__ gkey, uint32_t small, uint32_t medium,
+                                                         uint32_t *__restrict__ mlist, uint32_t *__restrict__ blist,
+                                                         unsigned int *__restrict__ counts)
 { const int r = (int) (((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (r >= nreads) return;
-  const uint32_t c0 = cbase[r], nc = cbase[r + 1] - c0, s0 = rstart[r];
-  for (uint32_t j = lane; j < nc; j += 64)
-    { const uint64_t v = lcl[s0 + j];
-      gstart[c0 + j] = (uint32_t) v;
-      gkey[c0 + j]   = ((uint64_t) r << bbits) | (v >> 32);
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t c0 = cbase[r], nc = cbase[r + 1] - c0, s0 = rstart[r], s1 = rstart[r + 1];
+  for (uint32_t j0 = 0; j0 < nc; j0 += 64)
+    { const uint32_t j = j0 + lane;
+      const bool ok = j < nc;
+      const uint64_t v = ok ? lcl[s0 + j] : 0;
+      const uint32_t st = (uint32_t) v;
+      uint32_t nx = (uint32_t) __shfl_down((int) st, 1);             // the next cluster's first hit
+      if (ok && (lane == 63 || j + 1 >= nc)) nx = (j + 1 < nc) ? (uint32_t) lcl[s0 + j + 1] : s1;
+      if (ok)
+        { gstart[c0 + j] = st;
+          gkey[c0 + j]   = ((uint64_t) r << bbits) | ((v >> 32) & 0x7fffffffull);
+        }
+      const uint32_t sz = ok ? nx - st : 0;
+      const bool wide = ok && (v >> 63) && sz > small;
+      const bool ism = wide && sz <= medium, isb = wide && sz > medium;
+      const uint64_t mm = __ballot(ism), mb = __ballot(isb);
+      if (mm)
+        { uint32_t base = 0;
+          if (lane == __ffsll((long long) mm) - 1) base = atomicAdd(counts, (uint32_t) __popcll(mm));
+          base = __shfl(base, __ffsll((long long) mm) - 1);
+          if (ism) mlist[base + (uint32_t) __popcll(mm & lt)] = c0 + j;
+        }
+      if (mb)
+        { uint32_t base = 0;
+          if (lane == __ffsll((long long) mb) - 1) base = atomicAdd(counts + 1, (uint32_t) __popcll(mb));
+          base = __shfl(base, __ffsll((long long) mb) - 1);
+          if (isb) blist[base + (uint32_t) __popcll(mb & lt)] = c0 + j;
+        }
     }
   if (r == nreads - 1 && lane == 0) gstart[cbase[nreads]] = nhits;
 }

@@ -74,8 +74,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t *data, int
 // fence, nothing else is communicated).  The status words are never cleared: they carry the number of the scan that
 // wrote them (epoch), and tickets count on from scan to scan.  15,000 three-kernel scans per 24 read blocks of the
 // bench workload (11-28 us per launch) were 14 ms per read block.
-constexpr int LB_ITEMS = 8;
+constexpr int LB_ITEMS = 16;
 constexpr int LB_TILE  = SCAN_THREADS * LB_ITEMS;
+constexpr int LB_LOOK  = 4;                          // status words a lane of the look-back reads per round (256 tiles a round)
+constexpr int64_t LB_MAX = (int64_t) 1 << 20;        // longer arrays take the three kernels (measured: 13.5 us either way at 1 M values, 55 against 31 us at 3.6 M; 6.7 against 10.8 us at 25 k)
 
 __device__ __forceinline__ uint64_t lb_pack(uint32_t epoch, uint32_t flag, uint32_t value)
 { return ((uint64_t) epoch << 34) | ((uint64_t) flag << 32) | (uint64_t) value; }
@@ -103,21 +105,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const uint32_t *
       if (tile == 0) s_prefix = 0;
     }
   if (tile > 0 && tid < 64)
-    { uint32_t prefix = 0;
+    { // All tiles of a scan are resident at once and start together, so a tile finds its predecessors' SUMS soon but
+      // their prefixes late: a round takes in 256 predecessors (four per lane, nearest first), adds up the sums in front
+      // of the nearest finished prefix, and goes further back only when there is none among them.
+      uint32_t prefix = 0;
       int64_t  p = (int64_t) tile - 1;                 // the nearest tile not yet accounted for
       while (true)
-        { const int64_t q = p - lane;
-          unsigned long long w;
-          do                                         // (a tile before the first counts as a finished prefix of zero)
-            w = (q >= 0) ? __hip_atomic_load(status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lb_pack(epoch, 2u, 0u);
-          while (__any((uint32_t) (w >> 34) != epoch || ((w >> 32) & 3ull) == 0));
-          const uint64_t done = __ballot(((w >> 32) & 3ull) == 2ull);
-          const int f = done ? __ffsll((long long) done) - 1 : 64;      // the nearest inclusive prefix among these 64
-          uint32_t x = (lane <= f) ? (uint32_t) w : 0u;
-          for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-          prefix += __shfl(x, 0);
+        { unsigned long long w[LB_LOOK];
+          bool wait;
+          do
+            { wait = false;
+#pragma unroll
+              for (int u = 0; u < LB_LOOK; u++)
+                { const int64_t q = p - (int64_t) lane * LB_LOOK - u;      // (a tile before the first: a finished prefix of zero)
+                  w[u] = (q >= 0) ? __hip_atomic_load(status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lb_pack(epoch, 2u, 0u);
+                  wait = wait || (uint32_t) (w[u] >> 34) != epoch || ((w[u] >> 32) & 3ull) == 0;
+                }
+            }
+          while (__any(wait));
+          // inside the lane: the sums up to and including its nearest finished prefix
+          uint32_t x = 0;
+          bool     fin = false;
+#pragma unroll
+          for (int u = 0; u < LB_LOOK; u++)
+            if (!fin)
+              { x += (uint32_t) w[u];
+                fin = ((w[u] >> 32) & 3ull) == 2ull;
+              }
+          const uint64_t done = __ballot(fin);
+          const int f = done ? __ffsll((long long) done) - 1 : 64;      // the lane with the nearest finished prefix
+          uint32_t y = (lane <= f) ? x : 0u;
+          for (int o = 32; o > 0; o >>= 1) y += __shfl_down(y, o);
+          prefix += __shfl(y, 0);
           if (f < 64) break;
-          p -= 64;
+          p -= 64 * LB_LOOK;
         }
       if (lane == 0)
         { s_prefix = prefix;
@@ -134,9 +155,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const uint32_t *
   if (total != nullptr && tid == SCAN_THREADS - 1 && (int64_t) (tile + 1) * LB_TILE >= n) *total = e;
 }
 
-// per scratch buffer (one per stream that scans): status words + ticket counter, the number of scans so far and of tiles
-struct LookbackState { void *p; uint32_t epoch, tiles; };
-static LookbackState g_lb[4] = {{nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}};
+// Scratch buffer of a stream that scans: [0] ticket counter, [8 ...] status words of the look-back (LB_MAX / LB_TILE
+// tiles), behind them the block sums of the three-kernel scan.  Per buffer: the allocation the words live in, the number
+// of scans so far and of tiles.
+constexpr size_t LB_WORDS = 8 + 2 * (size_t) (LB_MAX / LB_TILE) + 8;
+struct LookbackState { const void *buf; unsigned gen; uint32_t epoch, tiles; };
+static LookbackState g_lb[4] = {{nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}};
 
 void exclusive_scan_u32(const uint32_t *d_src, uint32_t *d_data, int64_t n, DevBuf<uint32_t> &bsum, uint32_t *d_total)
 { if (n <= 0)
@@ -144,28 +168,29 @@ void exclusive_scan_u32(const uint32_t *d_src, uint32_t *d_data, int64_t n, DevB
       return;
     }
   static const bool three = getenv("DMH_SCAN3") != nullptr;         // (the three-kernel scan, for comparison)
-  if (three)
+  if (three || n > LB_MAX)
     { if (d_src != d_data) HIP_CHECK(hipMemcpyAsync(d_data, d_src, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream()));
       int nb = ceil_div(n, SCAN_CHUNK);
-      bsum.ensure(nb, "scan block sums");
-      hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, stream(), d_data, n, bsum.p);
-      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, stream(), bsum.p, nb, d_total);
-      hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, stream(), d_data, n, bsum.p);
+      bsum.ensure(LB_WORDS + (size_t) nb, "scan block sums");
+      uint32_t *bs = bsum.p + LB_WORDS;
+      hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, stream(), d_data, n, bs);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, stream(), bs, nb, d_total);
+      hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, stream(), d_data, n, bs);
       HIP_CHECK(hipGetLastError());
       return;
     }
   const int nt = ceil_div(n, LB_TILE);
-  bsum.ensure(2 * (size_t) nt + 8, "scan tile states");
+  bsum.ensure(LB_WORDS, "scan tile states");
   LookbackState *L = nullptr;
-  for (auto &x : g_lb) if (x.p == bsum.p) L = &x;
-  if (L == nullptr || L->epoch >= 0x3ffffff0u)
+  for (auto &x : g_lb) if (x.buf == (const void *) &bsum) L = &x;
+  if (L == nullptr || L->gen != bsum.gen || L->epoch >= 0x3ffffff0u)
     { // a new (or re-allocated, or very old) scratch buffer: its words start out as "never written"
       if (L == nullptr)
         { L = &g_lb[0];
-          for (auto &x : g_lb) if (x.p == nullptr) { L = &x; break; }
+          for (auto &x : g_lb) if (x.buf == nullptr) { L = &x; break; }
         }
-      L->p = bsum.p; L->epoch = 0; L->tiles = 0;
-      HIP_CHECK(hipMemsetAsync(bsum.p, 0, sizeof(uint32_t) * bsum.cap, stream()));
+      L->buf = (const void *) &bsum; L->gen = bsum.gen; L->epoch = 0; L->tiles = 0;
+      HIP_CHECK(hipMemsetAsync(bsum.p, 0, sizeof(uint32_t) * LB_WORDS, stream()));
     }
   L->epoch += 1;
   unsigned long long *status = (unsigned long long *) (bsum.p + 8);
@@ -180,7 +205,7 @@ void exclusive_scan_u32(uint32_t *d_data, int64_t n, DevBuf<uint32_t> &bsum, uin
 
 // the scratch buffers have been released (dmh_reset): whatever they are when they come back, they start afresh
 void scan_state_reset()
-{ for (auto &x : g_lb) { x.p = nullptr; x.epoch = 0; x.tiles = 0; } }
+{ for (auto &x : g_lb) { x.buf = nullptr; x.gen = 0; x.epoch = 0; x.tiles = 0; } }
 
 // ---------------------------------------------------------------------------------------
 //  Radix sort pass: histogram -> scan -> stable scatter

@@ -221,6 +221,9 @@ int dmh_read_cover(DAZZ_DB *ablock, int aread, int16_t *out, int maxn);
 /* Radix sort of (uint64 key, uint32 value) pairs on key bits [0,nbits), stable (the kernel
  * under Sort_Kmers and the seed sort).  Host buffers in, sorted host buffers out.            */
 int dmh_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbits);
+/* the device-wide exclusive scan of the sorts and the filter (one look-back kernel; three kernels above 1 M values):
+   data[0..n) in place, *total = their sum, *ms (may be null) = mean device time of `reps` scans */
+int dmh_exclusive_scan(uint32_t *data, int64_t n, int reps, uint32_t *total, double *ms);
 
 /* Batched Local_Alignment (align.c:1727-1946) on the d-wave kernel.  Sequences are one byte per
  * base with a 4 on both sides of every sequence (the in-memory DAZZ_DB layout).  For job i:

@@ -140,3 +140,18 @@ def test_fully_masked_block_gives_empty_index():
     capi.lib().Set_Filter_Params(20, 0, 4)
     h, n = capi.sort_kmers(blk)
     assert n == 0 and not h
+
+
+@pytest.mark.parametrize("n", [1, 63, 4096, 4097, 25_001, 1_000_003, (1 << 20), (1 << 20) + 5, 9_000_001])
+def test_exclusive_scan_matches_numpy(n):
+    """The device-wide scan (single look-back kernel up to 1 M values, three kernels above) against numpy; run a few
+    times over so that the look-back's never-cleared status words (epochs) are exercised."""
+    import ctypes as C
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 200, n, dtype=np.uint32)
+    want = np.concatenate(([0], np.cumsum(a[:-1], dtype=np.uint64))).astype(np.uint32)
+    buf = a.copy()
+    tot = C.c_uint32(0)
+    assert capi.lib().dmh_exclusive_scan(buf.ctypes.data, n, 5, C.byref(tot), None) == 0
+    assert tot.value == int(a.sum(dtype=np.uint64)) & 0xffffffff
+    assert np.array_equal(buf, want)
