@@ -196,6 +196,9 @@ def main():
                     help="HIP events around k_radix_scatter only (default: around every kernel, about 1 ms per read block)")
     ap.add_argument("--no-stage-timing", action="store_true", help="no HIP events at all (no roofline)")
     ap.add_argument("--no-prefetch", action="store_true", help="do not queue the next block's index build early")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="Reporter of a block right behind its last pass (default: a few passes into the next block, "
+                         "Mapper.map_block(overlap=True): the GPU does not idle while the block's last batches finish)")
     ap.add_argument("--resident-reads", action="store_true",
                     help="read blocks pre-uploaded and pre-packed (inputs resident; the round-1 bench configuration)")
     ap.add_argument("--report-mode", type=int, default=2, choices=[0, 1, 2],
@@ -289,9 +292,8 @@ def main():
             for bb in (blk, nxt):                # map_block uploads (2-bit) and decodes what carries a slice
                 if bb is not None and not bb.resident:
                     bb.packed = bb.slice
-        t = m.map_block(blk, "READS.%d" % (seq[i] + 1), ref_blocks, ref_whole, "REF", next_reads=nxt)
-        if not args.resident_reads:
-            blk.release()
+        t = m.map_block(blk, "READS.%d" % (seq[i] + 1), ref_blocks, ref_whole, "REF", next_reads=nxt,
+                        overlap=not args.no_overlap, release=not args.resident_reads)
         return t
 
     # the warm-up runs the configuration that is timed (worker thread, streams, pinned pools and the allocator's
@@ -299,6 +301,7 @@ def main():
     L.dmh_async_report(args.report_mode)
     for i in range(args.warmup * per_step):
         visit(i)
+    m.finish()
     L.dmh_report_wait()
     L.dmh_timing_enable(0 if args.no_stage_timing else (2 if args.roofline_only else 1))
     L.dmh_timing_reset()
@@ -315,6 +318,7 @@ def main():
         for k in host:
             host[k] += t[k]
         bases += int(blocks[seq[i]][0].db.totlen)
+    m.finish()
     L.dmh_report_wait()
     L.dmh_sync()
     if dist is not None:

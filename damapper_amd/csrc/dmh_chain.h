@@ -28,8 +28,9 @@ void    chain_abandon(MergeResult &R);
 void cand_mirror(bool with_jumps);
 // The two halves of it: the lists as they are on the device, and the per-read objects made from them.
 // dst / dst_bytes: page-locked memory to copy into directly (cand_fetch_bytes() tells how much); nullptr = own vectors.
-size_t cand_fetch_bytes();
-void cand_fetch(CandRaw &raw, void *dst = nullptr, size_t dst_bytes = 0);
+// slot: the store (State::cand_slot) to read; -1 = the current block's
+size_t cand_fetch_bytes(int slot = -1);
+void cand_fetch(CandRaw &raw, void *dst = nullptr, size_t dst_bytes = 0, int slot = -1);
 void cand_build(const CandRaw &raw, std::vector<ReadState> &reads, const std::vector<uint16_t> *jd);
 
 }  // namespace dmh

@@ -1455,8 +1455,17 @@ namespace dmh {
 
 void chain_reset_reads(const DAZZ_DB *ablock)
 { State &st = S();
-  CandStore &cs = st.cands;
-  filter_discard();                         // hits of a block that never reached Reporter
+  // The block's store: its own when it has one (a restart: what it had collected is dropped), else a free one, else
+  // the one of the block before the current one (a block that never reached Reporter and never will: at most ONE
+  // block may wait for its Reporter call while the next one is being filtered)
+  int slot = st.cand_slot_of(ablock);
+  if (slot < 0)
+    for (int i = 0; i < 2 && slot < 0; i++)
+      if (st.cand_slot[i].block == nullptr) slot = i;
+  if (slot < 0) slot = st.cand_cur ^ 1;
+  filter_discard_block(slot);               // hits of a block that never reached Reporter
+  st.cand_cur = slot;
+  CandStore &cs = st.cands();
   const int n = ablock->nreads;
   st.cur_reads = ablock;
   st.reads.clear();
@@ -1527,7 +1536,7 @@ void chain_abandon(MergeResult &R)
 void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
 { State &st = S();
   const Params &pm = st.params;
-  if (st.cur_reads != ablock || st.cands.nreads != ablock->nreads)
+  if (st.cand_slot[R.cslot].block != ablock || st.cand_slot[R.cslot].nreads != ablock->nreads)
     fatal("Match_Filter: first call for a READS block must have start != 0 (map.c:1574)");
   if (R.cc == nullptr) R.cc = new ChainCtx();
   ChainCtx &C = *R.cc;
@@ -1731,8 +1740,9 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   if (nsum == 0) return 0;             // no chain reached the threshold: the lists stay as they are
 
   // ---- reporting order, domination rule and -p deltas on the device (map.c:1634-1730)
-  CandStore &cs = st.cands;
-  const int nreads = ablock->nreads;
+  CandStore &cs = st.cand_slot[R.cslot];
+  const int nreads = cs.nreads;
+  (void) ablock;
   static DevBuf<OrdChain> ord;
   static DevBuf<uint32_t> rgfirst, fresh, jl;
   static DevBuf<ChainSummary> packed;
@@ -1828,26 +1838,28 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
 //  Host view of the device lists (Reporter, stage-level API)
 // ---------------------------------------------------------------------------------------
 // The candidate lists as they are on the device (no Jump lists: they stay in HBM for the alignment kernel).
-size_t cand_fetch_bytes()
+size_t cand_fetch_bytes(int slot)
 { State &st = S();
-  CandStore &cs = st.cands;
-  st.tfilt += filter_flush();             // (the passes still waiting in the batch)
+  if (slot < 0) slot = st.cand_cur;
+  CandStore &cs = st.cand_slot[slot];
+  st.tfilt += filter_flush_block(slot);   // (the passes still waiting in the batch)
   const size_t n = (size_t) cs.nreads;
   size_t b = sizeof(DCand) * (size_t) cs.total_len + 64 + sizeof(uint32_t) * 2 * (n + 1) + 64;
   if (!cs.h_cov_off.empty()) b += sizeof(int16_t) * (size_t) cs.h_cov_off[n] + 64;
   return b;
 }
 
-void cand_fetch(CandRaw &raw, void *dst, size_t dst_bytes)
+void cand_fetch(CandRaw &raw, void *dst, size_t dst_bytes, int slot)
 { State &st = S();
-  CandStore &cs = st.cands;
-  st.tfilt += filter_flush();
+  if (slot < 0) slot = st.cand_cur;
+  CandStore &cs = st.cand_slot[slot];
+  st.tfilt += filter_flush_block(slot);
   const int n = cs.nreads;
   raw.nreads = n;
   raw.npool = cs.total_len;
   raw.cov_off = cs.h_cov_off;
   const size_t ncov = cs.h_cov_off.empty() ? 0 : (size_t) cs.h_cov_off[n];
-  if (dst != nullptr && dst_bytes >= cand_fetch_bytes())
+  if (dst != nullptr && dst_bytes >= cand_fetch_bytes(slot))
     { // straight into the caller's page-locked memory: one wait, no staging copy
       uint8_t *q = (uint8_t *) dst;
       auto take = [&](size_t bytes) { uint8_t *r = q; q += (bytes + 63) & ~(size_t) 63; return r; };
@@ -1911,7 +1923,7 @@ void cand_build(const CandRaw &raw, std::vector<ReadState> &reads, const std::ve
 
 void cand_mirror(bool with_jumps)
 { State &st = S();
-  CandStore &cs = st.cands;
+  CandStore &cs = st.cands();
   st.tfilt += filter_flush();             // (the passes still waiting in the batch)
   if (cs.mirror_valid && (cs.mirror_jumps || !with_jumps)) return;
   CandRaw raw;

@@ -1383,11 +1383,12 @@ void dmh_reset(void)
   st.reads.clear();
   st.cur_reads = nullptr;
   filter_discard();
-  { CandStore &cs = st.cands;
-    for (int i = 0; i < 2; i++) { cs.pool[i].release(); cs.seg_off[i].release(); cs.seg_len[i].release(); }
-    cs.jumps.release(); cs.cover.release(); cs.cov_off.release(); cs.ctl.release();
-    cs.block = nullptr; cs.nreads = 0; cs.total_len = 0; cs.jtop = 0; cs.mirror_valid = false;
-  }
+  for (CandStore &cs : st.cand_slot)
+    { for (int i = 0; i < 2; i++) { cs.pool[i].release(); cs.seg_off[i].release(); cs.seg_len[i].release(); }
+      cs.jumps.release(); cs.cover.release(); cs.cov_off.release(); cs.ctl.release();
+      cs.block = nullptr; cs.nreads = 0; cs.total_len = 0; cs.jtop = 0; cs.mirror_valid = false;
+    }
+  st.cand_cur = 0;
   st.tfilt = 0;
   st.last_seeds.clear();
   st.sort.hist.release();

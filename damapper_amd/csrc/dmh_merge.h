@@ -19,6 +19,7 @@ struct MergeResult
   DevBuf<uint64_t> alt_keys;     // sort partner of keys / vals (the sorted hits may end up here)
   DevBuf<uint32_t> alt_vals;
   const DAZZ_DB *ablock = nullptr;
+  int     cslot   = 0;           // the candidate store of the batch's READS block (State::cand_slot)
   int     npass   = 0, passbits = 0, qbits = 0;
   struct { int bbase, comp; } pass[MAXPASS];
   int64_t nhits   = 0;
@@ -63,7 +64,9 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
 // Sort, group, chain and filter what the batch holds and everything still in flight (no-op when there is nothing);
 // returns the change in candidates.
 int64_t filter_flush();
+int64_t filter_flush_block(int cslot);     // ... of ONE READS block only (the other's batches stay open / in flight)
 void    filter_discard();          // forget the batches of a READS block that never reached Reporter
+void    filter_discard_block(int cslot);
 MergeResult &filter_batch();
 
 }  // namespace dmh

@@ -1021,7 +1021,8 @@ static int64_t sizeof_db(const DAZZ_DB *db)
 // The batches: one being collected (ring[cur]) and up to IN_FLIGHT submitted ones whose chain kernels -- repeat piles
 // above all -- are still running while later passes are merged, sorted and chained.  They are finished in order.
 constexpr int IN_FLIGHT = 4;
-constexpr int NRING = IN_FLIGHT + 2;
+constexpr int NRING = IN_FLIGHT + 3;       // (+ the one being collected, the one being finished, and the one a pass has
+                                           //  just submitted while the oldest waits for the next pass's match kernels)
 static MergeResult g_ring[NRING];
 static int         g_cur = 0;
 static std::deque<int> g_inflight;
@@ -1151,6 +1152,12 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
     HIP_CHECK(hipGetLastError());
   }
+  // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
+  // main stream has the match kernels (and the previous pass's chain kernels) to run meanwhile
+  { static const int env_fl2 = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
+    const int keep2 = (VERBOSE || st.capture_seeds || st.opt_in_flight == 0) ? 0 : std::min(g_flight_cap, std::max(0, env_fl2));
+    while ((int) g_inflight.size() > keep2) *nfilt += finish_oldest();
+  }
   // one round trip for the pass: the number of matched runs and the two hit sums (the count is parked behind the sums)
   unsigned int nent = 0;
   unsigned long long hsum[3] = {0, 0, 0};
@@ -1247,6 +1254,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   if (!R.open)
     { R.open = true;
       R.ablock = ablock;
+      R.cslot = st.cand_cur;
       R.npass = 0;
       R.nhits = 0;
       R.clustered = cluster;
@@ -1364,7 +1372,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // lists after every call -- then nothing stays in flight
   static const int env_fl = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
   const int keep = (VERBOSE || st.capture_seeds || st.opt_in_flight == 0) ? 0 : std::min(g_flight_cap, std::max(0, env_fl));
-  while ((int) g_inflight.size() > keep) *nfilt += finish_oldest();
+  while ((int) g_inflight.size() > (keep > 0 ? keep + 1 : 0)) *nfilt += finish_oldest();
   return nhits;
 #undef R
 }
@@ -1431,6 +1439,37 @@ int64_t filter_flush()
   int64_t nfilt = 0;
   while (!g_inflight.empty()) nfilt += finish_oldest();
   return nfilt;
+}
+
+// Reporter of one READS block: its open batch is closed, its batches in flight are finished (they are the oldest: the
+// filter finishes in order); what the following block has queued meanwhile stays as it is
+int64_t filter_flush_block(int cslot)
+{ int64_t nfilt = 0;
+  { MergeResult &R = filter_batch();
+    if (R.open && R.cslot == cslot) close_batch(R);
+  }
+  while (true)
+    { bool any = false;
+      for (int y : g_inflight) any = any || (g_ring[y].cslot == cslot);
+      if (!any) break;
+      nfilt += finish_oldest();
+    }
+  return nfilt;
+}
+
+// the batches of ONE block are dropped (its store is about to be given to another block)
+void filter_discard_block(int cslot)
+{ bool any = false;
+  for (int y : g_inflight) any = any || (g_ring[y].cslot == cslot);
+  MergeResult &R = filter_batch();
+  if (R.open && R.cslot == cslot) { R.open = false; R.nhits = 0; R.npass = 0; }
+  if (!any) return;
+  join_side_streams();
+  std::deque<int> keep;
+  for (int y : g_inflight)
+    if (g_ring[y].cslot == cslot) { chain_abandon(g_ring[y]); g_ring[y].nhits = 0; g_ring[y].npass = 0; }
+    else keep.push_back(y);
+  g_inflight.swap(keep);
 }
 
 void filter_discard()
@@ -1728,7 +1767,9 @@ static void close_batch(MergeResult &R)
     if (&g_ring[i] == &R) slot = i;
   g_inflight.push_back(slot);
   report_poll();                 // (the chain kernels just queued keep the GPU busy meanwhile)
-  while ((int) g_inflight.size() > g_flight_cap) st.tfilt += finish_oldest();
+  // (the oldest batch is finished by the NEXT pass, behind its match kernels: finishing blocks the host for the
+  //  finish stream's round trips, and here the main stream would run dry meanwhile -- 0.57 ms per pass in the trace)
+  while ((int) g_inflight.size() > g_flight_cap + 1) st.tfilt += finish_oldest();
   for (int i = 0; i < NRING; i++)
     { bool busy = false;
       for (int y : g_inflight) busy = busy || (y == i);

@@ -1522,8 +1522,10 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   Spec *sp = (Spec *) asettings;
   if (sp == nullptr || sp->magic != SPEC_MAGIC)
     fatal("Reporter: the Align_Spec was not created by this library's New_Align_Spec");
-  if (st.cur_reads != ablock || st.cands.nreads != ablock->nreads)
+  const int cslot = st.cand_slot_of(ablock);
+  if (cslot < 0 || st.cand_slot[cslot].nreads != ablock->nreads)
     fatal("Reporter: called for a READS block that has not been through Match_Filter");
+  CandStore &cstore = st.cand_slot[cslot];
   // mode 2: the (VALU-bound) alignment kernel of this block is left running, at a partial grid, next to the filter
   // of the NEXT block, whose kernels mostly wait for memory.  (Round 1 deferred only for one-block references: the
   // per-pass host round trips of a many-block filter made the overlap a loss; with the passes batched it wins
@@ -1543,7 +1545,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     if (index_first) bg_flush();
   }
   { HostTimer hf("report_flush");
-    st.tfilt += filter_flush();
+    st.tfilt += filter_flush_block(cslot);     // (this block's batches: the next block's may be in flight behind them)
   }
   if (defer && !index_first) bg_flush();
   // the candidate lists: copied on the finish stream (the main stream is busy with the index sort)
@@ -1551,9 +1553,9 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   PinBuf *raw_pin = nullptr;
   { HostTimer hm("report_mirror");
     StreamScope on_finish(index_first ? finish_stream() : main_stream());
-    const size_t nb = cand_fetch_bytes();
+    const size_t nb = cand_fetch_bytes(cslot);
     raw_pin = pin_acquire(nb / sizeof(int) + 64);
-    cand_fetch(raw, raw_pin->p, sizeof(int) * raw_pin->cap);      // (their Jump lists stay in HBM)
+    cand_fetch(raw, raw_pin->p, sizeof(int) * raw_pin->cap, cslot);      // (their Jump lists stay in HBM)
   }
   { HostTimer hq("report_previous");
     report_finish_pending();                   // the previous block's alignments (deferred mode)
@@ -1609,14 +1611,16 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     for (int i = 0; i < nreads; i++) C->rlen[i] = ablock->reads[i].rlen;
     C->raw = std::move(raw);
     C->raw_pin = raw_pin;
-    st.reads.clear();
-    st.cur_reads = nullptr;
-    st.cands.block = nullptr;
-    st.cands.nreads = 0;
-    st.cands.mirror_valid = false;
-    P->jumps = st.cands.jumps;               // the kernel reads the Jump lists where the filter stored them
-    st.cands.jumps = DevBuf<uint16_t>();
-    st.cands.jtop = 0;
+    if (st.cur_reads == ablock)
+      { st.reads.clear();
+        st.cur_reads = nullptr;
+      }
+    cstore.block = nullptr;                  // (the store is free for the block after next)
+    cstore.nreads = 0;
+    cstore.mirror_valid = false;
+    P->jumps = cstore.jumps;                 // the kernel reads the Jump lists where the filter stored them
+    cstore.jumps = DevBuf<uint16_t>();
+    cstore.jtop = 0;
     C->job_of_first = std::move(job_of_first);
     P->C = C;
   }

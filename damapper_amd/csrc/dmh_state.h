@@ -149,8 +149,18 @@ struct State
   std::vector<int32_t> last_seeds;     // SeedPair records (4 ints each)
 
   // cross-call filter state (map.c:2885-2887 + DAZZ_READ.coff lists)
+  // Two READS blocks may be open at a time: the one the filter works on (cur_reads, cand_cur) and the one before it,
+  // whose last batches are still being finished and whose Reporter call is still to come -- a driver that starts the
+  // next block's passes first does not leave the GPU idle at the block boundary (damapper_amd/driver.py).  A store
+  // belongs to a block from its first Match_Filter call (start != 0) to its Reporter call.
   const DAZZ_DB *cur_reads = nullptr;
-  CandStore cands;                  // the candidate lists (device)
+  CandStore cand_slot[2];           // the candidate lists (device)
+  int       cand_cur = 0;
+  CandStore &cands() { return cand_slot[cand_cur]; }
+  int cand_slot_of(const DAZZ_DB *b) const
+  { for (int i = 0; i < 2; i++) if (b != nullptr && cand_slot[i].block == b) return i;
+    return -1;
+  }
   std::vector<ReadState> reads;     // host mirror of them, built on demand (cand_mirror)
   int      next_cand_id = 0;
   int64_t  tfilt = 0;

@@ -40,8 +40,13 @@ class Mapper:
         self.prefetch_deferred = prefetch_deferred
         self._ref_cache = None
         self.L.dmh_retain_ref_index(1 if retain_ref else 0)
+        # overlap mode of map_block: the block whose Reporter call is still to come, and the number of passes of the
+        # following block that are queued ahead of it
+        self._pending = None
+        self.overlap_passes = int(os.environ.get("DMH_OVERLAP_PASSES", "6"))
 
     def release_ref(self) -> None:
+        self.finish()
         self._drop_prefetched()
         if self._ref_cache:
             for (h, n, comp, k) in self._ref_cache:
@@ -100,12 +105,35 @@ class Mapper:
         self.spec = self.L.New_Align_Spec(self.ave_corr, self.spacing, f, 1)    # damapper.c:796
         return self.spec
 
+    def _report(self, pend) -> None:
+        """Reporter for a block whose filter passes are done (map.c:3227), then what main() does with the block."""
+        reads, reads_name, ref_whole, ref_name, mflag, rh, release = pend
+        maxlen = reads.db.maxlen
+        self.L.Reporter(reads_name.encode(), reads.ptr(), ref_name.encode(), ref_whole.ptr(), self.spec, mflag)
+        reads.db.maxlen = maxlen           # Reporter adds SPACING (map.c:3246); a block mapped again must not grow
+        if rh:
+            self.L.dmh_free_index(rh)      # Reporter released the device side; this frees the stub
+        if release:
+            reads.release()
+
+    def finish(self) -> None:
+        """Overlap mode: Reporter for the last block mapped (nothing follows it)."""
+        if self._pending is not None:
+            self._report(self._pending)
+            self._pending = None
+
     def map_block(self, reads: Block, reads_name: str, ref_blocks: Sequence[Block], ref_whole: Block,
                   ref_name: str, mflag: int = capi.FLAG_DOA, restore: bool = True,
-                  next_reads: Optional[Block] = None) -> Dict[str, float]:
+                  next_reads: Optional[Block] = None, overlap: bool = False, release: bool = False) -> Dict[str, float]:
         """One iteration of main()'s outer loop (damapper.c:825-880).  With `next_reads` the index of
         the following read block is queued on the GPU before this block's Reporter, so the device
-        never idles while the host selects and writes alignments (software pipelining of the block
+        never idles while the host selects and writes alignments.
+        overlap: the block's Reporter call is left to the NEXT map_block (or finish()): at a block boundary the last
+        batches of the filter are still being finished on their own stream (repeat piles: tens of milliseconds), and
+        Reporter has to wait for them; with the first `overlap_passes` Match_Filter passes of the following block
+        queued ahead of it the GPU has work meanwhile (the library keeps the candidate lists of two READS blocks).
+        release: reads.release() once its Reporter call has been made.  Results are unchanged either way.
+        (software pipelining of the block
         loop; results are unchanged)."""
         t = {}
         t0 = time.time()
@@ -122,16 +150,30 @@ class Mapper:
         else:
             self._drop_prefetched()        # a prefetched index for a block that did not come next
             rh, rn = capi.sort_kmers(reads)
-        if next_reads is not None and self.prefetch_deferred:
+        if next_reads is not None and self.prefetch_deferred and not overlap:
             # the next block's index build is deferred: its stages are queued in the gaps of this
             # block's filter and report phases (dmh_sort_kmers_async)
             h2, n2 = capi.sort_kmers(next_reads, deferred=True)
             self._prefetched = (next_reads, h2, n2)
         t["index_reads"] = time.time() - t0
         t1 = time.time()
+        npass = 0
+        t["report"] = 0.0
+
+        def passed():
+            # overlap mode: the previous block's Reporter call, a few passes into this block
+            nonlocal npass
+            npass += 1
+            if self._pending is not None and npass == self.overlap_passes:
+                tr = time.time()
+                self._report(self._pending)
+                self._pending = None
+                t["report"] += time.time() - tr
+
         if self.retain_ref:
             for (h, n, comp, k) in self._ref_indices(ref_blocks):
                 capi.match_filter(reads, ref_blocks[k], rh, rn, h, n, comp, 1 if (k == 0 and comp == 0) else 0)
+                passed()
         else:
             for k, blk in enumerate(ref_blocks):
                 for comp in (0, 1):
@@ -139,19 +181,26 @@ class Mapper:
                         blk.complement_inplace()                                      # damapper.c:853
                     h, n = capi.sort_kmers(blk)
                     capi.match_filter(reads, blk, rh, rn, h, n, comp, 1 if (k == 0 and comp == 0) else 0)
+                    passed()
                 if restore:
                     blk.complement_inplace()
-        t["filter"] = time.time() - t1
+        if self._pending is not None:        # (fewer passes than overlap_passes)
+            tr = time.time()
+            self._report(self._pending)
+            self._pending = None
+            t["report"] += time.time() - tr
+        t["filter"] = time.time() - t1 - t["report"]
+        if overlap:
+            self._pending = (reads, reads_name, ref_whole, ref_name, mflag, rh, release)
+            self._last_end = time.time()
+            t["total"] = self._last_end - t0
+            return t
         t2 = time.time()
         if next_reads is not None and not self.prefetch_deferred:
             h2, n2 = capi.sort_kmers(next_reads)
             self._prefetched = (next_reads, h2, n2)
-        maxlen = reads.db.maxlen
-        self.L.Reporter(reads_name.encode(), reads.ptr(), ref_name.encode(), ref_whole.ptr(), self.spec, mflag)
-        reads.db.maxlen = maxlen           # Reporter adds SPACING (map.c:3246); a block mapped again must not grow
-        t["report"] = time.time() - t2
-        if rh:
-            self.L.dmh_free_index(rh)      # Reporter released the device side; this frees the stub
+        self._report((reads, reads_name, ref_whole, ref_name, mflag, rh, release))
+        t["report"] += time.time() - t2
         self._last_end = time.time()
         t["total"] = self._last_end - t0
         return t

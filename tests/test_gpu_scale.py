@@ -41,10 +41,10 @@ def _threads():
     return p
 
 
-def _map_blocks_like_bench(d, ref_root, reads_root, out, report_mode=2, parts=None, **kw):
+def _map_blocks_like_bench(d, ref_root, reads_root, out, report_mode=2, parts=None, overlap=True, **kw):
     """The block loop of bench.py / damapper_amd.dispatch, in process: resident REF indices, packed read blocks from
-    the DB on disk, deferred index build of the next block, asynchronous Reporter.  `parts`: the read blocks to map
-    (1-based; default all)."""
+    the DB on disk, asynchronous Reporter, and -- overlap -- the Reporter call of a block made a few passes into the
+    next one (Mapper.map_block(overlap=True)).  `parts`: the read blocks to map (1-based; default all)."""
     L = capi.lib()
     cwd = os.getcwd()
     os.chdir(d)
@@ -60,8 +60,9 @@ def _map_blocks_like_bench(d, ref_root, reads_root, out, report_mode=2, parts=No
         L.dmh_async_report(report_mode)
         for x, blk in enumerate(blocks):
             nxt = blocks[x + 1] if x + 1 < len(blocks) else None
-            m.map_block(blk, "%s.%d" % (reads_root, parts[x]), ref_blocks, ref_whole, ref_root, next_reads=nxt)
-            blk.release()
+            m.map_block(blk, "%s.%d" % (reads_root, parts[x]), ref_blocks, ref_whole, ref_root, next_reads=nxt,
+                        overlap=overlap, release=True)
+        m.finish()
         L.dmh_report_wait()
         L.dmh_async_report(0)
         m.release_ref()
