@@ -17,6 +17,10 @@ void chain_reset_reads(const DAZZ_DB *ablock);
 // merge, sorts and chain kernels of the following passes do not depend on it.
 void    chain_submit(MergeResult &R, const DAZZ_DB *ablock);
 int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock);
+// ... step by step (three of them, each up to the next number the host needs from the device): true when the batch is
+// finished, *nfilt then has the change in candidates added to it
+bool    chain_finish_step(MergeResult &R, int64_t *nfilt);
+bool    chain_finish_started(MergeResult &R);
 
 // Drops the chain stage's per-batch buffers of a ring slot that is not in use (memory pressure).
 void    chain_release(MergeResult &R);

@@ -1502,6 +1502,15 @@ void chain_reset_reads(const DAZZ_DB *ablock)
     ablock->reads[i].coff = -1;
 }
 
+struct FinishState
+{ int       stage = 0;             // steps done
+  uint32_t *h_pin = nullptr;       // 16 page-locked words: [0] chain ends, [8..15] the candidate counters
+  hipEvent_t ev = nullptr;         // the copy into h_pin has landed
+  uint32_t  nsum = 0;
+  int64_t   result = 0;
+};
+
+
 // Everything the chain stage of one batch keeps between chain_submit and chain_finish
 struct ChainCtx
 { DevBuf<int32_t>  cost, bestcost;
@@ -1512,7 +1521,19 @@ struct ChainCtx
   hipEvent_t piles_done = nullptr;
   hipEvent_t submitted = nullptr;    // the batch's chain kernels are queued on the main stream up to here
   bool       has_piles = false, all64 = false;
+  // chain_finish: buffers that live from one of its steps to the next, and where it stands
+  DevBuf<uint32_t> goff, fresh, jl;
+  FinishState *fin = nullptr;
 };
+
+static FinishState &fin_of(ChainCtx &C)
+{ if (C.fin == nullptr)
+    { C.fin = new FinishState();
+      HIP_CHECK(hipHostMalloc((void **) &C.fin->h_pin, 16 * sizeof(uint32_t), hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&C.fin->ev, hipEventDisableTiming));
+    }
+  return *C.fin;
+}
 
 void chain_release(MergeResult &R)
 { if (R.cc == nullptr) return;
@@ -1522,12 +1543,14 @@ void chain_release(MergeResult &R)
   C.gcnt.release(); C.gbase.release(); C.pileretry.release();
   C.livebuf.release();
   C.out.release();
+  C.goff.release(); C.fresh.release(); C.jl.release();
 }
 
 // A batch in flight is dropped (filter_discard): its pile kernel may still be writing the chain arrays on the pile
 // stream, which join_side_streams does not cover -- whatever the main stream does next comes after it
 void chain_abandon(MergeResult &R)
-{ if (R.cc == nullptr || !R.cc->has_piles) return;
+{ if (R.cc != nullptr && R.cc->fin != nullptr) { R.cc->fin->stage = 0; R.cc->fin->result = 0; }
+  if (R.cc == nullptr || !R.cc->has_piles) return;
   HIP_CHECK(hipStreamWaitEvent(main_stream(), R.cc->piles_done, 0));
   if (finish_stream() != main_stream()) HIP_CHECK(hipStreamWaitEvent(finish_stream(), R.cc->piles_done, 0));
   R.cc->has_piles = false;
@@ -1697,15 +1720,20 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
 // batch that depend on nothing the main stream does meanwhile (the merge, sort and chain kernels of later batches) and
 // on which only the next batch's finish and Reporter depend.  The caller (finish_oldest) makes the main stream wait
 // for its end before the batch's ring slot is used again.
-int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
+// In THREE steps, each ending where the host needs a number from the device (chain ends; candidates and Jump pairs):
+// the number travels to page-locked memory behind an event, and the next step picks it up.  The filter calls the steps
+// at points of a pass where it has just queued work on the main stream (chain_finish_step), so that the host waits
+// for the finish stream's small kernels -- slow next to a machine-filling chain kernel -- as little as possible;
+// chain_finish runs whatever steps are left in one go.
+
+static void finish_step_a(MergeResult &R)
 { State &st = S();
   ChainCtx &C = *R.cc;
+  FinishState &F = fin_of(C);
   StreamScope on_finish(finish_stream());
   if (stream() != main_stream()) HIP_CHECK(hipStreamWaitEvent(stream(), C.submitted, 0));
   ChainArgs A = C.A;
-  DevBuf<uint32_t> &from = C.from, &ctl = C.ctl, &gcnt = C.gcnt, &gbase = C.gbase, &pileretry = C.pileretry;
-  DevBuf<ChainSummary> &out = C.out;
-  const int64_t nhits = R.nhits;
+  DevBuf<uint32_t> &ctl = C.ctl, &gcnt = C.gcnt, &pileretry = C.pileretry;
   if (C.has_piles)
     { // piles whose window outgrew the workgroup kernel's LDS: a last 64-lane launch (the piles have had the time of
       // the batches submitted since to finish)
@@ -1720,13 +1748,27 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
     }
   // chain ends per group -> first slot of every group's ends in the reference's order, and their number
   const uint32_t ng = (uint32_t) R.ngroups;
-  static DevBuf<uint32_t> goff;
-  goff.ensure((size_t) ng + 2, "chain ends per group");
-  exclusive_scan_u32((const uint32_t *) gcnt.p, goff.p, ng, st.sort_fin.bsum, goff.p + ng);
-  uint32_t nsum = 0;
+  C.goff.ensure((size_t) ng + 2, "chain ends per group");
+  exclusive_scan_u32((const uint32_t *) gcnt.p, C.goff.p, ng, st.sort_fin.bsum, C.goff.p + ng);
+  HIP_CHECK(hipMemcpyAsync(F.h_pin, C.goff.p + ng, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipEventRecord(F.ev, stream()));
+  F.stage = 1;
+}
+
+static void finish_step_b(MergeResult &R)
+{ State &st = S();
+  ChainCtx &C = *R.cc;
+  FinishState &F = fin_of(C);
+  StreamScope on_finish(finish_stream());
   { HostTimer ht("chain_wait");
-    copy_d2h(&nsum, goff.p + ng, sizeof(uint32_t), 1);
+    HIP_CHECK(hipEventSynchronize(F.ev));
   }
+  const uint32_t nsum = F.h_pin[0];
+  F.nsum = nsum;
+  DevBuf<uint32_t> &from = C.from, &gcnt = C.gcnt, &gbase = C.gbase;
+  DevBuf<ChainSummary> &out = C.out;
+  const int64_t nhits = R.nhits;
+  const uint32_t ng = (uint32_t) R.ngroups;
   { static const bool stats = getenv("DMH_STATS") != nullptr;
     if (stats)
       { uint32_t c3[3] = {0, 0, 0};
@@ -1737,17 +1779,18 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
       fprintf(stderr, "dmh: pass hits %lld groups %lld (clustered %d) lds<=%u medium %u big %u piles %u chain ends %u\n",
               (long long) nhits, (long long) R.ngroups, (int) R.clustered, R.small_cap, R.nmed, R.nbig, R.npiles, nsum);
   }
-  if (nsum == 0) return 0;             // no chain reached the threshold: the lists stay as they are
+  F.result = 0;
+  if (nsum == 0) { F.stage = 3; return; }        // no chain reached the threshold: the lists stay as they are
 
   // ---- reporting order, domination rule and -p deltas on the device (map.c:1634-1730)
   CandStore &cs = st.cand_slot[R.cslot];
   const int nreads = cs.nreads;
-  (void) ablock;
   static DevBuf<OrdChain> ord;
-  static DevBuf<uint32_t> rgfirst, fresh, jl;
+  static DevBuf<uint32_t> rgfirst;
   static DevBuf<ChainSummary> packed;
   static DevBuf<uint2> prange;
   static DevBuf<uint64_t> oword;
+  DevBuf<uint32_t> &fresh = C.fresh, &jl = C.jl, &goff = C.goff;
   if (st.opt_oom_finish > 0 && --st.opt_oom_finish == 0)
     simulate_out_of_memory();            // (test: the batch being finished must survive the reclaim, dmh_merge.hip)
   ord.ensure(nsum, "ordered chain ends");
@@ -1762,7 +1805,6 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   cs.seg_off[nx].ensure((size_t) nreads + 1, "candidate list offsets");
   cs.seg_len[nx].ensure((size_t) nreads + 1, "candidate list lengths");
   if (cs.pool[cs.cur].p == nullptr) cs.pool[cs.cur].ensure(16, "candidate lists");
-  uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   { StageTimer tm("chain_dominate", 40.0 * nsum);
     HIP_CHECK(hipMemsetAsync(cs.ctl.p, 0, 16 * sizeof(unsigned int), stream()));
     hipLaunchKernelGGL(k_pack_summaries, dim3(std::min<uint32_t>(ceil_div(ng, 256), 8192)), dim3(256), 0, stream(),
@@ -1806,7 +1848,27 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
                        (const uint32_t *) nullptr, (uint16_t *) nullptr, 0u, 0);
     exclusive_scan_u32((const uint32_t *) jl.p, jl.p + nsum + 1, nsum, st.sort_fin.bsum, cs.ctl.p + 3);
     HIP_CHECK(hipMemcpyAsync(cs.ctl.p + 4, cs.seg_off[nx].p + nreads, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
-    copy_d2h(h, cs.ctl.p, 8 * sizeof(uint32_t), 2);      // added, removed, fresh survivors, jump pairs, records in the new lists
+    // added, removed, fresh survivors, jump pairs, records in the new lists
+    HIP_CHECK(hipMemcpyAsync(F.h_pin + 8, cs.ctl.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipEventRecord(F.ev, stream()));
+  }
+  F.stage = 2;
+}
+
+static void finish_step_c(MergeResult &R)
+{ State &st = S();
+  ChainCtx &C = *R.cc;
+  FinishState &F = fin_of(C);
+  StreamScope on_finish(finish_stream());
+  { HostTimer ht("chain_wait");
+    HIP_CHECK(hipEventSynchronize(F.ev));
+  }
+  CandStore &cs = st.cand_slot[R.cslot];
+  const uint32_t nsum = F.nsum;
+  uint32_t h[8];
+  for (int i = 0; i < 8; i++) h[i] = F.h_pin[8 + i];
+  const int nx = cs.cur ^ 1;
+  { StageTimer tm("chain_jumps", 0.0);
     const size_t need = cs.jtop + h[3];
     if (need > cs.jumps.cap / 2)
       { // grow the jump pool, keeping what earlier passes stored
@@ -1820,9 +1882,9 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
       }
     if (h[2] > 0)
       hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.sab,
-                         (const uint32_t *) from.p, cs.pool[nx].p,
-                         (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,
-                         (const uint32_t *) (jl.p + nsum + 1), cs.jumps.p, (uint32_t) cs.jtop, 1);
+                         (const uint32_t *) C.from.p, cs.pool[nx].p,
+                         (const uint32_t *) C.fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, C.jl.p,
+                         (const uint32_t *) (C.jl.p + nsum + 1), cs.jumps.p, (uint32_t) cs.jtop, 1);
     HIP_CHECK(hipGetLastError());
   }
   cs.jtop += h[3];
@@ -1831,7 +1893,31 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
   cs.total_len = h[4];
   cs.mirror_valid = false;
   cs.mirror_jumps = false;
-  return (int64_t) h[0] - (int64_t) h[1];
+  F.result = (int64_t) h[0] - (int64_t) h[1];
+  F.stage = 3;
+}
+
+// one step of the batch's finish; true when nothing is left to do (*nfilt += the change in candidates)
+bool chain_finish_step(MergeResult &R, int64_t *nfilt)
+{ FinishState &F = fin_of(*R.cc);
+  if (F.stage == 0) finish_step_a(R);
+  else if (F.stage == 1) finish_step_b(R);
+  else if (F.stage == 2) finish_step_c(R);
+  if (F.stage < 3) return false;
+  *nfilt += F.result;
+  F.stage = 0;
+  F.result = 0;
+  return true;
+}
+
+bool chain_finish_started(MergeResult &R)
+{ return R.cc != nullptr && R.cc->fin != nullptr && R.cc->fin->stage > 0; }
+
+int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
+{ (void) ablock;
+  int64_t nfilt = 0;
+  while (!chain_finish_step(R, &nfilt)) ;
+  return nfilt;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1063,6 +1063,8 @@ constexpr int64_t BATCH_CAP = (int64_t) 160 << 20;
 
 static void    close_batch(MergeResult &R);
 static int64_t finish_oldest();
+static void    finish_tick_if_due(int64_t *nfilt);
+static int     flight_keep();
 static bool    filter_reclaim();
 static int     g_flight_cap = IN_FLIGHT;     // batches that may be in flight: one fewer after every time memory ran out
 
@@ -1154,9 +1156,10 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   }
   // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
   // main stream has the match kernels (and the previous pass's chain kernels) to run meanwhile
-  { static const int env_fl2 = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
-    const int keep2 = (VERBOSE || st.capture_seeds || st.opt_in_flight == 0) ? 0 : std::min(g_flight_cap, std::max(0, env_fl2));
-    while ((int) g_inflight.size() > keep2) *nfilt += finish_oldest();
+  { static const bool nosteps = getenv("DMH_FINISH_STEPS") == nullptr;
+    const int keep2 = flight_keep();
+    while ((int) g_inflight.size() > (nosteps || keep2 == 0 ? keep2 : keep2 + 1)) *nfilt += finish_oldest();
+    finish_tick_if_due(nfilt);              // (step 1 of 3; the others behind the expansion and behind the seed sort)
   }
   // one round trip for the pass: the number of matched runs and the two hit sums (the count is parked behind the sums)
   unsigned int nent = 0;
@@ -1338,6 +1341,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
         if (by_read)
           { // a read with more hits than the LDS of a workgroup takes (a tandem array: a pile) sends the whole pass
             // through the global sort, which takes the words in any order
+            finish_tick_if_due(nfilt);      // (the expansion is queued: the oldest batch's finish moves on a step)
             copy_d2h(g_rcnt, g_rstats.p, 4 * sizeof(uint32_t), 1);
             R.read_sorted = g_rcnt[3] <= g_rlim;
           }
@@ -1355,6 +1359,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
                            hitmode, passor, hk, hv);
       }
     HIP_CHECK(hipGetLastError());
+    if (!by_read) finish_tick_if_due(nfilt);
     static const bool check = getenv("DMH_CHECK_EMIT") != nullptr;
     if (check)
       { copy_d2h(&total, eoff.p + nent, sizeof(uint32_t));
@@ -1380,6 +1385,42 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
 static bool    g_finishing = false;          // inside chain_finish (its own allocations must not finish the next batch)
 static int     g_finishing_slot = -1;        // ... and the ring slot it works on: busy for filter_reclaim although it has left g_inflight
 
+// One step of finishing the oldest batch (chain_finish_step): called where a pass has just queued main-stream work, so
+// that the finish stream's small kernels run while the host is busy elsewhere.  Returns true when that batch is done.
+static void finish_retire(int x);
+static bool finish_tick(int64_t *nfilt)
+{ if (g_inflight.empty()) return false;
+  const int x = g_inflight.front();
+  MergeResult &R = g_ring[x];
+  g_finishing = true;
+  g_finishing_slot = x;
+  bool done;
+  { HostTimer hf("filter_finish");
+    done = chain_finish_step(R, nfilt);
+  }
+  g_finishing = false;
+  g_finishing_slot = -1;
+  if (done)
+    { g_inflight.pop_front();
+      finish_retire(x);
+    }
+  return done;
+}
+
+// batches the filter keeps in flight before it starts finishing the oldest
+static int flight_keep()
+{ State &st = S();
+  static const int env_fl = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
+  return (VERBOSE || st.capture_seeds || st.opt_in_flight == 0) ? 0 : std::min(g_flight_cap, std::max(0, env_fl));
+}
+
+// a step of the oldest batch's finish when one is due: more batches in flight than are kept, or that batch under way
+static void finish_tick_if_due(int64_t *nfilt)
+{ static const bool off = getenv("DMH_FINISH_STEPS") == nullptr;      // (opt-in: measured 187.2 against 182.6 ms per read block with one whole finish behind the match kernels)
+  if (off || g_inflight.empty()) return;
+  if ((int) g_inflight.size() > flight_keep() || chain_finish_started(g_ring[g_inflight.front()])) (void) finish_tick(nfilt);
+}
+
 static int64_t finish_oldest()
 { const int x = g_inflight.front();
   g_inflight.pop_front();
@@ -1392,6 +1433,12 @@ static int64_t finish_oldest()
   }
   g_finishing = false;
   g_finishing_slot = -1;
+  finish_retire(x);
+  return nfilt;
+}
+
+static void finish_retire(int x)
+{ MergeResult &R = g_ring[x];
   if (finish_stream() != main_stream())
     { // whatever the main stream does from here on (the slot's buffers are about to be used again, Reporter reads the
       // candidate lists) comes after the finish stream's last kernel
@@ -1402,7 +1449,6 @@ static int64_t finish_oldest()
     }
   R.nhits = 0;
   R.npass = 0;
-  return nfilt;
 }
 
 // Device memory ran out (dev_alloc): the batches in flight are finished -- in order, as always -- and every ring slot
@@ -1591,6 +1637,10 @@ static void close_batch(MergeResult &R)
           }
           StageTimer tm("seed_clusters", 0.0);
           exclusive_scan_u32(rncl.p, nr, st.sort.bsum, rncl.p + nr);
+          { int64_t nf = 0;                   // (the per-read sort is queued: the third step of the oldest batch's finish)
+            finish_tick_if_due(&nf);
+            st.tfilt += nf;
+          }
           copy_d2h(&ncl, rncl.p + nr, sizeof(uint32_t), 1);
           R.ngroups = ncl;
           R.gstart.ensure((size_t) ncl + 1, "cluster starts");
