@@ -61,7 +61,7 @@ STAGE_KERNEL = {
     "k_radix_scatter": "k_radix_scatter", "k_radix_hist": "k_radix_hist", "radix_scan": "k_scan_*",
     "kmer_emit": "k_kmer_emit", "merge_match": "k_merge_match (+reduce, scan)", "merge_emit": "k_merge_expand (+sizes, scan)",
     "seed_groups": "k_group_flag/write (+scan)", "chain_small_groups": "k_chain<16>", "chain_listed_groups": "k_chain<64>",
- "chain_lane_groups": "k_chain_lane", "chain_lds_groups": "k_chain_small",
+ "chain_lane_groups": "k_chain_lane", "chain_simple_groups": "k_chain_simple", "chain_lds_groups": "k_chain_small",
     "chain_piles": "k_chain_pile", "chain_dominate": "k_order_summaries + k_dominate (+ scans)", "seed_clusters": "k_cluster_flag/rekey (+scan)",
     "seed_pairs": "k_pair_flag/write (+scan)", "chain_spilled_piles": "k_chain<64> (spilled piles)", "chain_jumps": "k_chain_jumps",
     "align": "k_align_cands32", "align_wave64": "k_align_cands<128>", "align_global_band": "k_align_cands<8192>",

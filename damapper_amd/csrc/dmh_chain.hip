@@ -63,6 +63,7 @@ struct ChainArgs
   uint32_t       *gcount;             // per group: number of summaries it reported and the slot of the first one in `out`
   uint32_t       *gbase;              //   (k_order_summaries puts them into the reference's reporting order)
   const uint32_t *glast;              // cluster mode: per group the largest apos + 1 of its (aread, bread) pair; else nullptr
+  uint32_t       *gdone;              // per group: 1 = chained by k_chain_simple (k_chain_lane leaves it alone); may be nullptr
   uint32_t        pile_cap;           // k_chain_pile: entries of LDS it may use (<= PILE_CAP; smaller in tests)
 };
 
@@ -530,6 +531,112 @@ __global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_
 }
 
 // ---------------------------------------------------------------------------------------
+//  Simple groups without a walk.  Measured on the bench workload (DMH_CHAIN_PROFILE): 95.7 % of the hits of the
+//  lane-per-group kernel find exactly ONE live hit in their window -- the hit before them -- take it as their
+//  predecessor and remove it (the slope rule, map.c:1835-1841), so that the window holds one hit again; 4 % find none
+//  (the first hit of a group, or one more than MAX_GAP behind its predecessor in A).  A group that consists of such
+//  steps only is a sequence of plain chains: the score of a hit is its predecessor's plus min(K, advance) -- a
+//  segmented prefix sum --, every chain's best end is its last hit, and nothing depends on the order of evaluation.
+//  This kernel checks, for every group of up to size_max hits, that each hit P -> H (consecutive in the group's
+//  (apos, bpos) order) is either
+//     a break:  P.apos < H.apos - MAX_GAP (P has left the window when H scans it: H starts a chain), or
+//     a step:   P is H's only candidate -- on a larger diagonal with P.bpos >= H.bpos - MAX_GAP (map.c:1806-1807, the
+//               "left" neighbour) or on H's or a smaller diagonal with P.bpos <= H.bpos (the "right" one) -- and
+//               5 |diagonal difference| <= H.apos - P.apos, so that H removes P;
+//  anything else (P stays live beside H, or is no candidate) leaves the group to k_chain_lane.  For the groups that
+//  pass it writes what the walk would: the `from` links, one summary per chain that scores, gcount / gbase, and marks
+//  the group done.  One 16-lane group per chain group, sixteen hits per round; streaming: 8 B read and 4 B written
+//  per hit.  Same results by construction -- and by the parity tests, which run every route.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chain_simple(ChainArgs A, uint32_t size_max)
+{ constexpr int G = 16, GPB = 256 / G;
+  const int lane = threadIdx.x & (G - 1), sub = (threadIdx.x & 63) / G;
+  const int K = A.K;
+  const uint64_t stride = (uint64_t) gridDim.x * GPB;
+  uint64_t c0 = (uint64_t) blockIdx.x * GPB + threadIdx.x / G;
+  // the bounds of the lane group's next chain group are asked for a turn ahead (a group is some 200 bytes: without that
+  // every turn starts with a memory round trip for two numbers)
+  uint32_t ng0 = 0, ng1 = 0;
+  if (c0 < A.ngroups) { ng0 = A.gstart[c0]; ng1 = A.gstart[c0 + 1]; }
+  for (; __any(c0 < A.ngroups); c0 += stride)
+    { const bool mine = c0 < A.ngroups;
+      const uint32_t g = mine ? (uint32_t) c0 : 0;
+      const uint32_t g0 = ng0;
+      uint32_t n = mine ? ng1 - ng0 : 0;
+      if (c0 + stride < A.ngroups) { ng0 = A.gstart[c0 + stride]; ng1 = A.gstart[c0 + stride + 1]; }
+      if (n > size_max) n = 0;                        // (not ours: the listed-group kernels)
+      // One pass: links and chain ends are written as if every hit were a break or a step; whether that was so is
+      // known at the end, and only then is the group marked done (k_chain_lane walks the others and writes over this).
+      const uint32_t obase = (g0 + HITMIN - 1) / HITMIN;
+      uint32_t E = 0;
+      bool     bad = false;
+      int      ccost = 0, coa = 0, cob = 0;           // running chain at the end of the previous round: score, origin
+      uint64_t plast = 0;                             // the last hit of the previous round
+      const int lastv = (n > 0) ? (int) (A.glast ? A.glast[g] : (uint32_t) A.ab[g0 + n - 1]) + (A.glast ? 0 : 1) : 0;
+      for (uint32_t r0 = 0; __any(r0 < n); r0 += G)
+        { const uint32_t i = r0 + lane;
+          const bool in = i < n;
+          const uint64_t w  = in ? A.ab[g0 + i] : 0;
+          const uint64_t nw = (in && i + 1 < n) ? A.ab[g0 + i + 1] : 0;         // (the same cache line, but for the round's last lane)
+          uint64_t pw = ((uint64_t) (uint32_t) __shfl_up((int) (uint32_t) (w >> 32), 1, G) << 32) | (uint64_t) (uint32_t) __shfl_up((int) (uint32_t) w, 1, G);
+          if (lane == 0) pw = plast;
+          plast = ((uint64_t) (uint32_t) __shfl((int) (uint32_t) (w >> 32), G - 1, G) << 32) | (uint64_t) (uint32_t) __shfl((int) (uint32_t) w, G - 1, G);
+          const int a = (int) (uint32_t) w + 1, b = (int) (w >> 32) + 1, pa = (int) (uint32_t) pw + 1, pb = (int) (pw >> 32) + 1;
+          const int d = a - b, pd = pa - pb;
+          const bool brk = in && (i == 0 || pa < a - MAX_GAP);
+          { const bool cand = (pd > d) ? (pb >= b - MAX_GAP) : (pb <= b);
+            int dd = pd - d;
+            if (dd < 0) dd = -dd;
+            if (in && !brk && !(cand && 5 * dd <= a - pa)) bad = true;
+          }
+          const int  adv = (pd > d) ? a - pa : b - pb;                      // left neighbour: advance in A; right: in B
+          int inc = brk ? K : (adv >= K ? K : adv);
+          if (!in) inc = 0;
+          // segmented inclusive sum over the 16 lanes; a lane before the round's first break continues the carried chain
+          int  x = inc, oa = brk ? a : 0, ob = brk ? b : 0;
+          bool f = brk;                                                       // a break at or below me in this round
+#pragma unroll
+          for (int o = 1; o < G; o <<= 1)
+            { const int  y  = __shfl_up(x, o, G), ya = __shfl_up(oa, o, G), yb = __shfl_up(ob, o, G);
+              const bool yf = __shfl_up((int) f, o, G) != 0;
+              if (lane >= o && !f) { x += y; oa = ya; ob = yb; f = yf; }
+            }
+          if (!f) { x += ccost; oa = coa; ob = cob; }
+          // the end of a chain: the group's last hit, or the hit before a break
+          const int  na = (int) (uint32_t) nw + 1;
+          const bool last = in && (i + 1 == n);
+          const bool end  = in && (last || a < na - MAX_GAP);
+          const bool emit = end && x >= A.hithr;
+          const uint32_t em = (uint32_t) ((__ballot(emit) >> (sub * G)) & 0xffffull);
+          if (emit)
+            { const bool live = last && a >= lastv - MAX_GAP;                 // (its end is in the window when the group ends)
+              ChainSummary sm;
+              sm.group = g;
+              sm.live  = live ? 1u : 0u;
+              sm.okey  = live ? (((uint64_t) ((uint32_t) d + 0x80000000u) << 32) | (uint32_t) a) : (((uint64_t) (uint32_t) a << 32) | (uint32_t) b);
+              sm.cost  = x;
+              sm.ab    = oa - K;
+              sm.bb    = ob - K;
+              sm.ae    = a;
+              sm.be    = b;
+              sm.end   = g0 + i;
+              A.out[obase + E + (uint32_t) __popc(em & ((1u << lane) - 1u))] = sm;
+            }
+          E += (uint32_t) __popc(em);
+          if (in) A.from[g0 + i] = brk ? NIL : g0 + i - 1;
+          // carry: the chain running at the round's last lane
+          ccost = __shfl(x, G - 1, G); coa = __shfl(oa, G - 1, G); cob = __shfl(ob, G - 1, G);
+        }
+      const bool anybad = ((__ballot(bad) >> (sub * G)) & 0xffffull) != 0;
+      if (n > 0 && !anybad && lane == 0)
+        { A.gcount[g] = E;
+          A.gbase[g]  = obase;
+          A.gdone[g]  = 1u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 //  One LANE per group.  A lane group per chain group keeps 15 of its 16 lanes idle through the sequential part of
 //  every hit, and the 10^6-10^7 groups of a pass on a repeat-rich genome (B-clusters of some twenty hits) offer all
 //  the parallelism a GPU wants without any inside a group.  Here every lane walks groups of its own: the live
@@ -540,19 +647,28 @@ __global__ __launch_bounds__(256) void k_chain_small(ChainArgs A, uint32_t size_
 //  after that is looked up in the background).  A window of more than RW live hits, or more than RT trees with live
 //  members, sends the group to the lane-group kernels (A.retry).  Same rules, same results.
 // ---------------------------------------------------------------------------------------
-constexpr int RW = 8;      // window slots of a lane (registers)
-constexpr int RT = 5;      // tree slots of a lane (LDS)
+// RW window slots of a lane (registers) and RT tree slots (LDS).  Measured on the bench workload (DMH_CHAIN_PROFILE,
+// profiles/scripts/rs_profile.py): 95.7 % of the hits find ONE live hit in the window, 4.0 % none, 0.34 % two, 0.01 %
+// three; one tree 92.5 %, two 3.8 %, three 0.06 %.  So the launch is <3, 3>: the unrolled scan of the window is what a
+// hit costs, and at eight slots it was five times what the data needs.  A group that outgrows its slots (one in 400)
+// goes to the lane-group kernel.
+constexpr int LANE_RW = 3, LANE_RT = 3;
 #ifndef DMH_LANE_WALKS
 #define DMH_LANE_WALKS 4
 #endif
 #ifndef DMH_LANE_CH
 #define DMH_LANE_CH 8
 #endif
+#ifdef DMH_CHAIN_PROFILE
+__device__ unsigned long long g_lprof[24];     // [0..8] hits by live window entries before the hit, [12..17] by live trees
+#endif
 constexpr int LANE_WALKS = DMH_LANE_WALKS;    // hits a lane walks per step of the wavefront (divides the chunk)
 constexpr int LANE_BLOCK = 64;    // one wavefront per workgroup: 7.5 KB of LDS each, so the registers bound the occupancy
 
-__global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t size_max)
+template <int RW, int RT>
+__global__ __launch_bounds__(LANE_BLOCK, 5) void k_chain_lane(ChainArgs A, uint32_t size_max)
 { constexpr int NW = LANE_BLOCK / 64;
+  static_assert(LANE_WALKS == 4 && DMH_LANE_CH == 8, "a chunk is two steps of four hits");
   __shared__ int32_t  t_bc[NW][RT][64];                       // per tree slot: best score ...
   __shared__ uint32_t t_oa[NW][RT][64], t_ob[NW][RT][64];      //   origin (apos, bpos)
   __shared__ uint32_t t_ea[NW][RT][64], t_eb[NW][RT][64];      //   best end (apos, bpos)
@@ -576,27 +692,30 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
   // the next (10^6 lanes stream at once): 22 GB of HBM traffic per launch against 1.5 GB of data.  A chunk is
   // the lane's next 64 bytes (and the 32 bytes of links that go with them), requested together; the chunk after it
   // (or the first one of the lane's next group) is on its way while this one is walked.
-  constexpr int CH = DMH_LANE_CH;
-  uint64_t kb[CH], nbk[CH];
-  uint32_t fb[CH];
+  constexpr int CH = DMH_LANE_CH, HC = CH / 2;
+  // (the chunk in two halves of four: hit j of the group is element u = j mod 4 of the half j & 4 picks -- a select
+  //  between two registers; as ONE array of eight the compiler keeps it in scratch memory and loads by index)
+  uint64_t kb0[HC], kb1[HC], nb0[HC], nb1[HC];
+  uint32_t fb0[HC], fb1[HC];
 #pragma unroll
-  for (int t = 0; t < CH; t++) { kb[t] = 0; nbk[t] = 0; fb[t] = 0; }
-  bool     copy_nb = false;   // the chunk was finished in the last step: its successor is waiting in nbk
+  for (int t = 0; t < HC; t++) { kb0[t] = 0; kb1[t] = 0; nb0[t] = 0; nb1[t] = 0; fb0[t] = 0; fb1[t] = 0; }
+  bool     copy_nb = false;   // the chunk was finished in the last step: its successor is waiting in nb0 / nb1
   bool     flush = false, ending = false;    // ... its links are to be written; ... and it was the group's last
   uint32_t last_r = 0;        // apos of the group's last hit (live test of its ends), asked for when the group is taken
-  uint32_t lq0 = 0, lq1 = 0;  // bounds of group pg on their way (pst 2)
+  uint32_t lq0 = 0, lq1 = 0, ldone = 0;  // bounds of group pg on their way (pst 2), and whether k_chain_simple has done it
   int      nb_for = 0;        // the look-ahead chunk holds: 0 nothing, 1 the next chunk of this group, 2 the first chunk of group pg
   // the group after it: pst 1 = look its bounds up, 2 = bounds on their way, 4 = bounds there and fine, 3 = and its first
   // chunk requested, 9 = none left
   uint32_t pg = blockIdx.x * LANE_BLOCK + threadIdx.x, q0 = 0, q1 = 0;
   int      pst = 1;
   const uint32_t hlast = A.nhits - 1;
-  auto load_chunk = [&](uint64_t *ck, uint32_t at)
+  auto load_chunk = [&](uint32_t at)
   {
 #pragma unroll
-    for (int t = 0; t < CH; t++)
-      { const uint32_t x = (at + t < hlast) ? at + t : hlast;
-        ck[t] = A.ab[x];
+    for (int t = 0; t < HC; t++)
+      { const uint32_t x0 = (at + t < hlast) ? at + t : hlast, x1 = (at + HC + t < hlast) ? at + HC + t : hlast;
+        nb0[t] = A.ab[x0];
+        nb1[t] = A.ab[x1];
       }
   };
 
@@ -639,13 +758,13 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
       if (copy_nb || ((!active || ending) && pst == 3))
         {
 #pragma unroll
-          for (int t = 0; t < CH; t++) kb[t] = nbk[t];
+          for (int t = 0; t < HC; t++) { kb0[t] = nb0[t]; kb1[t] = nb1[t]; }
           nb_for = 0;
           copy_nb = false;
         }
       if (pst == 2)
         { q0 = lq0; q1 = lq1;            // (the registers a load is on its way to are read nowhere else)
-          if (q1 - q0 <= size_max) pst = 4;
+          if (q1 - q0 <= size_max && ldone == 0) pst = 4;      // (not a listed group's size, not chained already)
           else { pg += nthreads; pst = 1; }
         }
       // ---- what the last step left to be written: its group's ends (they read last_r: before any store, or the
@@ -665,8 +784,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
       if (was_flush)
         {
 #pragma unroll
-          for (int t = 0; t < CH; t++)
-            if ((uint32_t) t <= (jl & (CH - 1))) fo[t] = fb[t];
+          for (int t = 0; t < HC; t++)
+            { if ((uint32_t) t <= (jl & (CH - 1))) fo[t] = fb0[t];
+              if ((uint32_t) (t + HC) <= (jl & (CH - 1))) fo[t + HC] = fb1[t];
+            }
           flush = false;
         }
       bool taken = false;
@@ -686,6 +807,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
         { if (pg < A.ngroups)
             { lq0 = A.gstart[pg];
               lq1 = A.gstart[pg + 1];
+              ldone = A.gdone ? A.gdone[pg] : 0u;
               pst = 2;
             }
           else
@@ -698,7 +820,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
           if (active && nxt < n) { at = g0 + nxt; what = 1; }
           else if (pst == 4)     { at = q0; what = 2; }
           if (what != 0)
-            { load_chunk(nbk, at);
+            { load_chunk(at);
               nb_for = what;
               if (what == 2) pst = 3;
             }
@@ -707,15 +829,16 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
       if (__ballot(active || pst != 9) == 0) break;
       // ---- LANE_WALKS hits per step: the memory operations above have that much longer to complete, and their
       //      bookkeeping is shared (a chunk is a whole number of steps; a lane whose group ends inside one idles)
-#pragma unroll 1
+      // (a lane starts a group at the head of a step and walks one hit per turn while it walks at all, so j = u (mod 4):
+      //  hit j is register u or u + 4 of the chunk -- one select instead of a search through the eight)
+#pragma unroll
       for (int u = 0; u < LANE_WALKS; u++)
         { if (!active || ending || copy_nb) continue;
 
           // ---- hit j of the group (map.c:1781-1872)
           const uint32_t t8 = j & (CH - 1);
-          uint64_t hk = kb[0];
-#pragma unroll
-          for (int t = 1; t < CH; t++) hk = (t8 == (uint32_t) t) ? kb[t] : hk;
+          const bool hi4 = (j & 4u) != 0;
+          const uint64_t hk = hi4 ? kb1[u] : kb0[u];
           const int apos = (int) (uint32_t) hk + 1, bpos = (int) (hk >> 32) + 1;
           const int diag = apos - bpos, thresh = bpos - MAX_GAP, old = apos - MAX_GAP;
           // The window scan, written without branches (selects only): the left neighbour is the live hit with the
@@ -740,6 +863,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
               Rdx = br ? dx : Rdx; Rax = br ? ax : Rax; Rc = br ? w_cost[s] : Rc; Rm = br ? w_meta[s] : Rm; Rs = br ? (uint32_t) s : Rs;
             }
           vmask &= ~emask;
+#ifdef DMH_CHAIN_PROFILE
+          atomicAdd(&g_lprof[__popc(vmask)], 1ull);
+          atomicAdd(&g_lprof[12 + __popc(tmask)], 1ull);
+#endif
           const int  Rbx    = Rax - Rdx;
           const int  lcost0 = (Lax >= 0) ? ((apos >= Lax + K) ? Lc + K : Lc + (apos - Lax)) : 0;
           const int  rcost0 = (Rax >= 0) ? ((bpos >= Rbx + K) ? Rc + K : Rc + (bpos - Rbx)) : 0;
@@ -774,8 +901,8 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
           const int  bcst = havep ? t_bc[wv][tj][lane] : 0;
           const bool improved = !havep || c >= bcst;                   // (a new origin is its tree's best end)
           { const uint32_t fv = havep ? g0 + (pm & 0xffffffu) : NIL;
-#pragma unroll
-            for (int t = 0; t < CH; t++) fb[t] = (t8 == (uint32_t) t) ? fv : fb[t];
+            fb0[u] = hi4 ? fb0[u] : fv;
+            fb1[u] = hi4 ? fv : fb1[u];
           }
           if (improved && !overflow)
             { t_bc[wv][tj][lane] = c;
@@ -785,7 +912,10 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
             }
           { int dd = pd - diag;
             if (dd < 0) dd = -dd;
-            const bool kill = havep && improved && ((double) dd <= .2 * (double) (apos - pa));      // map.c:1837,1852
+            // map.c:1837,1852: (double) dd <= .2 * (double) (apos - pa).  In integers: the double nearest to .2 lies
+            // above it by 5.6e-17 of its value, so the rounded product is x / 5 or the next double above, never below,
+            // and for integers dd, x < 2^31 the test is 5 dd <= x exactly (x / 5 + eps reaches no further integer)
+            const bool kill = havep && improved && (5 * dd <= apos - pa);
             vmask &= ~(kill ? (1u << ps) : 0u);
           }
           { const uint32_t fm = ~vmask & ((1u << RW) - 1u);
@@ -803,7 +933,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_chain_lane(ChainArgs A, uint32_t
           if (overflow)
             { A.retry[atomicAdd(A.nretry, 1u)] = g;          // (the lane-group kernel starts the group afresh)
               active = false;
-              if (nb_for == 1) nb_for = 0;                   // (nbk holds the abandoned group's next chunk)
+              if (nb_for == 1) nb_for = 0;                   // (nb0 / nb1 hold the abandoned group's next chunk)
             }
           else if (j == n || t8 == CH - 1)
             { // the chunk's links go out together -- at the head of the next step, like the group's ends when this was
@@ -1442,6 +1572,14 @@ void chain_classify_groups(MergeResult &R)
 
 #ifdef DMH_CHAIN_PROFILE
 }  // namespace dmh
+extern "C" void dmh_lane_profile(unsigned long long *out, int reset)
+{ HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dmh::g_lprof), sizeof(unsigned long long) * 24));
+  if (reset)
+    { unsigned long long z[24] = {0};
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(dmh::g_lprof), z, sizeof(z)));
+    }
+}
 extern "C" void dmh_chain_profile(unsigned long long *out, int reset)
 { HIP_CHECK(hipDeviceSynchronize());
   HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(dmh::g_cprof), sizeof(unsigned long long) * 16));
@@ -1523,6 +1661,7 @@ struct ChainCtx
   bool       has_piles = false, all64 = false;
   // chain_finish: buffers that live from one of its steps to the next, and where it stands
   DevBuf<uint32_t> goff, fresh, jl;
+  DevBuf<uint32_t> gdone;            // groups chained by k_chain_simple
   FinishState *fin = nullptr;
 };
 
@@ -1543,7 +1682,7 @@ void chain_release(MergeResult &R)
   C.gcnt.release(); C.gbase.release(); C.pileretry.release();
   C.livebuf.release();
   C.out.release();
-  C.goff.release(); C.fresh.release(); C.jl.release();
+  C.goff.release(); C.fresh.release(); C.jl.release(); C.gdone.release();
 }
 
 // A batch in flight is dropped (filter_discard): its pile kernel may still be writing the chain arrays on the pile
@@ -1608,6 +1747,7 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
   A.gcount = gcnt.p;
   A.gbase  = gbase.p;
   A.glast  = R.clustered ? R.glast.p : nullptr;
+  A.gdone  = nullptr;
   A.pile_cap = PILE_CAP;
 
   static const int env_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
@@ -1652,7 +1792,17 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             piles_done = ev_done;
           }
         if (R.lane_max > 0)
-          { // one lane per group: every group below the wavefront-per-group size tries this first; the ones whose
+          { // groups that are plain chains need no walk (k_chain_simple: "chain_simple" test option / DMH_CHAIN_SIMPLE = 0: off)
+            static const int env_simple = getenv("DMH_CHAIN_SIMPLE") ? atoi(getenv("DMH_CHAIN_SIMPLE")) : 1;
+            if ((st.opt_chain_simple >= 0 ? st.opt_chain_simple : env_simple) != 0)
+              { C.gdone.ensure((size_t) R.ngroups + 1, "groups chained without a walk");
+                HIP_CHECK(hipMemsetAsync(C.gdone.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
+                A.gdone = C.gdone.p;
+                StageTimer t0("chain_simple_groups", 12.0 * nhits);
+                const int nbs = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
+                hipLaunchKernelGGL(k_chain_simple, dim3(nbs), dim3(256), 0, stream(), A, R.lane_max);
+              }
+            // one lane per group: every group below the wavefront-per-group size tries this first; the ones whose
             // window or tree table overflows are appended to the medium list
             ChainArgs Q = A;
             Q.retry  = R.medlist.p;
@@ -1666,12 +1816,12 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
                 hipDeviceProp_t prop;
                 HIP_CHECK(hipGetDevice(&dev));
                 HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_lane, LANE_BLOCK, 0));
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_lane<LANE_RW, LANE_RT>, LANE_BLOCK, 0));
                 resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
                 if (getenv("DMH_STATS")) fprintf(stderr, "dmh: k_chain_lane: %d workgroups of %d per CU\n", per_cu, LANE_BLOCK);
               }
             const int nb = (int) std::min<int64_t>((R.ngroups + LANE_BLOCK - 1) / LANE_BLOCK, resident);
-            hipLaunchKernelGGL(k_chain_lane, dim3(nb), dim3(LANE_BLOCK), 0, stream(), Q, R.lane_max);
+            hipLaunchKernelGGL((k_chain_lane<LANE_RW, LANE_RT>), dim3(nb), dim3(LANE_BLOCK), 0, stream(), Q, R.lane_max);
           }
         else if (R.small_cap > 0)
           { // the all-LDS kernel: groups dealt round-robin, as many lane groups as the GPU holds

@@ -36,3 +36,11 @@ print("workgroups %d, hits %d (%.0f per workgroup)" % (v[8], v[9], v[9] / max(1,
 for i, nm in enumerate(names):
     print("%-24s %6.1f %%  %8.0f cycles per workgroup" % (nm, 100.0 * v[i] / max(1, tot), v[i] / max(1, v[8])))
 print({k: round(x["ms"], 1) for k, x in sorted(capi.timings().items(), key=lambda kv: -kv[1]["ms"])[:10]})
+
+lp = (C.c_ulonglong * 24)()
+L.dmh_lane_profile.argtypes = [C.c_void_p, C.c_int]
+L.dmh_lane_profile(lp, 0)
+v = list(lp)
+tot = max(1, sum(v[:9]))
+print("k_chain_lane: hits by live window entries before the hit:", " ".join("%d:%.2f%%" % (i, 100.0 * v[i] / tot) for i in range(9)))
+print("k_chain_lane: hits by live trees:", " ".join("%d:%.2f%%" % (i, 100.0 * v[12 + i] / tot) for i in range(6)))
