@@ -556,14 +556,30 @@ __global__ __launch_bounds__(256) void k_chain_simple(ChainArgs A, uint32_t size
   uint64_t c0 = (uint64_t) blockIdx.x * GPB + threadIdx.x / G;
   // the bounds of the lane group's next chain group are asked for a turn ahead (a group is some 200 bytes: without that
   // every turn starts with a memory round trip for two numbers)
-  uint32_t ng0 = 0, ng1 = 0;
-  if (c0 < A.ngroups) { ng0 = A.gstart[c0]; ng1 = A.gstart[c0 + 1]; }
+  // ... and its first sixteen hits, with the hit behind each, and its pair's last apos: two turns ahead the bounds, one
+  // turn ahead what they point at
+  const uint32_t hlast = A.nhits - 1;
+  uint32_t ng0 = 0, ng1 = 0, fg0 = 0, fg1 = 0, nlastv = 0;
+  uint64_t fw = 0, fnw = 0;
+  if (c0 < A.ngroups)
+    { ng0 = A.gstart[c0]; ng1 = A.gstart[c0 + 1];
+      fw = A.ab[min(ng0 + (uint32_t) lane, hlast)]; fnw = A.ab[min(ng0 + (uint32_t) lane + 1u, hlast)];
+      nlastv = A.glast ? A.glast[c0] : (uint32_t) A.ab[min(ng1 - 1u, hlast)];
+    }
+  if (c0 + stride < A.ngroups) { fg0 = A.gstart[c0 + stride]; fg1 = A.gstart[c0 + stride + 1]; }
   for (; __any(c0 < A.ngroups); c0 += stride)
     { const bool mine = c0 < A.ngroups;
       const uint32_t g = mine ? (uint32_t) c0 : 0;
       const uint32_t g0 = ng0;
       uint32_t n = mine ? ng1 - ng0 : 0;
-      if (c0 + stride < A.ngroups) { ng0 = A.gstart[c0 + stride]; ng1 = A.gstart[c0 + stride + 1]; }
+      const uint64_t w0 = fw, nw0 = fnw;              // the first round's hits, asked for a turn ago
+      const uint32_t lastr = nlastv;
+      ng0 = fg0; ng1 = fg1;
+      if (c0 + stride < A.ngroups)
+        { fw = A.ab[min(ng0 + (uint32_t) lane, hlast)]; fnw = A.ab[min(ng0 + (uint32_t) lane + 1u, hlast)];
+          nlastv = A.glast ? A.glast[c0 + stride] : (uint32_t) A.ab[min(ng1 - 1u, hlast)];
+        }
+      if (c0 + 2 * stride < A.ngroups) { fg0 = A.gstart[c0 + 2 * stride]; fg1 = A.gstart[c0 + 2 * stride + 1]; }
       if (n > size_max) n = 0;                        // (not ours: the listed-group kernels)
       // One pass: links and chain ends are written as if every hit were a break or a step; whether that was so is
       // known at the end, and only then is the group marked done (k_chain_lane walks the others and writes over this).
@@ -572,12 +588,16 @@ __global__ __launch_bounds__(256) void k_chain_simple(ChainArgs A, uint32_t size
       bool     bad = false;
       int      ccost = 0, coa = 0, cob = 0;           // running chain at the end of the previous round: score, origin
       uint64_t plast = 0;                             // the last hit of the previous round
-      const int lastv = (n > 0) ? (int) (A.glast ? A.glast[g] : (uint32_t) A.ab[g0 + n - 1]) + (A.glast ? 0 : 1) : 0;
+      const int lastv = (int) lastr + (A.glast ? 0 : 1);
       for (uint32_t r0 = 0; __any(r0 < n); r0 += G)
         { const uint32_t i = r0 + lane;
           const bool in = i < n;
-          const uint64_t w  = in ? A.ab[g0 + i] : 0;
-          const uint64_t nw = (in && i + 1 < n) ? A.ab[g0 + i + 1] : 0;         // (the same cache line, but for the round's last lane)
+          uint64_t w, nw;
+          if (r0 == 0) { w = in ? w0 : 0; nw = (in && i + 1 < n) ? nw0 : 0; }
+          else
+            { w  = in ? A.ab[g0 + i] : 0;
+              nw = (in && i + 1 < n) ? A.ab[g0 + i + 1] : 0;                   // (the same cache line, but for the round's last lane)
+            }
           uint64_t pw = ((uint64_t) (uint32_t) __shfl_up((int) (uint32_t) (w >> 32), 1, G) << 32) | (uint64_t) (uint32_t) __shfl_up((int) (uint32_t) w, 1, G);
           if (lane == 0) pw = plast;
           plast = ((uint64_t) (uint32_t) __shfl((int) (uint32_t) (w >> 32), G - 1, G) << 32) | (uint64_t) (uint32_t) __shfl((int) (uint32_t) w, G - 1, G);

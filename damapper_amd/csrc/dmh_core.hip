@@ -1004,6 +1004,7 @@ struct SortJob
   int       stage;              // index into the stage list (see bg_step)
   const DAZZ_DB *block;         // emit stage: the block whose device copy is read
   int       Kmer;
+  int       posbits;            // > 0: positions emitted as (read << posbits) | rpos
 };
 static std::deque<SortJob> g_bg;
 
@@ -1063,7 +1064,7 @@ static void bg_step()
                              (const int64_t *) ix.d_boff, bd.nreads, ix.nchunk, ix.d_chunk);
           HIP_CHECK(hipGetLastError());
         }
-      kmer_emit(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, J.Kmer, J.keys, J.vals, J.kmers, J.stage, EMIT_PARTS);
+      kmer_emit(bd.d_bases(), bd.L, bd.d_boff, bd.nreads, J.Kmer, J.keys, J.vals, J.kmers, J.stage, EMIT_PARTS, J.posbits);
       J.stage += 1;
       return;
     }
@@ -1191,9 +1192,14 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
 
   delete ha;
   HostTimer *he = new HostTimer("sk_enqueue");
+  // positions straight as (read, rpos) words when they fit 32 bits and no mask wants block offsets (k_mask_flag)
+  { const int pb = ceil_log2_i(maxrl > 1 ? (int64_t) maxrl + 1 : 2), rb = ceil_log2_i(nreads > 1 ? nreads : 1);
+    static const bool off = getenv("DMH_NO_PACKED_POS") != nullptr;
+    if (!off && mask == nullptr && maxrl > 0 && pb + rb <= 32) ix.posbits = pb;
+  }
   if (!defer)
     { block_ready(bd);
-      kmer_emit(bd.d_bases(), L, bd.d_boff, nreads, pm.Kmer, keys, vals, kmers);
+      kmer_emit(bd.d_bases(), L, bd.d_boff, nreads, pm.Kmer, keys, vals, kmers, 0, 1, ix.posbits);
     }
   if (getenv("DMH_DEBUG_SYNC") != nullptr)
     { HostTimer hs("sk_emit_sync");
@@ -1317,6 +1323,7 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
       J.stage = 0;
       J.block = block;
       J.Kmer  = pm.Kmer;
+      J.posbits = ix.posbits;
       g_bg.push_back(J);
       if (kmers <= 1) bg_flush();
     }

@@ -1616,23 +1616,48 @@ static void close_batch(MergeResult &R)
             }
           // clusters ordered on 32-bit words when apos leaves the room ("read_sort" test option = 4: on 64-bit words)
           const bool k32 = R.pbits + rcb + 6 <= 32 && st.opt_read_sort != 4;
-          { // (8 B read + 8 B written per hit); the largest segments first: they are the longest jobs
+          { // (8 B read + 8 B written per hit).  The three workgroup sizes run one after the other, the largest segments
+            // first.  Next to each other (DMH_READ_SORT_FORK: the two larger sizes on streams of their own, to fill the
+            // tail of half-empty CUs each launch ends in) they take TWICE as long -- 75.7 against 36.7 ms per read block:
+            // a CU holds four small workgroups or one large one, and mixed they keep each other's LDS from being used
             StageTimer tm("read_sort", 16.0 * nhits);
+            static hipStream_t side[2] = {nullptr, nullptr};
+            static hipEvent_t  ev_go = nullptr, ev_back[2] = {nullptr, nullptr};
+            if (side[0] == nullptr)
+              { for (int i = 0; i < 2; i++)
+                  { HIP_CHECK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+                    HIP_CHECK(hipEventCreateWithFlags(&ev_back[i], hipEventDisableTiming));
+                  }
+                HIP_CHECK(hipEventCreateWithFlags(&ev_go, hipEventDisableTiming));
+              }
+            static const bool serial = getenv("DMH_READ_SORT_FORK") == nullptr;
+            const bool fork = !serial && (g_rcnt[2] > 0 || g_rcnt[1] > 0) && g_rcnt[0] > 0;
+            if (fork) HIP_CHECK(hipEventRecord(ev_go, stream()));
+            bool used[2] = {false, false};
             if (g_rcnt[2] > 0)
-              { RA.list = g_rlists.p + 2 * (size_t) nr;
-                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), stream(), RA);
-                else     hipLaunchKernelGGL((k_read_sort<RS_T2, false>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), stream(), RA);
+              { hipStream_t q = fork ? side[0] : stream();
+                if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[0] = true; }
+                RA.list = g_rlists.p + 2 * (size_t) nr;
+                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
+                else     hipLaunchKernelGGL((k_read_sort<RS_T2, false>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
               }
             if (g_rcnt[1] > 0)
-              { RA.list = g_rlists.p + (size_t) nr;
-                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), stream(), RA);
-                else     hipLaunchKernelGGL((k_read_sort<RS_T1, false>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), stream(), RA);
+              { hipStream_t q = fork ? side[1] : stream();
+                if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[1] = true; }
+                RA.list = g_rlists.p + (size_t) nr;
+                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
+                else     hipLaunchKernelGGL((k_read_sort<RS_T1, false>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
               }
             if (g_rcnt[0] > 0)
               { RA.list = g_rlists.p;
                 if (k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T0, false>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
               }
+            for (int i = 0; i < 2; i++)
+              if (used[i])
+                { HIP_CHECK(hipEventRecord(ev_back[i], side[i]));
+                  HIP_CHECK(hipStreamWaitEvent(stream(), ev_back[i], 0));
+                }
             HIP_CHECK(hipGetLastError());
           }
           StageTimer tm("seed_clusters", 0.0);

@@ -462,7 +462,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__res
                                                             const int64_t *__restrict__ boff, int nreads,
                                                             int K, uint64_t kmask,
                                                             uint64_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ vals, int64_t nk, int block_base)
+                                                            uint32_t *__restrict__ vals, int64_t nk, int block_base,
+                                                            int posbits)
 { __shared__ uint4    sraw[(EMIT_TILE + 64) / 16 + 1];   // the tile's bases + halo, as fetched (16-byte lines)
   __shared__ uint64_t scode[EMIT_TILE];
   __shared__ uint16_t sread[EMIT_TILE];     // read index relative to the tile's first read
@@ -541,13 +542,15 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_kmer_emit(const uint8_t *__res
         int64_t o = q - i * K - (K - 1);
         if (o >= 0 && o < nk)
           { keys[o] = scode[x];
-            vals[o] = (uint32_t) q;
+            // posbits > 0: the position as (read << posbits) | rpos, what the merge makes hits of (index_pack_positions
+            // would convert the sorted index later, with a table look-up per k-mer)
+            vals[o] = (posbits > 0) ? (((uint32_t) i << posbits) | (uint32_t) (q - boff[i])) : (uint32_t) q;
           }
       }
 }
 
 void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, int K,
-               uint64_t *d_keys, uint32_t *d_vals, int64_t nk, int part, int nparts)
+               uint64_t *d_keys, uint32_t *d_vals, int64_t nk, int part, int nparts, int posbits)
 { if (L <= 0) return;
   uint64_t kmask = (K >= 32) ? ~0ull : ((1ull << (2 * K)) - 1ull);
   int nb = ceil_div(L, EMIT_TILE);
@@ -556,7 +559,7 @@ void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nre
   if (b1 <= b0) return;
   StageTimer tm("kmer_emit", ((double) L + 16.0 * (double) nk) * (double) (b1 - b0) / (double) nb);
   hipLaunchKernelGGL(k_kmer_emit, dim3(b1 - b0), dim3(EMIT_THREADS), 0, stream(), d_bases, L, d_boff, nreads,
-                     K, kmask, d_keys, d_vals, nk, b0);
+                     K, kmask, d_keys, d_vals, nk, b0, posbits);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -211,7 +211,7 @@ void      drop_block(const DAZZ_DB *block);
 void      free_blockdev(BlockDev &bd);
 
 void kmer_emit(const uint8_t *d_bases, int64_t L, const int64_t *d_boff, int nreads, int K,
-               uint64_t *d_keys, uint32_t *d_vals, int64_t nk, int part = 0, int nparts = 1);
+               uint64_t *d_keys, uint32_t *d_vals, int64_t nk, int part = 0, int nparts = 1, int posbits = 0);
 
 IndexDev *index_of(void *table, const char *who);
 void      release_ref_index(IndexDev &ix);    // Match_Filter is done with a REF index: cache it or free it
