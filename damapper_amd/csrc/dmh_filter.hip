@@ -1,6 +1,7 @@
-// dmh_filter.hip -- Match_Filter (map.c:2889-3209): merge -> seed sort -> chain scoring ->
-// candidate lists.  Device stages live in dmh_merge.hip / dmh_chain.hip; the per-read
-// candidate bookkeeping (domination rule, Jump storage) is host code in dmh_chain.hip.
+// dmh_filter.hip -- Match_Filter (map.c:2889-3209): merge -> seed order -> chain scoring ->
+// candidate lists.  All stages are device code (dmh_merge.hip, dmh_readsort.h, dmh_chain.hip), the
+// candidate lists with the domination rule and the Jump storage included; this file is the entry
+// point with the reference's call contract.
 
 #include "dmh_state.h"
 #include "dmh_merge.h"

@@ -1289,7 +1289,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   const int  rs_cb = std::min(RS_CB, R.qbits);
   const bool by_read = R.word && R.npass == 0 && !env_per_entry && st.opt_expand != 0 &&
                        (st.opt_read_sort >= 0 ? st.opt_read_sort != 0 : env_rs != 0) &&
-                       (R.pbits + RS_DB - 1) / RS_DB + (R.qbits - rs_cb + R.bbits + RS_DB - 1) / RS_DB <= RS_MAXPASS;
+                       R.pbits + R.qbits - rs_cb + R.bbits <= 32;          // (the sort key of k_read_sort is one 32-bit word)
   R.read_sorted = false;
 
   // --- expand the entries under the limit into hits (map.c:3095-3099), behind the batch's earlier passes
@@ -1585,20 +1585,19 @@ static void close_batch(MergeResult &R)
           HIP_CHECK(hipMemsetAsync(rncl.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
           ReadSortArgs RA;
           RA.in = k0; RA.out = k1; RA.rstart = g_rstart.p;
-          // the coarse buckets of this route (32 kb: a locus rarely lies across two) and its radix passes: the digits
-          // of apos, then those of the coarse key, each field cut into equal digits of at most RS_DB bits
+          // the coarse buckets of this route (64 kb: a locus rarely lies across two) and its radix passes: the sort key
+          // apos | coarse key << pbits cut into equal digits of at most RS_DB bits
           const int rcb = std::min(RS_CB, qbits), kbits = qbits - rcb + R.bbits;
           RA.pbits = R.pbits; RA.qbits = qbits; RA.bbits = R.bbits; RA.cb = rcb;
+          RA.kbits = kbits;
           RA.npass = 0;
-          for (int f = 0; f < 2; f++)
-            { const int bits = f ? kbits : R.pbits, first = f ? R.pbits + rcb : 0;
-              const int nd = (bits + RS_DB - 1) / RS_DB;
-              for (int k = 0, at = 0; k < nd; k++)
-                { const int wdt = (bits - at + (nd - k) - 1) / (nd - k);
-                  RA.sh[RA.npass] = (uint8_t) (first + at); RA.wd[RA.npass] = (uint8_t) wdt;
-                  RA.npass += 1; at += wdt;
-                }
-            }
+          { const int bits = R.pbits + kbits, nd = (bits + RS_DB - 1) / RS_DB;
+            for (int k = 0, at = 0; k < nd; k++)
+              { const int wdt = (bits - at + (nd - k) - 1) / (nd - k);
+                RA.sh[RA.npass] = (uint8_t) at; RA.wd[RA.npass] = (uint8_t) wdt;
+                RA.npass += 1; at += wdt;
+              }
+          }
           // ("read_sort" test option = 5: ranks from ballots, as on a device whose LDS does not serve atomics in lane order)
           RA.ordered = (lds_atomics_ordered() && st.opt_read_sort != 5) ? 1 : 0;
           RA.lcl = lcl.p; RA.rncl = rncl.p;

@@ -33,7 +33,7 @@ constexpr int RS_E  = 16;        // words per thread: a workgroup of T threads t
 constexpr int RS_IN = 64;        // clusters of up to this many hits are ordered inside k_read_sort (= CS_SMALL)
 constexpr int RS_DB = 9;         // most bits of a radix digit
 constexpr int RS_MAXPASS = 8;
-constexpr int RS_CB = 15;        // coarse buckets of 32 kb: one locus in fifteen lies across a boundary
+constexpr int RS_CB = 16;        // coarse buckets of 64 kb: one locus in thirty lies across a boundary
 
 struct ReadSortArgs
 { const uint64_t *in;            // the pass's words, read by read (w = aread | bread | bpos | apos)
@@ -41,7 +41,8 @@ struct ReadSortArgs
   const uint32_t *rstart;        // first word of every read (+ end)
   const uint32_t *list;          // the reads this launch takes, one per workgroup (k_read_classes)
   int             pbits, qbits, bbits, cb;
-  int             npass;         // radix passes, least significant digit first: apos, then the coarse key
+  int             kbits;         // bits of the coarse key (bread, bpos >> cb)
+  int             npass;         // radix passes over the sort key apos | coarse key << pbits, least significant digit first
   uint8_t         sh[RS_MAXPASS], wd[RS_MAXPASS];        // first bit and width of each digit
   int             ordered;       // the LDS serves atomics in lane order (else: ballots)
   uint64_t       *lcl;           // per cluster, at rstart[r] + j: spans buckets << 63 | contig << 32 | first word
@@ -147,7 +148,12 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
 #endif
   RSPROF_LAP(0);
 
-  // ---- 1. stable LSD passes: apos, then the coarse key
+  // ---- 1. stable LSD passes over the sort key: apos in its low bits, the coarse key above (one word of at most 32 bits,
+  // so that a digit may lie across the two fields: 27 bits here, three passes of nine)
+  const uint64_t apm = (1ull << A.pbits) - 1ull;
+  const uint32_t ckm = (A.kbits >= 32) ? 0xffffffffu : ((1u << A.kbits) - 1u);
+  const int      csh = A.pbits + A.cb;
+  auto rs_key = [&](uint64_t x) -> uint32_t { return (uint32_t) (x & apm) | (((uint32_t) (x >> csh) & ckm) << A.pbits); };
   uint16_t *mywh = wh + (size_t) w * D;
   uint32_t *my32 = (uint32_t *) mywh;
   for (int p = 0; p < A.npass; p++)
@@ -163,14 +169,14 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
             { rk[j] = 0;
               if ((uint32_t) j < rounds)
                 { const uint32_t i = wbase + 64u * j + lane;
-                  const uint32_t d = (uint32_t) (key[j] >> sh) & dmask;
+                  const uint32_t d = (rs_key(key[j]) >> sh) & dmask;
                   if (i < n) rk[j] = atomicAdd(&my32[d >> 1], 1u << ((d & 1u) * 16u));
                 }
             }
 #pragma unroll
           for (int j = 0; j < E; j++)
             if ((uint32_t) j < rounds)
-              rk[j] = (rk[j] >> ((((uint32_t) (key[j] >> sh) & dmask) & 1u) * 16u)) & 0xffffu;
+              rk[j] = (rk[j] >> ((((rs_key(key[j]) >> sh) & dmask) & 1u) * 16u)) & 0xffffu;
         }
       else
         {
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
               if ((uint32_t) j < rounds)                       // (uniform)
                 { const uint32_t i  = wbase + 64u * j + lane;
                   const bool     ok = i < n;
-                  const uint32_t d  = (uint32_t) (key[j] >> sh) & dmask;
+                  const uint32_t d  = (rs_key(key[j]) >> sh) & dmask;
                   uint64_t peers = __ballot(ok);
                   for (int b = 0; b < wd; b++)
                     { const bool     bit = (d >> b) & 1u;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
         if ((uint32_t) j < rounds)
           { const uint32_t i = wbase + 64u * j + lane;
             if (i < n)
-              { const uint32_t d = (uint32_t) (key[j] >> sh) & dmask;
+              { const uint32_t d = (rs_key(key[j]) >> sh) & dmask;
                 buf[rk[j] + (uint32_t) mywh[d]] = key[j];
               }
           }
