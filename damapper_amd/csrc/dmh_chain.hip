@@ -1544,7 +1544,8 @@ constexpr uint32_t BIG_GROUP = 1024;
 
 constexpr uint32_t SMALL_CAP = 64;       // k_chain_small<16, 64>
 
-void chain_classify_groups(MergeResult &R)
+// the size classes of the chain kernels (before the groups exist: k_read_sort counts by them)
+void chain_group_limits(MergeResult &R)
 { State &st = S();
   static const int env_g    = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
   static const int env_pile = getenv("DMH_CHAIN_PILE") ? atoi(getenv("DMH_CHAIN_PILE")) : 4096;
@@ -1562,6 +1563,12 @@ void chain_classify_groups(MergeResult &R)
   static const int env_lane = getenv("DMH_CHAIN_LANE") ? atoi(getenv("DMH_CHAIN_LANE")) : 1;
   const int ln = (st.opt_chain_lane >= 0) ? st.opt_chain_lane : env_lane;
   R.lane_max = (ln != 0 && chain_g == 0 && sc != 0) ? std::min<uint32_t>(R.small_hi - 1, 0xffffffu) : 0;
+}
+
+// known (may be null): {groups of small_hi .. pile_min - 1 hits, piles, hits in piles} counted already (k_read_sort;
+// only with the lane kernel on, when no group is "medium" at this point): the lists are made, nothing is fetched
+void chain_classify_groups(MergeResult &R, const uint32_t *known)
+{ chain_group_limits(R);
   const uint32_t list_from = R.lane_max > 0 ? R.lane_max : R.small_cap;      // smaller groups are not listed
   R.biglist.ensure((size_t) R.ngroups + 64, "big groups");
   R.pilelist.ensure((size_t) R.ngroups + 64, "repeat piles");
@@ -1578,6 +1585,10 @@ void chain_classify_groups(MergeResult &R)
                      R.pile_min > 0 ? R.pile_min : 0xffffffffu, R.medlist.p, R.gcounts.p + 2, R.biglist.p, R.gcounts.p,
                      R.pilelist.p, R.gcounts.p + 1);
   HIP_CHECK(hipGetLastError());
+  if (known != nullptr && R.lane_max > 0)
+    { R.nbig = known[0]; R.npiles = known[1]; R.nmed = 0; R.pile_hits = known[2];
+      return;
+    }
   uint32_t cnt[4] = {0, 0, 0, 0};
   copy_d2h(cnt, R.gcounts.p, 4 * sizeof(uint32_t));
   R.nbig   = cnt[0];

@@ -53,7 +53,8 @@ struct MergeResult
 };
 
 // classifies the groups of R.gstart on the device and fetches the number of piles
-void chain_classify_groups(MergeResult &R);
+void chain_group_limits(MergeResult &R);        // (the size classes alone)
+void chain_classify_groups(MergeResult &R, const uint32_t *known = nullptr);
 
 // One Match_Filter pass up to the expanded hits (map.c:2984-3099): returns the number of hits it added.  May close the
 // batch first (when the pass does not fit it) and closes it afterwards unless batching is on; *nfilt accumulates the

@@ -1055,6 +1055,8 @@ static bool lds_atomics_ordered()
 // per-read route: segment starts of the pass being collected (main stream only; a dense pass is closed at once)
 static DevBuf<uint32_t> g_rstart, g_rowdst, g_rstats, g_rlists, g_wlist[2];
 static DevBuf<unsigned int> g_wcnt;
+static uint32_t g_known[5] = {0, 0, 0, 0, 0};     // clusters, clusters for the radix sort, big groups, piles, hits in piles (k_read_sort)
+static bool     g_have_known = false;
 static uint32_t g_rcnt[4] = {0, 0, 0, 0}, g_rlim = 0;      // reads per k_read_sort workgroup size, largest segment; its limit
 constexpr int RS_T0 = 256, RS_T1 = 512, RS_T2 = 1024;      // k_read_sort workgroups: segments of up to 4,096 / 8,192 / 16,384 hits
 
@@ -1601,6 +1603,14 @@ static void close_batch(MergeResult &R)
           // ("read_sort" test option = 5: ranks from ballots, as on a device whose LDS does not serve atomics in lane order)
           RA.ordered = (lds_atomics_ordered() && st.opt_read_sort != 5) ? 1 : 0;
           RA.lcl = lcl.p; RA.rncl = rncl.p;
+          // the clusters are counted by size while they are found, in the chain kernels' classes and the cluster sorts'
+          chain_group_limits(R);
+          g_wcnt.ensure(8, "cluster counters");
+          HIP_CHECK(hipMemsetAsync(g_wcnt.p, 0, 8 * sizeof(unsigned int), stream()));
+          RA.counts = g_wcnt.p;
+          RA.medium = (uint32_t) CS_MEDIUM;
+          RA.big_min = R.small_hi;
+          RA.pile_min = R.pile_min > 0 ? R.pile_min : 0xffffffffu;
           static bool attr = false;
           if (!attr)
             { attr = true;
@@ -1661,18 +1671,20 @@ static void close_batch(MergeResult &R)
           }
           StageTimer tm("seed_clusters", 0.0);
           exclusive_scan_u32(rncl.p, nr, st.sort.bsum, rncl.p + nr);
+          HIP_CHECK(hipMemcpyAsync(g_wcnt.p + 2, rncl.p + nr, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
           { int64_t nf = 0;                   // (the per-read sort is queued: the third step of the oldest batch's finish)
             finish_tick_if_due(&nf);
             st.tfilt += nf;
           }
-          copy_d2h(&ncl, rncl.p + nr, sizeof(uint32_t), 1);
+          // one round trip: clusters, clusters the radix sort has to finish, the chain kernels' big groups and piles
+          copy_d2h(g_known, g_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
+          ncl = g_known[0];
+          g_have_known = true;
           R.ngroups = ncl;
           R.gstart.ensure((size_t) ncl + 1, "cluster starts");
           R.gkey.ensure((size_t) ncl + 1, "cluster keys");
           g_wlist[0].ensure((size_t) ncl + 64, "clusters for the workgroup sort");
           g_wlist[1].ensure((size_t) ncl + 64, "clusters for the radix sort");
-          g_wcnt.ensure(4, "cluster sort counters");
-          HIP_CHECK(hipMemsetAsync(g_wcnt.p, 0, 4 * sizeof(unsigned int), stream()));
           hipLaunchKernelGGL(k_cluster_compact, dim3(ceil_div((int64_t) nr * 64, 256)), dim3(256), 0, stream(),
                              (const uint64_t *) lcl.p, (const uint32_t *) g_rstart.p, (const uint32_t *) rncl.p, nr, R.bbits,
                              (uint32_t) nhits, R.gstart.p, R.gkey.p, (uint32_t) RS_IN, (uint32_t) CS_MEDIUM,
@@ -1739,7 +1751,8 @@ static void close_batch(MergeResult &R)
                                  (uint32_t) CS_WAVE, (uint32_t) CS_MEDIUM);
               HIP_CHECK(hipGetLastError());
               unsigned int hc[2] = {0, 0};
-              copy_d2h(hc, g_wcnt.p, 2 * sizeof(unsigned int), 1);
+              if (g_known[1] > 0)             // (k_read_sort counted them: no round trip when there are none)
+                copy_d2h(hc, g_wcnt.p, 2 * sizeof(unsigned int), 1);
               if (hc[1] > 0)
                 { // repeat piles across buckets: stable radix passes on bpos (the high half of the word), then on apos
                   std::vector<uint32_t> big(hc[1]), gs((size_t) ncl + 1);
@@ -1803,7 +1816,9 @@ static void close_batch(MergeResult &R)
       }
     }
   R.sab = k0;
-  chain_classify_groups(R);          // (its copy of the pile count is the synchronisation point)
+  // (the lists of big groups and piles; their numbers come back with the copy -- or are known from k_read_sort)
+  chain_classify_groups(R, (rs && g_have_known) ? g_known + 2 : nullptr);
+  g_have_known = false;
   HIP_CHECK(hipGetLastError());
 
   if (st.capture_seeds)

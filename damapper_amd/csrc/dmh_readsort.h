@@ -47,6 +47,11 @@ struct ReadSortArgs
   int             ordered;       // the LDS serves atomics in lane order (else: ballots)
   uint64_t       *lcl;           // per cluster, at rstart[r] + j: spans buckets << 63 | contig << 32 | first word
   uint32_t       *rncl;          // clusters per read
+  // clusters by size, counted as they are found (the host reads them with the number of clusters: one round trip):
+  // counts[3] += clusters across buckets of more than `medium` hits (the radix sort finishes those), [4] += clusters of
+  // big_min .. pile_min - 1 hits, [5] += piles, [6] += hits in piles (the chain kernels' size classes)
+  uint32_t       *counts;
+  uint32_t        medium, big_min, pile_min;
 };
 
 template <int T>
@@ -338,7 +343,18 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
             { const uint32_t c = cid[j];
               multi = (mbits[c >> 5] >> (c & 31u)) & 1u;
               if ((flagw[wi] >> bi) & 1ull)
-                A.lcl[s0 + c] = ((uint64_t) multi << 63) | (((key[j] >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
+                { A.lcl[s0 + c] = ((uint64_t) multi << 63) | (((key[j] >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
+                  // the cluster's size: up to the next start (the sentinel ends the search)
+                  uint64_t m = (bi == 63) ? 0ull : (flagw[wi] & (~0ull << (bi + 1)));
+                  uint32_t ww = wi;
+                  while (m == 0) { ww += 1; m = flagw[ww]; }
+                  const uint32_t size = ww * 64 + (uint32_t) __ffsll((long long) m) - 1 - i;
+                  if (size >= A.big_min)
+                    { if (size >= A.pile_min) { atomicAdd(A.counts + 5, 1u); atomicAdd(A.counts + 6, size); }
+                      else atomicAdd(A.counts + 4, 1u);
+                    }
+                  if (multi && size > A.medium) atomicAdd(A.counts + 3, 1u);
+                }
             }
           if (__any(multi))                                    // (one locus in fifteen: most rounds skip this)
             { const uint64_t f0 = flagw[wi > 0 ? wi - 1 : 0], f1 = flagw[wi < nw ? wi : 0], f2 = flagw[wi + 1 < nw ? wi + 1 : 0];
