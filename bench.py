@@ -73,7 +73,7 @@ SIDE_STREAM = {"chain_piles"}
 # kernel symbols as rocprofv3 names them, for the PMC traffic summary under profiles/
 PMC_SYMBOL = {"k_radix_scatter": "dmh::k_radix_scatter", "k_radix_hist": "dmh::k_radix_hist", "chain_lane_groups": "dmh::k_chain_lane",
               "kmer_emit": "dmh::k_kmer_emit", "chain_piles": "dmh::k_chain_pile", "read_sort": "dmh::k_read_sort",
-              "merge_match": "dmh::k_merge_match", "align": "dmh::k_align_cands32"}
+              "merge_match": "dmh::k_merge_match", "align": "dmh::k_align_cands32", "chain_simple_groups": "dmh::k_chain_simple"}
 
 
 def ref_block_ranges(lens):
@@ -340,6 +340,9 @@ def main():
 
     timings = capi.timings()
     L.dmh_timing_enable(0)
+    if os.environ.get("DMH_BENCH_DUMP_TIMERS") and rank == 0:
+        for k, v in sorted(timings.items(), key=lambda kv: -kv[1]["ms"]):
+            sys.stderr.write("timer %-28s %10.2f ms %8d calls\n" % (k, v["ms"], v["launches"]))
 
     if rank == 0:
         value = tot_bases / dt / 1e9

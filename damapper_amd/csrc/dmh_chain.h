@@ -21,6 +21,8 @@ int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock);
 // finished, *nfilt then has the change in candidates added to it
 bool    chain_finish_step(MergeResult &R, int64_t *nfilt);
 bool    chain_finish_started(MergeResult &R);
+int     chain_finish_stage(MergeResult &R);        // steps of the finish done so far (0..2)
+bool    chain_finish_ready(MergeResult &R);        // the next step would neither block the host nor wait for a pile
 
 // Drops the chain stage's per-batch buffers of a ring slot that is not in use (memory pressure).
 void    chain_release(MergeResult &R);
@@ -34,7 +36,8 @@ void cand_mirror(bool with_jumps);
 // dst / dst_bytes: page-locked memory to copy into directly (cand_fetch_bytes() tells how much); nullptr = own vectors.
 // slot: the store (State::cand_slot) to read; -1 = the current block's
 size_t cand_fetch_bytes(int slot = -1);
-void cand_fetch(CandRaw &raw, void *dst = nullptr, size_t dst_bytes = 0, int slot = -1);
+// landed (only with dst): the copies are queued and the event recorded behind them instead of waited for.
+void cand_fetch(CandRaw &raw, void *dst = nullptr, size_t dst_bytes = 0, int slot = -1, hipEvent_t landed = nullptr);
 void cand_build(const CandRaw &raw, std::vector<ReadState> &reads, const std::vector<uint16_t> *jd);
 
 }  // namespace dmh

@@ -1622,6 +1622,8 @@ extern "C" void dmh_chain_profile(unsigned long long *out, int reset)
 namespace dmh {
 #endif
 
+static size_t g_jump_hint = 0;       // Jump pairs the largest READS block so far ended with
+
 void chain_reset_reads(const DAZZ_DB *ablock)
 { State &st = S();
   // The block's store: its own when it has one (a restart: what it had collected is dropped), else a free one, else
@@ -1644,6 +1646,10 @@ void chain_reset_reads(const DAZZ_DB *ablock)
   cs.nreads = n;
   cs.cur    = 0;
   cs.total_len = 0;
+  { // the jump pool starts at the size the block before this one ended with: it grows by copying (finish_step_c)
+    if (cs.jtop > g_jump_hint) g_jump_hint = cs.jtop;
+    if (g_jump_hint > 0) cs.jumps.ensure(2 * (g_jump_hint + g_jump_hint / 8) + 1024, "jump pool");
+  }
   cs.jtop   = 0;
   cs.mirror_valid = false;
   cs.mirror_jumps = false;
@@ -1673,8 +1679,9 @@ void chain_reset_reads(const DAZZ_DB *ablock)
 
 struct FinishState
 { int       stage = 0;             // steps done
-  uint32_t *h_pin = nullptr;       // 16 page-locked words: [0] chain ends, [8..15] the candidate counters
-  hipEvent_t ev = nullptr;         // the copy into h_pin has landed
+  uint32_t *h_pin = nullptr;       // 32 page-locked words: [0] chain ends, [1] its tag; [8..15] the candidate counters, [16] their tag
+  uint32_t  seq = 0;               // tag of the step under way: k_post_words writes it behind the words (the host polls it)
+  hipEvent_t ev = nullptr;         // ... and the event behind that kernel (errors surface here)
   uint32_t  nsum = 0;
   int64_t   result = 0;
 };
@@ -1696,10 +1703,35 @@ struct ChainCtx
   FinishState *fin = nullptr;
 };
 
+// Device words -> page-locked host memory, a tag behind them.  The host polls the tag: hipEventSynchronize on the
+// finish stream came back 1.6 ms after the copy had landed whenever the main stream was busy (r03 traces: the step after
+// the wait was queued the moment the main stream ran dry).
+__global__ void k_post_words(volatile uint32_t *host, const uint32_t *__restrict__ src, int n, int tag_at, uint32_t tag)
+{ if ((int) threadIdx.x < n) host[threadIdx.x] = src[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) host[tag_at] = tag;
+}
+
+static void finish_wait_tag(FinishState &F, int tag_at)
+{ static const bool use_event = getenv("DMH_FINISH_EVENT_WAIT") != nullptr;
+  if (use_event) { HIP_CHECK(hipEventSynchronize(F.ev)); return; }
+  uint64_t spins = 0;
+  while (__atomic_load_n(&F.h_pin[tag_at], __ATOMIC_ACQUIRE) != F.seq)
+    { __builtin_ia32_pause();
+      if ((++spins & 0xfffffu) == 0)
+        { const hipError_t e = hipEventQuery(F.ev);             // (a fault on the device must not leave the host spinning)
+          if (e == hipErrorNotReady) (void) hipGetLastError();
+          else if (e != hipSuccess) HIP_CHECK(e);
+        }
+    }
+}
+
 static FinishState &fin_of(ChainCtx &C)
 { if (C.fin == nullptr)
     { C.fin = new FinishState();
-      HIP_CHECK(hipHostMalloc((void **) &C.fin->h_pin, 16 * sizeof(uint32_t), hipHostMallocDefault));
+      HIP_CHECK(hipHostMalloc((void **) &C.fin->h_pin, 32 * sizeof(uint32_t), hipHostMallocDefault));
+      memset(C.fin->h_pin, 0, 32 * sizeof(uint32_t));
       HIP_CHECK(hipEventCreateWithFlags(&C.fin->ev, hipEventDisableTiming));
     }
   return *C.fin;
@@ -1931,7 +1963,9 @@ static void finish_step_a(MergeResult &R)
   const uint32_t ng = (uint32_t) R.ngroups;
   C.goff.ensure((size_t) ng + 2, "chain ends per group");
   exclusive_scan_u32((const uint32_t *) gcnt.p, C.goff.p, ng, st.sort_fin.bsum, C.goff.p + ng);
-  HIP_CHECK(hipMemcpyAsync(F.h_pin, C.goff.p + ng, sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+  F.seq += 1; if (F.seq == 0) F.seq = 1;
+  hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, stream(), (volatile uint32_t *) F.h_pin,
+                     (const uint32_t *) (C.goff.p + ng), 1, 1, F.seq);
   HIP_CHECK(hipEventRecord(F.ev, stream()));
   F.stage = 1;
 }
@@ -1941,8 +1975,8 @@ static void finish_step_b(MergeResult &R)
   ChainCtx &C = *R.cc;
   FinishState &F = fin_of(C);
   StreamScope on_finish(finish_stream());
-  { HostTimer ht("chain_wait");
-    HIP_CHECK(hipEventSynchronize(F.ev));
+  { HostTimer ht("chain_wait_a");
+    finish_wait_tag(F, 1);
   }
   const uint32_t nsum = F.h_pin[0];
   F.nsum = nsum;
@@ -2030,7 +2064,9 @@ static void finish_step_b(MergeResult &R)
     exclusive_scan_u32((const uint32_t *) jl.p, jl.p + nsum + 1, nsum, st.sort_fin.bsum, cs.ctl.p + 3);
     HIP_CHECK(hipMemcpyAsync(cs.ctl.p + 4, cs.seg_off[nx].p + nreads, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
     // added, removed, fresh survivors, jump pairs, records in the new lists
-    HIP_CHECK(hipMemcpyAsync(F.h_pin + 8, cs.ctl.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+    F.seq += 1; if (F.seq == 0) F.seq = 1;
+    hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, stream(), (volatile uint32_t *) (F.h_pin + 8),
+                       (const uint32_t *) cs.ctl.p, 8, 8, F.seq);
     HIP_CHECK(hipEventRecord(F.ev, stream()));
   }
   F.stage = 2;
@@ -2041,8 +2077,8 @@ static void finish_step_c(MergeResult &R)
   ChainCtx &C = *R.cc;
   FinishState &F = fin_of(C);
   StreamScope on_finish(finish_stream());
-  { HostTimer ht("chain_wait");
-    HIP_CHECK(hipEventSynchronize(F.ev));
+  { HostTimer ht("chain_wait_b");
+    finish_wait_tag(F, 16);
   }
   CandStore &cs = st.cand_slot[R.cslot];
   const uint32_t nsum = F.nsum;
@@ -2053,6 +2089,7 @@ static void finish_step_c(MergeResult &R)
     const size_t need = cs.jtop + h[3];
     if (need > cs.jumps.cap / 2)
       { // grow the jump pool, keeping what earlier passes stored
+        HostTimer hg("jump_pool_grow");
         DevBuf<uint16_t> nj;
         nj.ensure(2 * (need + need / 2) + 1024, "jump pool");
         if (cs.jtop > 0)
@@ -2069,6 +2106,7 @@ static void finish_step_c(MergeResult &R)
     HIP_CHECK(hipGetLastError());
   }
   cs.jtop += h[3];
+  if (cs.jtop > g_jump_hint) g_jump_hint = cs.jtop;
   if (cs.jtop >= 0x7fffffffull) fatal("Match_Filter: Jump lists of one READS block exceed 2^31 pairs");
   cs.cur = nx;
   cs.total_len = h[4];
@@ -2094,6 +2132,23 @@ bool chain_finish_step(MergeResult &R, int64_t *nfilt)
 bool chain_finish_started(MergeResult &R)
 { return R.cc != nullptr && R.cc->fin != nullptr && R.cc->fin->stage > 0; }
 
+int chain_finish_stage(MergeResult &R)
+{ return (R.cc != nullptr && R.cc->fin != nullptr) ? R.cc->fin->stage : 0; }
+
+// true when the batch's next step would not block the host nor park the finish stream behind a repeat pile: the
+// number the step starts from has landed (steps b, c), the piles of the batch have been walked (step a)
+bool chain_finish_ready(MergeResult &R)
+{ if (R.cc == nullptr) return true;
+  ChainCtx &C = *R.cc;
+  const int stage = chain_finish_stage(R);
+  if (stage >= 3 || (stage == 0 && !C.has_piles)) return true;
+  if (stage > 0) return __atomic_load_n(&C.fin->h_pin[stage == 1 ? 1 : 16], __ATOMIC_ACQUIRE) == C.fin->seq;
+  const hipError_t e = hipEventQuery(C.piles_done);
+  if (e == hipErrorNotReady) { (void) hipGetLastError(); return false; }
+  HIP_CHECK(e);
+  return true;
+}
+
 int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock)
 { (void) ablock;
   int64_t nfilt = 0;
@@ -2116,7 +2171,7 @@ size_t cand_fetch_bytes(int slot)
   return b;
 }
 
-void cand_fetch(CandRaw &raw, void *dst, size_t dst_bytes, int slot)
+void cand_fetch(CandRaw &raw, void *dst, size_t dst_bytes, int slot, hipEvent_t landed)
 { State &st = S();
   if (slot < 0) slot = st.cand_cur;
   CandStore &cs = st.cand_slot[slot];
@@ -2141,7 +2196,8 @@ void cand_fetch(CandRaw &raw, void *dst, size_t dst_bytes, int slot)
         }
       if (ncov > 0)
         HIP_CHECK(hipMemcpyAsync(pc, cs.cover.p, sizeof(int16_t) * ncov, hipMemcpyDeviceToHost, stream()));
-      HIP_CHECK(hipStreamSynchronize(stream()));
+      if (landed != nullptr) HIP_CHECK(hipEventRecord(landed, stream()));      // (the caller waits, when it needs the lists)
+      else HIP_CHECK(hipStreamSynchronize(stream()));
       raw.pool = pp; raw.off = po; raw.len = pl; raw.cov = pc;
     }
   else

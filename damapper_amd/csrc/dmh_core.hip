@@ -133,8 +133,37 @@ static void sync_all_streams()
 // harmless when the next user queues its work on the same stream, not when it is the filter's finish stream (or the
 // main stream, the other way round).  Every free block therefore remembers the stream it was freed under, blocks of the
 // asking stream are preferred, and a block that changes streams is only handed out once its old stream has drained.
-struct PoolBlock { void *p; size_t cap; hipStream_t owner; };
+// (ev: recorded on the owner stream when the block was freed -- once it has completed nobody can be using the block any
+//  more and it changes streams without anybody waiting.  Without it a finish-stream allocation that picked a block the
+//  main stream had freed made the host wait until the main stream ran dry: 3 ms of idle GPU, three times per read block.)
+struct PoolBlock { void *p; size_t cap; hipStream_t owner; hipEvent_t ev; };
 static std::vector<PoolBlock>    g_free;
+static std::vector<hipEvent_t>   g_pool_events;      // spare events
+
+static hipEvent_t pool_event()
+{ if (!g_pool_events.empty())
+    { hipEvent_t e = g_pool_events.back();
+      g_pool_events.pop_back();
+      return e;
+    }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+
+static bool pool_block_idle(const PoolBlock &b)
+{ if (b.ev == nullptr) return false;
+  const hipError_t e = hipEventQuery(b.ev);
+  if (e == hipSuccess) return true;
+  (void) hipGetLastError();
+  return false;
+}
+
+static void pool_drop(PoolBlock &b)          // the block goes back to the driver
+{ (void) hipFree(b.p);
+  if (b.ev != nullptr) g_pool_events.push_back(b.ev);
+  b.ev = nullptr;
+}
 static std::map<void *, size_t>  g_live;
 static size_t                    g_pooled = 0;
 static const size_t              POOL_MAX = (size_t) 96 << 30;
@@ -156,7 +185,7 @@ void simulate_out_of_memory()
   (void) g_reclaim();
   S().simulated_oom = false;
   g_reclaiming = false;
-  for (auto &b : g_free) (void) hipFree(b.p);
+  for (auto &b : g_free) pool_drop(b);
   g_free.clear();
   g_pooled = 0;
 }
@@ -176,10 +205,12 @@ void *dev_alloc(size_t bytes, const char *what)
   }
   int best = -1;
   const hipStream_t me = stream();
-  for (int pass = 0; pass < 2 && best < 0; pass++)          // first the blocks this stream freed itself
-    for (size_t i = 0; i < g_free.size(); i++)
-      if ((pass == 1 || g_free[i].owner == me) && g_free[i].cap >= bytes && g_free[i].cap <= 2 * bytes + (1 << 20))
-        if (best < 0 || g_free[i].cap < g_free[best].cap) best = (int) i;
+  bool idle = true;
+  for (int pass = 0; pass < 3 && best < 0; pass++)          // first the blocks this stream freed itself, then the ones
+    for (size_t i = 0; i < g_free.size(); i++)              // whose last user has finished, then the others (and wait)
+      if (g_free[i].cap >= bytes && g_free[i].cap <= 2 * bytes + (1 << 20) &&
+          (pass == 2 || g_free[i].owner == me || (pass == 1 && pool_block_idle(g_free[i]))))
+        if (best < 0 || g_free[i].cap < g_free[best].cap) { best = (int) i; idle = (pass < 2); }
   // DMH_POISON=<byte> (debugging): every allocation starts out filled with that byte, so that a kernel that reads what nobody wrote
   // misbehaves every time and not only when the memory happens to hold another process's leftovers
   // DMH_POISON_WHAT=a|b|c: only the allocations whose label contains one of these; DMH_POISON_LOG: print every label
@@ -218,7 +249,11 @@ void *dev_alloc(size_t bytes, const char *what)
       g_free.erase(g_free.begin() + best);
       g_pooled -= b.cap;
       g_live[b.p] = b.cap;
-      if (b.owner != me) HIP_CHECK(hipStreamSynchronize(b.owner));
+      if (!idle)
+        { HostTimer ht("pool_owner_wait");
+          HIP_CHECK(hipStreamSynchronize(b.owner));
+        }
+      if (b.ev != nullptr) g_pool_events.push_back(b.ev);
       if (poison)
         { HIP_CHECK(hipMemsetAsync(b.p, pbyte, b.cap, me));
           HIP_CHECK(hipStreamSynchronize(me));
@@ -230,11 +265,14 @@ void *dev_alloc(size_t bytes, const char *what)
       return b.p;
     }
   void *p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e;
+  { HostTimer ht("pool_hipMalloc");
+    e = hipMalloc(&p, bytes);
+  }
   if (e != hipSuccess)
     { // give the pool back and retry once
       (void) hipGetLastError();            // (the failure must not surface at some later launch check)
-      for (auto &b : g_free) (void) hipFree(b.p);
+      for (auto &b : g_free) pool_drop(b);
       g_free.clear();
       g_pooled = 0;
       e = hipMalloc(&p, bytes);
@@ -247,7 +285,7 @@ void *dev_alloc(size_t bytes, const char *what)
       const bool got = g_reclaim();
       g_reclaiming = false;
       if (got)
-        { for (auto &b : g_free) (void) hipFree(b.p);
+        { for (auto &b : g_free) pool_drop(b);
           g_free.clear();
           g_pooled = 0;
           e = hipMalloc(&p, bytes);
@@ -284,12 +322,14 @@ void dev_free(void *p)
       HIP_CHECK(hipFree(p));
       return;
     }
-  g_free.push_back({p, cap, stream()});
+  hipEvent_t ev = pool_event();
+  HIP_CHECK(hipEventRecord(ev, stream()));
+  g_free.push_back({p, cap, stream(), ev});
   g_pooled += cap;
 }
 
 static void pool_release()
-{ for (auto &b : g_free) (void) hipFree(b.p);
+{ for (auto &b : g_free) pool_drop(b);
   g_free.clear();
   g_pooled = 0;
 }

@@ -1020,7 +1020,7 @@ static int64_t sizeof_db(const DAZZ_DB *db)
 
 // The batches: one being collected (ring[cur]) and up to IN_FLIGHT submitted ones whose chain kernels -- repeat piles
 // above all -- are still running while later passes are merged, sorted and chained.  They are finished in order.
-constexpr int IN_FLIGHT = 4;
+constexpr int IN_FLIGHT = 8;
 constexpr int NRING = IN_FLIGHT + 3;       // (+ the one being collected, the one being finished, and the one a pass has
                                            //  just submitted while the oldest waits for the next pass's match kernels)
 static MergeResult g_ring[NRING];
@@ -1068,6 +1068,7 @@ static int64_t finish_oldest();
 static void    finish_tick_if_due(int64_t *nfilt);
 static bool    finish_tick(int64_t *nfilt);
 static int     flight_keep();
+static void    finish_pipeline(int64_t *nfilt);
 static bool    filter_reclaim();
 static int     g_flight_cap = IN_FLIGHT;     // batches that may be in flight: one fewer after every time memory ran out
 
@@ -1160,15 +1161,19 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
   // main stream has the match kernels (and the previous pass's chain kernels) to run meanwhile
   { static const bool nosteps = getenv("DMH_FINISH_STEPS") == nullptr;
+    static const bool pipe = getenv("DMH_FINISH_PIPE") != nullptr;      // (opt-in: measured 178.5 against 173.1 ms per read block)
     const int keep2 = flight_keep();
     while ((int) g_inflight.size() > (nosteps || keep2 == 0 ? keep2 : keep2 + 1)) *nfilt += finish_oldest();
+    if (pipe && nosteps && keep2 > 0) finish_pipeline(nfilt);
     finish_tick_if_due(nfilt);              // (step 1 of 3; the others behind the expansion and behind the seed sort)
   }
   // one round trip for the pass: the number of matched runs and the two hit sums (the count is parked behind the sums)
   unsigned int nent = 0;
   unsigned long long hsum[3] = {0, 0, 0};
   HIP_CHECK(hipMemcpyAsync(sums + 2, tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
-  copy_d2h(hsum, sums, sizeof(unsigned long long) * 3, 1);                         // the limit rule next
+  { HostTimer hw("wait_hit_sums");
+    copy_d2h(hsum, sums, sizeof(unsigned long long) * 3, 1);                       // the limit rule next
+  }
   nent = (unsigned int) (hsum[2] & 0xffffffffull);
   entries.ensure((size_t) nent + 64, "matched runs");
   if (nent > 0)
@@ -1345,7 +1350,9 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
           { // a read with more hits than the LDS of a workgroup takes (a tandem array: a pile) sends the whole pass
             // through the global sort, which takes the words in any order
             finish_tick_if_due(nfilt);      // (the expansion is queued: the oldest batch's finish moves on a step)
-            copy_d2h(g_rcnt, g_rstats.p, 4 * sizeof(uint32_t), 1);
+            { HostTimer hw("wait_read_classes");
+              copy_d2h(g_rcnt, g_rstats.p, 4 * sizeof(uint32_t), 1);
+            }
             R.read_sorted = g_rcnt[3] <= g_rlim;
           }
       }
@@ -1408,6 +1415,36 @@ static bool finish_tick(int64_t *nfilt)
       finish_retire(x);
     }
   return done;
+}
+
+// The finishes of the batches in flight as a pipeline: every batch takes ONE step per pass -- the step whose input
+// (the pile walks; the count of chain ends; the candidate counters) arrived during the pass before -- so the host
+// queues three steps of three batches on the finish stream and waits for none.  Steps b and c work on the candidate
+// lists of the READS block and are taken by the oldest batch only (step b of a batch reads what step c of the one
+// before it has put in place); step a (chain ends per group) has no such order.  A batch whose piles are still being
+// walked stays where it is -- and everything younger behind it -- until the bound on the batches in flight forces it
+// (finish_oldest, which waits).
+static void finish_pipeline(int64_t *nfilt)
+{ size_t i = 0;
+  g_finishing = true;
+  while (i < g_inflight.size())
+    { const int x = g_inflight[i];
+      MergeResult &R = g_ring[x];
+      const int stage = chain_finish_stage(R);
+      if ((stage == 0 || i == 0) && chain_finish_ready(R))
+        { bool done;
+          { HostTimer hf("filter_finish");
+            done = chain_finish_step(R, nfilt);
+          }
+          if (done)
+            { g_inflight.erase(g_inflight.begin() + (long) i);      // (i == 0: only steps b and c end a finish)
+              finish_retire(x);
+              continue;
+            }
+        }
+      i += 1;
+    }
+  g_finishing = false;
 }
 
 // batches the filter keeps in flight before it starts finishing the oldest
@@ -1678,9 +1715,16 @@ static void close_batch(MergeResult &R)
             st.tfilt += nf;
           }
           // one round trip: clusters, clusters the radix sort has to finish, the chain kernels' big groups and piles
-          copy_d2h(g_known, g_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
+          { HostTimer hw("wait_cluster_counts");
+            copy_d2h(g_known, g_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
+          }
           ncl = g_known[0];
           g_have_known = true;
+          { static const bool stats = getenv("DMH_STATS") != nullptr;
+            if (stats)
+              fprintf(stderr, "dmh: read sort: %lld hits, reads by workgroup size %u %u %u, largest segment %u, clusters %u\n",
+                      (long long) nhits, g_rcnt[0], g_rcnt[1], g_rcnt[2], g_rcnt[3], ncl);
+          }
           R.ngroups = ncl;
           R.gstart.ensure((size_t) ncl + 1, "cluster starts");
           R.gkey.ensure((size_t) ncl + 1, "cluster keys");

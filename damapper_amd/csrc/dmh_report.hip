@@ -13,6 +13,7 @@
 #include <math.h>
 #include <atomic>
 #include <thread>
+#include <future>
 #include <mutex>
 #include <condition_variable>
 #include <deque>
@@ -1234,6 +1235,12 @@ struct PendingReport
   int      nhold = 0;
   bool     on_aux = false;     // the kernel runs on the alignment stream
   HostTimer *ht = nullptr;
+  // deferred mode: the jobs are put together on a thread of their own while the main thread goes on with the next
+  // block's filter; whoever looks next (report_poll, finish_report) launches the first rung once they are in
+  std::future<void> builder;
+  bool     building = false;
+  size_t   pool_per_job = 0;   // ints of the record pool per job to start from
+  int      pool_div = 0;       // ("pool_div" test option)
 };
 
 static PendingReport *g_pending = nullptr;
@@ -1265,6 +1272,11 @@ static void launch_round(PendingReport &P)
 { hipStream_t ks = P.on_aux ? g_astream : stream();
   const int njobs = P.njobs;
   if (P.pool_cap > 0xfffffff0ull / 4) fatal("Reporter: alignment pool too large");
+  if (!P.jobs_up)
+    { d_jobs.ensure(njobs, "candidate jobs");
+      if (P.jumps.p == nullptr) P.jumps.ensure(16, "candidate jumps");
+      d_status.ensure(njobs, "candidate status");
+    }
   d_pool.ensure(P.pool_cap, "alignment pool");
   int nrun = P.todo.empty() ? njobs : (int) P.todo.size();
   const int *only = nullptr;
@@ -1450,7 +1462,12 @@ static bool collect_round(PendingReport &P)
 }
 
 static void finish_report(PendingReport *P)
-{ if (P->njobs > 0)
+{ if (P->building)
+    { P->builder.get();
+      P->building = false;
+      if (P->njobs > 0) launch_round(*P);
+    }
+  if (P->njobs > 0)
     { if (!P->collected)
         while (!collect_round(*P)) launch_round(*P);
     }
@@ -1483,7 +1500,15 @@ bool report_adopt_block(const DAZZ_DB *block)
 void report_poll()
 { PendingReport *P = g_pending;
   static const bool off = getenv("DMH_NO_REPORT_POLL") != nullptr;
-  if (off || P == nullptr || !P->on_aux || P->polled || P->njobs == 0) return;
+  if (off || P == nullptr || !P->on_aux || P->polled) return;
+  if (P->building)
+    { if (P->builder.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return;
+      P->builder.get();
+      P->building = false;
+      if (P->njobs > 0) launch_round(*P);
+      return;
+    }
+  if (P->njobs == 0) return;
   const hipError_t e = hipEventQuery(g_ev_done);
   if (e != hipSuccess) { (void) hipGetLastError(); return; }
   P->polled = true;
@@ -1548,14 +1573,23 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
     st.tfilt += filter_flush_block(cslot);     // (this block's batches: the next block's may be in flight behind them)
   }
   if (defer && !index_first) bg_flush();
-  // the candidate lists: copied on the finish stream (the main stream is busy with the index sort)
+  // the candidate lists: copied on the finish stream (the main stream is busy with the index sort).  Deferred mode:
+  // nobody waits for the copy here -- the jobs of the alignment kernel are put together on a thread of their own
+  // (2.4 ms per block of 25,000 reads, plus the copy), which starts by waiting for it; the main thread goes back to
+  // the filter of the next block, and the first report_poll that finds the jobs ready launches the kernel
+  // (DMH_SYNC_REPORT_JOBS: everything here, as before)
+  static const bool sync_jobs = getenv("DMH_SYNC_REPORT_JOBS") != nullptr;
+  const bool async_build = defer && !sync_jobs;
+  PendingReport *P = new PendingReport();
+  hipEvent_t ev_raw = nullptr;
+  if (async_build) HIP_CHECK(hipEventCreateWithFlags(&ev_raw, hipEventDisableTiming));
   CandRaw raw;
   PinBuf *raw_pin = nullptr;
   { HostTimer hm("report_mirror");
     StreamScope on_finish(index_first ? finish_stream() : main_stream());
     const size_t nb = cand_fetch_bytes(cslot);
     raw_pin = pin_acquire(nb / sizeof(int) + 64);
-    cand_fetch(raw, raw_pin->p, sizeof(int) * raw_pin->cap, cslot);      // (their Jump lists stay in HBM)
+    cand_fetch(raw, raw_pin->p, sizeof(int) * raw_pin->cap, cslot, ev_raw);      // (their Jump lists stay in HBM)
   }
   { HostTimer hq("report_previous");
     report_finish_pending();                   // the previous block's alignments (deferred mode)
@@ -1568,88 +1602,88 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
 
   ablock->maxlen += SPACING;                  // map.c:3246
 
-  PendingReport *P = new PendingReport();
   P->ht = new HostTimer("report_align");
-  std::unique_ptr<HostTimer> hj(new HostTimer("report_jobs"));
-
-  // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel: per read newest first,
-  //         tombstones left out -- the order in which cand_build numbers the Candidate objects of the report stage
-  std::vector<int> job_of_first(nreads + 1, 0);   // first job index of each read
-  for (int ar = 0; ar < nreads; ar++)
-    { job_of_first[ar] = (int) P->jobs.size();
-      if (raw.npool == 0) continue;
-      for (uint32_t i = raw.len[ar]; i-- > 0;)
-        { const DCand &c = raw.pool[raw.off[ar] + i];
-          if (c.flags & DC_TOMB) continue;
-          CandJob J;
-          J.aoff  = ablock->reads[ar].boff;
-          J.alen  = ablock->reads[ar].rlen;
-          J.boff  = bblock->reads[c.bread].boff;
-          J.blen  = bblock->reads[c.bread].rlen;
-          J.comp  = (c.flags & DC_COMP) ? 1 : 0;
-          J.alast = c.alast;
-          J.blast = c.blast;
-          J.npts  = (int) c.jlen;
-          J.joff  = c.joff;
-          J.pad   = 0;
-          P->jobs.push_back(J);
-        }
-    }
-  job_of_first[nreads] = (int) P->jobs.size();
-  const int njobs = (int) P->jobs.size();
-  P->njobs = njobs;
   P->doB   = doB;
   P->hithr = 3 * pm.Kmer;
-  P->recs.resize(njobs);
+  // kernel ladder: 0 = two candidates per wavefront (register band <= 30 diagonals, LDS pebbles),
+  // 1 = one per wavefront (register band <= 62, LDS ring 128, global pebbles), 2 = global ring 8192
+  static const bool no_pack = getenv("DMH_NO_PACK32") != nullptr;
+  P->level = (doB || no_pack) ? 1 : 0;
+  if (st.opt_align_level >= 0) P->level = std::max(P->level, std::min(2, st.opt_align_level));
 
-  { ReportCtx *C = new ReportCtx();
-    C->S_ = S_; C->NT = pm.NTHREADS; C->nshift = pm.NSHIFT; C->nreads = nreads; C->astart = ablock->tfirst;
-    C->doA = doA; C->doB = doB;
-    C->spacing = SPACING; C->profile = PROFILE; C->verbose = VERBOSE; C->best_tie = BEST_TIE;
-    C->aname = aname; C->bname = bname; C->sort_path = SORT_PATH;
-    C->rlen.resize(nreads);
-    for (int i = 0; i < nreads; i++) C->rlen[i] = ablock->reads[i].rlen;
-    C->raw = std::move(raw);
-    C->raw_pin = raw_pin;
-    if (st.cur_reads == ablock)
-      { st.reads.clear();
-        st.cur_reads = nullptr;
-      }
-    cstore.block = nullptr;                  // (the store is free for the block after next)
-    cstore.nreads = 0;
-    cstore.mirror_valid = false;
-    P->jumps = cstore.jumps;                 // the kernel reads the Jump lists where the filter stored them
-    cstore.jumps = DevBuf<uint16_t>();
-    cstore.jtop = 0;
-    C->job_of_first = std::move(job_of_first);
-    P->C = C;
-  }
+  ReportCtx *C = new ReportCtx();
+  C->S_ = S_; C->NT = pm.NTHREADS; C->nshift = pm.NSHIFT; C->nreads = nreads; C->astart = ablock->tfirst;
+  C->doA = doA; C->doB = doB;
+  C->spacing = SPACING; C->profile = PROFILE; C->verbose = VERBOSE; C->best_tie = BEST_TIE;
+  C->aname = aname; C->bname = bname; C->sort_path = SORT_PATH;
+  C->rlen.resize(nreads);
+  int maxalen = 0;
+  for (int i = 0; i < nreads; i++)
+    { C->rlen[i] = ablock->reads[i].rlen;
+      maxalen = std::max(maxalen, ablock->reads[i].rlen);
+    }
+  const size_t npool = raw.npool;              // candidates, tombstones included: at least as many as there will be jobs
+  C->raw = std::move(raw);
+  C->raw_pin = raw_pin;
+  if (st.cur_reads == ablock)
+    { st.reads.clear();
+      st.cur_reads = nullptr;
+    }
+  cstore.block = nullptr;                  // (the store is free for the block after next)
+  cstore.nreads = 0;
+  cstore.mirror_valid = false;
+  P->jumps = cstore.jumps;                 // the kernel reads the Jump lists where the filter stored them
+  cstore.jumps = DevBuf<uint16_t>();
+  cstore.jtop = 0;
+  P->C = C;
+  P->pool_per_job = 2 * (size_t) (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8));
+  P->pool_div = st.opt_pool_div;
 
-  if (njobs > 0)
-    { BlockDev &ad = upload_block(ablock, false);
-      BlockDev &bd = upload_block(bblock, false);
-      ensure_packed(ad, true);
-      ensure_packed(bd, false);
-      P->apk = ad.d_pk(); P->arc = ad.d_rc(); P->bpk = bd.d_pk();
-      P->spd = spec_dev(sp);
-      int maxalen = 0;
-      for (int ar = 0; ar < nreads; ar++) maxalen = std::max(maxalen, ablock->reads[ar].rlen);
-      P->tcap = trace_cap(maxalen, S_);
-
-      d_jobs.ensure(njobs, "candidate jobs");
-      if (P->jumps.p == nullptr) P->jumps.ensure(16, "candidate jumps");
-      d_status.ensure(njobs, "candidate status");
-      // (the jobs go to the device with the first launch, on its stream)
-
+  // ---- 1. all candidates of the block become one batch of chain jobs for the d-wave kernel: per read newest first,
+  //         tombstones left out -- the order in which cand_build numbers the Candidate objects of the report stage.
+  //         (What it reads of the two blocks is copied first: the thread may outlive this call.)
+  struct Where { int64_t boff; int rlen; };
+  std::vector<Where> aw(nreads), bw(bblock->nreads);
+  for (int i = 0; i < nreads; i++) aw[i] = Where{ablock->reads[i].boff, ablock->reads[i].rlen};
+  for (int i = 0; i < bblock->nreads; i++) bw[i] = Where{bblock->reads[i].boff, bblock->reads[i].rlen};
+  auto build = [P, C, ev_raw, nreads](const std::vector<Where> &aw, const std::vector<Where> &bw)
+    { if (ev_raw != nullptr)
+        { HIP_CHECK(hipEventSynchronize(ev_raw));
+          HIP_CHECK(hipEventDestroy(ev_raw));
+        }
+      HostTimer hj("report_jobs");
+      const CandRaw &raw = C->raw;
+      std::vector<int> job_of_first(nreads + 1, 0);   // first job index of each read
+      for (int ar = 0; ar < nreads; ar++)
+        { job_of_first[ar] = (int) P->jobs.size();
+          if (raw.npool == 0) continue;
+          for (uint32_t i = raw.len[ar]; i-- > 0;)
+            { const DCand &c = raw.pool[raw.off[ar] + i];
+              if (c.flags & DC_TOMB) continue;
+              CandJob J;
+              J.aoff  = aw[ar].boff;
+              J.alen  = aw[ar].rlen;
+              J.boff  = bw[c.bread].boff;
+              J.blen  = bw[c.bread].rlen;
+              J.comp  = (c.flags & DC_COMP) ? 1 : 0;
+              J.alast = c.alast;
+              J.blast = c.blast;
+              J.npts  = (int) c.jlen;
+              J.joff  = c.joff;
+              J.pad   = 0;
+              P->jobs.push_back(J);
+            }
+        }
+      job_of_first[nreads] = (int) P->jobs.size();
+      const int njobs = (int) P->jobs.size();
+      P->njobs = njobs;
+      P->recs.resize(njobs);
+      C->job_of_first = std::move(job_of_first);
+      if (njobs == 0) return;
       // pool: one record per accepted alignment; start from 2 per candidate and grow on demand
-      P->pool_cap = (size_t) njobs * 2 * (REC_HDR + (doB ? 3 : 1) * (maxalen / S_ + 8)) + 4096;
-      if (st.opt_pool_div > 1) P->pool_cap = P->pool_cap / st.opt_pool_div + 64;
+      P->pool_cap = (size_t) njobs * P->pool_per_job + 4096;
+      if (P->pool_div > 1) P->pool_cap = P->pool_cap / P->pool_div + 64;
       P->status.resize(njobs);
-      // kernel ladder: 0 = two candidates per wavefront (register band <= 30 diagonals, LDS pebbles),
-      // 1 = one per wavefront (register band <= 62, LDS ring 128, global pebbles), 2 = global ring 8192
-      static const bool no_pack = getenv("DMH_NO_PACK32") != nullptr;
-      P->level = (doB || no_pack) ? 1 : 0;
-      if (st.opt_align_level >= 0) P->level = std::max(P->level, std::min(2, st.opt_align_level));
       if (P->level == 0)
         { // the halves of a wavefront run in lock step: hand out like jobs together (same orientation,
           // similar length, equal chain end = equal first seed), long ones first:
@@ -1674,8 +1708,17 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
               std::stable_sort(todo.begin(), todo.end(), [&](int x, int y) { return key[x] < key[y]; });
             }
         }
+    };
 
-      hj.reset();
+  if (npool > 0)
+    { // what the kernel reads of the two blocks (main stream; launch_round orders the alignment stream behind it)
+      BlockDev &ad = upload_block(ablock, false);
+      BlockDev &bd = upload_block(bblock, false);
+      ensure_packed(ad, true);
+      ensure_packed(bd, false);
+      P->apk = ad.d_pk(); P->arc = ad.d_rc(); P->bpk = bd.d_pk();
+      P->spd = spec_dev(sp);
+      P->tcap = trace_cap(maxalen, S_);
       if (defer)
         { if (g_astream == nullptr)
             { // (DMH_ASTREAM_PRIO=1: the deferred alignment kernel on a low-priority stream -- experiments)
@@ -1703,8 +1746,16 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
                 }
             }
         }
-      launch_round(*P);
     }
+  if (async_build && npool > 0)
+    { P->building = true;
+      P->builder = std::async(std::launch::async, build, std::move(aw), std::move(bw));
+    }
+  else
+    { build(aw, bw);
+      if (P->njobs > 0) launch_round(*P);
+    }
+  const int njobs = P->building ? (int) npool : P->njobs;
 
   // the READS index is not needed any more (the alignment kernel reads the packed bases only); the
   // driver free()s the stub

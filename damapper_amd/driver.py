@@ -43,7 +43,7 @@ class Mapper:
         # overlap mode of map_block: the block whose Reporter call is still to come, and the number of passes of the
         # following block that are queued ahead of it
         self._pending = None
-        self.overlap_passes = int(os.environ.get("DMH_OVERLAP_PASSES", "6"))
+        self.overlap_passes = int(os.environ.get("DMH_OVERLAP_PASSES", "10"))
 
     def release_ref(self) -> None:
         self.finish()
