@@ -1057,7 +1057,9 @@ static DevBuf<uint32_t> g_rstart, g_rowdst, g_rstats, g_rlists, g_wlist[2];
 static DevBuf<unsigned int> g_wcnt;
 static uint32_t g_known[5] = {0, 0, 0, 0, 0};     // clusters, clusters for the radix sort, big groups, piles, hits in piles (k_read_sort)
 static bool     g_have_known = false;
-static uint32_t g_rcnt[4] = {0, 0, 0, 0}, g_rlim = 0;      // reads per k_read_sort workgroup size, largest segment; its limit
+static uint32_t g_rcnt[5] = {0, 0, 0, 0, 0}, g_rlim = 0;   // reads per k_read_sort workgroup size, largest segment, reads above the
+                                                            // limit (fetched for statistics and experiments only)
+static uint32_t g_rgrid[4] = {0, 0, 0, 0};                  // the most reads each size class can hold: the grids
 constexpr int RS_T0 = 256, RS_T1 = 512, RS_T2 = 1024;      // k_read_sort workgroups: segments of up to 4,096 / 8,192 / 16,384 hits
 
 // hits a batch may collect before it is closed (68 B of HBM per hit through the sort and the chain kernels)
@@ -1324,22 +1326,27 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
             const int nr = ablock->nreads;
             g_rstart.ensure((size_t) nr + 2, "first hit of each read");
             g_rowdst.ensure((size_t) nhits + 1, "place of each merge row in its read's segment");
-            g_rstats.ensure(4, "read segment statistics");
+            g_rstats.ensure(8, "read segment statistics");
             HIP_CHECK(hipMemsetAsync(g_rstart.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
-            HIP_CHECK(hipMemsetAsync(g_rstats.p, 0, sizeof(uint32_t) * 4, stream()));
+            HIP_CHECK(hipMemsetAsync(g_rstats.p, 0, sizeof(uint32_t) * 8, stream()));
             hipLaunchKernelGGL(k_row_place, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                                (const uint32_t *) esz.p, (const uint32_t *) eoff.p, (const uint32_t *) A.vals, MA,
                                g_rstart.p, g_rowdst.p);
             exclusive_scan_u32(g_rstart.p, nr, st.sort.bsum, g_rstart.p + nr);
             // the reads by segment size: one list per workgroup size of k_read_sort ("read_sort" test option = 2: the
             // largest workgroups take everything above 128 hits; = 3: segments above 512 hits count as too large)
-            g_rlists.ensure(3 * (size_t) nr + 16, "reads by segment size");
+            g_rlists.ensure(4 * (size_t) nr + 16, "reads by segment size");
             const uint32_t lim2 = (st.opt_read_sort == 3) ? 512u : (uint32_t) RS_T2 * RS_E;
             const uint32_t lim0 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T0 * RS_E);
             const uint32_t lim1 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T1 * RS_E);
             hipLaunchKernelGGL(k_read_classes, dim3(ceil_div(nr, 256)), dim3(256), 0, stream(), (const uint32_t *) g_rstart.p, nr,
                                lim0, lim1, lim2, g_rlists.p, g_rstats.p);
             g_rlim = lim2;
+            // a class of more than L hits per read holds fewer than nhits / L reads
+            g_rgrid[0] = (uint32_t) nr;
+            g_rgrid[1] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim0 + 1) + 1);
+            g_rgrid[2] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim1 + 1) + 1);
+            g_rgrid[3] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim2 + 1) + 1);
             rstart = g_rstart.p; rowdst = g_rowdst.p;
           }
         hipLaunchKernelGGL(k_merge_expand_tiled, dim3(ceil_div(nhits, EX_TILE)), dim3(256), 0, stream(),
@@ -1347,13 +1354,20 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
                          (const uint32_t *) A.vals,
                          (const uint32_t *) Bx.vals, MA, MB, bshift, pshift, hitmode, passor, hk, hv, rstart, rowdst);
         if (by_read)
-          { // a read with more hits than the LDS of a workgroup takes (a tandem array: a pile) sends the whole pass
-            // through the global sort, which takes the words in any order
+          { // every read is ordered by a workgroup of its own: in LDS, or -- a read with more hits than the LDS of a
+            // workgroup takes: a tandem array -- through global memory (k_read_sort_big).  The workgroups find the
+            // length of their list on the device; the host only asks for statistics and experiments
             finish_tick_if_due(nfilt);      // (the expansion is queued: the oldest batch's finish moves on a step)
-            { HostTimer hw("wait_read_classes");
-              copy_d2h(g_rcnt, g_rstats.p, 4 * sizeof(uint32_t), 1);
-            }
-            R.read_sorted = g_rcnt[3] <= g_rlim;
+            static const bool want = getenv("DMH_STATS") != nullptr || getenv("DMH_READ_SORT_FORK") != nullptr;
+            if (want)
+              { HostTimer hw("wait_read_classes");
+                copy_d2h(g_rcnt, g_rstats.p, 5 * sizeof(uint32_t), 1);
+              }
+            else
+              { for (int q = 0; q < 4; q++) g_rcnt[q == 3 ? 4 : q] = g_rgrid[q];
+                g_rcnt[2] = std::min(g_rcnt[2], 2048u);
+              }
+            R.read_sorted = true;
           }
       }
     else
@@ -1681,22 +1695,27 @@ static void close_batch(MergeResult &R)
             const bool fork = !serial && (g_rcnt[2] > 0 || g_rcnt[1] > 0) && g_rcnt[0] > 0;
             if (fork) HIP_CHECK(hipEventRecord(ev_go, stream()));
             bool used[2] = {false, false};
+            if (g_rcnt[4] > 0)
+              { // (first: the few workgroups of this launch run longest)
+                RA.list = g_rlists.p + 3 * (size_t) nr; RA.count = g_rstats.p + 4;
+                hipLaunchKernelGGL((k_read_sort_big<RS_T2>), dim3(std::min<uint32_t>(g_rcnt[4], 1024u)), dim3(RS_T2), 0, stream(), RA);
+              }
             if (g_rcnt[2] > 0)
               { hipStream_t q = fork ? side[0] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[0] = true; }
-                RA.list = g_rlists.p + 2 * (size_t) nr;
+                RA.list = g_rlists.p + 2 * (size_t) nr; RA.count = g_rstats.p + 2;
                 if (k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T2, false>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
               }
             if (g_rcnt[1] > 0)
               { hipStream_t q = fork ? side[1] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[1] = true; }
-                RA.list = g_rlists.p + (size_t) nr;
+                RA.list = g_rlists.p + (size_t) nr; RA.count = g_rstats.p + 1;
                 if (k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T1, false>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
               }
             if (g_rcnt[0] > 0)
-              { RA.list = g_rlists.p;
+              { RA.list = g_rlists.p; RA.count = g_rstats.p;
                 if (k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T0, false>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
               }
@@ -1722,8 +1741,8 @@ static void close_batch(MergeResult &R)
           g_have_known = true;
           { static const bool stats = getenv("DMH_STATS") != nullptr;
             if (stats)
-              fprintf(stderr, "dmh: read sort: %lld hits, reads by workgroup size %u %u %u, largest segment %u, clusters %u\n",
-                      (long long) nhits, g_rcnt[0], g_rcnt[1], g_rcnt[2], g_rcnt[3], ncl);
+              fprintf(stderr, "dmh: read sort: %lld hits, reads by workgroup size %u %u %u, through global memory %u, largest segment %u, clusters %u\n",
+                      (long long) nhits, g_rcnt[0], g_rcnt[1], g_rcnt[2], g_rcnt[4], g_rcnt[3], ncl);
           }
           R.ngroups = ncl;
           R.gstart.ensure((size_t) ncl + 1, "cluster starts");
@@ -1790,7 +1809,7 @@ static void close_batch(MergeResult &R)
               // has listed them): sorted where they lie, on both positions
               hipLaunchKernelGGL(k_csort_wide, dim3(4096), dim3(64), CS_WAVE * sizeof(uint64_t), stream(), k0,
                                  (const uint32_t *) R.gstart.p, (const uint32_t *) g_wlist[0].p, (const unsigned int *) g_wcnt.p,
-                                 (uint32_t) CS_SMALL, (uint32_t) CS_WAVE);
+                                 1u, (uint32_t) CS_WAVE);        // (k_read_sort_big lists small clusters too)
               hipLaunchKernelGGL(k_csort_wide, dim3(1024), dim3(256), CS_MEDIUM * sizeof(uint64_t), stream(), k0,
                                  (const uint32_t *) R.gstart.p, (const uint32_t *) g_wlist[0].p, (const unsigned int *) g_wcnt.p,
                                  (uint32_t) CS_WAVE, (uint32_t) CS_MEDIUM);

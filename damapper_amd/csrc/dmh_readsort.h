@@ -40,6 +40,7 @@ struct ReadSortArgs
   uint64_t       *out;           // the chain kernels' words, same positions
   const uint32_t *rstart;        // first word of every read (+ end)
   const uint32_t *list;          // the reads this launch takes, one per workgroup (k_read_classes)
+  const uint32_t *count;         // ... and how many they are (on the device: the grid is sized for the most there can be)
   int             pbits, qbits, bbits, cb;
   int             kbits;         // bits of the coarse key (bread, bpos >> cb)
   int             npass;         // radix passes over the sort key apos | coarse key << pbits, least significant digit first
@@ -130,7 +131,14 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   uint16_t *wpref = (uint16_t *) (mbits + (T * E / 32 + 2));  // starts before each flag word
   __shared__ uint32_t ws[W];
 
-  const uint32_t r  = A.list[blockIdx.x];
+  // (the grid is sized for the most reads the class can hold -- at most 2048 of the largest workgroups, which then take
+  //  several reads each)
+  constexpr bool LOOP = (T >= 1024);
+  uint32_t rb = blockIdx.x;
+  if (rb >= *A.count) return;                                 // (uniform)
+  do
+  {
+  const uint32_t r  = A.list[rb];
   const uint32_t s0 = A.rstart[r];
   const uint32_t n  = A.rstart[r + 1] - s0;                   // 0 < n <= T * E (k_read_classes)
 
@@ -432,6 +440,10 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
 #endif
   RSPROF_LAP(6);
+  if (!LOOP) break;
+  __syncthreads();                                             // (the next read of this workgroup starts with empty LDS)
+  rb += gridDim.x;
+  } while (rb < *A.count);
 }
 
 // dynamic LDS of k_read_sort<T>
@@ -441,22 +453,164 @@ template <int T> constexpr size_t read_sort_lds()
          + sizeof(uint16_t) * (T * RS_E / 64 + 2) + 64;
 }
 
+// A read with more hits than the largest workgroup's LDS takes (a tandem array: a repeat pile and what surrounds it): the
+// same steps through GLOBAL memory, one workgroup per read -- the segment in A.in and its place in A.out are the two
+// buffers of the radix passes (ranks from ballots; a wavefront owns a contiguous stretch of the words), the clusters
+// are cut and counted thread by thread over contiguous stretches, and no cluster is put in order here: every one that
+// spans buckets is marked "spans buckets" AND "not ordered" (bits 63, 62 of its record), whatever its size, for
+// k_cluster_compact to list.  A handful of reads per pass at most, and only opposite the repeat they come from.
+template <int T>
+__global__ __launch_bounds__(T) void k_read_sort_big(ReadSortArgs A)
+{ constexpr int W = T / 64, D = 1 << RS_DB;
+  __shared__ uint32_t wh[W * D];
+  __shared__ uint32_t ws[W];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint64_t apm = (1ull << A.pbits) - 1ull;
+  const uint32_t ckm = (A.kbits >= 32) ? 0xffffffffu : ((1u << A.kbits) - 1u);
+  const int      csh = A.pbits + A.cb;
+  auto rs_key = [&](uint64_t x) -> uint32_t { return (uint32_t) (x & apm) | (((uint32_t) (x >> csh) & ckm) << A.pbits); };
+  const uint64_t pm = (1ull << A.pbits) - 1ull, qm = (1ull << A.qbits) - 1ull, bm = (1ull << A.bbits) - 1ull;
+
+  for (uint32_t b = blockIdx.x; b < *A.count; b += gridDim.x)
+    { const uint32_t r  = A.list[b];
+      const uint32_t s0 = A.rstart[r];
+      const uint32_t n  = A.rstart[r + 1] - s0;
+      uint64_t *src = const_cast<uint64_t *>(A.in) + s0, *dst = A.out + s0;
+      const uint32_t per = (n + 64 * W - 1) / (64 * W) * 64;          // words of a wavefront
+      const uint32_t wb = min(n, (uint32_t) w * per), we = min(n, wb + per);
+
+      // ---- 1. stable LSD passes, src -> dst
+      for (int p = 0; p < A.npass; p++)
+        { const int sh = A.sh[p], wd = A.wd[p];
+          const uint32_t dmask = (1u << wd) - 1u;
+          for (int x = tid; x < W * D; x += T) wh[x] = 0;
+          __syncthreads();
+          for (uint32_t i0 = wb; i0 < we; i0 += 64)
+            { const uint32_t i = i0 + lane;
+              if (i < we) atomicAdd(&wh[w * D + ((rs_key(src[i]) >> sh) & dmask)], 1u);
+            }
+          __syncthreads();
+          { constexpr int PER = (D + T - 1) / T;
+            uint32_t c[PER][W], tot = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++)
+              { const int d = tid * PER + q;
+#pragma unroll
+                for (int v = 0; v < W; v++)
+                  { c[q][v] = (d < D) ? wh[v * D + d] : 0u;
+                    tot += c[q][v];
+                  }
+              }
+            uint32_t all;
+            uint32_t run = block_excl_scan_t<T>(tot, ws, &all);
+#pragma unroll
+            for (int q = 0; q < PER; q++)
+              { const int d = tid * PER + q;
+#pragma unroll
+                for (int v = 0; v < W; v++)
+                  { if (d < D) wh[v * D + d] = run;
+                    run += c[q][v];
+                  }
+              }
+          }
+          __syncthreads();
+          for (uint32_t i0 = wb; i0 < we; i0 += 64)                    // (uniform per wavefront)
+            { const uint32_t i = i0 + lane;
+              const bool ok = i < we;
+              const uint64_t x = ok ? src[i] : 0;
+              const uint32_t d = (rs_key(x) >> sh) & dmask;
+              uint64_t peers = __ballot(ok);
+              for (int bb = 0; bb < wd; bb++)
+                { const bool     bit = (d >> bb) & 1u;
+                  const uint64_t bal = __ballot(bit);
+                  peers &= bit ? bal : ~bal;
+                }
+              const uint32_t below = (uint32_t) __popcll(peers & lt);
+              const uint32_t cnt   = (uint32_t) __popcll(peers);
+              const uint32_t b0    = ok ? wh[w * D + d] : 0u;
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (ok && below == 0) wh[w * D + d] = b0 + cnt;
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (ok) dst[b0 + below] = x;
+            }
+          __threadfence_block();
+          __syncthreads();
+          uint64_t *t = src; src = dst; dst = t;
+        }
+
+      // ---- 2. clusters: thread t looks at the words [t c, (t + 1) c)
+      const uint32_t c = (n + T - 1) / T;
+      const uint32_t lo = min(n, (uint32_t) tid * c), hi = min(n, lo + c);
+      uint32_t nf = 0;
+      for (uint32_t i = lo; i < hi; i++)
+        { const uint64_t pv = (i > 0) ? src[i - 1] >> A.pbits : 0, cv = src[i] >> A.pbits;
+          if (i == 0 || cluster_start(pv, cv, A.qbits, A.cb)) nf += 1;
+        }
+      uint32_t ncl;
+      const uint32_t base = block_excl_scan_t<T>(nf, ws, &ncl);
+      { uint32_t cid = base;
+        for (uint32_t i = lo; i < hi; i++)
+          { const uint64_t x = src[i];
+            const uint64_t pv = (i > 0) ? src[i - 1] >> A.pbits : 0, cv = x >> A.pbits;
+            if (i == 0 || cluster_start(pv, cv, A.qbits, A.cb))
+              { A.lcl[s0 + cid] = (1ull << 62) | (((x >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
+                cid += 1;
+              }
+          }
+      }
+      __threadfence_block();
+      __syncthreads();
+      { uint32_t cid = base;                                   // (clusters started before word i, this thread's included)
+        for (uint32_t i = lo; i < hi; i++)
+          { const uint64_t pv = (i > 0) ? src[i - 1] >> A.pbits : 0, cv = src[i] >> A.pbits;
+            if (i == 0 || cluster_start(pv, cv, A.qbits, A.cb)) cid += 1;
+            else if ((pv >> A.cb) != (cv >> A.cb))
+              atomicOr((unsigned long long *) (A.lcl + s0 + cid - 1), 1ull << 63);
+          }
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (uint32_t j = tid; j < ncl; j += T)
+        { const uint64_t v = A.lcl[s0 + j];
+          const uint32_t st = (uint32_t) v;
+          const uint32_t nx = (j + 1 < ncl) ? (uint32_t) A.lcl[s0 + j + 1] : s0 + n;
+          const uint32_t size = nx - st;
+          if (size >= A.big_min)
+            { if (size >= A.pile_min) { atomicAdd(A.counts + 5, 1u); atomicAdd(A.counts + 6, size); }
+              else atomicAdd(A.counts + 4, 1u);
+            }
+          if ((v >> 63) && size > A.medium) atomicAdd(A.counts + 3, 1u);
+        }
+      if (tid == 0) A.rncl[r] = ncl;
+      // ---- 3. the chain kernels' words (apos | bpos << 32), in A.out
+      for (uint32_t i = tid; i < n; i += T)
+        { const uint64_t x = src[i];
+          A.out[s0 + i] = (x & pm) | (((x >> A.pbits) & qm) << 32);
+        }
+      __threadfence_block();
+      __syncthreads();
+    }
+}
+
 // The reads by segment size, one list per workgroup size of k_read_sort (lists[c] at c * nreads): class 0 up to lim[0]
-// hits, class 1 up to lim[1], class 2 up to lim[2]; reads without hits are in no list; stats[0..2] = list lengths,
-// stats[3] = the largest segment (larger than lim[2]: the pass takes the global sort).
+// hits, class 1 up to lim[1], class 2 up to lim[2], class 3 (k_read_sort_big) everything larger; reads without hits
+// are in no list; stats[0..2], stats[4] = list lengths, stats[3] = the largest segment.
 __global__ __launch_bounds__(256) void k_read_classes(const uint32_t *__restrict__ rstart, int nreads, uint32_t lim0,
                                                       uint32_t lim1, uint32_t lim2, uint32_t *__restrict__ lists,
                                                       uint32_t *__restrict__ stats)
 { const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
   const uint64_t lt = (1ull << lane) - 1ull;
   const uint32_t n = (r < nreads) ? rstart[r + 1] - rstart[r] : 0;
-  const int c = (n == 0) ? -1 : (n <= lim0 ? 0 : (n <= lim1 ? 1 : (n <= lim2 ? 2 : -1)));
+  const int c = (n == 0) ? -1 : (n <= lim0 ? 0 : (n <= lim1 ? 1 : (n <= lim2 ? 2 : 3)));
 #pragma unroll
-  for (int k = 0; k < 3; k++)
+  for (int k = 0; k < 4; k++)
     { const uint64_t m = __ballot(c == k);
       if (m == 0) continue;
       uint32_t base = 0;
-      if (lane == __ffsll((long long) m) - 1) base = atomicAdd(stats + k, (uint32_t) __popcll(m));
+      if (lane == __ffsll((long long) m) - 1) base = atomicAdd(stats + (k < 3 ? k : 4), (uint32_t) __popcll(m));
       base = __shfl(base, __ffsll((long long) m) - 1);
       if (c == k) lists[(size_t) k * nreads + base + (uint32_t) __popcll(m & lt)] = (uint32_t) r;
     }
@@ -487,10 +641,10 @@ __global__ __launch_bounds__(256) void k_cluster_compact(const uint64_t *__restr
       if (ok && (lane == 63 || j + 1 >= nc)) nx = (j + 1 < nc) ? (uint32_t) lcl[s0 + j + 1] : s1;
       if (ok)
         { gstart[c0 + j] = st;
-          gkey[c0 + j]   = ((uint64_t) r << bbits) | ((v >> 32) & 0x7fffffffull);
+          gkey[c0 + j]   = ((uint64_t) r << bbits) | ((v >> 32) & 0x3fffffffull);
         }
       const uint32_t sz = ok ? nx - st : 0;
-      const bool wide = ok && (v >> 63) && sz > small;
+      const bool wide = ok && (v >> 63) && (sz > small || ((v >> 62) & 1ull));      // (bit 62: not ordered where it was found)
       const bool ism = wide && sz <= medium, isb = wide && sz > medium;
       const uint64_t mm = __ballot(ism), mb = __ballot(isb);
       if (mm)
