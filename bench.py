@@ -59,7 +59,8 @@ WORKLOADS = {
 # kernels whose time is HBM streaming: algorithmic bytes are meaningful as a bandwidth
 STAGE_KERNEL = {
     "k_radix_scatter": "k_radix_scatter", "k_radix_hist": "k_radix_hist", "radix_scan": "k_scan_*",
-    "kmer_emit": "k_kmer_emit", "merge_match": "k_merge_match (+reduce, scan)", "merge_emit": "k_merge_expand (+sizes, scan)",
+    "kmer_emit": "k_kmer_emit", "merge_match": "k_merge_match", "merge_fixup": "k_merge_fixup (+reduce, scan)",
+    "merge_emit": "k_merge_expand (+sizes, scan)",
     "seed_groups": "k_group_flag/write (+scan)", "chain_small_groups": "k_chain<16>", "chain_listed_groups": "k_chain<64>",
  "chain_lane_groups": "k_chain_lane", "chain_simple_groups": "k_chain_simple", "chain_lds_groups": "k_chain_small",
     "chain_piles": "k_chain_pile", "chain_dominate": "k_order_summaries + k_dominate (+ scans)", "seed_clusters": "k_cluster_flag/rekey (+scan)",
@@ -70,6 +71,10 @@ STAGE_KERNEL = {
 # enclosing stages (their kernels are timed one by one as well): not candidates for "dominant kernel"
 ENCLOSING = {"kmer_sort", "seed_sort", "cluster_sort", "chain", "sort_pairs"}
 SIDE_STREAM = {"chain_piles"}
+# stages that are ONE kernel on the main stream: the candidates for "the dominant kernel" (the finish stream's stages --
+# chain_jumps, chain_dominate -- and the alignment stream's run next to these, a dozen small kernels each)
+SINGLE_MAIN = {"merge_match", "chain_simple_groups", "chain_lane_groups", "chain_small_groups", "chain_listed_groups",
+               "chain_lds_groups", "k_radix_scatter", "k_radix_hist", "kmer_emit", "merge_buckets"}
 # kernel symbols as rocprofv3 names them, for the PMC traffic summary under profiles/
 PMC_SYMBOL = {"k_radix_scatter": "dmh::k_radix_scatter", "k_radix_hist": "dmh::k_radix_hist", "chain_lane_groups": "dmh::k_chain_lane",
               "kmer_emit": "dmh::k_kmer_emit", "chain_piles": "dmh::k_chain_pile", "read_sort": "dmh::k_read_sort",
@@ -195,6 +200,8 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="HIP events around k_radix_scatter only (default: around every kernel, about 1 ms per read block)")
     ap.add_argument("--no-stage-timing", action="store_true", help="no HIP events at all (no roofline)")
+    ap.add_argument("--event-blocks", type=int, default=8,
+                    help="one read block in this many of a rank's blocks carries the HIP events of the stage timers (0 or 1: every block)")
     ap.add_argument("--no-prefetch", action="store_true", help="do not queue the next block's index build early")
     ap.add_argument("--no-overlap", action="store_true",
                     help="Reporter of a block right behind its last pass (default: a few passes into the next block, "
@@ -303,7 +310,9 @@ def main():
         visit(i)
     m.finish()
     L.dmh_report_wait()
-    L.dmh_timing_enable(0 if args.no_stage_timing else (2 if args.roofline_only else 1))
+    tlevel = 0 if args.no_stage_timing else (2 if args.roofline_only else 1)
+    t_from = int(os.environ.get("DMH_BENCH_TIMING_FROM", "0"))       # (experiment: events only from this timed step on)
+    L.dmh_timing_enable(tlevel if t_from == 0 else 0)
     L.dmh_timing_reset()
     if dist is not None:
         import torch
@@ -313,7 +322,20 @@ def main():
     t0 = time.time()
     bases = 0
     host = {"index_reads": 0.0, "filter": 0.0, "report": 0.0, "between_blocks": 0.0}
+    step_t = []
+    # HIP events around every stage of every launch cost 3 % of a step (11 us per pair of records, 3,600 pairs per
+    # step): by default ONE read block of every timed step carries them -- every launch of that block, on the streams
+    # the kernels run on -- and the others none (--event-blocks 0: all of them)
+    ev_every = args.event_blocks if args.event_blocks > 0 else 1
+    sampled_blocks = 0
     for i in range(args.warmup * per_step, len(seq)):
+        k = i - args.warmup * per_step
+        if k % per_step == 0:
+            step_t.append(time.time())
+        if t_from == 0 or len(step_t) - 1 >= t_from:
+            on = (k % per_step) % ev_every == (min(ev_every, per_step) // 2)
+            sampled_blocks += 1 if (on and tlevel) else 0
+            L.dmh_timing_enable(tlevel if on else 0)
         t = visit(i)
         for k in host:
             host[k] += t[k]
@@ -326,6 +348,9 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
     dt = time.time() - t0
+    if os.environ.get("DMH_BENCH_STEP_TIMES") and rank == 0:
+        step_t.append(time.time())
+        sys.stderr.write("step times (ms): %s\n" % " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(step_t, step_t[1:])))
 
     tot_bases = float(bases)
     if dist is not None:
@@ -378,7 +403,8 @@ def main():
         # own, next to the following passes' kernels): its duration is latency, not machine time, so it is reported
         # separately and the dominant kernel is picked among the ones that have the GPU to themselves
         side = {k: kern.pop(k) for k in list(kern) if k in SIDE_STREAM}
-        dominant = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+        single = {k: v for k, v in kern.items() if k in SINGLE_MAIN}
+        dominant = max(single, key=lambda k: single[k]["ms"]) if single else None
         roof = roof_of(dominant) if dominant else None
         if roof is None and dominant:
             v = kern[dominant]
@@ -388,6 +414,24 @@ def main():
                     "share_of_gpu_time": round(v["ms"] / gpu_ms, 3) if gpu_ms > 0 else None}
         hbm_stage = roof_of("k_radix_scatter") if dominant != "k_radix_scatter" else None
         stages = {k: round(v["ms"], 2) for k, v in sorted(timings.items(), key=lambda kv: -kv[1]["ms"])}
+
+        # the whole path against SURVEY 8(d)'s algorithmic bytes per read block (the reference's 16-byte records):
+        # N_r + 16 K_r (1 + 2 P_k) + 16 K_r G + 16 H (1 + 2 P_s + 1), P_k = 5 byte passes of the k-mer sort, P_s = 5 of
+        # the seed sort (2 bytes of maxlen, 1 of the REF block's contigs, 2 of the READS block's reads), G = passes,
+        # H = hits of the block (from the expansion stage of the sampled blocks)
+        path_roof = None
+        nblk_total = args.steps * nbatch
+        if sampled_blocks > 0 and "merge_emit" in timings and nblk_total > 0:
+            n_r = tot_bases / (args.steps * nbatch)
+            k_r = n_r - args.block_reads * 19.0
+            hits = timings["merge_emit"]["bytes"] / 16.0 / sampled_blocks
+            g = 2 * len(ranges)
+            b_alg = n_r + 16.0 * k_r * 11 + 16.0 * k_r * g + 16.0 * hits * 12
+            sec = dt / nblk_total * world
+            path_roof = {"bound": "hbm", "alg_bytes_per_read_block": round(b_alg), "hits_per_read_block": round(hits),
+                         "achieved": round(b_alg / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": float("%.3g" % (b_alg / sec / 1e9 / HBM_PEAK_GBS)),
+                         "formula": "SURVEY 8(d): N_r + 16 K_r (1 + 2*5) + 16 K_r G + 16 H (1 + 2*5 + 1) per read block / wall time per read block"}
 
         cpu, parity = None, None
         if not args.no_cpu_baseline:
@@ -414,7 +458,12 @@ def main():
                        "ms_per_read_block": round(dt / max(1, nblk_total) * world * 1e3, 2),
                        "parallelism": "read blocks sharded x%d" % world,
                        "setup_seconds": {"reference_and_indices": round(t_ref, 1), "total": round(t_setup, 1)}},
-            "roofline": roof, "hbm_stage": hbm_stage,
+            "roofline": roof, "hbm_stage": hbm_stage, "path_roofline": path_roof,
+            "stage_events": {"read_blocks_with_events": sampled_blocks, "read_blocks_timed": nblk_total // max(1, world),
+                             "note": "HIP events (hipEventRecord on the kernels' own streams) around every stage of every "
+                                     "launch of the sampled read blocks, inside the timed region; launches / ms in roofline, "
+                                     "hbm_stage and device_stage_ms are those blocks' (events on every block: --event-blocks 0, "
+                                     "3 % slower)"},
             "side_stream_kernels": {STAGE_KERNEL.get(k, k): {"ms": round(v["ms"], 2), "launches": int(v["launches"]),
                                                             "avg_ms": round(v["ms"] / max(1, v["launches"]), 3),
                                                             "alg_bytes_per_launch": v["bytes"] / max(1, v["launches"]),

@@ -421,6 +421,44 @@ static std::vector<PendingEv> g_pending;
 static bool g_timing = false;
 static bool g_timing_roofline_only = false;     // dmh_timing_enable(2): events around the roofline kernel only
 
+static std::vector<hipEvent_t> g_timer_events;       // spare timing events
+static size_t g_harvest_at = 256;
+
+static hipEvent_t timer_event()          // (g_tmu held)
+{ if (!g_timer_events.empty())
+    { hipEvent_t e = g_timer_events.back();
+      g_timer_events.pop_back();
+      return e;
+    }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+
+// The event pairs that have completed are read and go back to the spare list.  (Left to pile up until the timings were
+// asked for -- 40,000 live events after six bench steps -- every step ran slower than the one before: 1341, 1378,
+// 1399 ms against 1300 without events.)
+static void harvest_timers()             // (g_tmu held)
+{ size_t keep = 0;
+  for (size_t i = 0; i < g_pending.size(); i++)
+    { PendingEv &p = g_pending[i];
+      const hipError_t e = hipEventQuery(p.e1);
+      if (e == hipSuccess)
+        { float ms = 0;
+          HIP_CHECK(hipEventElapsedTime(&ms, p.e0, p.e1));
+          g_slots[p.idx].ms += ms;
+          g_timer_events.push_back(p.e0);
+          g_timer_events.push_back(p.e1);
+        }
+      else
+        { (void) hipGetLastError();
+          g_pending[keep++] = p;
+        }
+    }
+  g_pending.resize(keep);
+  g_harvest_at = keep + 256;
+}
+
 static int slot_of(const char *name)
 { for (size_t i = 0; i < g_slots.size(); i++)
     if (g_slots[i].name == name) return (int) i;
@@ -445,8 +483,11 @@ StageTimer::StageTimer(const char *name, double bytes, hipStream_t on)
     g_slots[idx].bytes += bytes;
     g_slots[idx].launches += 1;
   }
-  HIP_CHECK(hipEventCreate(&e0));
-  HIP_CHECK(hipEventCreate(&e1));
+  { std::lock_guard<std::mutex> lk(g_tmu);
+    if (g_pending.size() >= g_harvest_at) harvest_timers();
+    e0 = timer_event();
+    e1 = timer_event();
+  }
   HIP_CHECK(hipEventRecord(e0, s));
 }
 
@@ -495,10 +536,11 @@ static void drain_timers()
     { float ms = 0;
       HIP_CHECK(hipEventElapsedTime(&ms, p.e0, p.e1));
       g_slots[p.idx].ms += ms;
-      HIP_CHECK(hipEventDestroy(p.e0));
-      HIP_CHECK(hipEventDestroy(p.e1));
+      g_timer_events.push_back(p.e0);
+      g_timer_events.push_back(p.e1);
     }
   g_pending.clear();
+  g_harvest_at = 256;
 }
 
 // ---- block upload -----------------------------------------------------------------------

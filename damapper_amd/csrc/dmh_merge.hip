@@ -1141,7 +1141,11 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   unsigned long long *sums = gram.p + MAXGRAM + 1;         // [0] all hits, [1] hits of the runs below MAXGRAM
   HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(unsigned long long) * 3, stream()));
   HIP_CHECK(hipMemsetAsync(mctl.p, 0, 4 * sizeof(unsigned int), stream()));
-  { StageTimer tm("merge_match", 16.0 * (A.n + Bx.n));
+  { // bytes the kernel has to read in this layout: 8 per READ k-mer, 4 per bucket and 2 (the low bits) or 8 (the key) per
+    // REF k-mer -- SURVEY 8(d) prices the merge at the reference's 16-byte records, 16 (A.n + B.n), which is more than
+    // this kernel moves
+    StageTimer tm("merge_match", 8.0 * A.n + 4.0 * ((double) ((int64_t) 1 << (Kshift - Bx.bshift)) + 2) +
+                                 (BL.klow != nullptr ? 2.0 : 8.0) * Bx.n);
     if (Bx.probe_keys == 4 && BL.klow != nullptr)
       hipLaunchKernelGGL((k_merge_match<4, true>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
                          (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
@@ -1154,6 +1158,8 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     else
       hipLaunchKernelGGL((k_merge_match<2, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
                          (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
+  }
+  { StageTimer tm("merge_fixup", 0.0);
     hipLaunchKernelGGL(k_merge_fixup, dim3(ntiles), dim3(FX_THREADS), 0, stream(), (const uint64_t *) A.keys, A.n, BL,
                        tentries.p, (const uint32_t *) tcount.p, thits.p);
     hipLaunchKernelGGL(k_merge_reduce, dim3(64), dim3(256), 0, stream(), (const unsigned long long *) thits.p, ntiles, sums);
