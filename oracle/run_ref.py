@@ -36,4 +36,4 @@ def run_reference(workdir: str, ref_root: str, read_roots: Sequence[str], flags:
     dt = time.time() - t0
     if p.returncode != 0:
         raise RuntimeError("reference failed (%d): %s\n%s" % (p.returncode, " ".join(cmd), p.stderr[-2000:]))
-    return dt, p.stdout
+    return dt, (p.stdout + "\n" + p.stderr if capture else p.stdout)

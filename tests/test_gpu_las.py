@@ -359,6 +359,31 @@ def test_reference_driver_with_ref_index_cache(tmp_path, monkeypatch):
         assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
 
 
+def test_resident_driver_recipe_matches_reference(tmp_path):
+    """INTEGRATION.md's driver change (REF blocks read, complemented and indexed ONCE, dmh_retain_ref_index(1);
+    oracle/resident_driver.py applies it to the reference's damapper.c, oracle/_ref/damapper_hip_resident): three
+    READS blocks against a three-block REF, -p and a mask-free -v run -- the same files as the all-CPU reference."""
+    run_ref = _run_ref()
+    if not os.path.exists(os.path.join(run_ref.REF_DIR, "damapper_hip_resident")):
+        pytest.skip("oracle/_ref/damapper_hip_resident not built")
+    g, reads = make_dataset("repeat", 246, [200000, 150000, 120000], 75, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=260000)
+    dazzdb.write_db(d, "READS", reads, block_size=260000)      # three read blocks
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    nrb, _ = dazzdb.read_stub(os.path.join(d, "REF.db"))
+    assert nb >= 3 and nrb >= 2
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    run_ref.run_reference(d, "REF", blocks, flags=["-v", "-p"], threads=4, keep="las_ref")
+    _, log = run_ref.run_reference(d, "REF", blocks, flags=["-v", "-p"], threads=4, keep="las_res",
+                                   binary="damapper_hip_resident")
+    assert log.count("Building indices for REF.") == nrb          # once per REF block, not once per READS block
+    for b in blocks:
+        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        _, hr = las.read_las_set(os.path.join(d, "las_res"), b + ".REF.M@.las")
+        assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
+
+
 def test_dispatcher_maps_every_read_block(tmp_path):
     """damapper_amd.dispatch (read blocks -> GPUs, resume by output file) against the reference run on
     the same blocks."""
