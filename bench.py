@@ -371,7 +371,9 @@ def main():
 
     if rank == 0:
         value = tot_bases / dt / 1e9
-        kern = {k: v for k, v in timings.items() if not k.startswith("host:") and k not in ENCLOSING and v["ms"] > 0}
+        kern = {k: v for k, v in timings.items() if not k.startswith("host:") and not k.startswith("count:")
+                and k not in ENCLOSING and v["ms"] > 0}
+        counters = {k[6:]: int(v["launches"]) for k, v in timings.items() if k.startswith("count:")}
         gpu_ms = sum(v["ms"] for v in kern.values())
 
         def roof_of(name):
@@ -413,7 +415,7 @@ def main():
                     "avg_ms": round(v["ms"] / max(1, v["launches"]), 4),
                     "share_of_gpu_time": round(v["ms"] / gpu_ms, 3) if gpu_ms > 0 else None}
         hbm_stage = roof_of("k_radix_scatter") if dominant != "k_radix_scatter" else None
-        stages = {k: round(v["ms"], 2) for k, v in sorted(timings.items(), key=lambda kv: -kv[1]["ms"])}
+        stages = {k: round(v["ms"], 2) for k, v in sorted(timings.items(), key=lambda kv: -kv[1]["ms"]) if not k.startswith("count:")}
 
         # the whole path against SURVEY 8(d)'s algorithmic bytes per read block (the reference's 16-byte records):
         # N_r + 16 K_r (1 + 2 P_k) + 16 K_r G + 16 H (1 + 2 P_s + 1), P_k = 5 byte passes of the k-mer sort, P_s = 5 of
@@ -473,6 +475,8 @@ def main():
             "cpu_baseline": cpu, "parity": parity,
             "host_seconds": {k: round(v, 3) for k, v in host.items()},
             "device_stage_ms": stages,
+            # the d-wave ladder on the sampled blocks: candidates each rung ran, and why some had to run again one rung up
+            "alignment_ladder": counters,
         }
         print(json.dumps(out))
         sys.stdout.flush()

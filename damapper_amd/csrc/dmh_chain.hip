@@ -64,6 +64,9 @@ struct ChainArgs
   uint32_t       *gbase;              //   (k_order_summaries puts them into the reference's reporting order)
   const uint32_t *glast;              // cluster mode: per group the largest apos + 1 of its (aread, bread) pair; else nullptr
   uint32_t       *gdone;              // per group: 1 = chained by k_chain_simple (k_chain_lane leaves it alone); may be nullptr
+  uint32_t       *wide;               // k_chain_lane: groups of walk_max hits or more that k_chain_simple has left are not
+  unsigned int   *nwide;              //   walked by ONE lane but appended here (the wavefront-per-group launch's list)
+  uint32_t        walk_max;
   uint32_t        pile_cap;           // k_chain_pile: entries of LDS it may use (<= PILE_CAP; smaller in tests)
 };
 
@@ -784,8 +787,12 @@ __global__ __launch_bounds__(LANE_BLOCK, 5) void k_chain_lane(ChainArgs A, uint3
         }
       if (pst == 2)
         { q0 = lq0; q1 = lq1;            // (the registers a load is on its way to are read nowhere else)
-          if (q1 - q0 <= size_max && ldone == 0) pst = 4;      // (not a listed group's size, not chained already)
-          else { pg += nthreads; pst = 1; }
+          const uint32_t sz = q1 - q0;
+          if (sz <= size_max && ldone == 0 && sz < A.walk_max) pst = 4;      // (not a listed group's size, not chained already)
+          else
+            { if (sz <= size_max && ldone == 0) A.wide[atomicAdd(A.nwide, 1u)] = pg;      // (too long a walk for one lane)
+              pg += nthreads; pst = 1;
+            }
         }
       // ---- what the last step left to be written: its group's ends (they read last_r: before any store, or the
       //      wait for it would wait for the stores too), its chunk's links
@@ -1541,6 +1548,7 @@ __global__ void k_big_groups(const uint32_t *__restrict__ gstart, uint32_t ngrou
 // wavefront, repeat piles one per workgroup; dmh_test_option("chain_g") / DMH_CHAIN_G force one group width
 // for everything below the pile threshold, "chain_pile" / DMH_CHAIN_PILE move that threshold (0 = no piles)
 constexpr uint32_t BIG_GROUP = 1024;
+constexpr uint32_t SIMPLE_MAX = 4096;
 
 constexpr uint32_t SMALL_CAP = 64;       // k_chain_small<16, 64>
 
@@ -1552,7 +1560,15 @@ void chain_group_limits(MergeResult &R)
   static const int env_small = getenv("DMH_CHAIN_SMALL") ? atoi(getenv("DMH_CHAIN_SMALL")) : (int) SMALL_CAP;
   const int chain_g = st.opt_chain_g ? st.opt_chain_g : env_g;
   R.pile_min = (st.opt_chain_pile >= 0) ? (uint32_t) st.opt_chain_pile : (uint32_t) env_pile;
-  R.small_hi = (chain_g == 0) ? BIG_GROUP : 0xffffffffu;
+  // with k_chain_simple on, groups of up to SIMPLE_MAX hits get their chance there -- the true locus of a 30 kb read is
+  // a plain chain of 1,200 hits -- and k_chain_lane hands the ones of BIG_GROUP hits and more that are left to the
+  // wavefront-per-group launch; without it those groups are listed for that launch right away
+  static const int env_lane0 = getenv("DMH_CHAIN_LANE") ? atoi(getenv("DMH_CHAIN_LANE")) : 1;
+  static const int env_simple0 = getenv("DMH_CHAIN_SIMPLE") ? atoi(getenv("DMH_CHAIN_SIMPLE")) : 1;
+  const bool simple_on = (st.opt_chain_lane >= 0 ? st.opt_chain_lane : env_lane0) != 0 &&
+                         (st.opt_chain_simple >= 0 ? st.opt_chain_simple : env_simple0) != 0 &&
+                         (st.opt_chain_small >= 0 ? st.opt_chain_small : env_small) != 0;
+  R.small_hi = (chain_g == 0) ? (simple_on ? SIMPLE_MAX : BIG_GROUP) : 0xffffffffu;
   if (R.pile_min > 0) R.small_hi = std::min(R.small_hi, R.pile_min);
   // groups of up to small_cap hits go to the all-LDS kernel (not when a group width is forced for everything)
   int sc = (st.opt_chain_small >= 0) ? st.opt_chain_small : env_small;
@@ -1811,6 +1827,7 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
   A.gbase  = gbase.p;
   A.glast  = R.clustered ? R.glast.p : nullptr;
   A.gdone  = nullptr;
+  A.wide = nullptr; A.nwide = nullptr; A.walk_max = 0xffffffffu;
   A.pile_cap = PILE_CAP;
 
   static const int env_g = getenv("DMH_CHAIN_G") ? atoi(getenv("DMH_CHAIN_G")) : 0;
@@ -1870,6 +1887,9 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             ChainArgs Q = A;
             Q.retry  = R.medlist.p;
             Q.nretry = R.gcounts.p + 2;
+            Q.wide   = R.biglist.p;
+            Q.nwide  = R.gcounts.p;
+            Q.walk_max = BIG_GROUP;
             StageTimer t0("chain_lane_groups", 16.0 * nhits);        // 16 B per hit, read once by the chain stage
             // persistent lanes: exactly as many workgroups as the GPU holds at once (a second round of them would run
             // on a half-empty GPU)

@@ -108,6 +108,8 @@ struct StageTimer
   hipEvent_t e0, e1;
 };
 
+void timing_count(const char *name, int64_t n);     // a counter in the same table (reported as `launches`, 0 ms)
+
 // wall-clock time of a host section, reported next to the device stages as "host:<name>"
 struct HostTimer
 { HostTimer(const char *name);

@@ -536,6 +536,13 @@ HostTimer::~HostTimer()
   if (idx < (int) g_slots.size()) g_slots[idx].ms += dt;     // (the table may have been reset meanwhile)
 }
 
+// a counter in the timing table: name, 0 ms, n "launches" (e.g. the candidates the d-wave kernel has to run again, by cause)
+void timing_count(const char *name, int64_t n)
+{ if (!g_timing || g_timing_roofline_only) return;
+  std::lock_guard<std::mutex> lk(g_tmu);
+  g_slots[slot_of(name)].launches += n;
+}
+
 static void drain_timers()
 { if (g_pending.empty()) return;
   report_finish_pending();          // (its kernel's events live on the alignment stream)

@@ -16,6 +16,7 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
 { State &st = S();
   Params &pm = st.params;
   int64_t nhits = 0, nfilt = 0;
+  report_poll();             // (a deferred Reporter whose jobs are ready launches its kernel; one that has finished is collected)
   if (start)
     { HostTimer ht("mf_reset_reads");
       chain_reset_reads(ablock);

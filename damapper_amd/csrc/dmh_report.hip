@@ -1433,6 +1433,22 @@ static bool collect_round(PendingReport &P)
   else ran = P.todo;
   std::vector<int> again;
   bool need_pool = false, need_up = false;
+  { // why candidates have to run again, per rung of the ladder (dmh_timing_get: "count:align...")
+    int64_t nband = 0, npeb = 0, npool = 0;
+    for (int j : ran)
+      if (P.status[j] == AL_ERR_BAND) nband += 1;
+      else if (P.status[j] == AL_ERR_PEBBLES) npeb += 1;
+      else if (P.status[j] == 100) npool += 1;
+    static const char *cname[3][4] = {
+      {"count:align32_candidates", "count:align32_band_over_30", "count:align32_pebbles_over_288", "count:align32_pool_full"},
+      {"count:align64_candidates", "count:align64_band_over_ring", "count:align64_pebbles", "count:align64_pool_full"},
+      {"count:align_global_candidates", "count:align_global_band", "count:align_global_pebbles", "count:align_global_pool_full"}};
+    const int lv = std::min(2, std::max(0, P.level));
+    timing_count(cname[lv][0], (int64_t) ran.size());
+    if (nband) timing_count(cname[lv][1], nband);
+    if (npeb)  timing_count(cname[lv][2], npeb);
+    if (npool) timing_count(cname[lv][3], npool);
+  }
   for (int j : ran)
     if (P.status[j] != AL_OK)
       { again.push_back(j);
@@ -1560,6 +1576,7 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   // previous block's alignment kernel, which is only collected further down
   static const int defer_max = getenv("DMH_DEFER_MAX_PASSES") ? atoi(getenv("DMH_DEFER_MAX_PASSES")) : 1 << 30;
   const bool defer = (g_async == 2) && st.mf_calls <= defer_max;
+  st.mf_calls_block = st.mf_calls;
   st.mf_calls = 0;
   // the index sort of the NEXT block: all of it now (deferred mode) -- ahead of this block's alignment kernel, and on
   // the main stream while the finish stream drains this block's last batches (a dozen small kernels and two round
@@ -1579,7 +1596,9 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   // the filter of the next block, and the first report_poll that finds the jobs ready launches the kernel
   // (DMH_SYNC_REPORT_JOBS: everything here, as before)
   static const bool sync_jobs = getenv("DMH_SYNC_REPORT_JOBS") != nullptr;
-  const bool async_build = defer && !sync_jobs;
+  // (not for a block of a few passes: there the alignment kernel is the longest thing on the GPU and has to start now,
+  //  not at the next poll)
+  const bool async_build = defer && !sync_jobs && st.mf_calls_block > 6;
   PendingReport *P = new PendingReport();
   hipEvent_t ev_raw = nullptr;
   if (async_build) HIP_CHECK(hipEventCreateWithFlags(&ev_raw, hipEventDisableTiming));
