@@ -1600,6 +1600,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "batch") == 0)       st.opt_batch = value;
   else if (strcmp(key, "expand") == 0)      st.opt_expand = value;
   else if (strcmp(key, "in_flight") == 0)   st.opt_in_flight = value;
+  else if (strcmp(key, "hit_limit") == 0)   st.opt_hit_limit = value;
   else if (strcmp(key, "seed_word") == 0)   st.opt_seed_word = value;
   else if (strcmp(key, "fin_stream") == 0)  st.opt_fin_stream = value;
   else if (strcmp(key, "alloc_fail") == 0)  g_alloc_fail = value > 0 ? value : 0;

@@ -1246,7 +1246,11 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     { printf("   Hit count = %lld\n", (long long) nhits);
       fflush(stdout);
     }
-  if (nhits >= (int64_t) 0xfffffff0ll)
+  // hits are numbered in 32 bits from here on (group starts, links, chain ends): a pass of 2^32 hits and more is
+  // refused -- the reference's -M rule keeps a pass under (M - DBs) / 32 hits, i.e. below 2^32 for -M up to 137 GB,
+  // and a 375 Mbp block pair reaches 10^9 only against a one-family reference ("hit_limit" test option: the refusal
+  // at a smaller number)
+  if (nhits >= (st.opt_hit_limit > 0 ? (int64_t) st.opt_hit_limit : (int64_t) 0xfffffff0ll))
     fatal("Match_Filter: %lld seed hits in one block pair exceed the 32-bit slot range; use smaller blocks or -M",
           (long long) nhits);
   if (nhits == 0) return 0;

@@ -42,3 +42,16 @@ j=json.loads(open('$f').read().strip().splitlines()[-1]); print('  ', j['value']
 head -14 "$O/kernel_stats.csv"
 cat "$O/pmc_sq_summary.txt"
 head -30 "$O/stream_gaps.txt"
+# the other workloads, each with its CPU-reference leg and the parity check of the timed output
+if [ "${3:-}" = "workloads" ]; then
+  for w in ecoli chr1 grch38-random; do
+    timeout -k 10 500 python3 bench.py --workload $w --steps 3 --warmup 1 > "$O/bench_$w.json" 2> "$O/bench_$w.err" || exit 1
+    python3 -c "
+import json
+j=json.loads(open('$O/bench_$w.json').read().strip().splitlines()[-1]); print('$w', j['value'], j['config']['ms_per_read_block'], (j.get('cpu_baseline') or {}).get('value'), (j.get('parity') or {}).get('differing'), (j.get('parity') or {}).get('records'))"
+  done
+  timeout -k 10 560 python3 bench.py --read-lengths lognormal --steps 3 --warmup 1 > "$O/bench_lognormal.json" 2> "$O/bench_lognormal.err" || exit 1
+  python3 -c "
+import json
+j=json.loads(open('$O/bench_lognormal.json').read().strip().splitlines()[-1]); print('lognormal', j['value'], j['config']['ms_per_read_block'], (j.get('cpu_baseline') or {}).get('value'), (j.get('parity') or {}).get('differing'), (j.get('parity') or {}).get('records'))"
+fi

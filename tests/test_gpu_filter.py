@@ -85,3 +85,25 @@ def test_profile_deltas_match_reference(case):
     assert nz > 0
     for (ca, _), (cb, _) in zip(ref["cands"], hip["cands"]):
         assert np.array_equal(ca, cb)
+
+
+def test_pass_beyond_the_hit_range_is_refused():
+    """Hits are numbered in 32 bits behind the merge; a pass of 2^32 hits and more ends the process with a message
+    (dmh_merge.hip; the reference itself caps a pass by -M, map.c:2992-3055).  The "hit_limit" test option moves the
+    refusal to 1,000 hits so that it can be seen: in a process of its own, since fatal() is Clean_Exit + exit(1)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r + '/oracle')\n"
+        "from util_pipeline import Api, make_dataset, run_filter\n"
+        "from damapper_amd import capi\n"
+        "g, reads = make_dataset('repeat', 3, [250000], 30)\n"
+        "capi.lib().dmh_test_option(b'hit_limit', 1000)\n"
+        "run_filter(Api('hip'), reads, g, [0, 1], K=20, supp=0, mem_limit=8 << 30)\n"
+        "print('NOT REFUSED')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+         os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "NOT REFUSED" not in p.stdout, p.stdout + p.stderr
+    assert "exceed the 32-bit slot range" in p.stderr, p.stderr[-2000:]
