@@ -324,8 +324,8 @@ def main():
     host = {"index_reads": 0.0, "filter": 0.0, "report": 0.0, "between_blocks": 0.0}
     step_t = []
     # HIP events around every stage of every launch cost 3 % of a step (11 us per pair of records, 3,600 pairs per
-    # step): by default ONE read block of every timed step carries them -- every launch of that block, on the streams
-    # the kernels run on -- and the others none (--event-blocks 0: all of them)
+    # step): by default ONE read block in eight of a rank's timed visits carries them -- every launch of that block, on
+    # the streams the kernels run on -- and the others none (--event-blocks 0: all of them)
     ev_every = args.event_blocks if args.event_blocks > 0 else 1
     sampled_blocks = 0
     for i in range(args.warmup * per_step, len(seq)):
@@ -333,7 +333,8 @@ def main():
         if k % per_step == 0:
             step_t.append(time.time())
         if t_from == 0 or len(step_t) - 1 >= t_from:
-            on = (k % per_step) % ev_every == (min(ev_every, per_step) // 2)
+            nvis = len(seq) - args.warmup * per_step
+            on = k % ev_every == min(ev_every // 2, nvis - 1)      # (of the rank's visits, whatever the number of ranks)
             sampled_blocks += 1 if (on and tlevel) else 0
             L.dmh_timing_enable(tlevel if on else 0)
         t = visit(i)

@@ -1889,7 +1889,10 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             Q.nretry = R.gcounts.p + 2;
             Q.wide   = R.biglist.p;
             Q.nwide  = R.gcounts.p;
-            Q.walk_max = BIG_GROUP;
+            static const uint32_t env_walk = getenv("DMH_WALK_MAX") ? (uint32_t) atoi(getenv("DMH_WALK_MAX")) : BIG_GROUP;
+            Q.walk_max = env_walk;
+            static const bool walk_to_16 = getenv("DMH_WALK_TO_16") != nullptr;       // (experiment: the long walks to k_chain<16>)
+            if (walk_to_16) { Q.wide = R.medlist.p; Q.nwide = R.gcounts.p + 2; }
             StageTimer t0("chain_lane_groups", 16.0 * nhits);        // 16 B per hit, read once by the chain stage
             // persistent lanes: exactly as many workgroups as the GPU holds at once (a second round of them would run
             // on a half-empty GPU)

@@ -1059,6 +1059,7 @@ static uint32_t g_known[5] = {0, 0, 0, 0, 0};     // clusters, clusters for the 
 static bool     g_have_known = false;
 static uint32_t g_rcnt[5] = {0, 0, 0, 0, 0}, g_rlim = 0;   // reads per k_read_sort workgroup size, largest segment, reads above the
                                                             // limit (fetched for statistics and experiments only)
+static bool     g_rs_small = false;                        // this pass: no 1024-thread workgroups (see k_read_classes' limits)
 static uint32_t g_rgrid[4] = {0, 0, 0, 0};                  // the most reads each size class can hold: the grids
 constexpr int RS_T0 = 256, RS_T1 = 512, RS_T2 = 1024;      // k_read_sort workgroups: segments of up to 4,096 / 8,192 / 16,384 hits
 
@@ -1346,7 +1347,14 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
             // the reads by segment size: one list per workgroup size of k_read_sort ("read_sort" test option = 2: the
             // largest workgroups take everything above 128 hits; = 3: segments above 512 hits count as too large)
             g_rlists.ensure(4 * (size_t) nr + 16, "reads by segment size");
-            const uint32_t lim2 = (st.opt_read_sort == 3) ? 512u : (uint32_t) RS_T2 * RS_E;
+            // While the deferred alignment kernel of the previous block runs (20 ms, its workgroups persistent, LDS pebbles
+            // on every CU) a 1024-thread workgroup with 140 KB of LDS finds no CU to run on until that kernel ENDS, and the
+            // main stream stands still behind it (the trace: 10-17 ms for a launch that takes 0.06): the reads of that
+            // class then go through global memory with small workgroups, which fit anywhere ("read_sort" test option = 6:
+            // always)
+            g_rs_small = report_in_flight() || st.opt_read_sort == 6 || st.opt_read_sort == 7;      // (7 = 3 + 6)
+            const uint32_t lim2 = (st.opt_read_sort == 3 || st.opt_read_sort == 7) ? 512u
+                                  : (g_rs_small ? (uint32_t) RS_T1 * RS_E : (uint32_t) RS_T2 * RS_E);
             const uint32_t lim0 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T0 * RS_E);
             const uint32_t lim1 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T1 * RS_E);
             hipLaunchKernelGGL(k_read_classes, dim3(ceil_div(nr, 256)), dim3(256), 0, stream(), (const uint32_t *) g_rstart.p, nr,
@@ -1708,9 +1716,12 @@ static void close_batch(MergeResult &R)
             if (g_rcnt[4] > 0)
               { // (first: the few workgroups of this launch run longest)
                 RA.list = g_rlists.p + 3 * (size_t) nr; RA.count = g_rstats.p + 4;
-                hipLaunchKernelGGL((k_read_sort_big<RS_T2>), dim3(std::min<uint32_t>(g_rcnt[4], 1024u)), dim3(RS_T2), 0, stream(), RA);
+                if (g_rs_small)
+                  hipLaunchKernelGGL((k_read_sort_big<RS_T0>), dim3(std::min<uint32_t>(g_rcnt[4], 2048u)), dim3(RS_T0), 0, stream(), RA);
+                else
+                  hipLaunchKernelGGL((k_read_sort_big<RS_T2>), dim3(std::min<uint32_t>(g_rcnt[4], 1024u)), dim3(RS_T2), 0, stream(), RA);
               }
-            if (g_rcnt[2] > 0)
+            if (g_rcnt[2] > 0 && !g_rs_small)
               { hipStream_t q = fork ? side[0] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[0] = true; }
                 RA.list = g_rlists.p + 2 * (size_t) nr; RA.count = g_rstats.p + 2;

@@ -162,6 +162,7 @@ def test_ragged_and_degenerate_reads(tmp_path):
                                   dict(cluster=1, fin_stream=0), dict(fin_stream=0), dict(cluster=1, alloc_fail=30), dict(cluster=1, alloc_fail=90), dict(alloc_fail=150),
                                   dict(cluster=1, oom_finish=2), dict(oom_finish=1), dict(cluster=1, read_sort=0),
                                   dict(cluster=1, read_sort=2), dict(cluster=1, read_sort=3), dict(cluster=1, read_sort=5),
+                                  dict(cluster=1, read_sort=7),
                                   dict(chain_simple=0), dict(cluster=1, chain_simple=0)],
                          ids=["four_per_wavefront", "wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
                               "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table", "merge_low16_probes",
@@ -171,7 +172,8 @@ def test_ragged_and_degenerate_reads(tmp_path):
                               "clusters_key_value_sort", "clusters_key_value_sort_per_entry", "clusters_expand_per_entry",
                               "clusters_finish_on_main_stream", "finish_on_main_stream", "clusters_memory_runs_out_30", "clusters_memory_runs_out_90", "memory_runs_out_150",
                               "clusters_memory_runs_out_inside_finish", "memory_runs_out_inside_finish", "clusters_global_seed_sort",
-                              "clusters_read_sort_large_workgroups", "clusters_read_sort_oversize_fallback", "clusters_read_sort_ballot_ranks",
+                              "clusters_read_sort_large_workgroups", "clusters_read_sort_oversize_through_global_memory", "clusters_read_sort_ballot_ranks",
+                              "clusters_read_sort_oversize_small_workgroups",
                               "no_simple_groups", "clusters_no_simple_groups"])
 def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes

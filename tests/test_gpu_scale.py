@@ -151,8 +151,9 @@ def test_configs4_resident_multi_block_reference_n95_p(tmp_path):
         assert want.max() >= 10                      # repeat coverage shows
 
 
-@pytest.mark.parametrize("cluster,read_sort", [(-1, -1), (0, -1), (-1, 0), (-1, 2), (-1, 5)],
-                         ids=["auto", "pairs", "auto_global_seed_sort", "auto_large_workgroups", "auto_ballot_ranks"])
+@pytest.mark.parametrize("cluster,read_sort", [(-1, -1), (0, -1), (-1, 0), (-1, 2), (-1, 5), (-1, 6)],
+                         ids=["auto", "pairs", "auto_global_seed_sort", "auto_large_workgroups", "auto_ballot_ranks",
+                              "auto_no_1024_thread_workgroups"])
 def test_one_family_repeat_stress(cluster, read_sort, tmp_path):
     run_ref = _run_ref()
     d = str(tmp_path)
