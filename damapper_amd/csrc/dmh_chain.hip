@@ -1712,6 +1712,8 @@ struct ChainCtx
   ChainArgs  A;
   hipEvent_t piles_done = nullptr;
   hipEvent_t submitted = nullptr;    // the batch's chain kernels are queued on the main stream up to here
+  hipEvent_t lane_done = nullptr, tail_done = nullptr;     // ... and its tail launches on the tail stream (has_tail)
+  bool       has_tail = false;
   bool       has_piles = false, all64 = false;
   // chain_finish: buffers that live from one of its steps to the next, and where it stands
   DevBuf<uint32_t> goff, fresh, jl;
@@ -1768,6 +1770,11 @@ void chain_release(MergeResult &R)
 // stream, which join_side_streams does not cover -- whatever the main stream does next comes after it
 void chain_abandon(MergeResult &R)
 { if (R.cc != nullptr && R.cc->fin != nullptr) { R.cc->fin->stage = 0; R.cc->fin->result = 0; }
+  if (R.cc != nullptr && R.cc->has_tail)
+    { HIP_CHECK(hipStreamWaitEvent(main_stream(), R.cc->tail_done, 0));
+      if (finish_stream() != main_stream()) HIP_CHECK(hipStreamWaitEvent(finish_stream(), R.cc->tail_done, 0));
+      R.cc->has_tail = false;
+    }
   if (R.cc == nullptr || !R.cc->has_piles) return;
   HIP_CHECK(hipStreamWaitEvent(main_stream(), R.cc->piles_done, 0));
   if (finish_stream() != main_stream()) HIP_CHECK(hipStreamWaitEvent(finish_stream(), R.cc->piles_done, 0));
@@ -1871,17 +1878,46 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             HIP_CHECK(hipEventRecord(ev_done, pstream));
             piles_done = ev_done;
           }
+        bool tail_from_lane = false;
         if (R.lane_max > 0)
           { // groups that are plain chains need no walk (k_chain_simple: "chain_simple" test option / DMH_CHAIN_SIMPLE = 0: off)
             static const int env_simple = getenv("DMH_CHAIN_SIMPLE") ? atoi(getenv("DMH_CHAIN_SIMPLE")) : 1;
+            static const int env_tail0 = getenv("DMH_CHAIN_TAIL") ? atoi(getenv("DMH_CHAIN_TAIL")) : 3;
+            bool simple_on_tail = false;
             if ((st.opt_chain_simple >= 0 ? st.opt_chain_simple : env_simple) != 0)
               { C.gdone.ensure((size_t) R.ngroups + 1, "groups chained without a walk");
                 HIP_CHECK(hipMemsetAsync(C.gdone.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
                 A.gdone = C.gdone.p;
+                // (the whole chain stage of a dense pass on the tail stream: 150.4 ms per read block; DMH_CHAIN_TAIL=1: from
+                //  the lane kernel on, 152.5; = 2: only the launches behind the lane kernel, 158.5; = 0: none, 164.7)
+                simple_on_tail = (env_tail0 == 3) && tail_stream() != main_stream() && stream() == main_stream();
+                if (simple_on_tail)
+                  { if (C.lane_done == nullptr)
+                      { HIP_CHECK(hipEventCreateWithFlags(&C.lane_done, hipEventDisableTiming));
+                        HIP_CHECK(hipEventCreateWithFlags(&C.tail_done, hipEventDisableTiming));
+                      }
+                    HIP_CHECK(hipEventRecord(C.lane_done, stream()));
+                    HIP_CHECK(hipStreamWaitEvent(tail_stream(), C.lane_done, 0));
+                  }
+                StreamScope on_tail0(simple_on_tail ? tail_stream() : stream());
                 StageTimer t0("chain_simple_groups", 12.0 * nhits);
                 const int nbs = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
                 hipLaunchKernelGGL(k_chain_simple, dim3(nbs), dim3(256), 0, stream(), A, R.lane_max);
               }
+            // the tail: from here on the launches walk what k_chain_simple has left (7 % of the hits of a dense pass,
+            // the time of each launch the LENGTH of its longest walk) -- on the tail stream, next to the following
+            // pass's match kernels
+            static const int env_tail = getenv("DMH_CHAIN_TAIL") ? atoi(getenv("DMH_CHAIN_TAIL")) : 3;
+            tail_from_lane = (env_tail == 1 || env_tail == 3) && tail_stream() != main_stream() && stream() == main_stream();
+            if (tail_from_lane && !simple_on_tail)
+              { if (C.lane_done == nullptr)
+                  { HIP_CHECK(hipEventCreateWithFlags(&C.lane_done, hipEventDisableTiming));
+                    HIP_CHECK(hipEventCreateWithFlags(&C.tail_done, hipEventDisableTiming));
+                  }
+                HIP_CHECK(hipEventRecord(C.lane_done, stream()));
+                HIP_CHECK(hipStreamWaitEvent(tail_stream(), C.lane_done, 0));
+              }
+            StreamScope on_tail(tail_from_lane ? tail_stream() : stream());
             // one lane per group: every group below the wavefront-per-group size tries this first; the ones whose
             // window or tree table overflows are appended to the medium list
             ChainArgs Q = A;
@@ -1906,7 +1942,10 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
                 resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
                 if (getenv("DMH_STATS")) fprintf(stderr, "dmh: k_chain_lane: %d workgroups of %d per CU\n", per_cu, LANE_BLOCK);
               }
-            const int nb = (int) std::min<int64_t>((R.ngroups + LANE_BLOCK - 1) / LANE_BLOCK, resident);
+            // (on the tail stream it shares the GPU with the next pass's match kernels: DMH_LANE_GRID_DIV, experiments)
+            static const int grid_div = getenv("DMH_LANE_GRID_DIV") ? std::max(1, atoi(getenv("DMH_LANE_GRID_DIV"))) : 1;
+            const int nb = (int) std::min<int64_t>((R.ngroups + LANE_BLOCK - 1) / LANE_BLOCK,
+                                                    tail_from_lane ? std::max(1, resident / grid_div) : resident);
             hipLaunchKernelGGL((k_chain_lane<LANE_RW, LANE_RT>), dim3(nb), dim3(LANE_BLOCK), 0, stream(), Q, R.lane_max);
           }
         else if (R.small_cap > 0)
@@ -1915,6 +1954,19 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             const int nb = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
             hipLaunchKernelGGL((k_chain_small<16, (int) SMALL_CAP>), dim3(nb), dim3(256), 0, stream(), A, R.small_cap);
           }
+        // the tail: what follows walks the lists the lane kernel has left -- on the tail stream, behind that kernel
+        hipStream_t ts = (R.lane_max > 0) ? tail_stream() : main_stream();
+        const bool tail = ts != main_stream() && stream() == main_stream();
+        if (tail && !tail_from_lane)
+          { if (C.lane_done == nullptr)
+              { HIP_CHECK(hipEventCreateWithFlags(&C.lane_done, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&C.tail_done, hipEventDisableTiming));
+              }
+            HIP_CHECK(hipEventRecord(C.lane_done, stream()));
+            HIP_CHECK(hipStreamWaitEvent(ts, C.lane_done, 0));
+          }
+        {
+        StreamScope on_tail(tail ? ts : stream());
         if (R.nmed > 0 || R.lane_max > 0)
           { // medium groups: window in LDS, a list with its own ticket counter (ctl[3])
             ChainArgs M = A;
@@ -1938,6 +1990,11 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
           const uint32_t lblocks = std::min<uint32_t>(std::max<uint32_t>((R.nbig + 3) / 4 + 64, 256), 256 * 8);
           StageTimer t2("chain_listed_groups", 0.0);
           hipLaunchKernelGGL(k_chain<64>, dim3(lblocks), dim3(256), 0, stream(), A);
+        }
+        if (tail)
+          { HIP_CHECK(hipEventRecord(C.tail_done, stream()));
+            C.has_tail = true;
+          }
         }
         C.has_piles = (piles_done != nullptr);
       }
@@ -1968,6 +2025,10 @@ static void finish_step_a(MergeResult &R)
   FinishState &F = fin_of(C);
   StreamScope on_finish(finish_stream());
   if (stream() != main_stream()) HIP_CHECK(hipStreamWaitEvent(stream(), C.submitted, 0));
+  if (C.has_tail)
+    { HIP_CHECK(hipStreamWaitEvent(stream(), C.tail_done, 0));
+      C.has_tail = false;
+    }
   ChainArgs A = C.A;
   DevBuf<uint32_t> &ctl = C.ctl, &gcnt = C.gcnt, &pileretry = C.pileretry;
   if (C.has_piles)

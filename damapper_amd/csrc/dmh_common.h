@@ -39,6 +39,7 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 hipStream_t stream();              // the stream this thread's launches go to: the main stream unless a StreamScope is open
 hipStream_t main_stream();
 void        join_side_streams();   // the main stream waits for everything queued on the finish stream so far
+hipStream_t tail_stream();         // where the chain stage's last, latency-bound launches of a batch run (dmh_core.hip)
 hipStream_t finish_stream();       // where the filter finishes its batches (chain_finish); the main stream when switched off
 struct StreamScope                 // stream() = s for the calling thread while the scope lives
 { explicit StreamScope(hipStream_t s);

@@ -117,9 +117,25 @@ hipStream_t finish_stream()
   return g_fstream;
 }
 
+// The chain stage's tail -- the lane-group and wavefront-per-group launches that walk what k_chain_lane has handed
+// on: a few hundred groups, their time the LENGTH of the longest walk, the GPU nearly empty -- runs here, next to the
+// following pass's match kernels (DMH_CHAIN_TAIL=0 or the "fin_stream" test option = 0: on the main stream).
+static hipStream_t g_tstream = nullptr;
+hipStream_t tail_stream()
+{ init_device();
+  static const int env_ts = getenv("DMH_CHAIN_TAIL") ? atoi(getenv("DMH_CHAIN_TAIL")) : 1;
+  if (env_ts == 0 || S().opt_fin_stream == 0) return g_stream;
+  if (g_tstream == nullptr) HIP_CHECK(hipStreamCreateWithFlags(&g_tstream, hipStreamNonBlocking));
+  return g_tstream;
+}
+
 void join_side_streams()
 { static hipEvent_t ev = nullptr;
   if (ev == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (g_tstream != nullptr)
+    { HIP_CHECK(hipEventRecord(ev, g_tstream));
+      HIP_CHECK(hipStreamWaitEvent(g_stream, ev, 0));
+    }
   if (g_fstream != nullptr)
     { HIP_CHECK(hipEventRecord(ev, g_fstream));
       HIP_CHECK(hipStreamWaitEvent(g_stream, ev, 0));
@@ -132,6 +148,7 @@ StreamScope::~StreamScope() { g_stream_scope = prev; }
 static void sync_all_streams()
 { init_device();
   HIP_CHECK(hipStreamSynchronize(g_upstream));
+  if (g_tstream != nullptr) HIP_CHECK(hipStreamSynchronize(g_tstream));
   if (g_fstream != nullptr) HIP_CHECK(hipStreamSynchronize(g_fstream));
   HIP_CHECK(hipStreamSynchronize(g_stream));
 }

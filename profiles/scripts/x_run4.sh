@@ -1,7 +1,6 @@
 mkdir -p gpurun_out/fp
 run() { name=$1; shift; env "$@" python bench.py --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/fp/$name.json 2> gpurun_out/fp/$name.err; python -c "
-import json,sys; d=json.loads(open('gpurun_out/fp/$name.json').read().strip().splitlines()[-1]); s=d['device_stage_ms']; n=d['stage_events']['read_blocks_with_events']; print('$name', d['value'], d['config']['ms_per_read_block'], {k: round(s.get(k,0)/n,1) for k in ('chain_simple_groups','chain_lane_groups','chain_small_groups','chain_listed_groups')})"; }
-run w512_16 DMH_WALK_MAX=512 DMH_WALK_TO_16=1
-run w256_16 DMH_WALK_MAX=256 DMH_WALK_TO_16=1
-run w128_16 DMH_WALK_MAX=128 DMH_WALK_TO_16=1
-run w2048 DMH_WALK_MAX=2048
+import json,sys; d=json.loads(open('gpurun_out/fp/$name.json').read().strip().splitlines()[-1]); s=d['device_stage_ms']; n=d['stage_events']['read_blocks_with_events']; print('$name', d['value'], d['config']['ms_per_read_block'], {k: round(s.get(k,0)/n,1) for k in ('chain_simple_groups','chain_lane_groups','chain_small_groups','chain_listed_groups','merge_match','read_sort','merge_emit')})"; }
+run t3 DMH_CHAIN_TAIL=3
+run t1 DMH_CHAIN_TAIL=1
+run t3b DMH_CHAIN_TAIL=3
