@@ -124,7 +124,7 @@ static hipStream_t g_tstream = nullptr;
 hipStream_t tail_stream()
 { init_device();
   static const int env_ts = getenv("DMH_CHAIN_TAIL") ? atoi(getenv("DMH_CHAIN_TAIL")) : 1;
-  if (env_ts == 0 || S().opt_fin_stream == 0) return g_stream;
+  if (env_ts == 0 || S().opt_fin_stream == 0 || S().opt_tails == 0) return g_stream;
   if (g_tstream == nullptr) HIP_CHECK(hipStreamCreateWithFlags(&g_tstream, hipStreamNonBlocking));
   return g_tstream;
 }
@@ -1618,6 +1618,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "expand") == 0)      st.opt_expand = value;
   else if (strcmp(key, "in_flight") == 0)   st.opt_in_flight = value;
   else if (strcmp(key, "hit_limit") == 0)   st.opt_hit_limit = value;
+  else if (strcmp(key, "tails") == 0)       st.opt_tails = value;
   else if (strcmp(key, "seed_word") == 0)   st.opt_seed_word = value;
   else if (strcmp(key, "fin_stream") == 0)  st.opt_fin_stream = value;
   else if (strcmp(key, "alloc_fail") == 0)  g_alloc_fail = value > 0 ? value : 0;

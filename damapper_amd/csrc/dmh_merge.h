@@ -50,6 +50,11 @@ struct MergeResult
   uint32_t lane_max = 0;                       // > 0: groups of up to this many hits try the lane-per-group kernel first
   uint32_t small_cap = 0;                      // groups of up to this many hits go to the all-LDS kernel
   bool     classified = false;
+  // the per-read seed order of a dense pass (dmh_readsort.h): first hit of each read, size-class lists and their
+  // lengths, clusters per read, cluster records, cluster counters, clusters listed for the wide sorts; largest apos per pair
+  DevBuf<uint32_t> rs_start, rs_stats, rs_lists, rs_ncl, rs_wlist[2], pmax;
+  DevBuf<uint64_t> rs_lcl;
+  DevBuf<unsigned int> rs_wcnt;
 };
 
 // classifies the groups of R.gstart on the device and fetches the number of piles

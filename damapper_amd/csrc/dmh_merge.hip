@@ -1053,8 +1053,8 @@ static bool lds_atomics_ordered()
 }
 
 // per-read route: segment starts of the pass being collected (main stream only; a dense pass is closed at once)
-static DevBuf<uint32_t> g_rstart, g_rowdst, g_rstats, g_rlists, g_wlist[2];
-static DevBuf<unsigned int> g_wcnt;
+static DevBuf<uint32_t> g_rowdst;        // (the other per-read-sort buffers belong to the batch: MergeResult::rs_*, its tail runs
+                                         //  on a stream of its own next to the following pass)
 static uint32_t g_known[5] = {0, 0, 0, 0, 0};     // clusters, clusters for the radix sort, big groups, piles, hits in piles (k_read_sort)
 static bool     g_have_known = false;
 static uint32_t g_rcnt[5] = {0, 0, 0, 0, 0}, g_rlim = 0;   // reads per k_read_sort workgroup size, largest segment, reads above the
@@ -1335,18 +1335,18 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
         if (by_read)
           { // segment of every read: hits per read counted row by row, then scanned over the reads
             const int nr = ablock->nreads;
-            g_rstart.ensure((size_t) nr + 2, "first hit of each read");
+            R.rs_start.ensure((size_t) nr + 2, "first hit of each read");
             g_rowdst.ensure((size_t) nhits + 1, "place of each merge row in its read's segment");
-            g_rstats.ensure(8, "read segment statistics");
-            HIP_CHECK(hipMemsetAsync(g_rstart.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
-            HIP_CHECK(hipMemsetAsync(g_rstats.p, 0, sizeof(uint32_t) * 8, stream()));
+            R.rs_stats.ensure(8, "read segment statistics");
+            HIP_CHECK(hipMemsetAsync(R.rs_start.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
+            HIP_CHECK(hipMemsetAsync(R.rs_stats.p, 0, sizeof(uint32_t) * 8, stream()));
             hipLaunchKernelGGL(k_row_place, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent,
                                (const uint32_t *) esz.p, (const uint32_t *) eoff.p, (const uint32_t *) A.vals, MA,
-                               g_rstart.p, g_rowdst.p);
-            exclusive_scan_u32(g_rstart.p, nr, st.sort.bsum, g_rstart.p + nr);
+                               R.rs_start.p, g_rowdst.p);
+            exclusive_scan_u32(R.rs_start.p, nr, st.sort.bsum, R.rs_start.p + nr);
             // the reads by segment size: one list per workgroup size of k_read_sort ("read_sort" test option = 2: the
             // largest workgroups take everything above 128 hits; = 3: segments above 512 hits count as too large)
-            g_rlists.ensure(4 * (size_t) nr + 16, "reads by segment size");
+            R.rs_lists.ensure(4 * (size_t) nr + 16, "reads by segment size");
             // While the deferred alignment kernel of the previous block runs (20 ms, its workgroups persistent, LDS pebbles
             // on every CU) a 1024-thread workgroup with 140 KB of LDS finds no CU to run on until that kernel ENDS, and the
             // main stream stands still behind it (the trace: 10-17 ms for a launch that takes 0.06): the reads of that
@@ -1357,15 +1357,15 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
                                   : (g_rs_small ? (uint32_t) RS_T1 * RS_E : (uint32_t) RS_T2 * RS_E);
             const uint32_t lim0 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T0 * RS_E);
             const uint32_t lim1 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T1 * RS_E);
-            hipLaunchKernelGGL(k_read_classes, dim3(ceil_div(nr, 256)), dim3(256), 0, stream(), (const uint32_t *) g_rstart.p, nr,
-                               lim0, lim1, lim2, g_rlists.p, g_rstats.p);
+            hipLaunchKernelGGL(k_read_classes, dim3(ceil_div(nr, 256)), dim3(256), 0, stream(), (const uint32_t *) R.rs_start.p, nr,
+                               lim0, lim1, lim2, R.rs_lists.p, R.rs_stats.p);
             g_rlim = lim2;
             // a class of more than L hits per read holds fewer than nhits / L reads
             g_rgrid[0] = (uint32_t) nr;
             g_rgrid[1] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim0 + 1) + 1);
             g_rgrid[2] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim1 + 1) + 1);
             g_rgrid[3] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim2 + 1) + 1);
-            rstart = g_rstart.p; rowdst = g_rowdst.p;
+            rstart = R.rs_start.p; rowdst = g_rowdst.p;
           }
         hipLaunchKernelGGL(k_merge_expand_tiled, dim3(ceil_div(nhits, EX_TILE)), dim3(256), 0, stream(),
                          (const MergeEntry *) entries.p, nent, (const uint32_t *) eoff.p, (const uint32_t *) tfirst.p,
@@ -1379,7 +1379,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
             static const bool want = getenv("DMH_STATS") != nullptr || getenv("DMH_READ_SORT_FORK") != nullptr;
             if (want)
               { HostTimer hw("wait_read_classes");
-                copy_d2h(g_rcnt, g_rstats.p, 5 * sizeof(uint32_t), 1);
+                copy_d2h(g_rcnt, R.rs_stats.p, 5 * sizeof(uint32_t), 1);
               }
             else
               { for (int q = 0; q < 4; q++) g_rcnt[q == 3 ? 4 : q] = g_rgrid[q];
@@ -1544,6 +1544,8 @@ static bool filter_reclaim()
       R.keys.release(); R.alt_keys.release(); R.vals.release(); R.alt_vals.release();
       R.gstart.release(); R.gkey.release(); R.cog.release(); R.ocfirst.release(); R.glast.release();
       R.biglist.release(); R.pilelist.release(); R.medlist.release();
+      R.rs_start.release(); R.rs_stats.release(); R.rs_lists.release(); R.rs_ncl.release(); R.rs_lcl.release();
+      R.rs_wcnt.release(); R.rs_wlist[0].release(); R.rs_wlist[1].release(); R.pmax.release();
       chain_release(R);
     }
   static const bool stats = getenv("DMH_STATS") != nullptr;
@@ -1601,6 +1603,7 @@ void filter_discard()
 // joins the ones in flight
 static void close_batch(MergeResult &R)
 { State &st = S();
+  std::unique_ptr<StreamScope> tail_scope;       // set where the pass moves to the tail stream (per-read route)
   const int64_t nhits = R.nhits;
   const DAZZ_DB *ablock = R.ablock;
   R.open = false;
@@ -1650,13 +1653,13 @@ static void close_batch(MergeResult &R)
       const bool local_sort = R.word || local_cluster_sort(R.pbits);
       if (rs)
         { const int nr = ablock->nreads;
-          static DevBuf<uint64_t> lcl;
-          static DevBuf<uint32_t> rncl;
+          DevBuf<uint64_t> &lcl = R.rs_lcl;
+          DevBuf<uint32_t> &rncl = R.rs_ncl;
           lcl.ensure((size_t) nhits + 1, "cluster records per read");
           rncl.ensure((size_t) nr + 2, "clusters per read");
           HIP_CHECK(hipMemsetAsync(rncl.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
           ReadSortArgs RA;
-          RA.in = k0; RA.out = k1; RA.rstart = g_rstart.p;
+          RA.in = k0; RA.out = k1; RA.rstart = R.rs_start.p;
           // the coarse buckets of this route (64 kb: a locus rarely lies across two) and its radix passes: the sort key
           // apos | coarse key << pbits cut into equal digits of at most RS_DB bits
           const int rcb = std::min(RS_CB, qbits), kbits = qbits - rcb + R.bbits;
@@ -1675,9 +1678,9 @@ static void close_batch(MergeResult &R)
           RA.lcl = lcl.p; RA.rncl = rncl.p;
           // the clusters are counted by size while they are found, in the chain kernels' classes and the cluster sorts'
           chain_group_limits(R);
-          g_wcnt.ensure(8, "cluster counters");
-          HIP_CHECK(hipMemsetAsync(g_wcnt.p, 0, 8 * sizeof(unsigned int), stream()));
-          RA.counts = g_wcnt.p;
+          R.rs_wcnt.ensure(8, "cluster counters");
+          HIP_CHECK(hipMemsetAsync(R.rs_wcnt.p, 0, 8 * sizeof(unsigned int), stream()));
+          RA.counts = R.rs_wcnt.p;
           RA.medium = (uint32_t) CS_MEDIUM;
           RA.big_min = R.small_hi;
           RA.pile_min = R.pile_min > 0 ? R.pile_min : 0xffffffffu;
@@ -1715,7 +1718,7 @@ static void close_batch(MergeResult &R)
             bool used[2] = {false, false};
             if (g_rcnt[4] > 0)
               { // (first: the few workgroups of this launch run longest)
-                RA.list = g_rlists.p + 3 * (size_t) nr; RA.count = g_rstats.p + 4;
+                RA.list = R.rs_lists.p + 3 * (size_t) nr; RA.count = R.rs_stats.p + 4;
                 if (g_rs_small)
                   hipLaunchKernelGGL((k_read_sort_big<RS_T0>), dim3(std::min<uint32_t>(g_rcnt[4], 2048u)), dim3(RS_T0), 0, stream(), RA);
                 else
@@ -1724,19 +1727,19 @@ static void close_batch(MergeResult &R)
             if (g_rcnt[2] > 0 && !g_rs_small)
               { hipStream_t q = fork ? side[0] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[0] = true; }
-                RA.list = g_rlists.p + 2 * (size_t) nr; RA.count = g_rstats.p + 2;
+                RA.list = R.rs_lists.p + 2 * (size_t) nr; RA.count = R.rs_stats.p + 2;
                 if (k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T2, false>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
               }
             if (g_rcnt[1] > 0)
               { hipStream_t q = fork ? side[1] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[1] = true; }
-                RA.list = g_rlists.p + (size_t) nr; RA.count = g_rstats.p + 1;
+                RA.list = R.rs_lists.p + (size_t) nr; RA.count = R.rs_stats.p + 1;
                 if (k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T1, false>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
               }
             if (g_rcnt[0] > 0)
-              { RA.list = g_rlists.p; RA.count = g_rstats.p;
+              { RA.list = R.rs_lists.p; RA.count = R.rs_stats.p;
                 if (k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T0, false>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
               }
@@ -1749,17 +1752,31 @@ static void close_batch(MergeResult &R)
           }
           StageTimer tm("seed_clusters", 0.0);
           exclusive_scan_u32(rncl.p, nr, st.sort.bsum, rncl.p + nr);
-          HIP_CHECK(hipMemcpyAsync(g_wcnt.p + 2, rncl.p + nr, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+          HIP_CHECK(hipMemcpyAsync(R.rs_wcnt.p + 2, rncl.p + nr, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
           { int64_t nf = 0;                   // (the per-read sort is queued: the third step of the oldest batch's finish)
             finish_tick_if_due(&nf);
             st.tfilt += nf;
           }
           // one round trip: clusters, clusters the radix sort has to finish, the chain kernels' big groups and piles
           { HostTimer hw("wait_cluster_counts");
-            copy_d2h(g_known, g_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
+            copy_d2h(g_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
           }
           ncl = g_known[0];
           g_have_known = true;
+          // The rest of the pass -- numbering the clusters, the sorts of the few that span buckets, the pairs, the chain
+          // stage -- needs no number from the device any more and nothing the following pass touches (its buffers are
+          // the batch's own): it runs on the tail stream, next to that pass's merge kernels.  (Not when a pile across
+          // buckets needs the radix sort, whose scratch is the main stream's; DMH_BACK_TAIL=0: off.)
+          { static const bool env_bt = getenv("DMH_BACK_TAIL") == nullptr || atoi(getenv("DMH_BACK_TAIL")) != 0;
+            if (env_bt && g_known[1] == 0 && !st.capture_seeds && !VERBOSE && tail_stream() != main_stream() &&
+                stream() == main_stream())
+              { static hipEvent_t ev_fork = nullptr;
+                if (ev_fork == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(ev_fork, stream()));
+                HIP_CHECK(hipStreamWaitEvent(tail_stream(), ev_fork, 0));
+                tail_scope.reset(new StreamScope(tail_stream()));
+              }
+          }
           { static const bool stats = getenv("DMH_STATS") != nullptr;
             if (stats)
               fprintf(stderr, "dmh: read sort: %lld hits, reads by workgroup size %u %u %u, through global memory %u, largest segment %u, clusters %u\n",
@@ -1768,12 +1785,12 @@ static void close_batch(MergeResult &R)
           R.ngroups = ncl;
           R.gstart.ensure((size_t) ncl + 1, "cluster starts");
           R.gkey.ensure((size_t) ncl + 1, "cluster keys");
-          g_wlist[0].ensure((size_t) ncl + 64, "clusters for the workgroup sort");
-          g_wlist[1].ensure((size_t) ncl + 64, "clusters for the radix sort");
+          R.rs_wlist[0].ensure((size_t) ncl + 64, "clusters for the workgroup sort");
+          R.rs_wlist[1].ensure((size_t) ncl + 64, "clusters for the radix sort");
           hipLaunchKernelGGL(k_cluster_compact, dim3(ceil_div((int64_t) nr * 64, 256)), dim3(256), 0, stream(),
-                             (const uint64_t *) lcl.p, (const uint32_t *) g_rstart.p, (const uint32_t *) rncl.p, nr, R.bbits,
+                             (const uint64_t *) lcl.p, (const uint32_t *) R.rs_start.p, (const uint32_t *) rncl.p, nr, R.bbits,
                              (uint32_t) nhits, R.gstart.p, R.gkey.p, (uint32_t) RS_IN, (uint32_t) CS_MEDIUM,
-                             g_wlist[0].p, g_wlist[1].p, g_wcnt.p);
+                             R.rs_wlist[0].p, R.rs_wlist[1].p, R.rs_wcnt.p);
           std::swap(k0, k1);
         }
       else if (R.word)
@@ -1818,10 +1835,12 @@ static void close_batch(MergeResult &R)
         { StageTimer tm("cluster_sort", 16.0 * nhits);
           static DevBuf<uint32_t> mlist, blist;
           static DevBuf<unsigned int> cnt;
-          mlist.ensure((size_t) ncl + 64, "clusters for the workgroup sort");
-          blist.ensure((size_t) ncl + 64, "clusters for the radix sort");
-          cnt.ensure(4, "cluster sort counters");
-          HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned int), stream()));
+          if (!rs)
+            { mlist.ensure((size_t) ncl + 64, "clusters for the workgroup sort");
+              blist.ensure((size_t) ncl + 64, "clusters for the radix sort");
+              cnt.ensure(4, "cluster sort counters");
+              HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned int), stream()));
+            }
           if (!rs)
             hipLaunchKernelGGL(k_csort_classify, dim3(ceil_div(ncl, 1024)), dim3(1024), 0, stream(), (const uint32_t *) R.gstart.p,
                                ncl, mlist.p, blist.p, cnt.p);
@@ -1829,19 +1848,19 @@ static void close_batch(MergeResult &R)
             { // only the clusters that span coarse buckets and were too large for k_read_sort are left (k_cluster_compact
               // has listed them): sorted where they lie, on both positions
               hipLaunchKernelGGL(k_csort_wide, dim3(4096), dim3(64), CS_WAVE * sizeof(uint64_t), stream(), k0,
-                                 (const uint32_t *) R.gstart.p, (const uint32_t *) g_wlist[0].p, (const unsigned int *) g_wcnt.p,
+                                 (const uint32_t *) R.gstart.p, (const uint32_t *) R.rs_wlist[0].p, (const unsigned int *) R.rs_wcnt.p,
                                  1u, (uint32_t) CS_WAVE);        // (k_read_sort_big lists small clusters too)
               hipLaunchKernelGGL(k_csort_wide, dim3(1024), dim3(256), CS_MEDIUM * sizeof(uint64_t), stream(), k0,
-                                 (const uint32_t *) R.gstart.p, (const uint32_t *) g_wlist[0].p, (const unsigned int *) g_wcnt.p,
+                                 (const uint32_t *) R.gstart.p, (const uint32_t *) R.rs_wlist[0].p, (const unsigned int *) R.rs_wcnt.p,
                                  (uint32_t) CS_WAVE, (uint32_t) CS_MEDIUM);
               HIP_CHECK(hipGetLastError());
               unsigned int hc[2] = {0, 0};
               if (g_known[1] > 0)             // (k_read_sort counted them: no round trip when there are none)
-                copy_d2h(hc, g_wcnt.p, 2 * sizeof(unsigned int), 1);
+                copy_d2h(hc, R.rs_wcnt.p, 2 * sizeof(unsigned int), 1);
               if (hc[1] > 0)
                 { // repeat piles across buckets: stable radix passes on bpos (the high half of the word), then on apos
                   std::vector<uint32_t> big(hc[1]), gs((size_t) ncl + 1);
-                  copy_d2h(big.data(), g_wlist[1].p, sizeof(uint32_t) * hc[1]);
+                  copy_d2h(big.data(), R.rs_wlist[1].p, sizeof(uint32_t) * hc[1]);
                   copy_d2h(gs.data(), R.gstart.p, sizeof(uint32_t) * ((size_t) ncl + 1));
                   for (uint32_t c : big)
                     { const int64_t b0 = gs[c], bn = (int64_t) gs[c + 1] - b0;
@@ -1888,11 +1907,11 @@ static void close_batch(MergeResult &R)
         R.cog.ensure((size_t) ncl + 2, "pair of cluster");
         R.ocfirst.ensure((size_t) ncl + 2, "first cluster of pair");
         R.glast.ensure((size_t) ncl + 1, "last apos of pair");
-        static DevBuf<uint32_t> pmax;
+        DevBuf<uint32_t> &pmax = R.pmax;
         pmax.ensure((size_t) ncl + 2, "largest apos of pair");
         int nb = ceil_div(ncl, 256);
         hipLaunchKernelGGL(k_pair_flag, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p, pmax.p);
-        exclusive_scan_u32(R.cog.p, ncl, st.sort.bsum, R.cog.p + ncl);
+        exclusive_scan_u32(R.cog.p, ncl, (tail_scope ? st.sort_tail : st.sort).bsum, R.cog.p + ncl);
         hipLaunchKernelGGL(k_pair_max, dim3(nb), dim3(256), 0, stream(), (const uint64_t *) R.gkey.p, ncl, R.cog.p,
                            (const uint32_t *) (R.cog.p + ncl), R.ocfirst.p, (const uint64_t *) k0,
                            (const uint32_t *) R.gstart.p, pmax.p);
@@ -1935,6 +1954,7 @@ static void close_batch(MergeResult &R)
         }
     }
   chain_submit(R, ablock);
+  tail_scope.reset();            // (what follows is the main stream's business again)
   // the batch is in flight; collect the next one in a free slot of the ring
   int slot = -1;
   for (int i = 0; i < NRING; i++)

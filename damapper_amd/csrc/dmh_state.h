@@ -169,6 +169,7 @@ struct State
   int  opt_align_level = -1;    // first rung of the alignment kernel ladder (0 two per wavefront, 1, 2); -1 default
   int  opt_chain_g     = 0;     // lanes per chain group for ALL groups (16/32/64); 0 = 16 + 64 by group size
   int  mf_calls = 0;            // Match_Filter calls since the last Reporter (passes per READS block)
+  int     opt_tails = -1;       // 0: nothing moves to the tail stream (every kernel of a pass has the GPU to itself: bench.py's "alone" figures)
   int     opt_hit_limit = 0;    // > 0: a pass of this many hits is refused (test of the 2^32 refusal)
   int     mf_calls_block = 0;   // ... of the block Reporter is working on
   int  opt_merge_dense = -1;    // REF bucket table: 1 = one bucket per entry + four-key probes, 0 = four buckets per entry + two-key probes, -1 = by size
@@ -200,6 +201,7 @@ struct State
   SortScratch sort;
   SortScratch sort_aux;         // scratch of the deferred index build (lives across Match_Filter calls)
   SortScratch sort_fin;         // scratch of the scans of chain_finish (its own stream)
+  SortScratch sort_tail;        // ... and of the scans behind the per-read seed order (the tail stream)
 };
 
 State &S();
