@@ -1619,6 +1619,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "in_flight") == 0)   st.opt_in_flight = value;
   else if (strcmp(key, "hit_limit") == 0)   st.opt_hit_limit = value;
   else if (strcmp(key, "tails") == 0)       st.opt_tails = value;
+  else if (strcmp(key, "defer_close") == 0) st.opt_defer_close = value;
   else if (strcmp(key, "seed_word") == 0)   st.opt_seed_word = value;
   else if (strcmp(key, "fin_stream") == 0)  st.opt_fin_stream = value;
   else if (strcmp(key, "alloc_fail") == 0)  g_alloc_fail = value > 0 ? value : 0;

@@ -55,6 +55,8 @@ struct MergeResult
   DevBuf<uint32_t> rs_start, rs_stats, rs_lists, rs_ncl, rs_wlist[2], pmax;
   DevBuf<uint64_t> rs_lcl;
   DevBuf<unsigned int> rs_wcnt;
+  uint32_t  *h_known = nullptr;                // page-locked: the counters of a close that stopped behind the per-read sort
+  hipEvent_t ev_known = nullptr;               //   (close_batch phases 1 / 2)
 };
 
 // classifies the groups of R.gstart on the device and fetches the number of piles

@@ -1066,7 +1066,10 @@ constexpr int RS_T0 = 256, RS_T1 = 512, RS_T2 = 1024;      // k_read_sort workgr
 // hits a batch may collect before it is closed (68 B of HBM per hit through the sort and the chain kernels)
 constexpr int64_t BATCH_CAP = (int64_t) 160 << 20;
 
-static void    close_batch(MergeResult &R);
+static void    close_batch(MergeResult &R, int phase = 0);
+static void    close_pending();
+static int     g_pending_close = -1;       // ring slot whose close stopped at the cluster-count copy (close_batch phase 1)
+static bool    g_closing = false;          // inside the second half of such a close
 static int64_t finish_oldest();
 static void    finish_tick_if_due(int64_t *nfilt);
 static bool    finish_tick(int64_t *nfilt);
@@ -1169,6 +1172,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   }
   // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
   // main stream has the match kernels (and the previous pass's chain kernels) to run meanwhile
+  close_pending();       // (the previous pass's second half: behind this pass's match kernels)
   { static const bool nosteps = getenv("DMH_FINISH_STEPS") == nullptr;
     static const bool pipe = getenv("DMH_FINISH_PIPE") != nullptr;      // (opt-in: measured 178.5 against 173.1 ms per read block)
     const int keep2 = flight_keep();
@@ -1414,7 +1418,18 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   R.pass[R.npass].comp  = comp;
   R.npass += 1;
   R.nhits += nhits;
-  if (!R.passbits) close_batch(R);
+  if (!R.passbits)
+    { // (Experiment, DMH_DEFER_CLOSE=1 or the "defer_close" test option = 1.  Per-read route: the close stops behind the
+      //  per-read sort -- queued on the tail stream, its counters on their way to page-locked memory -- and is taken up by
+      //  the NEXT pass once its match kernels are queued, so that the sort runs next to them.  Measured: 202 against 146 ms
+      //  per read block.  The sort takes twice as long next to the match kernels (LDS-bound workgroups of 35-70 KB among
+      //  the match kernel's waves), and the host -- which then waits for the sort, for the oldest batch's finish and for
+      //  the hit sums one after the other with only the match kernels queued -- leaves the main stream idle most of a pass.)
+      static const bool env_dc = getenv("DMH_DEFER_CLOSE") != nullptr && atoi(getenv("DMH_DEFER_CLOSE")) != 0;
+      const bool defer_close = (env_dc || st.opt_defer_close > 0) && R.word && R.read_sorted && !st.capture_seeds && !VERBOSE &&
+                               flight_keep() > 0 && st.opt_defer_close != 0 && tail_stream() != main_stream() && R.nhits > 0;
+      close_batch(R, defer_close ? 1 : 0);
+    }
   // batches in flight: under -v every call reports its own candidate counts, and the stage-level API looks at the
   // lists after every call -- then nothing stays in flight
   static const int env_fl = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
@@ -1528,6 +1543,7 @@ static void finish_retire(int x)
 // per hit; three such batches in flight next to 120 GB of indices do not fit 288 GB, one at a time does.
 static bool filter_reclaim()
 { bool got = false;
+  if (!g_finishing && !g_closing) close_pending();
   if (!g_finishing)
     while (!g_inflight.empty())
       { S().tfilt += finish_oldest();
@@ -1536,7 +1552,7 @@ static bool filter_reclaim()
   if (g_flight_cap > 0 && !S().simulated_oom) g_flight_cap -= 1;
   HIP_CHECK(hipDeviceSynchronize());          // (buffers are about to go back to the driver)
   for (int i = 0; i < NRING; i++)
-    { bool busy = (i == g_cur) || (i == g_finishing_slot);       // (chain_finish still reads the slot it is finishing)
+    { bool busy = (i == g_cur) || (i == g_finishing_slot) || (i == g_pending_close);       // (chain_finish still reads the slot it is finishing)
       for (int y : g_inflight) busy = busy || (y == i);
       if (busy) continue;
       MergeResult &R = g_ring[i];
@@ -1554,7 +1570,8 @@ static bool filter_reclaim()
 }
 
 int64_t filter_flush()
-{ MergeResult &R = filter_batch();
+{ close_pending();
+  MergeResult &R = filter_batch();
   if (R.open) close_batch(R);
   int64_t nfilt = 0;
   while (!g_inflight.empty()) nfilt += finish_oldest();
@@ -1565,6 +1582,7 @@ int64_t filter_flush()
 // filter finishes in order); what the following block has queued meanwhile stays as it is
 int64_t filter_flush_block(int cslot)
 { int64_t nfilt = 0;
+  close_pending();
   { MergeResult &R = filter_batch();
     if (R.open && R.cslot == cslot) close_batch(R);
   }
@@ -1579,7 +1597,8 @@ int64_t filter_flush_block(int cslot)
 
 // the batches of ONE block are dropped (its store is about to be given to another block)
 void filter_discard_block(int cslot)
-{ bool any = false;
+{ close_pending();
+  bool any = false;
   for (int y : g_inflight) any = any || (g_ring[y].cslot == cslot);
   MergeResult &R = filter_batch();
   if (R.open && R.cslot == cslot) { R.open = false; R.nhits = 0; R.npass = 0; }
@@ -1593,7 +1612,8 @@ void filter_discard_block(int cslot)
 }
 
 void filter_discard()
-{ join_side_streams();             // (their kernels may still read the batches that are dropped here)
+{ close_pending();
+  join_side_streams();             // (their kernels may still read the batches that are dropped here)
   for (int y : g_inflight) chain_abandon(g_ring[y]);       // ... and the pile stream's, which the join does not cover
   g_inflight.clear();
   for (int i = 0; i < NRING; i++) { g_ring[i].open = false; g_ring[i].nhits = 0; g_ring[i].npass = 0; }
@@ -1601,9 +1621,21 @@ void filter_discard()
 
 // sort and groups for everything the batch holds, then its chain kernels are queued (chain_submit) and the batch
 // joins the ones in flight
-static void close_batch(MergeResult &R)
+static void close_pending()
+{ if (g_pending_close < 0 || g_closing) return;
+  const int x = g_pending_close;
+  g_pending_close = -1;
+  g_closing = true;
+  close_batch(g_ring[x], 2);
+  g_closing = false;
+}
+
+// phase 0: everything.  Per-read route only: phase 1 = up to the per-read sort and the copy of its counters (queued on
+// the tail stream; the batch becomes g_pending_close and the next one is collected in another slot), phase 2 = the rest.
+static void close_batch(MergeResult &R, int phase)
 { State &st = S();
   std::unique_ptr<StreamScope> tail_scope;       // set where the pass moves to the tail stream (per-read route)
+  if (phase != 2) close_pending();               // (one close at a time)
   const int64_t nhits = R.nhits;
   const DAZZ_DB *ablock = R.ablock;
   R.open = false;
@@ -1655,6 +1687,18 @@ static void close_batch(MergeResult &R)
         { const int nr = ablock->nreads;
           DevBuf<uint64_t> &lcl = R.rs_lcl;
           DevBuf<uint32_t> &rncl = R.rs_ncl;
+          if (phase == 1)
+            { // the sort and the copy of its counters go to the tail stream, behind the expansion just queued
+              static hipEvent_t ev_fork1 = nullptr;
+              if (ev_fork1 == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_fork1, hipEventDisableTiming));
+              HIP_CHECK(hipEventRecord(ev_fork1, stream()));
+              HIP_CHECK(hipStreamWaitEvent(tail_stream(), ev_fork1, 0));
+              tail_scope.reset(new StreamScope(tail_stream()));
+            }
+          else if (phase == 2)
+            tail_scope.reset(new StreamScope(tail_stream()));       // (where phase 1 left off)
+          if (phase != 2)
+          {
           lcl.ensure((size_t) nhits + 1, "cluster records per read");
           rncl.ensure((size_t) nr + 2, "clusters per read");
           HIP_CHECK(hipMemsetAsync(rncl.p, 0, sizeof(uint32_t) * ((size_t) nr + 2), stream()));
@@ -1751,18 +1795,53 @@ static void close_batch(MergeResult &R)
             HIP_CHECK(hipGetLastError());
           }
           StageTimer tm("seed_clusters", 0.0);
-          exclusive_scan_u32(rncl.p, nr, st.sort.bsum, rncl.p + nr);
+          exclusive_scan_u32(rncl.p, nr, (tail_scope ? st.sort_tail : st.sort).bsum, rncl.p + nr);
           HIP_CHECK(hipMemcpyAsync(R.rs_wcnt.p + 2, rncl.p + nr, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream()));
+          }
+          if (phase == 1)
+            { // the counters travel to page-locked memory; the next pass picks the close up (close_pending)
+              if (R.h_known == nullptr)
+                { HIP_CHECK(hipHostMalloc((void **) &R.h_known, 8 * sizeof(uint32_t), hipHostMallocDefault));
+                  HIP_CHECK(hipEventCreateWithFlags(&R.ev_known, hipEventDisableTiming));
+                }
+              HIP_CHECK(hipMemcpyAsync(R.h_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+              HIP_CHECK(hipEventRecord(R.ev_known, stream()));
+              tail_scope.reset();
+              int slot = -1;
+              for (int i = 0; i < NRING; i++)
+                if (&g_ring[i] == &R) slot = i;
+              g_pending_close = slot;
+              for (int i = 0; i < NRING; i++)
+                { bool busy = (i == slot);
+                  for (int y : g_inflight) busy = busy || (y == i);
+                  if (!busy) { g_cur = i; break; }
+                }
+              return;
+            }
           { int64_t nf = 0;                   // (the per-read sort is queued: the third step of the oldest batch's finish)
             finish_tick_if_due(&nf);
             st.tfilt += nf;
           }
           // one round trip: clusters, clusters the radix sort has to finish, the chain kernels' big groups and piles
           { HostTimer hw("wait_cluster_counts");
-            copy_d2h(g_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
+            if (phase == 2)
+              { HIP_CHECK(hipEventSynchronize(R.ev_known));
+                for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
+              }
+            else
+              copy_d2h(g_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
           }
           ncl = g_known[0];
           g_have_known = true;
+          if (phase == 2 && g_known[1] > 0)
+            { // a pile across buckets: the radix sort's scratch is the main stream's -- the rest of this close goes there,
+              // behind what the tail stream has done so far
+              static hipEvent_t ev_join = nullptr;
+              if (ev_join == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+              HIP_CHECK(hipEventRecord(ev_join, stream()));
+              tail_scope.reset();
+              HIP_CHECK(hipStreamWaitEvent(stream(), ev_join, 0));
+            }
           // The rest of the pass -- numbering the clusters, the sorts of the few that span buckets, the pairs, the chain
           // stage -- needs no number from the device any more and nothing the following pass touches (its buffers are
           // the batch's own): it runs on the tail stream, next to that pass's merge kernels.  (Not when a pile across
@@ -1783,6 +1862,7 @@ static void close_batch(MergeResult &R)
                       (long long) nhits, g_rcnt[0], g_rcnt[1], g_rcnt[2], g_rcnt[4], g_rcnt[3], ncl);
           }
           R.ngroups = ncl;
+          StageTimer tmc("seed_clusters", 0.0);
           R.gstart.ensure((size_t) ncl + 1, "cluster starts");
           R.gkey.ensure((size_t) ncl + 1, "cluster keys");
           R.rs_wlist[0].ensure((size_t) ncl + 64, "clusters for the workgroup sort");
@@ -1975,6 +2055,7 @@ static void close_batch(MergeResult &R)
   // (the oldest batch is finished by the NEXT pass, behind its match kernels: finishing blocks the host for the
   //  finish stream's round trips, and here the main stream would run dry meanwhile -- 0.57 ms per pass in the trace)
   while ((int) g_inflight.size() > g_flight_cap + 1) st.tfilt += finish_oldest();
+  if (phase == 2) return;            // (the next batch is being collected already)
   for (int i = 0; i < NRING; i++)
     { bool busy = false;
       for (int y : g_inflight) busy = busy || (y == i);
