@@ -1428,7 +1428,15 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
       static const bool env_dc = getenv("DMH_DEFER_CLOSE") != nullptr && atoi(getenv("DMH_DEFER_CLOSE")) != 0;
       const bool defer_close = (env_dc || st.opt_defer_close > 0) && R.word && R.read_sorted && !st.capture_seeds && !VERBOSE &&
                                flight_keep() > 0 && st.opt_defer_close != 0 && tail_stream() != main_stream() && R.nhits > 0;
-      close_batch(R, defer_close ? 1 : 0);
+      // (The light version, DMH_DEFER_CLOSE=2: the close stops BEHIND the round trip for the cluster counters --
+      //  everything up to there on the main stream, as ever -- and the next pass queues the second half on the tail stream
+      //  right after its own match kernels, so that the main stream gets those 0.5 ms earlier (the host takes that long to
+      //  queue the forty launches of a second half).  Measured: 158 against 146 ms per read block -- the second half then
+      //  runs next to the expansion and the per-read sort instead of next to the match kernels.)
+      static const bool env_dl = getenv("DMH_DEFER_CLOSE") != nullptr && atoi(getenv("DMH_DEFER_CLOSE")) == 2;
+      const bool defer_light = !defer_close && env_dl && st.opt_defer_close != 0 && R.word && R.read_sorted &&
+                               !st.capture_seeds && !VERBOSE && flight_keep() > 0 && tail_stream() != main_stream() && R.nhits > 0;
+      close_batch(R, defer_close ? 1 : (defer_light ? 3 : 0));
     }
   // batches in flight: under -v every call reports its own candidate counts, and the stage-level API looks at the
   // lists after every call -- then nothing stays in flight
@@ -1696,7 +1704,9 @@ static void close_batch(MergeResult &R, int phase)
               tail_scope.reset(new StreamScope(tail_stream()));
             }
           else if (phase == 2)
-            tail_scope.reset(new StreamScope(tail_stream()));       // (where phase 1 left off)
+            { if (R.h_known[7] == 1u) HIP_CHECK(hipStreamWaitEvent(tail_stream(), R.ev_known, 0));      // (the light version)
+              tail_scope.reset(new StreamScope(tail_stream()));       // (else: where phase 1 left off)
+            }
           if (phase != 2)
           {
           lcl.ensure((size_t) nhits + 1, "cluster records per read");
@@ -1804,6 +1814,7 @@ static void close_batch(MergeResult &R, int phase)
                 { HIP_CHECK(hipHostMalloc((void **) &R.h_known, 8 * sizeof(uint32_t), hipHostMallocDefault));
                   HIP_CHECK(hipEventCreateWithFlags(&R.ev_known, hipEventDisableTiming));
                 }
+              R.h_known[7] = 0u;
               HIP_CHECK(hipMemcpyAsync(R.h_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
               HIP_CHECK(hipEventRecord(R.ev_known, stream()));
               tail_scope.reset();
@@ -1824,13 +1835,36 @@ static void close_batch(MergeResult &R, int phase)
           }
           // one round trip: clusters, clusters the radix sort has to finish, the chain kernels' big groups and piles
           { HostTimer hw("wait_cluster_counts");
-            if (phase == 2)
+            if (phase == 2 && R.h_known[7] == 1u)
+              for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
+            else if (phase == 2)
               { HIP_CHECK(hipEventSynchronize(R.ev_known));
                 for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
               }
             else
               copy_d2h(g_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
           }
+          if (phase == 3 && g_known[1] == 0)
+            { // stop here: the counters are kept with the batch, the tail stream will start behind what the main stream
+              // has done up to now (the event), the next pass takes the close up (close_pending)
+              if (R.h_known == nullptr)
+                { HIP_CHECK(hipHostMalloc((void **) &R.h_known, 8 * sizeof(uint32_t), hipHostMallocDefault));
+                  HIP_CHECK(hipEventCreateWithFlags(&R.ev_known, hipEventDisableTiming));
+                }
+              for (int q = 0; q < 5; q++) R.h_known[q] = g_known[q];
+              R.h_known[7] = 1u;            // (phase 2: nothing to wait for, the tail stream waits for ev_known)
+              HIP_CHECK(hipEventRecord(R.ev_known, stream()));
+              int slot = -1;
+              for (int i = 0; i < NRING; i++)
+                if (&g_ring[i] == &R) slot = i;
+              g_pending_close = slot;
+              for (int i = 0; i < NRING; i++)
+                { bool busy = (i == slot);
+                  for (int y : g_inflight) busy = busy || (y == i);
+                  if (!busy) { g_cur = i; break; }
+                }
+              return;
+            }
           ncl = g_known[0];
           g_have_known = true;
           if (phase == 2 && g_known[1] > 0)
