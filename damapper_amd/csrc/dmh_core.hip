@@ -125,7 +125,16 @@ hipStream_t tail_stream()
 { init_device();
   static const int env_ts = getenv("DMH_CHAIN_TAIL") ? atoi(getenv("DMH_CHAIN_TAIL")) : 1;
   if (env_ts == 0 || S().opt_fin_stream == 0 || S().opt_tails == 0) return g_stream;
-  if (g_tstream == nullptr) HIP_CHECK(hipStreamCreateWithFlags(&g_tstream, hipStreamNonBlocking));
+  if (g_tstream == nullptr)
+    { static const int prio = getenv("DMH_TAIL_PRIO") ? atoi(getenv("DMH_TAIL_PRIO")) : 0;      // (1: highest, -1: lowest; experiments)
+      if (prio != 0)
+        { int least = 0, greatest = 0;
+          HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+          HIP_CHECK(hipStreamCreateWithPriority(&g_tstream, hipStreamNonBlocking, prio > 0 ? greatest : least));
+        }
+      else
+        HIP_CHECK(hipStreamCreateWithFlags(&g_tstream, hipStreamNonBlocking));
+    }
   return g_tstream;
 }
 
