@@ -163,6 +163,15 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  *                        and two-key probes / 16 undecided bits per bucket, four-key probes on the 2-byte low-bits
  *                        array (-1: by index size; takes effect for indices built afterwards)
  *   "pool_div" n         start with 1/n of the alignment pool (forces the grow-and-retry path)
+ *   "read_sort" n        cluster mode, dense passes: 0 = the global radix sort instead of one workgroup per read; 2 = the
+ *                        1024-thread workgroups from 129 hits; 3 = reads of more than 512 hits through global memory
+ *                        (k_read_sort_big); 5 = ranks from ballots instead of ordered LDS atomics; 6 = no 1024-thread
+ *                        workgroups (as while an alignment kernel is deferred); 7 = 3 and 6
+ *   "chain_simple" 0     plain-chain groups are walked like the others (no k_chain_simple)
+ *   "oom_finish" n       memory "runs out" inside the n-th finish of a batch from now
+ *   "tails" 0            nothing runs on the tail stream: every kernel of a pass has the GPU to itself
+ *   "defer_close" 1      the close of a dense pass is taken up by the next Match_Filter call (experiment)
+ *   "hit_limit" n        a pass of n hits or more is refused (the refusal at 2^32 hits, at a testable size)
  * Returns 0, or -1 for an unknown key.                                                                       */
 int dmh_test_option(const char *key, int value);
 
