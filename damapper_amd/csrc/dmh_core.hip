@@ -898,10 +898,16 @@ static int preload_block_2bit(DAZZ_DB *block, const uint8_t *bps, int64_t nbytes
 // ---- index registry -----------------------------------------------------------------------
 
 void index_wait_ready(IndexDev &ix)
-{ if (ix.pending) bg_flush(); }
+{ if (ix.pending) bg_flush();
+  if (ix.built != nullptr)
+    { HIP_CHECK(hipStreamWaitEvent(main_stream(), ix.built, 0));
+      HIP_CHECK(hipEventDestroy(ix.built));
+      ix.built = nullptr;
+    }
+}
 
 static void free_index(IndexDev &ix)
-{ if (ix.pending) bg_flush();
+{ index_wait_ready(ix);
   if (ix.borrowed)               // the buffers belong to a cache entry
     { ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr; ix.d_bstart = nullptr;
       return;
@@ -1129,6 +1135,7 @@ struct SortJob
   const DAZZ_DB *block;         // emit stage: the block whose device copy is read
   int       Kmer;
   int       posbits;            // > 0: positions emitted as (read << posbits) | rpos
+  hipStream_t q = nullptr;      // the stream all its stages run on (nullptr: the main stream)
 };
 static std::deque<SortJob> g_bg;
 
@@ -1174,6 +1181,7 @@ static void bg_step()
 { bg_parts_init();
   SortJob &J = g_bg.front();
   State   &st = S();
+  StreamScope on_its_stream(J.q != nullptr ? J.q : main_stream());
   if (J.stage < EMIT_PARTS)
     { auto b = st.blocks.find(J.block);
       if (b == st.blocks.end()) fatal("deferred index build lost its block");
@@ -1214,6 +1222,10 @@ static void bg_step()
       if (it == st.indices.end()) fatal("deferred index build lost its index");
       adopt_sorted(it->second, st.sort_aux, J.keys, J.vals, J.k0, J.v0, J.kmers0, J.kmers);
       it->second.pending = false;
+      if (J.q != nullptr && J.q != main_stream())
+        { if (it->second.built == nullptr) HIP_CHECK(hipEventCreateWithFlags(&it->second.built, hipEventDisableTiming));
+          HIP_CHECK(hipEventRecord(it->second.built, J.q));
+        }
       g_bg.pop_front();
     }
 }
@@ -1229,6 +1241,20 @@ void bg_pump(int nstages)
   if (g_bg.empty() || report_in_flight()) return;
   for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step();
 }
+
+// One stage per call of the deferred build that is waiting, on the TAIL stream: the filter calls this at the end of a
+// dense pass, so that the index of the NEXT read block is sorted -- HBM-bound -- next to the LDS- and latency-bound
+// second halves of this block's passes instead of alone at the block boundary (DMH_INDEX_ON_TAIL=0: off).
+void bg_pump_tail(int nstages)
+{ static const bool on = getenv("DMH_INDEX_ON_TAIL") == nullptr || atoi(getenv("DMH_INDEX_ON_TAIL")) != 0;
+  if (!on || g_bg.empty() || tail_stream() == main_stream()) return;
+  SortJob &J = g_bg.front();
+  if (J.stage == 0 && J.q == nullptr) J.q = tail_stream();
+  if (J.q == nullptr) return;                   // (started on the main stream: it stays there)
+  for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step();
+}
+
+bool bg_on_tail() { return !g_bg.empty() && g_bg.front().q != nullptr && g_bg.front().q != main_stream(); }
 
 void bg_flush()
 { StreamScope on_main(main_stream());

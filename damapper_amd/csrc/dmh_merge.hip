@@ -1437,6 +1437,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
       const bool defer_light = !defer_close && env_dl && st.opt_defer_close != 0 && R.word && R.read_sorted &&
                                !st.capture_seeds && !VERBOSE && flight_keep() > 0 && tail_stream() != main_stream() && R.nhits > 0;
       close_batch(R, defer_close ? 1 : (defer_light ? 3 : 0));
+      if (R.word) bg_pump_tail(1);      // (a stage of the next read block's index, behind this pass's second half)
     }
   // batches in flight: under -v every call reports its own candidate counts, and the stage-level API looks at the
   // lists after every call -- then nothing stays in flight

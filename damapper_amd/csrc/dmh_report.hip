@@ -1584,12 +1584,12 @@ void Reporter(char *aname, DAZZ_DB *ablock, char *bname, DAZZ_DB *bblock, Align_
   // (not ahead of a batch of sparse passes that is still open: its sort and chain kernels are this block's work)
   const bool index_first = defer && !filter_batch().open;
   { HostTimer hb("report_bg_flush");
-    if (index_first) bg_flush();
+    if (index_first && !bg_on_tail()) bg_flush();      // (a build on the tail stream goes on stage by stage with the passes)
   }
   { HostTimer hf("report_flush");
     st.tfilt += filter_flush_block(cslot);     // (this block's batches: the next block's may be in flight behind them)
   }
-  if (defer && !index_first) bg_flush();
+  if (defer && !index_first && !bg_on_tail()) bg_flush();
   // the candidate lists: copied on the finish stream (the main stream is busy with the index sort).  Deferred mode:
   // nobody waits for the copy here -- the jobs of the alignment kernel are put together on a thread of their own
   // (2.4 ms per block of 25,000 reads, plus the copy), which starts by waiting for it; the main thread goes back to

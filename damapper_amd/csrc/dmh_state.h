@@ -63,6 +63,7 @@ struct IndexDev
   bool      borrowed  = false;
   int       borrows   = 0;      // cache entry: records currently borrowing its buffers (never evicted meanwhile)
   bool      pending = false;    // a deferred build (dmh_sort_kmers_async) has stages left to queue
+  hipEvent_t built = nullptr;   // the build ran on the tail stream: recorded behind its last stage (the main stream waits at first use)
 };
 
 constexpr int CHUNK_SHIFT = 9;

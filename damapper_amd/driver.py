@@ -44,6 +44,7 @@ class Mapper:
         # following block that are queued ahead of it
         self._pending = None
         self.overlap_passes = int(os.environ.get("DMH_OVERLAP_PASSES", "10"))
+        self.prefetch_overlap = os.environ.get("DMH_PREFETCH_OVERLAP", "1") != "0"
 
     def release_ref(self) -> None:
         self.finish()
@@ -150,7 +151,9 @@ class Mapper:
         else:
             self._drop_prefetched()        # a prefetched index for a block that did not come next
             rh, rn = capi.sort_kmers(reads)
-        if next_reads is not None and self.prefetch_deferred and not overlap:
+        # (overlap mode: the library runs the stages of that build on its tail stream, one behind each pass of this
+        #  block -- DMH_PREFETCH_OVERLAP=0: the index is built when the block's own turn comes, as before)
+        if next_reads is not None and self.prefetch_deferred and (not overlap or self.prefetch_overlap):
             # the next block's index build is deferred: its stages are queued in the gaps of this
             # block's filter and report phases (dmh_sort_kmers_async)
             h2, n2 = capi.sort_kmers(next_reads, deferred=True)
