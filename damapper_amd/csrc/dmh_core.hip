@@ -1245,8 +1245,17 @@ void bg_pump(int nstages)
 // One stage per call of the deferred build that is waiting, on the TAIL stream: the filter calls this at the end of a
 // dense pass, so that the index of the NEXT read block is sorted -- HBM-bound -- next to the LDS- and latency-bound
 // second halves of this block's passes instead of alone at the block boundary (DMH_INDEX_ON_TAIL=0: off).
+// (DMH_INDEX_ON_TAIL=2, experiment: the stage goes to the MAIN stream instead, at the point of a pass where that stream
+//  has just run dry -- behind the round trip for the cluster counters, while the host queues the second half on the tail)
+void bg_pump_gap(int nstages)
+{ static const bool on = getenv("DMH_INDEX_ON_TAIL") != nullptr && atoi(getenv("DMH_INDEX_ON_TAIL")) == 2;
+  if (!on || g_bg.empty() || g_bg.front().q != nullptr) return;
+  StreamScope on_main(main_stream());
+  for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step();
+}
+
 void bg_pump_tail(int nstages)
-{ static const bool on = getenv("DMH_INDEX_ON_TAIL") == nullptr || atoi(getenv("DMH_INDEX_ON_TAIL")) != 0;
+{ static const bool on = getenv("DMH_INDEX_ON_TAIL") == nullptr || atoi(getenv("DMH_INDEX_ON_TAIL")) == 1;
   if (!on || g_bg.empty() || tail_stream() == main_stream()) return;
   SortJob &J = g_bg.front();
   if (J.stage == 0 && J.q == nullptr) J.q = tail_stream();
