@@ -1644,6 +1644,7 @@ static void close_pending()
 static void close_batch(MergeResult &R, int phase)
 { State &st = S();
   std::unique_ptr<StreamScope> tail_scope;       // set where the pass moves to the tail stream (per-read route)
+  std::unique_ptr<HostTimer> post_sync;          // host time from the counter round trip to the end of the close
   if (phase != 2) close_pending();               // (one close at a time)
   const int64_t nhits = R.nhits;
   const DAZZ_DB *ablock = R.ablock;
@@ -1869,6 +1870,7 @@ static void close_batch(MergeResult &R, int phase)
             }
           ncl = g_known[0];
           g_have_known = true;
+          post_sync.reset(new HostTimer("close_behind_counters"));
           if (phase == 2 && g_known[1] > 0)
             { // a pile across buckets: the radix sort's scratch is the main stream's -- the rest of this close goes there,
               // behind what the tail stream has done so far
@@ -2069,7 +2071,9 @@ static void close_batch(MergeResult &R, int phase)
           st.last_seeds[4 * i + 3] = (int) (hs[i].pair >> R.bbits);
         }
     }
-  chain_submit(R, ablock);
+  { HostTimer hs("chain_submit_host");
+    chain_submit(R, ablock);
+  }
   tail_scope.reset();            // (what follows is the main stream's business again)
   // the batch is in flight; collect the next one in a free slot of the ring
   int slot = -1;
