@@ -40,6 +40,8 @@ def lib() -> C.CDLL:
     L.dmh_ref_cache.restype = None
     L.dmh_test_option.argtypes = [C.c_char_p, C.c_int]
     L.dmh_test_option.restype = C.c_int
+    L.dmh_next_pass.argtypes = [C.c_void_p, C.c_void_p]
+    L.dmh_next_pass.restype = None
     L.dmh_sort_kmers_async.argtypes = [P(DAZZ_DB), P(C.c_int)]
     L.dmh_sort_kmers_async.restype = C.c_void_p
     L.Match_Filter.argtypes = [P(DAZZ_DB), P(DAZZ_DB), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -107,7 +109,7 @@ def exported_symbols() -> List[str]:
             "dmh_last_seed_count", "dmh_last_seeds", "dmh_last_limit", "dmh_read_candidates",
             "dmh_candidate_jumps", "dmh_read_cover", "dmh_sort_pairs", "dmh_exclusive_scan", "dmh_local_alignment",
             "dmh_timing_enable", "dmh_timing_reset", "dmh_timing_count", "dmh_timing_get", "dmh_sync",
-            "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free", "dmh_test_option", "dmh_ref_cache",
+            "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free", "dmh_test_option", "dmh_next_pass", "dmh_ref_cache",
             "dmh_preload_block_2bit", "dmh_download_block", "dmh_prepare_block", "dmh_device_memory"]
 
 

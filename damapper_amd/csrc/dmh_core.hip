@@ -908,6 +908,7 @@ void index_wait_ready(IndexDev &ix)
 
 static void free_index(IndexDev &ix)
 { index_wait_ready(ix);
+  filter_forget_index(&ix);
   if (ix.borrowed)               // the buffers belong to a cache entry
     { ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr; ix.d_bstart = nullptr;
       return;
@@ -1664,6 +1665,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "hit_limit") == 0)   st.opt_hit_limit = value;
   else if (strcmp(key, "tails") == 0)       st.opt_tails = value;
   else if (strcmp(key, "defer_close") == 0) st.opt_defer_close = value;
+  else if (strcmp(key, "front_early") == 0) st.opt_front_early = value;
   else if (strcmp(key, "seed_word") == 0)   st.opt_seed_word = value;
   else if (strcmp(key, "fin_stream") == 0)  st.opt_fin_stream = value;
   else if (strcmp(key, "alloc_fail") == 0)  g_alloc_fail = value > 0 ? value : 0;

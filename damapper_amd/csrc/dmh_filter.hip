@@ -61,6 +61,17 @@ void Match_Filter(DAZZ_DB *ablock, DAZZ_DB *bblock, void *atable, int alen, void
     }
 }
 
+// Pipelining hook (optional, results unchanged): the Match_Filter call AFTER the next one will be made with these two
+// index handles.  The library may then queue that pass's match + count kernels -- which depend on the indices only --
+// before the next call's last round trip to the host, so that the GPU's main stream does not wait while the host
+// queues the rest of that call.  A wrong or missing hint costs time, never results.
+void dmh_next_pass(void *atable, void *btable)
+{ if (atable == nullptr || btable == nullptr) { filter_hint_next_pass(nullptr, nullptr, 0); return; }
+  IndexDev *A = index_of(atable, "dmh_next_pass");
+  IndexDev *B = index_of(btable, "dmh_next_pass");
+  filter_hint_next_pass(A, B, S().params.Kshift);
+}
+
 int64_t dmh_last_seed_count(void) { return (int64_t) (S().last_seeds.size() / 4); }
 
 int dmh_last_seeds(void *out)

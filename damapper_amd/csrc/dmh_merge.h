@@ -76,5 +76,9 @@ int64_t filter_flush_block(int cslot);     // ... of ONE READS block only (the o
 void    filter_discard();          // forget the batches of a READS block that never reached Reporter
 void    filter_discard_block(int cslot);
 MergeResult &filter_batch();
+// the driver's word on the pass that follows the one about to be made (dmh_next_pass): its front -- match + count, which
+// depends on the two indices only -- may be queued before this pass's last round trip
+void    filter_hint_next_pass(IndexDev *A, IndexDev *B, int Kshift);
+void    filter_forget_index(const IndexDev *ix);      // an index is being freed
 
 }  // namespace dmh

@@ -1084,15 +1084,22 @@ static bool local_cluster_sort(int pbits)
   return !(global_csort || S().opt_cluster_sort == 0 || pbits > 20);
 }
 
-int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &Bx,
-                   int Kshift, int comp, int64_t *nfilt)
-{ State &st = S();
-  MergeResult *Rp = &filter_batch();
-#define R (*Rp)
-  HostTimer ht("merge_and_sort");
-  static const bool hooked = (set_reclaim_hook(filter_reclaim), true);
-  (void) hooked;
+// The front of a pass -- the REF index's bucket table (first use), match + count (map.c:2984-2988), the open look-ups,
+// the hit sums and the scan over the tiles' entry counts: everything up to the first round trip.  It depends on the two
+// indices only and leaves its results in buffers no later stage of the PREVIOUS pass reads, so the filter may queue
+// it early: merge_pass does at its start, or -- when the driver has said which pass comes next (dmh_next_pass) --
+// close_batch does for the FOLLOWING pass, in front of its wait for the cluster counters: the main stream then goes
+// straight on while the host queues the second half of the pass on the tail stream (0.5 ms).
+static DevBuf<unsigned long long> g_gram, g_thits;
+static DevBuf<MergeEntry> g_entries, g_tentries;
+static DevBuf<uint32_t>   g_tcount;
+static DevBuf<unsigned int> g_mctl;
+static const IndexDev *g_front_a = nullptr, *g_front_b = nullptr;       // the pass whose front is queued already
+static IndexDev *g_hint_a = nullptr, *g_hint_b = nullptr;               // the pass the driver says comes next
+static int g_hint_kshift = 0;
 
+static void match_front(IndexDev &A, IndexDev &Bx, int Kshift)
+{ State &st = S();
   // --- bucket table over the REF index: part of the index, built the first time it is merged against
   //     (a retained REF index meets every READS block)
   if (Bx.d_bstart == nullptr)
@@ -1132,10 +1139,10 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   BLookup BL{Bx.keys, Bx.d_bstart, Bx.bshift, Bx.low_off ? (const uint16_t *) (Bx.d_bstart + Bx.low_off) : nullptr};
 
   // --- match + count (map.c:2984-2988)
-  static DevBuf<unsigned long long> gram, thits;
-  static DevBuf<MergeEntry> entries, tentries;
-  static DevBuf<uint32_t>   tcount;
-  static DevBuf<unsigned int> mctl;
+  DevBuf<unsigned long long> &gram = g_gram, &thits = g_thits;
+  DevBuf<MergeEntry> &tentries = g_tentries;
+  DevBuf<uint32_t>   &tcount = g_tcount;
+  DevBuf<unsigned int> &mctl = g_mctl;
   const int64_t ntiles = ceil_div(A.n, MG_TILE);
   gram.ensure(MAXGRAM + 8, "hit histogram");
   mctl.ensure(4, "merge counters");
@@ -1170,6 +1177,36 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
     HIP_CHECK(hipGetLastError());
   }
+  g_front_a = &A;
+  g_front_b = &Bx;
+}
+
+void filter_hint_next_pass(IndexDev *A, IndexDev *B, int Kshift)
+{ g_hint_a = A; g_hint_b = B; g_hint_kshift = Kshift; }
+
+void filter_forget_index(const IndexDev *ix)
+{ if (g_hint_a == ix || g_hint_b == ix) { g_hint_a = nullptr; g_hint_b = nullptr; }
+  if (g_front_a == ix || g_front_b == ix) { g_front_a = nullptr; g_front_b = nullptr; }
+}
+
+int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &Bx,
+                   int Kshift, int comp, int64_t *nfilt)
+{ State &st = S();
+  MergeResult *Rp = &filter_batch();
+#define R (*Rp)
+  HostTimer ht("merge_and_sort");
+  static const bool hooked = (set_reclaim_hook(filter_reclaim), true);
+  (void) hooked;
+
+  // --- the front of the pass (match_front above), unless the previous pass has queued it already
+  if (!(g_front_a == &A && g_front_b == &Bx)) match_front(A, Bx, Kshift);
+  g_front_a = nullptr; g_front_b = nullptr;
+  DevBuf<MergeEntry> &entries = g_entries, &tentries = g_tentries;
+  DevBuf<uint32_t>   &tcount = g_tcount;
+  DevBuf<unsigned long long> &gram = g_gram;
+  DevBuf<unsigned int> &mctl = g_mctl;
+  const int64_t ntiles = ceil_div(A.n, MG_TILE);
+  unsigned long long *sums = gram.p + MAXGRAM + 1;         // [0] all hits, [1] hits of the runs below MAXGRAM
   // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
   // main stream has the match kernels (and the previous pass's chain kernels) to run meanwhile
   close_pending();       // (the previous pass's second half: behind this pass's match kernels)
@@ -1841,6 +1878,24 @@ static void close_batch(MergeResult &R, int phase)
               for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
             else if (phase == 2)
               { HIP_CHECK(hipEventSynchronize(R.ev_known));
+                for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
+              }
+            else if (g_hint_a != nullptr && g_hint_b != nullptr && g_hint_a->keys != nullptr && g_hint_b->keys != nullptr &&
+                     !g_hint_a->pending && !g_hint_b->pending && g_hint_a->built == nullptr && g_hint_b->built == nullptr &&
+                     stream() == main_stream() &&
+                     st.opt_front_early != 0)
+              { // the counters set off for page-locked memory, the FOLLOWING pass's front is queued behind them, and
+                // only then does the host wait for the counters
+                if (R.h_known == nullptr)
+                  { HIP_CHECK(hipHostMalloc((void **) &R.h_known, 8 * sizeof(uint32_t), hipHostMallocDefault));
+                    HIP_CHECK(hipEventCreateWithFlags(&R.ev_known, hipEventDisableTiming));
+                  }
+                HIP_CHECK(hipMemcpyAsync(R.h_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+                HIP_CHECK(hipEventRecord(R.ev_known, stream()));
+                IndexDev *ha = g_hint_a, *hb = g_hint_b;
+                g_hint_a = nullptr; g_hint_b = nullptr;
+                match_front(*ha, *hb, g_hint_kshift);
+                HIP_CHECK(hipEventSynchronize(R.ev_known));
                 for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
               }
             else

@@ -171,6 +171,7 @@ struct State
   int  opt_chain_g     = 0;     // lanes per chain group for ALL groups (16/32/64); 0 = 16 + 64 by group size
   int  mf_calls = 0;            // Match_Filter calls since the last Reporter (passes per READS block)
   int     opt_defer_close = -1; // 0: a pass is closed before Match_Filter returns (no second half left to the next pass)
+  int     opt_front_early = -1; // 0: a pass's front is never queued by the pass before it (dmh_next_pass ignored)
   int     opt_tails = -1;       // 0: nothing moves to the tail stream (every kernel of a pass has the GPU to itself: bench.py's "alone" figures)
   int     opt_hit_limit = 0;    // > 0: a pass of this many hits is refused (test of the 2^32 refusal)
   int     mf_calls_block = 0;   // ... of the block Reporter is working on

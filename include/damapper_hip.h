@@ -175,6 +175,15 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  * Returns 0, or -1 for an unknown key.                                                                       */
 int dmh_test_option(const char *key, int value);
 
+/* Pipelining hook (optional; results unchanged): called BEFORE a Match_Filter call, it names the two index handles of
+ * the Match_Filter call that will FOLLOW that one (same READS index, the next REF index).  The library then queues the
+ * following pass's match + count kernels -- which depend on the two indices only (map.c:2984-2988) -- in front of
+ * the coming call's last wait for the device, so that the GPU goes straight on while the host queues the rest of
+ * that call's work.  A missing or wrong hint costs time, never results; (NULL, NULL) withdraws it.
+ * (Measured on the GRCh38-sized bench workload: no gain -- 148.5 against 144.9 ms per read block, DESIGN.md 3b --, so
+ * damapper_amd/driver.py only uses it with DMH_HINT_PASSES=1.)                                                   */
+void dmh_next_pass(void *atable, void *btable);
+
 /* Page-locked host memory for a driver that loads blocks itself: a block whose `bases` live in such
  * memory is uploaded by one DMA without staging (a block in ordinary malloc memory, as the reference
  * driver's, goes through two pinned staging buffers).  NULL when no device is available.              */
