@@ -1901,7 +1901,8 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
                   }
                 StreamScope on_tail0(simple_on_tail ? tail_stream() : stream());
                 StageTimer t0("chain_simple_groups", 12.0 * nhits);
-                const int nbs = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
+                static const int env_sg = getenv("DMH_SIMPLE_GRID") ? std::max(64, atoi(getenv("DMH_SIMPLE_GRID"))) : 256 * 8;
+                const int nbs = (int) std::min<int64_t>((R.ngroups + 15) / 16, env_sg);
                 hipLaunchKernelGGL(k_chain_simple, dim3(nbs), dim3(256), 0, stream(), A, R.lane_max);
               }
             // the tail: from here on the launches walk what k_chain_simple has left (7 % of the hits of a dense pass,
