@@ -156,8 +156,11 @@ class Mapper:
             self._drop_prefetched()        # a prefetched index for a block that did not come next
             rh, rn = capi.sort_kmers(reads)
         # (overlap mode: the library runs the stages of that build on its tail stream, one behind each pass of this
-        #  block -- DMH_PREFETCH_OVERLAP=0: the index is built when the block's own turn comes, as before)
-        if next_reads is not None and self.prefetch_deferred and (not overlap or self.prefetch_overlap):
+        #  block -- DMH_PREFETCH_OVERLAP=0: the index is built when the block's own turn comes, as before.
+        #  With few passes per block most stages would be left for the block boundary anyway, behind the tail stream's
+        #  other work: ecoli (2 passes) 8.3 against 9.2 Gbp/s -- so only from a dozen passes on.)
+        if next_reads is not None and self.prefetch_deferred and \
+           (not overlap or (self.prefetch_overlap and 2 * len(ref_blocks) >= 12)):
             # the next block's index build is deferred: its stages are queued in the gaps of this
             # block's filter and report phases (dmh_sort_kmers_async)
             h2, n2 = capi.sort_kmers(next_reads, deferred=True)

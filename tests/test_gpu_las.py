@@ -473,6 +473,36 @@ def test_dispatcher_maps_every_read_block(tmp_path):
             assert open(os.path.join(d, "las_disp", fn), "rb").read() == open(os.path.join(d, "las_disp3", fn), "rb").read(), fn
 
 
+@pytest.mark.parametrize("envvar", ["DMH_NO_PACKED_POS", "DMH_NO_PACK32", "DMH_CHAIN_TAIL", "DMH_BACK_TAIL", "DMH_INDEX_ON_TAIL",
+                                    "DMH_NO_LDS_ORDER"])
+def test_layout_switches_read_from_the_environment(envvar, tmp_path):
+    """Switches that are read once per process: the dispatcher in a process of its own with the switch set, its files
+    against the reference's.  DMH_NO_PACKED_POS: k-mer positions as block offsets, turned into (read, rpos) by a table
+    look-up; DMH_NO_PACK32: every candidate aligned one per wavefront; the three tail-stream switches = 0: everything on
+    the main stream; DMH_NO_LDS_ORDER: ranks from ballots (as on a device whose LDS atomics are not served in lane order)."""
+    import subprocess
+    import sys
+    run_ref = _run_ref()
+    g, reads = make_dataset("repeat", 147, [180000, 160000], 60, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=200000)
+    dazzdb.write_db(d, "READS", reads, block_size=330000)
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    run_ref.run_reference(d, "REF", blocks, flags=["-M8"], threads=4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    env[envvar] = "0" if envvar.endswith("TAIL") else "1"
+    cmd = [sys.executable, "-m", "damapper_amd.dispatch", os.path.join(d, "REF.db"), os.path.join(d, "READS.db"),
+           "--gpus", "1", "--out", os.path.join(d, "las_env")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    for b in blocks:
+        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        _, hr = las.read_las_set(os.path.join(d, "las_env"), b + ".REF.M@.las")
+        assert len(rr) > 0 and rr == hr, b
+
+
 def test_device_side_block_decode_equals_load_all_reads(tmp_path):
     """dmh_preload_block_2bit (the .bps slice uploaded as it is and unpacked by a kernel) leaves the same
     device image as uploading the host-decoded block: read lengths of every residue mod 4, one-base reads,
