@@ -461,6 +461,9 @@ __global__ __launch_bounds__(256) void k_merge_expand_big(const MergeEntry *__re
 // (the entry-per-thread kernels above write every entry's pairs from one thread: 3 bytes of HBM traffic per byte of
 // hits).  The tile's entries are found by two searches in the offsets, their offsets go to LDS, every slot then finds
 // its entry there.  Zero-sized entries (runs at or above the limit) simply never contain a slot.
+#ifndef DMH_EX_UNROLL
+#define DMH_EX_UNROLL 2
+#endif
 constexpr int EX_TILE = 2048;
 constexpr int EX_OFFS = 2 * EX_TILE + 2;
 
@@ -502,31 +505,57 @@ __global__ __launch_bounds__(256) void k_merge_expand_tiled(const MergeEntry *__
   if (inlds)
     for (uint32_t i = threadIdx.x; i <= ne; i += 256) s_off[i] = eoff[e_lo + i];
   __syncthreads();
-#pragma unroll 2
-  for (int k = 0; k < EX_TILE / 256; k++)
+  // A thread's EX_TILE / 256 slots in PHASES -- all their entries, then all their positions, then all their places --
+  // so that the loads of a phase are in flight together: slot by slot the kernel waited for four dependent round trips
+  // per hit (86 % of its wave cycles, at full occupancy).
+  constexpr int NK = EX_TILE / 256;
+  uint32_t ee[NK], tt[NK];
+  MergeEntry en[NK];
+  bool ok[NK];
+#pragma unroll
+  for (int k = 0; k < NK; k++)
     { const uint32_t o = o0 + threadIdx.x + 256u * (uint32_t) k;
-      if (o >= o1) break;
-      uint32_t lo = 0, hi = ne;                // last i in [0, ne) with off[i] <= o
+      ok[k] = o < o1;
+      const uint32_t oc = ok[k] ? o : o1 - 1;
+      uint32_t lo = 0, hi = ne;                // last i in [0, ne) with off[i] <= oc
       if (inlds)
         while (hi - lo > 1)
           { const uint32_t m = (lo + hi) >> 1;
-            if (s_off[m] <= o) lo = m; else hi = m;
+            if (s_off[m] <= oc) lo = m; else hi = m;
           }
       else
         while (hi - lo > 1)
           { const uint32_t m = (lo + hi) >> 1;
-            if (eoff[e_lo + m] <= o) lo = m; else hi = m;
+            if (eoff[e_lo + m] <= oc) lo = m; else hi = m;
           }
-      const uint32_t   e  = e_lo + lo;
-      const MergeEntry en = entries[e];
-      const uint32_t   t  = o - (inlds ? s_off[lo] : eoff[e]);
-      const uint32_t   a  = t / en.mb, b = t - a * en.mb;
-      uint32_t ar, ap, br, bp;
-      locate(MA, avals[en.a0 + a], ar, ap);
-      locate(MB, bvals[en.b0 + b], br, bp);
-      const uint32_t dst = (rstart != nullptr) ? rstart[ar] + rowdst[o - b] + b : o;
-      put_hit(hkeys, hvals, dst, ar, ap, br, bp, bshift, pshift, swap, passor);
+      ee[k] = e_lo + lo;
+      tt[k] = oc - (inlds ? s_off[lo] : eoff[e_lo + lo]);
     }
+#pragma unroll
+  for (int k = 0; k < NK; k++) en[k] = entries[ee[k]];
+  uint32_t qa[NK], qb[NK], bb[NK];
+#pragma unroll
+  for (int k = 0; k < NK; k++)
+    { const uint32_t a = tt[k] / en[k].mb;
+      bb[k] = tt[k] - a * en[k].mb;
+      qa[k] = avals[en[k].a0 + a];
+      qb[k] = bvals[en[k].b0 + bb[k]];
+    }
+  uint32_t ar[NK], ap[NK], br[NK], bp[NK], dst[NK];
+#pragma unroll
+  for (int k = 0; k < NK; k++)
+    { locate(MA, qa[k], ar[k], ap[k]);
+      locate(MB, qb[k], br[k], bp[k]);
+    }
+#pragma unroll
+  for (int k = 0; k < NK; k++)
+    { const uint32_t o = o0 + threadIdx.x + 256u * (uint32_t) k;
+      const uint32_t oc = ok[k] ? o : o1 - 1;
+      dst[k] = (rstart != nullptr) ? rstart[ar[k]] + rowdst[oc - bb[k]] + bb[k] : oc;
+    }
+#pragma unroll
+  for (int k = 0; k < NK; k++)
+    if (ok[k]) put_hit(hkeys, hvals, dst[k], ar[k], ap[k], br[k], bp[k], bshift, pshift, swap, passor);
 }
 
 // Rows of the merge: READ k-mer a of an entry with its mb partners.  Every row takes mb consecutive slots of its
