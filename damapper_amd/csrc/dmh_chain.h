@@ -26,6 +26,7 @@ bool    chain_finish_ready(MergeResult &R);        // the next step would neithe
 
 // Drops the chain stage's per-batch buffers of a ring slot that is not in use (memory pressure).
 void    chain_release(MergeResult &R);
+bool    chain_drop_unused();          // memory ran out inside chain_submit's allocations: the ones made so far are given back
 // A submitted batch is dropped unfinished: later work on the main and finish streams waits for its pile kernel.
 void    chain_abandon(MergeResult &R);
 

@@ -1781,6 +1781,18 @@ void chain_abandon(MergeResult &R)
   R.cc->has_piles = false;
 }
 
+static ChainCtx *g_alloc_ctx = nullptr;      // chain_submit is allocating this batch's buffers (none of them used yet)
+
+bool chain_drop_unused()
+{ if (g_alloc_ctx == nullptr) return false;
+  ChainCtx &C = *g_alloc_ctx;
+  const bool got = C.cost.p || C.from.p || C.rootof.p || C.best.p || C.bestcost.p || C.livebuf.p || C.state.p || C.tmp.p || C.out.p;
+  C.cost.release(); C.bestcost.release();
+  C.from.release(); C.rootof.release(); C.best.release(); C.state.release(); C.tmp.release();
+  C.livebuf.release(); C.out.release(); C.gcnt.release(); C.gbase.release();
+  return got;
+}
+
 void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
 { State &st = S();
   const Params &pm = st.params;
@@ -1795,18 +1807,26 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
   DevBuf<ChainSummary> &out = C.out;
 
   const int64_t nhits = R.nhits;
-  cost.ensure(nhits, "chain cost");
-  from.ensure(nhits, "chain from");
-  rootof.ensure(nhits, "chain origin");
-  best.ensure(nhits, "chain best end");
-  bestcost.ensure(nhits, "chain best score");
-  livebuf.ensure(nhits + 1, "chain live set");
-  state.ensure(nhits, "chain state");
-  tmp.ensure(nhits, "chain scratch");
-  ctl.ensure(8, "chain counters");
-  out.ensure(nhits / HITMIN + 64, "chain summaries");
-  gcnt.ensure((size_t) R.ngroups + 1, "chain ends per group");
-  gbase.ensure((size_t) R.ngroups + 1, "first chain end per group");
+  // (Nothing has used these buffers yet: when one of the allocations runs out of memory the reclaim may drop the ones
+  //  already made -- chain_drop_unused: finishing the batches in flight takes memory itself -- and the round is made again.)
+  g_alloc_ctx = &C;
+  for (int round = 0; round < 4; round++)
+    { cost.ensure(nhits, "chain cost");
+      from.ensure(nhits, "chain from");
+      rootof.ensure(nhits, "chain origin");
+      best.ensure(nhits, "chain best end");
+      bestcost.ensure(nhits, "chain best score");
+      livebuf.ensure(nhits + 1, "chain live set");
+      state.ensure(nhits, "chain state");
+      tmp.ensure(nhits, "chain scratch");
+      ctl.ensure(8, "chain counters");
+      out.ensure(nhits / HITMIN + 64, "chain summaries");
+      gcnt.ensure((size_t) R.ngroups + 1, "chain ends per group");
+      gbase.ensure((size_t) R.ngroups + 1, "first chain end per group");
+      if (cost.p && from.p && rootof.p && best.p && bestcost.p && livebuf.p && state.p && tmp.p && ctl.p && out.p && gcnt.p && gbase.p)
+        break;
+    }
+  g_alloc_ctx = nullptr;
   HIP_CHECK(hipMemsetAsync(ctl.p, 0, 8 * sizeof(uint32_t), stream()));
   HIP_CHECK(hipMemsetAsync(gcnt.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
 

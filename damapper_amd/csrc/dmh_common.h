@@ -90,8 +90,10 @@ template <typename T> struct DevBuf
   void ensure(size_t n, const char *what)
   { if (n > cap)
       { if (p) dev_free(p);
-        cap = n + n / 8 + 256;
-        p   = (T *) dev_alloc(cap * sizeof(T), what);
+        p = nullptr; cap = 0;            // (dev_alloc may run the memory reclaim, which may look at this buffer)
+        const size_t want = n + n / 8 + 256;
+        p   = (T *) dev_alloc(want * sizeof(T), what);
+        cap = want;
         gen += 1;
       }
   }
@@ -112,6 +114,8 @@ struct StageTimer
   hipEvent_t e0, e1;
 };
 
+bool   sort_scratch_release();                      // memory ran out: the k-mer sorts' partner buffers (dmh_core.hip)
+double dev_live_gb();                               // device memory this library holds (buffers handed out, not the pool)
 void timing_count(const char *name, int64_t n);     // a counter in the same table (reported as `launches`, 0 ms)
 
 // wall-clock time of a host section, reported next to the device stages as "host:<name>"

@@ -200,6 +200,7 @@ static void pool_drop(PoolBlock &b)          // the block goes back to the drive
   b.ev = nullptr;
 }
 static std::map<void *, size_t>  g_live;
+static std::map<void *, const char *> g_live_what;     // (labels, for the out-of-memory message)
 static size_t                    g_pooled = 0;
 static const size_t              POOL_MAX = (size_t) 96 << 30;
 
@@ -224,6 +225,8 @@ void simulate_out_of_memory()
   g_free.clear();
   g_pooled = 0;
 }
+
+double dev_live_gb();
 
 void *dev_alloc(size_t bytes, const char *what)
 { init_device();
@@ -284,6 +287,7 @@ void *dev_alloc(size_t bytes, const char *what)
       g_free.erase(g_free.begin() + best);
       g_pooled -= b.cap;
       g_live[b.p] = b.cap;
+      g_live_what[b.p] = what;
       if (!idle)
         { HostTimer ht("pool_owner_wait");
           HIP_CHECK(hipStreamSynchronize(b.owner));
@@ -313,6 +317,13 @@ void *dev_alloc(size_t bytes, const char *what)
       e = hipMalloc(&p, bytes);
       if (e != hipSuccess) (void) hipGetLastError();
     }
+  if (e != hipSuccess && getenv("DMH_STATS") != nullptr)
+    { size_t fr = 0, tot = 0;
+      (void) hipMemGetInfo(&fr, &tot);
+      fprintf(stderr, "dmh: allocation of %zu bytes (%s) failed; reclaim hook %s, %s; device %.1f of %.1f GB free, library holds %.1f GB\n",
+              bytes, what, g_reclaim != nullptr ? "set" : "not set", g_reclaiming ? "already reclaiming" : "free", fr / 1e9, tot / 1e9,
+              dev_live_gb());
+    }
   if (e != hipSuccess && g_reclaim != nullptr && !g_reclaiming)
     { // last resort: what other stages can do without (batches in flight are finished, their buffers dropped)
       (void) hipGetLastError();
@@ -328,8 +339,24 @@ void *dev_alloc(size_t bytes, const char *what)
         }
     }
   if (e != hipSuccess)
-    fatal("out of device memory allocating %zu bytes (%s): %s", bytes, what, hipGetErrorString(e));
+    { size_t fr = 0, tot = 0, live = 0;
+      (void) hipMemGetInfo(&fr, &tot);
+      for (auto &kv : g_live) live += kv.second;
+      { // the largest holders by label
+        std::map<std::string, double> by;
+        for (auto &kv : g_live) by[g_live_what.count(kv.first) ? g_live_what[kv.first] : "?"] += kv.second / 1e9;
+        std::vector<std::pair<double, std::string>> top;
+        for (auto &kv : by) top.push_back({-kv.second, kv.first});
+        std::sort(top.begin(), top.end());
+        for (size_t i = 0; i < top.size() && i < 16; i++)
+          fprintf(stderr, "damapper_hip:   %8.2f GB  %s\n", -top[i].first, top[i].second.c_str());
+      }
+      fatal("out of device memory allocating %zu bytes (%s): %s [device: %.1f of %.1f GB free; this library holds %.1f GB in %zu "
+            "buffers, %.1f GB pooled]", bytes, what, hipGetErrorString(e), fr / 1e9, tot / 1e9, live / 1e9, g_live.size(),
+            g_pooled / 1e9);
+    }
   g_live[p] = bytes;
+  g_live_what[p] = what;
   if (poison)
     { HIP_CHECK(hipMemsetAsync(p, pbyte, bytes, me));
       HIP_CHECK(hipStreamSynchronize(me));
@@ -342,6 +369,12 @@ void *dev_alloc(size_t bytes, const char *what)
 }
 
 void set_reclaim_hook(bool (*fn)()) { g_reclaim = fn; }
+
+double dev_live_gb()
+{ double b = 0;
+  for (auto &kv : g_live) b += (double) kv.second;
+  return b / 1e9;
+}
 
 void dev_free(void *p)
 { if (p == nullptr) return;
@@ -1262,6 +1295,20 @@ void bg_pump_tail(int nstages)
   if (J.stage == 0 && J.q == nullptr) J.q = tail_stream();
   if (J.q == nullptr) return;                   // (started on the main stream: it stays there)
   for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step();
+}
+
+// Memory ran out: the ping-pong partners of the k-mer sorts (12 GB behind a GRCh38-sized reference) are idle unless a
+// deferred index build is under way; they come back with the next sort.
+bool sort_scratch_release()
+{ if (!g_bg.empty()) return false;
+  State &st = S();
+  bool got = false;
+  for (SortScratch *sc : {&st.sort, &st.sort_aux})
+    { if (sc->keys_alt.p != nullptr || sc->vals_alt.p != nullptr) got = true;
+      sc->keys_alt.release();
+      sc->vals_alt.release();
+    }
+  return got;
 }
 
 bool bg_on_tail() { return !g_bg.empty() && g_bg.front().q != nullptr && g_bg.front().q != main_stream(); }

@@ -1380,7 +1380,12 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   const int  rs_cb = std::min(RS_CB, R.qbits);
   const bool by_read = R.word && R.npass == 0 && !env_per_entry && st.opt_expand != 0 &&
                        (st.opt_read_sort >= 0 ? st.opt_read_sort != 0 : env_rs != 0) &&
-                       R.pbits + R.qbits - rs_cb + R.bbits <= 32;          // (the sort key of k_read_sort is one 32-bit word)
+                       R.pbits + R.qbits - rs_cb + R.bbits <= 32 &&        // (the sort key of k_read_sort is one 32-bit word)
+                       // (a pass in which the AVERAGE read has more hits than the LDS kernels take -- a one-family reference:
+                       //  28,000 per read -- would send every read through k_read_sort_big, one workgroup each through global
+                       //  memory: 4.5 s per read block against 1.9 with the global sort, which is made for that; test options
+                       //  that force a route are obeyed)
+                       (st.opt_read_sort > 0 || nhits <= (int64_t) ablock->nreads * (RS_T2 * RS_E / 2));
   R.read_sorted = false;
 
   // --- expand the entries under the limit into hits (map.c:3095-3099), behind the batch's earlier passes
@@ -1510,6 +1515,15 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   static const int env_fl = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
   const int keep = (VERBOSE || st.capture_seeds || st.opt_in_flight == 0) ? 0 : std::min(g_flight_cap, std::max(0, env_fl));
   while ((int) g_inflight.size() > (keep > 0 ? keep + 1 : 0)) *nfilt += finish_oldest();
+  // nothing in flight, nothing being collected: the next pass goes where buffers of its size lie already (with every batch
+  // finished at once the ring otherwise alternates between two slots -- 57 GB each against a one-family reference, and
+  // the idle one is what the memory reclaim then frees and the next pass allocates again, every pass)
+  if (g_inflight.empty() && g_pending_close < 0 && !g_ring[g_cur].open)
+    { int warm = g_cur;
+      for (int i = 0; i < NRING; i++)
+        if (g_ring[i].keys.cap > g_ring[warm].keys.cap) warm = i;
+      g_cur = warm;
+    }
   return nhits;
 #undef R
 }
@@ -1616,17 +1630,8 @@ static void finish_retire(int x)
 // Device memory ran out (dev_alloc): the batches in flight are finished -- in order, as always -- and every ring slot
 // that is neither being collected nor in flight gives its buffers back.  A pass of 10^9 hits needs some 80 bytes
 // per hit; three such batches in flight next to 120 GB of indices do not fit 288 GB, one at a time does.
-static bool filter_reclaim()
-{ bool got = false;
-  if (!g_finishing && !g_closing) close_pending();
-  if (!g_finishing)
-    while (!g_inflight.empty())
-      { S().tfilt += finish_oldest();
-        got = true;
-      }
-  if (g_flight_cap > 0 && !S().simulated_oom) g_flight_cap -= 1;
-  HIP_CHECK(hipDeviceSynchronize());          // (buffers are about to go back to the driver)
-  for (int i = 0; i < NRING; i++)
+static void release_idle_slots(bool &got)
+{ for (int i = 0; i < NRING; i++)
     { bool busy = (i == g_cur) || (i == g_finishing_slot) || (i == g_pending_close);       // (chain_finish still reads the slot it is finishing)
       for (int y : g_inflight) busy = busy || (y == i);
       if (busy) continue;
@@ -1639,8 +1644,43 @@ static bool filter_reclaim()
       R.rs_wcnt.release(); R.rs_wlist[0].release(); R.rs_wlist[1].release(); R.pmax.release();
       chain_release(R);
     }
+}
+
+static bool filter_reclaim()
+{ bool got = false;
+  // first what nobody is using -- ring slots that are neither being collected nor in flight, the k-mer sorts' partner
+  // buffers --: finishing the batches in flight takes memory itself (a gigabyte of scan results per 2 * 10^8 groups), and
+  // the allocation that failed may have left none
+  const int flying = (int) g_inflight.size();
+  if (!g_finishing && !g_closing)
+    { HIP_CHECK(hipDeviceSynchronize());
+      release_idle_slots(got);
+      if (sort_scratch_release()) got = true;
+      if (chain_drop_unused()) got = true;
+    }
+  if (!g_finishing && !g_closing) close_pending();
+  if (!g_finishing)
+    while (!g_inflight.empty())
+      { S().tfilt += finish_oldest();
+        got = true;
+      }
+  // (what was in flight next to the batch that did not fit is one batch too many)
+  if (g_flight_cap > 0 && !S().simulated_oom) g_flight_cap = std::max(0, std::min(g_flight_cap - 1, flying - 1));
+  HIP_CHECK(hipDeviceSynchronize());          // (buffers are about to go back to the driver)
+  const double live_before = dev_live_gb();
+  release_idle_slots(got);
   static const bool stats = getenv("DMH_STATS") != nullptr;
-  if (stats) fprintf(stderr, "dmh: out of device memory: batches in flight finished, idle ring slots released\n");
+  if (stats)
+    { int nbusy = 0;
+      for (int i = 0; i < NRING; i++)
+        { bool busy = (i == g_cur) || (i == g_finishing_slot) || (i == g_pending_close);
+          for (int y : g_inflight) busy = busy || (y == i);
+          nbusy += busy ? 1 : 0;
+        }
+      fprintf(stderr, "dmh: out of device memory: batches in flight finished (%d left, finishing %d, closing %d), idle ring slots "
+              "released (%d busy, collecting slot %d, pending %d), in-flight cap now %d; %.1f -> %.1f GB held\n", (int) g_inflight.size(), (int) g_finishing,
+              (int) g_closing, nbusy, g_cur, g_pending_close, g_flight_cap, live_before, dev_live_gb());
+    }
   return got;
 }
 
