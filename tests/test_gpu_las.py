@@ -227,6 +227,28 @@ def _variant_base():
     return _VARIANT["base"]
 
 
+@pytest.mark.parametrize("cluster", [-1, 1], ids=["auto", "clusters"])
+def test_memory_runs_out_at_every_allocation(cluster, tmp_path):
+    """The n-th device allocation "runs out of memory" (the batches in flight are finished, idle buffers and the pool
+    go back to the driver, the allocation is made again), for every n over the first passes of the variant data set:
+    whichever buffer is being grown at that moment -- the reclaim may look at it: a stale pointer in DevBuf::ensure
+    was freed twice there until round 3 -- the files stay the same."""
+    from damapper_amd import capi
+    d = str(tmp_path)
+    base = _variant_base()
+    _variant_dbs(d)
+    L = capi.lib()
+    try:
+        assert L.dmh_test_option(b"cluster", cluster) == 0
+        for n in range(5, 200, 4):
+            assert L.dmh_test_option(b"alloc_fail", n) == 0
+            alt = _variant_run(d, "las_alt")
+            assert base == alt, "alloc_fail = %d" % n
+    finally:
+        for k, v in VARIANT_DEFAULTS.items():
+            L.dmh_test_option(k.encode(), v)
+
+
 def test_variant_dataset_matches_reference(tmp_path):
     """Pins the 30-odd forced routes above: the default route's record stream and -p track on THEIR data set
     (repeat-rich genome, dropout reads, a poly-A and a trinucleotide read) against the compiled reference."""
