@@ -1921,8 +1921,7 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
                   }
                 StreamScope on_tail0(simple_on_tail ? tail_stream() : stream());
                 StageTimer t0("chain_simple_groups", 12.0 * nhits);
-                static const int env_sg = getenv("DMH_SIMPLE_GRID") ? std::max(64, atoi(getenv("DMH_SIMPLE_GRID"))) : 256 * 8;
-                const int nbs = (int) std::min<int64_t>((R.ngroups + 15) / 16, env_sg);
+                const int nbs = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
                 hipLaunchKernelGGL(k_chain_simple, dim3(nbs), dim3(256), 0, stream(), A, R.lane_max);
               }
             // the tail: from here on the launches walk what k_chain_simple has left (7 % of the hits of a dense pass,
@@ -1948,8 +1947,6 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             Q.nwide  = R.gcounts.p;
             static const uint32_t env_walk = getenv("DMH_WALK_MAX") ? (uint32_t) atoi(getenv("DMH_WALK_MAX")) : BIG_GROUP;
             Q.walk_max = env_walk;
-            static const bool walk_to_16 = getenv("DMH_WALK_TO_16") != nullptr;       // (experiment: the long walks to k_chain<16>)
-            if (walk_to_16) { Q.wide = R.medlist.p; Q.nwide = R.gcounts.p + 2; }
             StageTimer t0("chain_lane_groups", 16.0 * nhits);        // 16 B per hit, read once by the chain stage
             // persistent lanes: exactly as many workgroups as the GPU holds at once (a second round of them would run
             // on a half-empty GPU)
@@ -1963,10 +1960,7 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
                 resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
                 if (getenv("DMH_STATS")) fprintf(stderr, "dmh: k_chain_lane: %d workgroups of %d per CU\n", per_cu, LANE_BLOCK);
               }
-            // (on the tail stream it shares the GPU with the next pass's match kernels: DMH_LANE_GRID_DIV, experiments)
-            static const int grid_div = getenv("DMH_LANE_GRID_DIV") ? std::max(1, atoi(getenv("DMH_LANE_GRID_DIV"))) : 1;
-            const int nb = (int) std::min<int64_t>((R.ngroups + LANE_BLOCK - 1) / LANE_BLOCK,
-                                                    tail_from_lane ? std::max(1, resident / grid_div) : resident);
+            const int nb = (int) std::min<int64_t>((R.ngroups + LANE_BLOCK - 1) / LANE_BLOCK, resident);
             hipLaunchKernelGGL((k_chain_lane<LANE_RW, LANE_RT>), dim3(nb), dim3(LANE_BLOCK), 0, stream(), Q, R.lane_max);
           }
         else if (R.small_cap > 0)

@@ -39,7 +39,6 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 hipStream_t stream();              // the stream this thread's launches go to: the main stream unless a StreamScope is open
 hipStream_t main_stream();
 void        join_side_streams();   // the main stream waits for everything queued on the finish stream so far
-void        bg_pump_gap(int nstages);    // ... on the main stream (experiment)
 void        bg_pump_tail(int nstages);   // stages of a deferred index build on the tail stream (dmh_core.hip)
 hipStream_t tail_stream();         // where the chain stage's last, latency-bound launches of a batch run (dmh_core.hip)
 hipStream_t finish_stream();       // where the filter finishes its batches (chain_finish); the main stream when switched off

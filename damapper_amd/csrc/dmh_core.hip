@@ -125,16 +125,8 @@ hipStream_t tail_stream()
 { init_device();
   static const int env_ts = getenv("DMH_CHAIN_TAIL") ? atoi(getenv("DMH_CHAIN_TAIL")) : 1;
   if (env_ts == 0 || S().opt_fin_stream == 0 || S().opt_tails == 0) return g_stream;
-  if (g_tstream == nullptr)
-    { static const int prio = getenv("DMH_TAIL_PRIO") ? atoi(getenv("DMH_TAIL_PRIO")) : 0;      // (1: highest, -1: lowest; experiments)
-      if (prio != 0)
-        { int least = 0, greatest = 0;
-          HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-          HIP_CHECK(hipStreamCreateWithPriority(&g_tstream, hipStreamNonBlocking, prio > 0 ? greatest : least));
-        }
-      else
-        HIP_CHECK(hipStreamCreateWithFlags(&g_tstream, hipStreamNonBlocking));
-    }
+  // (default priority: at the highest 149, at the lowest 150.5 against 146 ms per read block)
+  if (g_tstream == nullptr) HIP_CHECK(hipStreamCreateWithFlags(&g_tstream, hipStreamNonBlocking));
   return g_tstream;
 }
 
@@ -1279,15 +1271,6 @@ void bg_pump(int nstages)
 // One stage per call of the deferred build that is waiting, on the TAIL stream: the filter calls this at the end of a
 // dense pass, so that the index of the NEXT read block is sorted -- HBM-bound -- next to the LDS- and latency-bound
 // second halves of this block's passes instead of alone at the block boundary (DMH_INDEX_ON_TAIL=0: off).
-// (DMH_INDEX_ON_TAIL=2, experiment: the stage goes to the MAIN stream instead, at the point of a pass where that stream
-//  has just run dry -- behind the round trip for the cluster counters, while the host queues the second half on the tail)
-void bg_pump_gap(int nstages)
-{ static const bool on = getenv("DMH_INDEX_ON_TAIL") != nullptr && atoi(getenv("DMH_INDEX_ON_TAIL")) == 2;
-  if (!on || g_bg.empty() || g_bg.front().q != nullptr) return;
-  StreamScope on_main(main_stream());
-  for (int i = 0; i < nstages && !g_bg.empty(); i++) bg_step();
-}
-
 void bg_pump_tail(int nstages)
 { static const bool on = getenv("DMH_INDEX_ON_TAIL") == nullptr || atoi(getenv("DMH_INDEX_ON_TAIL")) == 1;
   if (!on || g_bg.empty() || tail_stream() == main_stream()) return;

@@ -1970,7 +1970,6 @@ static void close_batch(MergeResult &R, int phase)
             else
               copy_d2h(g_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), 1);
           }
-          if (phase == 0) bg_pump_gap(1);
           if (phase == 3 && g_known[1] == 0)
             { // stop here: the counters are kept with the batch, the tail stream will start behind what the main stream
               // has done up to now (the event), the next pass takes the close up (close_pending)
