@@ -16,6 +16,7 @@
 #ifndef DAMAPPER_HIP_H
 #define DAMAPPER_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

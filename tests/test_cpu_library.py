@@ -101,3 +101,14 @@ def test_block_sharding_two_ranks_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert p.stdout.count("ok") == 2
+
+
+def test_header_compiles_as_c(tmp_path):
+    """include/damapper_hip.h is a C header (the boundary is a C ABI): gcc -fsyntax-only on a C file that includes it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.c"
+    src.write_text('#include "damapper_hip.h"\nint main(void) { dmh_next_pass(0, 0); return 0; }\n')
+    p = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"), str(src)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr
