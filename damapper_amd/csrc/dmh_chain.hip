@@ -1741,6 +1741,18 @@ static void finish_wait_tag(FinishState &F, int tag_at)
         { const hipError_t e = hipEventQuery(F.ev);             // (a fault on the device must not leave the host spinning)
           if (e == hipErrorNotReady) (void) hipGetLastError();
           else if (e != hipSuccess) HIP_CHECK(e);
+          else
+            { // the kernel that posts the tag has completed: the tag must be visible (coherent page-locked memory).  If it
+              // is not -- non-coherent host memory (HIP_HOST_COHERENT=0), or a stale sequence number -- say so instead of
+              // spinning for ever
+              __atomic_thread_fence(__ATOMIC_SEQ_CST);
+              if (__atomic_load_n(&F.h_pin[tag_at], __ATOMIC_ACQUIRE) == F.seq) break;
+              HIP_CHECK(hipEventSynchronize(F.ev));
+              if (__atomic_load_n(&F.h_pin[tag_at], __ATOMIC_ACQUIRE) != F.seq)
+                fatal("chain_finish: the device has finished but its counters never arrived (tag %u, expected %u): "
+                      "page-locked memory is not coherent (HIP_HOST_COHERENT=0?)", F.h_pin[tag_at], F.seq);
+              break;
+            }
         }
     }
 }
@@ -1748,7 +1760,7 @@ static void finish_wait_tag(FinishState &F, int tag_at)
 static FinishState &fin_of(ChainCtx &C)
 { if (C.fin == nullptr)
     { C.fin = new FinishState();
-      HIP_CHECK(hipHostMalloc((void **) &C.fin->h_pin, 32 * sizeof(uint32_t), hipHostMallocDefault));
+      HIP_CHECK(hipHostMalloc((void **) &C.fin->h_pin, 32 * sizeof(uint32_t), hipHostMallocCoherent));
       memset(C.fin->h_pin, 0, 32 * sizeof(uint32_t));
       HIP_CHECK(hipEventCreateWithFlags(&C.fin->ev, hipEventDisableTiming));
     }
@@ -1825,6 +1837,9 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
       gbase.ensure((size_t) R.ngroups + 1, "first chain end per group");
       if (cost.p && from.p && rootof.p && best.p && bestcost.p && livebuf.p && state.p && tmp.p && ctl.p && out.p && gcnt.p && gbase.p)
         break;
+      if (round == 3)
+        fatal("Match_Filter: out of device memory for the chain buffers of a pass of %lld hits (the allocations keep evicting each other)",
+              (long long) nhits);
     }
   g_alloc_ctx = nullptr;
   HIP_CHECK(hipMemsetAsync(ctl.p, 0, 8 * sizeof(uint32_t), stream()));

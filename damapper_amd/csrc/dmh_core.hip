@@ -1164,6 +1164,14 @@ struct SortJob
   hipStream_t q = nullptr;      // the stream all its stages run on (nullptr: the main stream)
 };
 static std::deque<SortJob> g_bg;
+// The deferred builds share ONE scratch (State::sort_aux: histogram, scan sums, ping-pong partners) but not always one
+// stream: a job runs on the main stream or on the tail stream (bg_pump_tail).  An event behind the last stage of the
+// job that finished last orders whoever touches the scratch next on ANOTHER stream -- the next job's first stage, or
+// the main-stream scope under which Sort_Kmers grows (frees) the partner buffers.
+static hipEvent_t  g_bg_done_ev = nullptr;
+static hipStream_t g_bg_done_q  = nullptr;
+static void bg_order_behind_last_job(hipStream_t q)
+{ if (g_bg_done_q != nullptr && g_bg_done_q != q) HIP_CHECK(hipStreamWaitEvent(q, g_bg_done_ev, 0)); }
 
 // the sorted data may sit in the scratch partner: the index then takes over the partner's buffers and
 // the sort scratch keeps the ones allocated for the index (no device copy)
@@ -1216,7 +1224,8 @@ static void bg_step()
       if (it == st.indices.end()) fatal("deferred index build lost its index");
       IndexDev &ix = it->second;
       if (J.stage == 0)
-        { block_ready(bd);
+        { bg_order_behind_last_job(stream());      // (the previous job's last passes may still be reading the scratch on another stream)
+          block_ready(bd);
           HIP_CHECK(hipMemcpyAsync(ix.d_boff, bd.d_boff, sizeof(int64_t) * (bd.nreads + 1), hipMemcpyDeviceToDevice, stream()));
           hipLaunchKernelGGL(k_chunk_table, dim3(ceil_div(ix.nchunk, 256)), dim3(256), 0, stream(),
                              (const int64_t *) ix.d_boff, bd.nreads, ix.nchunk, ix.d_chunk);
@@ -1252,6 +1261,9 @@ static void bg_step()
         { if (it->second.built == nullptr) HIP_CHECK(hipEventCreateWithFlags(&it->second.built, hipEventDisableTiming));
           HIP_CHECK(hipEventRecord(it->second.built, J.q));
         }
+      if (g_bg_done_ev == nullptr) HIP_CHECK(hipEventCreateWithFlags(&g_bg_done_ev, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(g_bg_done_ev, stream()));
+      g_bg_done_q = stream();
       g_bg.pop_front();
     }
 }
@@ -1349,7 +1361,12 @@ static void *sort_kmers_impl(DAZZ_DB *block, int *len, bool deferred)
     }
   // a build can only be deferred when the length of the index is known up front
   const bool defer = deferred && mask == nullptr && pm.TooFrequent == INT32_MAX;
-  if (defer) bg_flush();                         // one deferred build at a time (it owns sort_aux)
+  if (defer)
+    { bg_flush();                                // one deferred build at a time (it owns sort_aux)
+      // the flush only QUEUES what was left of the previous job, on that job's stream: the partner buffers grown (freed)
+      // below under the main stream's scope must not change hands while its last scatter pass reads them on the tail stream
+      bg_order_behind_last_job(main_stream());
+    }
   SortScratch &scr = defer ? st.sort_aux : st.sort;
 
   if (VERBOSE)

@@ -1105,7 +1105,9 @@ static bool    finish_tick(int64_t *nfilt);
 static int     flight_keep();
 static void    finish_pipeline(int64_t *nfilt);
 static bool    filter_reclaim();
-static int     g_flight_cap = IN_FLIGHT;     // batches that may be in flight: one fewer after every time memory ran out
+static int     g_flight_cap = IN_FLIGHT;     // batches that may be in flight: fewer after every time memory ran out, one more
+                                             //   again after every READS block that went through without (filter_flush_block)
+static bool    g_reclaimed_in_block = false; // memory ran out since the last READS block was flushed
 
 // cluster mode: every cluster sorted where it lies (k_csort_*) rather than all hits through the radix sort again
 static bool local_cluster_sort(int pbits)
@@ -1666,6 +1668,7 @@ static bool filter_reclaim()
       }
   // (what was in flight next to the batch that did not fit is one batch too many)
   if (g_flight_cap > 0 && !S().simulated_oom) g_flight_cap = std::max(0, std::min(g_flight_cap - 1, flying - 1));
+  g_reclaimed_in_block = true;
   HIP_CHECK(hipDeviceSynchronize());          // (buffers are about to go back to the driver)
   const double live_before = dev_live_gb();
   release_idle_slots(got);
@@ -1697,15 +1700,23 @@ int64_t filter_flush()
 // filter finishes in order); what the following block has queued meanwhile stays as it is
 int64_t filter_flush_block(int cslot)
 { int64_t nfilt = 0;
+  bool did = false;
   close_pending();
   { MergeResult &R = filter_batch();
-    if (R.open && R.cslot == cslot) close_batch(R);
+    if (R.open && R.cslot == cslot) { close_batch(R); did = true; }
   }
   while (true)
     { bool any = false;
       for (int y : g_inflight) any = any || (g_ring[y].cslot == cslot);
       if (!any) break;
       nfilt += finish_oldest();
+      did = true;
+    }
+  // one transient shortage must not cost every later block its batches in flight: a block that went through without one
+  // gives a batch back (a cap that is too high again only costs another reclaim)
+  if (did)
+    { if (!g_reclaimed_in_block && g_flight_cap < IN_FLIGHT) g_flight_cap += 1;
+      g_reclaimed_in_block = false;
     }
   return nfilt;
 }
@@ -1732,6 +1743,8 @@ void filter_discard()
   for (int y : g_inflight) chain_abandon(g_ring[y]);       // ... and the pile stream's, which the join does not cover
   g_inflight.clear();
   for (int i = 0; i < NRING; i++) { g_ring[i].open = false; g_ring[i].nhits = 0; g_ring[i].npass = 0; }
+  g_flight_cap = IN_FLIGHT;                    // (dmh_reset / a new run: what memory allowed before says nothing any more)
+  g_reclaimed_in_block = false;
 }
 
 // sort and groups for everything the batch holds, then its chain kernels are queued (chain_submit) and the batch
