@@ -4,6 +4,28 @@
 
 namespace dmh {
 
+constexpr int MAX_GAP   = 1000;   // map.c:36
+constexpr int MIN_PIECE = 300;    // map.c:37
+constexpr int HITMIN    = 3;      // map.c:34
+
+constexpr uint32_t NIL = 0xffffffffu;
+
+constexpr uint32_t ST_LIVE    = 1;   // in the tree
+constexpr uint32_t ST_DEAD    = 0;   // removed by the slope rule, or expired
+
+// The best end of a chain tree that scores, as the chain kernels leave it (slots derived from the group's first hit).
+struct ChainSummary
+{ uint32_t group, live;     // live: the end was still in the window when its group finished; LIVE_LATER: k_pack_summaries
+                            //   works group, live and okey out (the per-read kernel of dmh_readsort.h knows neither the
+                            //   group's number nor its pair's last hit)
+  // reporting order inside a group (map.c:1634-1642): live ends by (diagonal, apos) descending, then
+  // expired ends most recent first -- the host sorts on (group, live desc, okey desc)
+  uint64_t okey;
+  int32_t  cost, ab, ae, bb, be;
+  uint32_t end;
+};
+constexpr uint32_t LIVE_LATER = 2;
+
 // map.c:1574-1588: reset the per-read candidate lists and -p counters of the READS block.
 void chain_reset_reads(const DAZZ_DB *ablock);
 
@@ -16,6 +38,11 @@ void chain_reset_reads(const DAZZ_DB *ablock);
 // few of them may be in flight: a pile is a sequential walk of tens of milliseconds on ONE workgroup, and the
 // merge, sorts and chain kernels of the following passes do not depend on it.
 void    chain_submit(MergeResult &R, const DAZZ_DB *ablock);
+// fused route (dmh_readsort.h): the batch's link / chain-end buffers and per-group counters, for the kernels that fill
+// them BEFORE chain_submit (which then leaves them as they are and skips k_chain_simple)
+void    chain_prepare_hits(MergeResult &R, uint32_t **from, ChainSummary **out);
+void    chain_prepare_groups(MergeResult &R, uint32_t **gcount, uint32_t **gbase, uint32_t **gdone);
+bool    chain_simple_wanted(const MergeResult &R);     // k_chain_simple would run for this batch (lane kernel and option on)
 int64_t chain_finish(MergeResult &R, const DAZZ_DB *ablock);
 // ... step by step (three of them, each up to the next number the host needs from the device): true when the batch is
 // finished, *nfilt then has the change in candidates added to it

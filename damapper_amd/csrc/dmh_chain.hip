@@ -19,25 +19,6 @@
 
 namespace dmh {
 
-constexpr int MAX_GAP   = 1000;   // map.c:36
-constexpr int MIN_PIECE = 300;    // map.c:37
-constexpr int HITMIN    = 3;      // map.c:34
-
-constexpr uint32_t NIL = 0xffffffffu;
-
-constexpr uint32_t ST_LIVE    = 1;   // in the tree
-constexpr uint32_t ST_DEAD    = 0;   // removed by the slope rule, or expired
-
-
-struct ChainSummary
-{ uint32_t group, live;     // live: the end was still in the window when its group finished
-  // reporting order inside a group (map.c:1634-1642): live ends by (diagonal, apos) descending, then
-  // expired ends most recent first -- the host sorts on (group, live desc, okey desc)
-  uint64_t okey;
-  int32_t  cost, ab, ae, bb, be;
-  uint32_t end;
-};
-
 struct ChainArgs
 { const uint64_t *ab;          // the sorted hits, one word each: apos in the low half, bpos in the high half (0-based)
   const uint32_t *gstart;
@@ -1284,7 +1265,8 @@ __global__ __launch_bounds__(256) void k_pack_summaries(const ChainSummary *__re
                                                         const uint32_t *__restrict__ cog,
                                                         const uint32_t *__restrict__ ocfirst,
                                                         ChainSummary *__restrict__ packed, uint2 *__restrict__ range,
-                                                        uint64_t *__restrict__ oword)
+                                                        uint64_t *__restrict__ oword,
+                                                        const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ glast)
 { for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x)
     { const uint32_t En = gcount[g];
       if (En == 0) continue;
@@ -1297,7 +1279,17 @@ __global__ __launch_bounds__(256) void k_pack_summaries(const ChainSummary *__re
       const uint2 r = make_uint2(goff[c0], goff[c1]);
       const uint32_t dst = goff[g], mb = gbase[g];
       for (uint32_t e = 0; e < En; e++)
-        { const ChainSummary s = out[mb + e];
+        { ChainSummary s = out[mb + e];
+          if (s.live == LIVE_LATER)
+            { // an end reported by the per-read kernel (dmh_readsort.h, step 5): the chain's last hit; live when it is the
+              // group's last hit and still in the window at the pair's last hit (k_chain_simple's rule)
+              const bool live = (s.end + 1u == gstart[g + 1]) && s.ae >= (int) glast[g] - MAX_GAP;
+              const int  d = s.ae - s.be;
+              s.group = g;
+              s.live  = live ? 1u : 0u;
+              s.okey  = live ? (((uint64_t) ((uint32_t) d + 0x80000000u) << 32) | (uint32_t) s.ae)
+                             : (((uint64_t) (uint32_t) s.ae << 32) | (uint32_t) s.be);
+            }
           packed[dst + e] = s;
           range[dst + e]  = r;
           oword[dst + e]  = order_word(s.live, s.okey);
@@ -1718,6 +1710,8 @@ struct ChainCtx
   // chain_finish: buffers that live from one of its steps to the next, and where it stands
   DevBuf<uint32_t> goff, fresh, jl;
   DevBuf<uint32_t> gdone;            // groups chained by k_chain_simple
+  bool       prefilled = false;      // fused route (dmh_readsort.h): from, out, gcnt, gbase and gdone hold the per-read kernel's
+                                     //   results when chain_submit is called -- not to be cleared, dropped or made again
   FinishState *fin = nullptr;
 };
 
@@ -1798,11 +1792,41 @@ static ChainCtx *g_alloc_ctx = nullptr;      // chain_submit is allocating this 
 bool chain_drop_unused()
 { if (g_alloc_ctx == nullptr) return false;
   ChainCtx &C = *g_alloc_ctx;
-  const bool got = C.cost.p || C.from.p || C.rootof.p || C.best.p || C.bestcost.p || C.livebuf.p || C.state.p || C.tmp.p || C.out.p;
+  bool got = C.cost.p || C.rootof.p || C.best.p || C.bestcost.p || C.livebuf.p || C.state.p || C.tmp.p;
   C.cost.release(); C.bestcost.release();
-  C.from.release(); C.rootof.release(); C.best.release(); C.state.release(); C.tmp.release();
-  C.livebuf.release(); C.out.release(); C.gcnt.release(); C.gbase.release();
+  C.rootof.release(); C.best.release(); C.state.release(); C.tmp.release();
+  C.livebuf.release();
+  if (!C.prefilled)                    // (fused route: these hold results already)
+    { got = got || C.from.p || C.out.p;
+      C.from.release(); C.out.release(); C.gcnt.release(); C.gbase.release();
+    }
   return got;
+}
+
+bool chain_simple_wanted(const MergeResult &R)
+{ static const int env_simple = getenv("DMH_CHAIN_SIMPLE") ? atoi(getenv("DMH_CHAIN_SIMPLE")) : 1;
+  const State &st = S();
+  return R.lane_max > 0 && (st.opt_chain_simple >= 0 ? st.opt_chain_simple : env_simple) != 0;
+}
+
+// Fused route (dmh_readsort.h): the per-read kernel writes links and chain ends, k_cluster_compact the per-group
+// counters -- both before chain_submit.  The buffers are the batch's chain buffers, made here.
+void chain_prepare_hits(MergeResult &R, uint32_t **from, ChainSummary **out)
+{ if (R.cc == nullptr) R.cc = new ChainCtx();
+  ChainCtx &C = *R.cc;
+  C.from.ensure(R.nhits, "chain from");
+  C.out.ensure(R.nhits / HITMIN + 64, "chain summaries");
+  C.prefilled = true;
+  *from = C.from.p;
+  *out  = C.out.p;
+}
+
+void chain_prepare_groups(MergeResult &R, uint32_t **gcount, uint32_t **gbase, uint32_t **gdone)
+{ ChainCtx &C = *R.cc;
+  C.gcnt.ensure((size_t) R.ngroups + 1, "chain ends per group");
+  C.gbase.ensure((size_t) R.ngroups + 1, "first chain end per group");
+  C.gdone.ensure((size_t) R.ngroups + 1, "groups chained without a walk");
+  *gcount = C.gcnt.p; *gbase = C.gbase.p; *gdone = C.gdone.p;
 }
 
 void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
@@ -1842,8 +1866,10 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
               (long long) nhits);
     }
   g_alloc_ctx = nullptr;
+  const bool prefilled = C.prefilled;       // (this batch's; the flag is the ring slot's and is set again by the next fused pass)
+  C.prefilled = false;
   HIP_CHECK(hipMemsetAsync(ctl.p, 0, 8 * sizeof(uint32_t), stream()));
-  HIP_CHECK(hipMemsetAsync(gcnt.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
+  if (!prefilled) HIP_CHECK(hipMemsetAsync(gcnt.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
 
   ChainArgs &A = C.A;
   A.ab = R.sab;
@@ -1919,7 +1945,9 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             static const int env_simple = getenv("DMH_CHAIN_SIMPLE") ? atoi(getenv("DMH_CHAIN_SIMPLE")) : 1;
             static const int env_tail0 = getenv("DMH_CHAIN_TAIL") ? atoi(getenv("DMH_CHAIN_TAIL")) : 3;
             bool simple_on_tail = false;
-            if ((st.opt_chain_simple >= 0 ? st.opt_chain_simple : env_simple) != 0)
+            if (prefilled)
+              A.gdone = C.gdone.p;            // (the plain chains are done: dmh_readsort.h step 5)
+            else if ((st.opt_chain_simple >= 0 ? st.opt_chain_simple : env_simple) != 0)
               { C.gdone.ensure((size_t) R.ngroups + 1, "groups chained without a walk");
                 HIP_CHECK(hipMemsetAsync(C.gdone.p, 0, sizeof(uint32_t) * ((size_t) R.ngroups + 1), stream()));
                 A.gdone = C.gdone.p;
@@ -2141,7 +2169,7 @@ static void finish_step_b(MergeResult &R)
                        (const uint32_t *) gcnt.p, (const uint32_t *) goff.p,
                        R.clustered ? (const uint32_t *) R.cog.p : (const uint32_t *) nullptr,
                        R.clustered ? (const uint32_t *) R.ocfirst.p : (const uint32_t *) nullptr, packed.p, prange.p,
-                       oword.p);
+                       oword.p, (const uint32_t *) R.gstart.p, R.clustered ? (const uint32_t *) R.glast.p : (const uint32_t *) nullptr);
     hipLaunchKernelGGL(k_order_summaries, dim3(ceil_div(nsum, 256)), dim3(256), 0, stream(),
                        (const ChainSummary *) packed.p, (const uint2 *) prange.p, (const uint64_t *) oword.p, nsum,
                        (const uint64_t *) R.gkey.p, ord.p);

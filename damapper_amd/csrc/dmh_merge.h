@@ -6,6 +6,11 @@ namespace dmh {
 
 constexpr int MAXPASS = 32;        // Match_Filter passes one batch can hold (5 pass bits in the seed key)
 
+// A row of the merge as k_row_list leaves it: partners (RW_MB bits; < MAXGRAM under the -M limit rule) | apos << RW_MB |
+// first partner's index in the REF index << 32
+constexpr int      RW_MB = 14, RW_AP = 18;
+constexpr uint64_t RW_MBMASK = (1ull << RW_MB) - 1ull, RW_APMASK = (1ull << RW_AP) - 1ull;
+
 // Seed hits on their way from the merge to the chain kernels.  With batching on, consecutive Match_Filter calls of
 // a READS block only APPEND their hits (the pass number becomes part of the sort key, between aread and bread);
 // the batch is sorted, chained and put through the domination rule in one go when it is closed (filter_flush:
@@ -39,6 +44,13 @@ struct MergeResult
   bool     clustered = false;
   bool     word = false;                       // cluster mode with one word per hit through the seed sort (no vals)
   bool     read_sorted = false;                // ... and the hits written read by read, to be ordered per read in LDS
+  bool     fused = false;                      // ... or not written at all: the per-read kernel expands the merge's rows itself,
+                                               //   orders the hits and scores the plain chains (dmh_readsort.h, round 4)
+  const uint64_t *f_rows = nullptr;            //   the pass's row table, the READS index's read offsets, the REF index's
+  const int64_t  *f_rowbase = nullptr;         //   positions: valid from merge_pass to the close that follows it
+  const uint32_t *f_bvals = nullptr;
+  int             f_bposbits = 0;
+  DevBuf<uint32_t> rs_lcnt;                    //   per cluster of a read: chain ends reported | done << 31
   DevBuf<uint64_t> gkey;                       // per group: (aread << bbits) | bread
   DevBuf<uint32_t> cog, ocfirst, glast;        // cluster mode: pair number of each cluster, first cluster of each pair
                                                // (+ end), and per cluster its pair's largest apos + 1

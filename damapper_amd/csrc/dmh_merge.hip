@@ -576,6 +576,69 @@ __global__ void k_row_place(const MergeEntry *__restrict__ entries, uint32_t n, 
     }
 }
 
+// Fused route (dmh_readsort.h): the rows of the merge listed PER READ instead of expanded.  Row (entry, a) -- READ k-mer a
+// of a matched run with its mb partners -- becomes one 8-byte record in its read's stretch of the row table: the stretch of
+// read r starts at boff[r] (a read has fewer rows than bases, so the stretches cannot meet), the place inside it comes
+// from an atomic count of the read's rows, and rcount[r] sums the read's hits as k_row_place does.  One wavefront per
+// tile of k_merge_match, straight from the tiles' own windows of the entry list (toff = the scanned tile counts), so
+// neither the compact entry list nor the entries' offsets are needed: k_merge_gather, k_entry_sizes, the scan over the
+// entries, k_tile_first and k_merge_expand_tiled of round 3's route do not run.
+__global__ __launch_bounds__(256) void k_row_list(const MergeEntry *__restrict__ tile_entries,
+                                                  const uint32_t *__restrict__ toff, int64_t ntiles, uint32_t total,
+                                                  int64_t limit, const uint32_t *__restrict__ avals, int aposbits,
+                                                  const int64_t *__restrict__ boff, uint32_t *__restrict__ rcount,
+                                                  uint32_t *__restrict__ nrow, uint64_t *__restrict__ rows)
+{ const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= ntiles) return;
+  const uint32_t b = toff[wave];
+  const uint32_t e = (wave + 1 < ntiles) ? toff[wave + 1] : total;
+  const MergeEntry *src = tile_entries + (size_t) wave * MG_TILE;
+  const uint32_t apm = (1u << aposbits) - 1u;
+  for (uint32_t x = lane; x < e - b; x += 64)
+    { const MergeEntry en = src[x];
+      const unsigned long long ct = (unsigned long long) en.ma * en.mb;
+      if (ct == 0 || (int64_t) ct >= limit) continue;          // (map.c:978-979; an open look-up without partners has mb = 0)
+      for (uint32_t a = 0; a < en.ma; a++)
+        { const uint32_t q  = avals[en.a0 + a];
+          const uint32_t ar = q >> aposbits, ap = q & apm;
+          const uint32_t at = atomicAdd(&nrow[ar], 1u);
+          atomicAdd(&rcount[ar], en.mb);
+          rows[boff[ar] + at] = ((uint64_t) en.b0 << 32) | ((uint64_t) ap << RW_MB) | (uint64_t) en.mb;
+        }
+    }
+}
+
+// ... and the few reads whose hits do not fit the LDS of a workgroup (k_read_sort_big orders them through global
+// memory): their rows expanded into words at the read's segment, one workgroup per read of the list.
+__global__ __launch_bounds__(256) void k_rows_expand_big(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count,
+                                                         const uint64_t *__restrict__ rows, const int64_t *__restrict__ rowbase,
+                                                         const uint32_t *__restrict__ nrow, const uint32_t *__restrict__ rstart,
+                                                         const uint32_t *__restrict__ bvals, int bposbits, int pbits, int qbits,
+                                                         int bshift, uint64_t *__restrict__ hkeys)
+{ __shared__ uint32_t ws[4];
+  const uint32_t bpm = (1u << bposbits) - 1u;
+  for (uint32_t lb = blockIdx.x; lb < *count; lb += gridDim.x)
+    { const uint32_t r = list[lb], nr = nrow[r], s0 = rstart[r];
+      const uint64_t *rw = rows + rowbase[r];
+      uint32_t done = 0;                                        // hits of the rows before this chunk
+      for (uint32_t x0 = 0; x0 < nr; x0 += 256)
+        { const uint32_t x = x0 + threadIdx.x;
+          const uint64_t rc = (x < nr) ? rw[x] : 0ull;
+          const uint32_t mb = (uint32_t) (rc & RW_MBMASK);
+          uint32_t all;
+          const uint32_t o = done + block_excl_scan(mb, ws, &all);
+          const uint64_t lo = (uint64_t) r << bshift | ((rc >> RW_MB) & RW_APMASK);
+          for (uint32_t t = 0; t < mb; t++)
+            { const uint32_t q = bvals[(uint32_t) (rc >> 32) + t];
+              hkeys[s0 + o + t] = lo | ((uint64_t) (q >> bposbits) << (pbits + qbits)) | ((uint64_t) (q & bpm) << pbits);
+            }
+          done += all;
+        }
+      __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 //  Group boundaries of the sorted hits: one group per (aread, bread)
 // ---------------------------------------------------------------------------------------
@@ -1082,6 +1145,8 @@ static bool lds_atomics_ordered()
 }
 
 // per-read route: segment starts of the pass being collected (main stream only; a dense pass is closed at once)
+static DevBuf<uint64_t> g_rows;          // fused route: the row table of the pass being collected (read by its per-read kernel,
+                                         //   which is queued before the next pass lists its rows)
 static DevBuf<uint32_t> g_rowdst;        // (the other per-read-sort buffers belong to the batch: MergeResult::rs_*, its tail runs
                                          //  on a stream of its own next to the following pass)
 static uint32_t g_known[5] = {0, 0, 0, 0, 0};     // clusters, clusters for the radix sort, big groups, piles, hits in piles (k_read_sort)
@@ -1256,10 +1321,16 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     copy_d2h(hsum, sums, sizeof(unsigned long long) * 3, 1);                       // the limit rule next
   }
   nent = (unsigned int) (hsum[2] & 0xffffffffull);
-  entries.ensure((size_t) nent + 64, "matched runs");
-  if (nent > 0)
-    hipLaunchKernelGGL(k_merge_gather, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(),
-                       (const MergeEntry *) tentries.p, (const uint32_t *) tcount.p, ntiles, nent, entries.p);
+  // the compact entry list, made when somebody needs it (the fused per-read route reads the tiles' own windows)
+  bool gathered = false;
+  auto gather_entries = [&]()
+  { if (gathered) return;
+    gathered = true;
+    entries.ensure((size_t) nent + 64, "matched runs");
+    if (nent > 0)
+      hipLaunchKernelGGL(k_merge_gather, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(),
+                         (const MergeEntry *) tentries.p, (const uint32_t *) tcount.p, ntiles, nent, entries.p);
+  };
 
   // --- limit (map.c:2992-3055)
   int64_t limit, nhits;
@@ -1280,6 +1351,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
         }
       else
         { std::vector<unsigned long long> histo(MAXGRAM + 1, 0);
+          gather_entries();
           HIP_CHECK(hipMemsetAsync(gram.p, 0, sizeof(unsigned long long) * (MAXGRAM + 1), stream()));
           if (nent > 0)
             hipLaunchKernelGGL(k_entry_hist, dim3(ceil_div(nent, 256)), dim3(256), 0, stream(),
@@ -1389,16 +1461,75 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
                        //  that force a route are obeyed)
                        (st.opt_read_sort > 0 || nhits <= (int64_t) ablock->nreads * (RS_T2 * RS_E / 2));
   R.read_sorted = false;
+  R.fused = false;
+  // ... and FUSED (round 4, dmh_readsort.h): the rows of the merge are listed per read, and the per-read kernel expands,
+  // orders and -- plain chains -- scores them without a trip of the hits through HBM.  Needs what the row records
+  // assume: partner counts below 2^14 (the -M limit rule's MAXGRAM), apos in 18 bits, (read, rpos) words in both indices;
+  // "fuse" test option / DMH_FUSE = 0: round 3's route
+  static const int env_fuse = getenv("DMH_FUSE") ? atoi(getenv("DMH_FUSE")) : 1;
+  static const bool env_dc0 = getenv("DMH_DEFER_CLOSE") != nullptr && atoi(getenv("DMH_DEFER_CLOSE")) == 1;
+  const bool fuse = by_read && (st.opt_fuse >= 0 ? st.opt_fuse != 0 : env_fuse != 0) && limit <= (int64_t) MAXGRAM &&
+                    R.pbits <= RW_AP && A.posbits > 0 && Bx.posbits > 0 && !(env_dc0 || st.opt_defer_close > 0) &&
+                    A.L + 1 < ((int64_t) 1 << 32);
+  if (fuse)
+    { StageTimer tm("merge_rows", 16.0 * nhits);
+      const int nr = ablock->nreads;
+      R.rs_start.ensure(2 * ((size_t) nr + 2), "first hit of each read, rows of each read");
+      R.rs_stats.ensure(8, "read segment statistics");
+      g_rows.ensure((size_t) A.L + 2, "rows of the merge, read by read");
+      uint32_t *nrow = R.rs_start.p + nr + 2;
+      HIP_CHECK(hipMemsetAsync(R.rs_start.p, 0, sizeof(uint32_t) * 2 * ((size_t) nr + 2), stream()));
+      HIP_CHECK(hipMemsetAsync(R.rs_stats.p, 0, sizeof(uint32_t) * 8, stream()));
+      hipLaunchKernelGGL(k_row_list, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(), (const MergeEntry *) tentries.p,
+                         (const uint32_t *) tcount.p, ntiles, nent, limit, (const uint32_t *) A.vals, A.posbits,
+                         (const int64_t *) A.d_boff, R.rs_start.p, nrow, g_rows.p);
+      exclusive_scan_u32(R.rs_start.p, nr, st.sort.bsum, R.rs_start.p + nr);
+      R.rs_lists.ensure(4 * (size_t) nr + 16, "reads by segment size");
+      g_rs_small = report_in_flight() || st.opt_read_sort == 6 || st.opt_read_sort == 7;      // (see the unfused route below)
+      const uint32_t lim2 = (st.opt_read_sort == 3 || st.opt_read_sort == 7) ? 512u
+                            : (g_rs_small ? (uint32_t) RS_T1 * RS_E : (uint32_t) RS_T2 * RS_E);
+      const uint32_t lim0 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T0 * RS_E);
+      const uint32_t lim1 = std::min(lim2, (st.opt_read_sort == 2) ? 128u : (uint32_t) RS_T1 * RS_E);
+      hipLaunchKernelGGL(k_read_classes, dim3(ceil_div(nr, 256)), dim3(256), 0, stream(), (const uint32_t *) R.rs_start.p, nr,
+                         lim0, lim1, lim2, R.rs_lists.p, R.rs_stats.p);
+      g_rlim = lim2;
+      g_rgrid[0] = (uint32_t) nr;
+      g_rgrid[1] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim0 + 1) + 1);
+      g_rgrid[2] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim1 + 1) + 1);
+      g_rgrid[3] = (uint32_t) std::min<int64_t>(nr, nhits / ((int64_t) lim2 + 1) + 1);
+      // the reads beyond the LDS kernels (a tandem array's: one or two per block) get their words the old way
+      hipLaunchKernelGGL(k_rows_expand_big, dim3(std::min<uint32_t>(g_rgrid[3], 256u)), dim3(256), 0, stream(),
+                         (const uint32_t *) (R.rs_lists.p + 3 * (size_t) nr), (const uint32_t *) (R.rs_stats.p + 4),
+                         (const uint64_t *) g_rows.p, (const int64_t *) A.d_boff, (const uint32_t *) nrow,
+                         (const uint32_t *) R.rs_start.p, (const uint32_t *) Bx.vals, Bx.posbits, R.pbits, R.qbits, bshift,
+                         R.keys.p);
+      HIP_CHECK(hipGetLastError());
+      finish_tick_if_due(nfilt);
+      static const bool want = getenv("DMH_STATS") != nullptr;
+      if (want)
+        { HostTimer hw("wait_read_classes");
+          copy_d2h(g_rcnt, R.rs_stats.p, 5 * sizeof(uint32_t), 1);
+        }
+      else
+        { for (int q = 0; q < 4; q++) g_rcnt[q == 3 ? 4 : q] = g_rgrid[q];
+          g_rcnt[2] = std::min(g_rcnt[2], 2048u);
+        }
+      R.read_sorted = true;
+      R.fused = true;
+      R.f_rows = g_rows.p; R.f_rowbase = A.d_boff; R.f_bvals = Bx.vals; R.f_bposbits = Bx.posbits;
+    }
 
   // --- expand the entries under the limit into hits (map.c:3095-3099), behind the batch's earlier passes
   static DevBuf<uint32_t> esz, eoff, ebig;
-  esz.ensure((size_t) nent + 1, "entry sizes");
-  eoff.ensure((size_t) nent + 2, "entry offsets");
-  ebig.ensure((size_t) nent + 1, "big entries");
   uint32_t total = 0, nbig = 0;
   uint64_t *hk = R.keys.p + R.nhits;
   uint32_t *hv = R.vals.p + R.nhits;
+  if (!fuse)
   { StageTimer tm("merge_emit", 16.0 * nhits);
+    gather_entries();
+    esz.ensure((size_t) nent + 1, "entry sizes");
+    eoff.ensure((size_t) nent + 2, "entry offsets");
+    ebig.ensure((size_t) nent + 1, "big entries");
     int nb = ceil_div(nent, 256);
     hipLaunchKernelGGL(k_entry_sizes, dim3(nb), dim3(256), 0, stream(), (const MergeEntry *) entries.p, nent, limit, esz.p);
     exclusive_scan_u32((const uint32_t *) esz.p, eoff.p, nent, st.sort.bsum, eoff.p + nent);
@@ -1643,7 +1774,7 @@ static void release_idle_slots(bool &got)
       R.gstart.release(); R.gkey.release(); R.cog.release(); R.ocfirst.release(); R.glast.release();
       R.biglist.release(); R.pilelist.release(); R.medlist.release();
       R.rs_start.release(); R.rs_stats.release(); R.rs_lists.release(); R.rs_ncl.release(); R.rs_lcl.release();
-      R.rs_wcnt.release(); R.rs_wlist[0].release(); R.rs_wlist[1].release(); R.pmax.release();
+      R.rs_wcnt.release(); R.rs_wlist[0].release(); R.rs_wlist[1].release(); R.pmax.release(); R.rs_lcnt.release();
       chain_release(R);
     }
 }
@@ -1859,9 +1990,32 @@ static void close_batch(MergeResult &R, int phase)
           RA.medium = (uint32_t) CS_MEDIUM;
           RA.big_min = R.small_hi;
           RA.pile_min = R.pile_min > 0 ? R.pile_min : 0xffffffffu;
+          RA.rows = nullptr; RA.rowbase = nullptr; RA.nrow = nullptr; RA.bvals = nullptr; RA.bposbits = 0;
+          RA.from = nullptr; RA.sums = nullptr; RA.lcnt = nullptr; RA.K = 0; RA.hithr = 0; RA.simple_max = 0;
+          if (R.fused)
+            { RA.rows = R.f_rows; RA.rowbase = R.f_rowbase; RA.nrow = R.rs_start.p + nr + 2;
+              RA.bvals = R.f_bvals; RA.bposbits = R.f_bposbits;
+              // plain chains are scored by the same kernel when k_chain_simple would run for this batch: the batch's link
+              // and chain-end buffers are made now, the per-cluster results go through lcnt to k_cluster_compact
+              chain_prepare_hits(R, &RA.from, &RA.sums);
+              if (chain_simple_wanted(R))
+                { R.rs_lcnt.ensure((size_t) nhits + 1, "chain ends per cluster of a read");
+                  RA.lcnt = R.rs_lcnt.p;
+                  RA.K = st.params.Kmer; RA.hithr = HITMIN * st.params.Kmer;
+                  RA.simple_max = R.lane_max;
+                }
+            }
           static bool attr = false;
           if (!attr)
             { attr = true;
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_T1>()));
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_T1>()));
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_T2>()));
+              HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int) read_sort_lds<RS_T2>()));
               HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int) read_sort_lds<RS_T1>()));
               HIP_CHECK(hipFuncSetAttribute((const void *) k_read_sort<RS_T1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1903,19 +2057,25 @@ static void close_batch(MergeResult &R, int phase)
               { hipStream_t q = fork ? side[0] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[0] = true; }
                 RA.list = R.rs_lists.p + 2 * (size_t) nr; RA.count = R.rs_stats.p + 2;
-                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
+                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
+                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T2, false, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
+                else if (k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T2, false>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
               }
             if (g_rcnt[1] > 0)
               { hipStream_t q = fork ? side[1] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[1] = true; }
                 RA.list = R.rs_lists.p + (size_t) nr; RA.count = R.rs_stats.p + 1;
-                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
+                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
+                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T1, false, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
+                else if (k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T1, false>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
               }
             if (g_rcnt[0] > 0)
               { RA.list = R.rs_lists.p; RA.count = R.rs_stats.p;
-                if (k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
+                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
+                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T0, false, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
+                else if (k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T0, false>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
               }
             for (int i = 0; i < 2; i++)
@@ -2041,10 +2201,13 @@ static void close_batch(MergeResult &R, int phase)
           R.gkey.ensure((size_t) ncl + 1, "cluster keys");
           R.rs_wlist[0].ensure((size_t) ncl + 64, "clusters for the workgroup sort");
           R.rs_wlist[1].ensure((size_t) ncl + 64, "clusters for the radix sort");
+          uint32_t *f_gcount = nullptr, *f_gbase = nullptr, *f_gdone = nullptr;
+          if (R.fused) chain_prepare_groups(R, &f_gcount, &f_gbase, &f_gdone);
           hipLaunchKernelGGL(k_cluster_compact, dim3(ceil_div((int64_t) nr * 64, 256)), dim3(256), 0, stream(),
                              (const uint64_t *) lcl.p, (const uint32_t *) R.rs_start.p, (const uint32_t *) rncl.p, nr, R.bbits,
                              (uint32_t) nhits, R.gstart.p, R.gkey.p, (uint32_t) RS_IN, (uint32_t) CS_MEDIUM,
-                             R.rs_wlist[0].p, R.rs_wlist[1].p, R.rs_wcnt.p);
+                             R.rs_wlist[0].p, R.rs_wlist[1].p, R.rs_wcnt.p,
+                             (const uint32_t *) ((R.fused && chain_simple_wanted(R)) ? R.rs_lcnt.p : nullptr), f_gcount, f_gbase, f_gdone);
           std::swap(k0, k1);
         }
       else if (R.word)

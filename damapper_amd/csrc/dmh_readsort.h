@@ -25,6 +25,21 @@
 // The order of the rows inside a segment as the merge leaves it is arbitrary (atomic placement), which is harmless:
 // the hits of a read are distinct in (bread, bpos, apos).  HBM traffic per hit: 8 B written by the merge, 8 B read and
 // 8 B written here.
+//
+// FUSED (round 4; k_read_sort<T, K32, true>): the hits of a read never exist in HBM before they are in chain order.
+//   0. the workgroup takes the read's ROWS of the merge -- one 8-byte record {first REF partner, apos, partners} per READ
+//      k-mer with hits, left in the read's own stretch of a row table by k_row_list (dmh_merge.hip) -- into LDS, turns
+//      the partner counts into offsets (a scan), marks the first slot of every row in a bit map, and every thread makes
+//      the words of ITS slots in registers: row = bits set at or below the slot (one popcount on a word the whole
+//      wavefront reads), partner = slot - offset, one 4-byte gather from the REF index's position array
+//      (map.c:984-994: the pairs of a row in REF-index order).  Steps 1-4 as above.
+//   5. the words in final order go back to LDS and the groups that are PLAIN CHAINS are scored where they lie -- what
+//      k_chain_simple (dmh_chain.hip) does from HBM: every hit a break or a step, scores a segmented prefix sum
+//      (map.c:1781-1872) -- by a 16-lane group per cluster; links and chain ends go out, the cluster's record says how
+//      many ends it reported and that it is done, and k_cluster_compact hands that to the chain stage (gcount / gbase /
+//      gdone), which walks what is left.
+// HBM traffic per hit: 4 B gathered (REF position), 8 + 4 B written (word, link).  k_merge_expand_tiled, k_row_place,
+// k_read_sort and k_chain_simple of round 3 are this one kernel.
 #pragma once
 
 namespace dmh {
@@ -53,13 +68,26 @@ struct ReadSortArgs
   // big_min .. pile_min - 1 hits, [5] += piles, [6] += hits in piles (the chain kernels' size classes)
   uint32_t       *counts;
   uint32_t        medium, big_min, pile_min;
+  // fused route, front: the rows of the merge instead of expanded words
+  const uint64_t *rows;          // row records (RW_*), read r's at rowbase[r] + [0, nrow[r])
+  const int64_t  *rowbase;       //   (the READS block's read offsets: a read has fewer rows than bases)
+  const uint32_t *nrow;
+  const uint32_t *bvals;         // the REF index's positions, (contig << bposbits) | bpos
+  int             bposbits;
+  // fused route, back: plain chains scored in place (simple_max = 0: not at all)
+  uint32_t       *from;          // per hit: predecessor (NIL for a chain's first hit)
+  ChainSummary   *sums;          // chain ends, at slot (first hit of the cluster + HITMIN - 1) / HITMIN onwards
+  uint32_t       *lcnt;          // per cluster, at rstart[r] + j: chain ends reported | done << 31 (0: left to the chain kernels)
+  int             K, hithr;
+  uint32_t        simple_max;    // clusters of up to this many hits are tried
 };
+
 
 template <int T>
 __device__ __forceinline__ uint32_t block_excl_scan_t(uint32_t v, uint32_t *ws, uint32_t *total)
 { constexpr int W = T / 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t x = wave_incl_scan(v, lane);
+  const uint32_t x = wave_incl_scan_dpp(v);
   if (lane == 63) ws[w] = x;
   __syncthreads();
   uint32_t wbase = 0, tot = 0;
@@ -120,7 +148,13 @@ __global__ __launch_bounds__(256) void k_lds_order_test(uint32_t seed, uint32_t 
   if (nbad) atomicAdd(bad, nbad);
 }
 
-template <int T, bool K32>
+template <int T> constexpr size_t read_sort_lds_words()
+{ return ((sizeof(uint64_t) * (size_t) T * RS_E + sizeof(uint16_t) * (size_t) (T / 64) * (1 << RS_DB)
+           + sizeof(uint64_t) * (T * RS_E / 64 + 2) + sizeof(uint32_t) * (T * RS_E / 32 + 2)
+           + sizeof(uint16_t) * (T * RS_E / 64 + 2) + 64) + 7) / 8;
+}
+
+template <int T, bool K32, bool FUSE = false>
 __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
 { constexpr int W = T / 64, D = 1 << RS_DB, E = RS_E;
   extern __shared__ __attribute__((aligned(16))) uint64_t rs_lds[];
@@ -129,7 +163,10 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   uint64_t *flagw = (uint64_t *) (wh + (size_t) W * D);       // cluster-start bits, one word per 64 hits (+ sentinel)
   uint32_t *mbits = (uint32_t *) (flagw + (T * E / 64 + 2));  // per cluster: spans buckets (T * E / 32 + 2 words)
   uint16_t *wpref = (uint16_t *) (mbits + (T * E / 32 + 2));  // starts before each flag word
+  // (fused route, step 5) per cluster: not a sequence of plain chains / not to be tried
+  uint32_t *cbad  = (uint32_t *) (rs_lds + read_sort_lds_words<T>());
   __shared__ uint32_t ws[W];
+  __shared__ uint32_t ws2[W];
 
   // (the grid is sized for the most reads the class can hold -- at most 2048 of the largest workgroups, which then take
   //  several reads each)
@@ -150,11 +187,85 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   const uint64_t lt = (1ull << lane) - 1ull;
 
   uint64_t key[E];
+  if (!FUSE)
+    {
 #pragma unroll
-  for (int j = 0; j < E; j++)
-    { const uint32_t i = wbase + 64u * j + lane;
-      const uint64_t v = __builtin_nontemporal_load(A.in + s0 + (i < n ? i : n - 1));
-      key[j] = (i < n) ? v : ~0ull;
+      for (int j = 0; j < E; j++)
+        { const uint32_t i = wbase + 64u * j + lane;
+          const uint64_t v = __builtin_nontemporal_load(A.in + s0 + (i < n ? i : n - 1));
+          key[j] = (i < n) ? v : ~0ull;
+        }
+    }
+  else
+    { // ---- 0. the read's rows -> LDS, partner counts -> offsets, first slot of every row -> a bit; then every slot's word
+      const uint32_t  nr = A.nrow[r];                          // 0 < nr <= n
+      const uint64_t *rw = A.rows + A.rowbase[r];
+      uint64_t *rflag = flagw;                                 // (the cluster flags' place: free until step 2)
+      uint16_t *rpref = wpref;
+      const uint32_t nfw = n / 64 + 1;
+      for (uint32_t x = tid; x < nfw; x += T) rflag[x] = 0;
+      const uint32_t rrounds = (nr + 64 * W - 1) / (64 * W);   // <= E
+      const uint32_t rbase   = (uint32_t) w * rrounds * 64;    // the wavefront's rows: [rbase, rbase + 64 rrounds)
+      uint64_t rec[E];
+      uint32_t off[E];
+      uint32_t carry = 0;
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        { rec[j] = 0; off[j] = 0;
+          if ((uint32_t) j < rrounds)
+            { const uint32_t x = rbase + 64u * j + lane;
+              rec[j] = (x < nr) ? __builtin_nontemporal_load(rw + x) : 0ull;
+              const uint32_t mb  = (uint32_t) (rec[j] & RW_MBMASK);
+              const uint32_t inc = wave_incl_scan_dpp(mb);
+              off[j] = carry + inc - mb;
+              carry += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+            }
+        }
+      if (lane == 0) ws[w] = carry;
+      __syncthreads();
+      uint32_t wv0 = 0;
+#pragma unroll
+      for (int v = 0; v < W; v++)
+        if (v < w) wv0 += ws[v];
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        if ((uint32_t) j < rrounds)
+          { const uint32_t x = rbase + 64u * j + lane;
+            if (x < nr)
+              { const uint32_t o = wv0 + off[j];                // < n <= T * E <= 2^14
+                buf[x] = (rec[j] & ~RW_MBMASK) | (uint64_t) o;
+                atomicOr((unsigned long long *) &rflag[o >> 6], 1ull << (o & 63u));
+              }
+          }
+      __syncthreads();
+      { uint32_t c = ((uint32_t) tid < nfw) ? (uint32_t) __popcll(rflag[tid]) : 0u, all;
+        const uint32_t e = block_excl_scan_t<T>(c, ws, &all);
+        if ((uint32_t) tid < nfw) rpref[tid] = (uint16_t) e;
+      }
+      __syncthreads();
+      uint32_t q[E];
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        { key[j] = 0; q[j] = 0;
+          if ((uint32_t) j < rounds)                             // (uniform)
+            { // (unconditional loads from clamped slots: a guarded load is a branch with a wait at its join)
+              const uint32_t i = wbase + 64u * j + lane, ic = (i < n) ? i : n - 1;
+              const uint32_t wi = ic >> 6, bi = ic & 63u;
+              const uint32_t row = (uint32_t) rpref[wi] + (uint32_t) __popcll(rflag[wi] & (~0ull >> (63u - bi))) - 1u;
+              const uint64_t rc = buf[row];
+              key[j] = (rc >> RW_MB) & RW_APMASK;                // apos for now
+              q[j]   = A.bvals[(uint32_t) (rc >> 32) + (ic - (uint32_t) (rc & RW_MBMASK))];
+            }
+        }
+      const uint32_t bpm = (1u << A.bposbits) - 1u;
+      const int      top = A.pbits + A.qbits;
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        { const uint32_t i = wbase + 64u * j + lane;
+          const uint64_t v = ((uint64_t) (q[j] >> A.bposbits) << top) | ((uint64_t) (q[j] & bpm) << A.pbits) | key[j];
+          key[j] = (i < n) ? v : ~0ull;
+        }
+      __syncthreads();                                           // (the rows have been read: buf and the flag words are free)
     }
 #ifdef DMH_RS_PROFILE
   __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
@@ -282,13 +393,19 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   const uint32_t nw = n / 64 + 1;                              // flag words, the sentinel bit n included
   uint32_t chg = 0;                                            // bit j: my word of round j opens a new bucket inside its cluster
   for (int x = tid; x < (int) (n / 32 + 1); x += T) mbits[x] = 0;
+  if (FUSE)
+    for (int x = tid; x < (int) (n / 32 + 1); x += T) cbad[x] = 0;
 #pragma unroll
   for (int j = 0; j < E; j++)
     if ((uint32_t) j < rounds)
       { const uint32_t i = wbase + 64u * j + lane;
         bool f = false;
+        // (the predecessor: the lane below, or -- lane 0 -- the last lane of the wavefront's round before; the first
+        //  round's comes from the wavefront before, through LDS)
+        uint64_t pk = wave_from_below(key[j]);
+        if (lane == 0) pk = (j == 0) ? buf[wbase > 0 && wbase - 1 < n ? wbase - 1 : 0] : wave_lane_u64(key[j > 0 ? j - 1 : 0], 63);
         if (i < n)
-          { const uint64_t pv = (i > 0) ? buf[i - 1] >> A.pbits : 0, cv = key[j] >> A.pbits;
+          { const uint64_t pv = (i > 0) ? pk >> A.pbits : 0, cv = key[j] >> A.pbits;
             f = (i == 0) || cluster_start(pv, cv, A.qbits, A.cb);
             if (!f && (pv >> A.cb) != (cv >> A.cb)) chg |= 1u << j;
           }
@@ -357,6 +474,8 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
                   uint32_t ww = wi;
                   while (m == 0) { ww += 1; m = flagw[ww]; }
                   const uint32_t size = ww * 64 + (uint32_t) __ffsll((long long) m) - 1 - i;
+                  // (step 5 leaves alone: a cluster that is not in chain order when this kernel is done with it, or too large)
+                  if (FUSE && ((multi && size > (uint32_t) RS_IN) || size > A.simple_max)) atomicOr(&cbad[c >> 5], 1u << (c & 31u));
                   if (size >= A.big_min)
                     { if (size >= A.pile_min) { atomicAdd(A.counts + 5, 1u); atomicAdd(A.counts + 6, size); }
                       else atomicAdd(A.counts + 4, 1u);
@@ -435,22 +554,188 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
             if (m) dst = s + rank;
           }
         if (i < n) A.out[s0 + dst] = key[j];
+        if (FUSE) se[j] = dst;
       }
 #ifdef DMH_RS_PROFILE
   __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
 #endif
   RSPROF_LAP(6);
+
+  // ---- 5. plain chains scored where they lie (k_chain_simple's rules, dmh_chain.hip; map.c:1781-1872) -- hit by hit, not
+  // cluster by cluster: a position is a BREAK (first hit of its cluster, or more than MAX_GAP behind its predecessor in A)
+  // or must be a step (the predecessor is its only candidate and is removed by it), else its cluster is left to the chain
+  // kernels ("bad", a bit per cluster).  Chains are the runs between breaks: the score of a chain's end is the difference of
+  // two prefix sums of the per-hit increments (one scan over the read; the sums at the chain ends are kept, by chain number
+  // = breaks at or below the position), and the ends that score are counted per cluster in a bit map.
+  if (FUSE && A.simple_max > 0)
+    { __syncthreads();                                           // (the ranking above has read buf for the last time)
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        if ((uint32_t) j < rounds)
+          { const uint32_t i = wbase + 64u * j + lane;
+            if (i < n) buf[se[j]] = key[j];
+          }
+      uint64_t *bkw    = (uint64_t *) mbits;                     // breaks, a bit per position (+ the sentinel n)
+      uint16_t *bkpref = wh;                                     // breaks before each word of them
+      uint32_t *pe     = (uint32_t *) (wh + (T * E / 64 + 2));   // prefix sum at every chain's end, by chain number
+      constexpr uint32_t PECAP = (uint32_t) ((W * D * 2 - 2 * (T * E / 64 + 2)) / 4);
+      __syncthreads();
+      const int K = A.K;
+      uint32_t P[E];
+      uint32_t endm = 0, carry = 0;
+      // the wavefront's words in registers (its positions are consecutive: the neighbours of a position are the lanes
+      // beside it, the last lane of the round before, the first of the round after -- one LDS read per position)
+      uint64_t wq[E];
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        { wq[j] = 0;
+          if ((uint32_t) j < rounds)
+            { const uint32_t i = wbase + 64u * j + lane;
+              wq[j] = buf[i < n ? i : n - 1];
+            }
+        }
+      const uint32_t wend = wbase + 64u * rounds;                // the position behind the wavefront's last
+      uint64_t below = buf[wbase > 0 ? (wbase - 1 < n ? wbase - 1 : n - 1) : 0];
+      const uint64_t after = buf[wend < n ? wend : n - 1];
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        { P[j] = 0;
+          if ((uint32_t) j < rounds)
+            { const uint32_t i = wbase + 64u * j + lane, wi = i >> 6, bi = i & 63u;
+              const bool in = i < n;
+              const uint64_t wv = wq[j];
+              uint64_t pw = wave_from_below(wv), xw = wave_from_above(wv);
+              if (lane == 0) pw = below;
+              below = wave_lane_u64(wv, 63);
+              { const uint64_t nx0 = ((uint32_t) (j + 1) < rounds && j + 1 < E) ? wave_lane_u64(wq[j + 1 < E ? j + 1 : j], 0) : after;
+                if (lane == 63) xw = nx0;
+              }
+              const uint64_t fw = flagw[wi < nw ? wi : 0];       // (bit n is the sentinel: a start)
+              const bool cs  = in && ((fw >> bi) & 1ull);
+              const bool csn = in && (bi < 63 ? ((fw >> (bi + 1)) & 1ull) != 0 : (flagw[wi + 1] & 1ull) != 0);
+              const int a = (int) (uint32_t) wv + 1, b = (int) (wv >> 32) + 1, pa = (int) (uint32_t) pw + 1, pb = (int) (pw >> 32) + 1;
+              const int d = a - b, pd = pa - pb;
+              const bool brk = in && (cs || pa < a - MAX_GAP);
+              bool bad = false;
+              { const bool cand = (pd > d) ? (pb >= b - MAX_GAP) : (pb <= b);
+                int dd = pd - d;
+                if (dd < 0) dd = -dd;
+                bad = in && !brk && !(cand && 5 * dd <= a - pa);
+              }
+              const int adv = (pd > d) ? a - pa : b - pb;          // left neighbour: advance in A; right: in B
+              const uint32_t inc = !in ? 0u : (uint32_t) (brk ? K : (adv >= K ? K : adv));
+              const int  na  = (int) (uint32_t) xw + 1;
+              const bool end = in && (csn || a < na - MAX_GAP);
+              if (end) endm |= 1u << j;
+              if (in) A.from[s0 + i] = brk ? NIL : s0 + i - 1;
+              const uint64_t bm = __ballot(brk || i == n);
+              if (lane == 0 && wi < nw) bkw[wi] = bm;
+              if (bad)
+                { const uint32_t c = (uint32_t) wpref[wi] + (uint32_t) __popcll(fw & (~0ull >> (63u - bi))) - 1u;
+                  atomicOr(&cbad[c >> 5], 1u << (c & 31u));
+                }
+              const uint32_t sc = wave_incl_scan_dpp(inc);
+              P[j] = carry + sc;
+              carry += (uint32_t) __builtin_amdgcn_readlane((int) sc, 63);
+            }
+        }
+      if (tid == 0 && n == rounds * 64 * W) bkw[n / 64] = 1ull;
+      if (lane == 0) ws2[w] = carry;
+      __syncthreads();
+      uint32_t wv0 = 0;
+#pragma unroll
+      for (int v = 0; v < W; v++)
+        if (v < w) wv0 += ws2[v];
+      uint32_t nchain;
+      { uint32_t c = 0;
+        if ((uint32_t) tid < nw)
+          { uint64_t m = bkw[tid];
+            if ((uint32_t) tid == n / 64) m &= ~(1ull << (n & 63));           // (the sentinel is not a chain)
+            c = (uint32_t) __popcll(m);
+          }
+        const uint32_t e = block_excl_scan_t<T>(c, ws, &nchain);
+        if ((uint32_t) tid < nw) bkpref[tid] = (uint16_t) e;
+      }
+      __syncthreads();
+      const bool fits = nchain <= PECAP;                         // (else: a read of singletons -- all of it left to the chain kernels)
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        if (fits && ((endm >> j) & 1u))
+          { const uint32_t i = wbase + 64u * j + lane, wi = i >> 6, bi = i & 63u;
+            pe[(uint32_t) bkpref[wi] + (uint32_t) __popcll(bkw[wi] & (~0ull >> (63u - bi))) - 1u] = wv0 + P[j];
+          }
+      __syncthreads();
+      // A thread per CLUSTER (a read has some 150): its first hit is the c-th start bit -- the word by a search in the
+      // prefix counts, the bit by clearing c' lower ones --, its chains are the breaks inside it, the score of each the
+      // difference of two neighbouring prefix sums; the chains that score are reported (in any order: k_order_summaries
+      // ranks them), their number and "done" is the cluster's record for the chain stage
+      for (uint32_t c = (uint32_t) tid; c < ncl; c += T)
+        { uint32_t lo = 0, hi = nw;                              // last word with wpref[] <= c
+          while (hi - lo > 1)
+            { const uint32_t m = (lo + hi) >> 1;
+              if ((uint32_t) wpref[m] <= c) lo = m; else hi = m;
+            }
+          uint64_t fm = flagw[lo];
+          if (lo == n / 64) fm &= ~(1ull << (n & 63));
+          for (uint32_t t = c - (uint32_t) wpref[lo]; t > 0; t--) fm &= fm - 1;
+          const uint32_t cs = lo * 64 + (uint32_t) __ffsll((long long) fm) - 1;
+          uint32_t ce;
+          { const uint32_t bi = cs & 63u;
+            uint64_t m = (bi == 63) ? 0ull : (flagw[lo] & (~0ull << (bi + 1)));
+            uint32_t ww = lo;
+            while (m == 0) { ww += 1; m = flagw[ww]; }
+            ce = ww * 64 + (uint32_t) __ffsll((long long) m) - 1;
+          }
+          uint32_t v = 0;
+          if (fits && !((cbad[c >> 5] >> (c & 31u)) & 1u))
+            { const uint32_t obase = (s0 + cs + HITMIN - 1) / HITMIN;
+              uint32_t k = (uint32_t) bkpref[cs >> 6] + (uint32_t) __popcll(bkw[cs >> 6] & (~0ull >> (63u - (cs & 63u)))) - 1u;
+              uint32_t prev = (k > 0) ? pe[k - 1] : 0u, En = 0;
+              uint32_t st = cs;                                  // first hit of the chain at hand
+              while (st < ce)
+                { // its last hit: the position before the next break (the sentinel n is one)
+                  uint32_t ww = st >> 6;
+                  uint64_t m = ((st & 63u) == 63u) ? 0ull : (bkw[ww] & (~0ull << ((st & 63u) + 1)));
+                  while (m == 0) { ww += 1; m = bkw[ww]; }
+                  const uint32_t nx = ww * 64 + (uint32_t) __ffsll((long long) m) - 1;
+                  const uint32_t cur = pe[k];
+                  if ((int) (cur - prev) >= A.hithr)
+                    { const uint64_t ow = buf[st], ev = buf[nx - 1];
+                      ChainSummary sm;
+                      sm.group = 0;                              // (its number in the pass, whether the end is still in the
+                      sm.live  = LIVE_LATER;                     //  window when its PAIR ends, and the order key that follows
+                      sm.okey  = 0;                              //  from that: k_pack_summaries)
+                      sm.cost  = (int) (cur - prev);
+                      sm.ab    = (int) (uint32_t) ow + 1 - K;
+                      sm.bb    = (int) (ow >> 32) + 1 - K;
+                      sm.ae    = (int) (uint32_t) ev + 1;
+                      sm.be    = (int) (ev >> 32) + 1;
+                      sm.end   = s0 + nx - 1;
+                      A.sums[obase + En] = sm;
+                      En += 1;
+                    }
+                  prev = cur; k += 1; st = nx;
+                }
+              v = En | 0x80000000u;
+            }
+          A.lcnt[s0 + c] = v;
+        }
+#ifdef DMH_RS_PROFILE
+      __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+#endif
+      RSPROF_LAP(7);
+    }
   if (!LOOP) break;
   __syncthreads();                                             // (the next read of this workgroup starts with empty LDS)
   rb += gridDim.x;
   } while (rb < *A.count);
 }
 
-// dynamic LDS of k_read_sort<T>
+// dynamic LDS of k_read_sort<T>: the unfused kernel's arrays, in 8-byte words (read_sort_lds_words, declared ahead of the
+// kernel), and behind them the bit map of the fused route's step 5
 template <int T> constexpr size_t read_sort_lds()
-{ return sizeof(uint64_t) * (size_t) T * RS_E + sizeof(uint16_t) * (size_t) (T / 64) * (1 << RS_DB)
-         + sizeof(uint64_t) * (T * RS_E / 64 + 2) + sizeof(uint32_t) * (T * RS_E / 32 + 2)
-         + sizeof(uint16_t) * (T * RS_E / 64 + 2) + 64;
+{ return sizeof(uint64_t) * read_sort_lds_words<T>()
+         + sizeof(uint64_t) * (T * RS_E / 64 + 2) + sizeof(uint32_t) * (T * RS_E / 32 + 2);
 }
 
 // A read with more hits than the largest workgroup's LDS takes (a tandem array: a repeat pile and what surrounds it): the
@@ -585,6 +870,8 @@ __global__ __launch_bounds__(T) void k_read_sort_big(ReadSortArgs A)
           if ((v >> 63) && size > A.medium) atomicAdd(A.counts + 3, 1u);
         }
       if (tid == 0) A.rncl[r] = ncl;
+      if (A.lcnt != nullptr)                                   // (fused route: nothing of this read is chained here)
+        for (uint32_t j = tid; j < ncl; j += T) A.lcnt[s0 + j] = 0;
       // ---- 3. the chain kernels' words (apos | bpos << 32), in A.out
       for (uint32_t i = tid; i < n; i += T)
         { const uint64_t x = src[i];
@@ -622,12 +909,15 @@ __global__ __launch_bounds__(256) void k_read_classes(const uint32_t *__restrict
 // cbase = exclusive scan of rncl: the clusters of read r become clusters cbase[r] ... of the pass.  One wavefront per read.
 // Clusters that span coarse buckets and were too large for k_read_sort are listed for the sorts that finish them:
 // mlist (up to `medium` hits, k_csort_wide) and blist (larger: the radix sort); counts[0], counts[1] = list lengths.
+// gcount != nullptr (fused route): the chain stage's per-group arrays are filled here from lcnt (nullptr: all zero).
 __global__ __launch_bounds__(256) void k_cluster_compact(const uint64_t *__restrict__ lcl, const uint32_t *__restrict__ rstart,
                                                          const uint32_t *__restrict__ cbase, int nreads, int bbits,
                                                          uint32_t nhits, uint32_t *__restrict__ gstart,
                                                          uint64_t *__restrict__ gkey, uint32_t small, uint32_t medium,
                                                          uint32_t *__restrict__ mlist, uint32_t *__restrict__ blist,
-                                                         unsigned int *__restrict__ counts)
+                                                         unsigned int *__restrict__ counts,
+                                                         const uint32_t *__restrict__ lcnt, uint32_t *__restrict__ gcount,
+                                                         uint32_t *__restrict__ gbase, uint32_t *__restrict__ gdone)
 { const int r = (int) (((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (r >= nreads) return;
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -642,6 +932,13 @@ __global__ __launch_bounds__(256) void k_cluster_compact(const uint64_t *__restr
       if (ok)
         { gstart[c0 + j] = st;
           gkey[c0 + j]   = ((uint64_t) r << bbits) | ((v >> 32) & 0x3fffffffull);
+          if (gcount != nullptr)
+            { // fused route: what k_read_sort made of the cluster (chain ends reported, done) as the chain stage keeps it
+              const uint32_t lc = (lcnt != nullptr) ? lcnt[s0 + j] : 0u;
+              gcount[c0 + j] = lc & 0x7fffffffu;
+              gbase[c0 + j]  = (st + (uint32_t) HITMIN - 1u) / (uint32_t) HITMIN;
+              gdone[c0 + j]  = lc >> 31;
+            }
         }
       const uint32_t sz = ok ? nx - st : 0;
       const bool wide = ok && (v >> 63) && (sz > small || ((v >> 62) & 1ull));      // (bit 62: not ordered where it was found)

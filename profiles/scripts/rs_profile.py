@@ -30,8 +30,9 @@ for b in range(3):
     m.map_block(reads, "READS.1", [blk], ref_whole, "REF")
 L.dmh_rs_profile(out, 0)
 v = list(out)
-names = ["load", "rank (ballots)", "digit scan", "scatter + reload", "flags + scan", "convert + records", "cluster ranks + store"]
-tot = sum(v[:7])
+names = ["load / rows -> words", "rank (ballots)", "digit scan", "scatter + reload", "flags + scan", "convert + records", "cluster ranks + store",
+         "plain chains (fused)"]
+tot = sum(v[:8])
 print("workgroups %d, hits %d (%.0f per workgroup)" % (v[8], v[9], v[9] / max(1, v[8])))
 for i, nm in enumerate(names):
     print("%-24s %6.1f %%  %8.0f cycles per workgroup" % (nm, 100.0 * v[i] / max(1, tot), v[i] / max(1, v[8])))
