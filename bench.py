@@ -60,13 +60,13 @@ WORKLOADS = {
 STAGE_KERNEL = {
     "k_radix_scatter": "k_radix_scatter", "k_radix_hist": "k_radix_hist", "radix_scan": "k_scan_*",
     "kmer_emit": "k_kmer_emit", "merge_match": "k_merge_match", "merge_fixup": "k_merge_fixup (+reduce, scan)",
-    "merge_emit": "k_merge_expand (+sizes, scan)",
+    "merge_emit": "k_merge_expand (+sizes, scan)", "merge_rows": "k_row_list (+scan, classes)",
     "seed_groups": "k_group_flag/write (+scan)", "chain_small_groups": "k_chain<16>", "chain_listed_groups": "k_chain<64>",
  "chain_lane_groups": "k_chain_lane", "chain_simple_groups": "k_chain_simple", "chain_lds_groups": "k_chain_small",
     "chain_piles": "k_chain_pile", "chain_dominate": "k_order_summaries + k_dominate (+ scans)", "seed_clusters": "k_cluster_flag/rekey (+scan)",
     "seed_pairs": "k_pair_flag/write (+scan)", "chain_spilled_piles": "k_chain<64> (spilled piles)", "chain_jumps": "k_chain_jumps",
     "align": "k_align_cands32", "align_wave64": "k_align_cands<128>", "align_global_band": "k_align_cands<8192>",
-    "read_sort": "k_read_sort", "unpack_2bit": "k_unpack_2bit", "pack_bases": "k_pack_fwd", "pack_revcomp": "k_pack_rc", "merge_buckets": "k_bucket_bounds",
+    "read_sort": "k_read_sort (fused: rows -> ordered hits -> plain chains)", "unpack_2bit": "k_unpack_2bit", "pack_bases": "k_pack_fwd", "pack_revcomp": "k_pack_rc", "merge_buckets": "k_bucket_bounds",
 }
 # enclosing stages (their kernels are timed one by one as well): not candidates for "dominant kernel"
 ENCLOSING = {"kmer_sort", "seed_sort", "cluster_sort", "chain", "sort_pairs"}
@@ -451,10 +451,11 @@ def main():
         # H = hits of the block (from the expansion stage of the sampled blocks)
         path_roof = None
         nblk_total = args.steps * nbatch
-        if sampled_blocks > 0 and "merge_emit" in timings and nblk_total > 0:
+        hit_stage = "merge_rows" if "merge_rows" in timings else "merge_emit"     # (fused route / round 3's: 16 B per hit either way)
+        if sampled_blocks > 0 and hit_stage in timings and nblk_total > 0:
             n_r = tot_bases / (args.steps * nbatch)
             k_r = n_r - args.block_reads * 19.0
-            hits = timings["merge_emit"]["bytes"] / 16.0 / sampled_blocks
+            hits = (timings[hit_stage]["bytes"] + (timings["merge_emit"]["bytes"] if hit_stage == "merge_rows" and "merge_emit" in timings else 0.0)) / 16.0 / sampled_blocks
             g = 2 * len(ranges)
             b_alg = n_r + 16.0 * k_r * 11 + 16.0 * k_r * g + 16.0 * hits * 12
             sec = dt / nblk_total * world
@@ -503,6 +504,10 @@ def main():
             "cpu_baseline": cpu, "parity": parity,
             "host_seconds": {k: round(v, 3) for k, v in host.items()},
             "device_stage_ms": stages,
+            # the same stages with the GPU to themselves (the extra untimed visit of ONE read block with nothing on the tail
+            # stream): what a read block costs in machine time when nothing overlaps
+            "device_stage_ms_alone_one_block": {k: round(v["ms"], 2) for k, v in sorted(alone.items(), key=lambda kv: -kv[1]["ms"])
+                                                if not k.startswith("count:") and not k.startswith("host:") and k not in ENCLOSING},
             # the d-wave ladder on the sampled blocks: candidates each rung ran, and why some had to run again one rung up
             "alignment_ladder": counters,
         }

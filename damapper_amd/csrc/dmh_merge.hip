@@ -1990,7 +1990,7 @@ static void close_batch(MergeResult &R, int phase)
           RA.medium = (uint32_t) CS_MEDIUM;
           RA.big_min = R.small_hi;
           RA.pile_min = R.pile_min > 0 ? R.pile_min : 0xffffffffu;
-          RA.rows = nullptr; RA.rowbase = nullptr; RA.nrow = nullptr; RA.bvals = nullptr; RA.bposbits = 0;
+          RA.rows = nullptr; RA.rowbase = nullptr; RA.nrow = nullptr; RA.bvals = nullptr; RA.bposbits = 0; RA.rowsort = 0;
           RA.from = nullptr; RA.sums = nullptr; RA.lcnt = nullptr; RA.K = 0; RA.hithr = 0; RA.simple_max = 0;
           if (R.fused)
             { RA.rows = R.f_rows; RA.rowbase = R.f_rowbase; RA.nrow = R.rs_start.p + nr + 2;
@@ -2005,6 +2005,27 @@ static void close_batch(MergeResult &R, int phase)
                   RA.simple_max = R.lane_max;
                 }
             }
+          // Fused route: with the rows in apos order the hits start out ordered by (apos, contig, bpos), and the radix passes
+          // cover the coarse key alone -- when the bit map over the apos values fits the digit counters' place of the
+          // workgroup size at hand (10 bytes per 64 values in 16 T bytes: reads of up to 16 k / 32 k / 64 k bases)
+          ReadSortArgs RB = RA;                      // the launch arguments with that configuration
+          auto rowsort_fits = [&](int T) { return R.fused && ((((size_t) 1 << R.pbits) + 63) / 64) * 10 + 16 <= (size_t) 16 * T; };
+          if (R.fused)
+            { static const bool env_rs2 = getenv("DMH_ROW_SORT") == nullptr || atoi(getenv("DMH_ROW_SORT")) != 0;
+              RB.rowsort = env_rs2 ? 1 : 0;
+              RB.npass = 0;
+              const int nd = (kbits + RS_DB - 1) / RS_DB;
+              for (int k = 0, at = 0; k < nd; k++)
+                { const int wdt = (kbits - at + (nd - k) - 1) / (nd - k);
+                  RB.sh[RB.npass] = (uint8_t) (R.pbits + at); RB.wd[RB.npass] = (uint8_t) wdt;
+                  RB.npass += 1; at += wdt;
+                }
+            }
+          auto args_for = [&](int T, const ReadSortArgs &base) -> ReadSortArgs
+          { ReadSortArgs X = (RB.rowsort && rowsort_fits(T)) ? RB : RA;
+            X.list = base.list; X.count = base.count;
+            return X;
+          };
           static bool attr = false;
           if (!attr)
             { attr = true;
@@ -2057,8 +2078,8 @@ static void close_batch(MergeResult &R, int phase)
               { hipStream_t q = fork ? side[0] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[0] = true; }
                 RA.list = R.rs_lists.p + 2 * (size_t) nr; RA.count = R.rs_stats.p + 2;
-                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
-                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T2, false, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
+                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, args_for(RS_T2, RA));
+                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T2, false, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, args_for(RS_T2, RA));
                 else if (k32) hipLaunchKernelGGL((k_read_sort<RS_T2, true>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T2, false>), dim3(g_rcnt[2]), dim3(RS_T2), read_sort_lds<RS_T2>(), q, RA);
               }
@@ -2066,15 +2087,15 @@ static void close_batch(MergeResult &R, int phase)
               { hipStream_t q = fork ? side[1] : stream();
                 if (fork) { HIP_CHECK(hipStreamWaitEvent(q, ev_go, 0)); used[1] = true; }
                 RA.list = R.rs_lists.p + (size_t) nr; RA.count = R.rs_stats.p + 1;
-                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
-                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T1, false, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
+                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, args_for(RS_T1, RA));
+                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T1, false, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, args_for(RS_T1, RA));
                 else if (k32) hipLaunchKernelGGL((k_read_sort<RS_T1, true>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T1, false>), dim3(g_rcnt[1]), dim3(RS_T1), read_sort_lds<RS_T1>(), q, RA);
               }
             if (g_rcnt[0] > 0)
               { RA.list = R.rs_lists.p; RA.count = R.rs_stats.p;
-                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
-                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T0, false, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
+                if (R.fused && k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), args_for(RS_T0, RA));
+                else if (R.fused)   hipLaunchKernelGGL((k_read_sort<RS_T0, false, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), args_for(RS_T0, RA));
                 else if (k32) hipLaunchKernelGGL((k_read_sort<RS_T0, true>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
                 else     hipLaunchKernelGGL((k_read_sort<RS_T0, false>), dim3(g_rcnt[0]), dim3(RS_T0), read_sort_lds<RS_T0>(), stream(), RA);
               }

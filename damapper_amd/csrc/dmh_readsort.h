@@ -74,6 +74,7 @@ struct ReadSortArgs
   const uint32_t *nrow;
   const uint32_t *bvals;         // the REF index's positions, (contig << bposbits) | bpos
   int             bposbits;
+  int             rowsort;       // the rows are put into apos order first (the passes then cover the coarse key alone)
   // fused route, back: plain chains scored in place (simple_max = 0: not at all)
   uint32_t       *from;          // per hit: predecessor (NIL for a chain's first hit)
   ChainSummary   *sums;          // chain ends, at slot (first hit of the cluster + HITMIN - 1) / HITMIN onwards
@@ -215,12 +216,53 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
           if ((uint32_t) j < rrounds)
             { const uint32_t x = rbase + 64u * j + lane;
               rec[j] = (x < nr) ? __builtin_nontemporal_load(rw + x) : 0ull;
-              const uint32_t mb  = (uint32_t) (rec[j] & RW_MBMASK);
-              const uint32_t inc = wave_incl_scan_dpp(mb);
-              off[j] = carry + inc - mb;
-              carry += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
             }
         }
+      if (A.rowsort)
+        { // The rows into apos order (a read has one row per apos): a bit per apos value in the digit counters' place, the
+          // rank of a row = bits below its own.  The words made below then start out in (apos, contig, bpos) order -- a row's
+          // partners are in REF-index order --, so the radix passes only have to order the COARSE key: two passes, not three.
+          uint64_t *abm = (uint64_t *) wh;
+          const uint32_t aw = ((1u << A.pbits) + 63u) / 64u;
+          uint16_t *apf = (uint16_t *) (abm + aw);
+          for (uint32_t x = tid; x < aw; x += T) abm[x] = 0;
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < E; j++)
+            if ((uint32_t) j < rrounds)
+              { const uint32_t x = rbase + 64u * j + lane, ap = (uint32_t) ((rec[j] >> RW_MB) & RW_APMASK);
+                if (x < nr) atomicOr((unsigned long long *) &abm[ap >> 6], 1ull << (ap & 63u));
+              }
+          __syncthreads();
+          { const uint32_t per = (aw + T - 1) / T, lo = min(aw, (uint32_t) tid * per), hi = min(aw, lo + per);
+            uint32_t c = 0, all;
+            for (uint32_t x = lo; x < hi; x++) c += (uint32_t) __popcll(abm[x]);
+            uint32_t e = block_excl_scan_t<T>(c, ws, &all);
+            for (uint32_t x = lo; x < hi; x++) { apf[x] = (uint16_t) e; e += (uint32_t) __popcll(abm[x]); }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < E; j++)
+            if ((uint32_t) j < rrounds)
+              { const uint32_t x = rbase + 64u * j + lane, ap = (uint32_t) ((rec[j] >> RW_MB) & RW_APMASK);
+                if (x < nr) buf[(uint32_t) apf[ap >> 6] + (uint32_t) __popcll(abm[ap >> 6] & ((1ull << (ap & 63u)) - 1ull))] = rec[j];
+              }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < E; j++)
+            if ((uint32_t) j < rrounds)
+              { const uint32_t x = rbase + 64u * j + lane;
+                rec[j] = (x < nr) ? buf[x] : 0ull;
+              }
+        }
+#pragma unroll
+      for (int j = 0; j < E; j++)
+        if ((uint32_t) j < rrounds)
+          { const uint32_t mb  = (uint32_t) (rec[j] & RW_MBMASK);
+            const uint32_t inc = wave_incl_scan_dpp(mb);
+            off[j] = carry + inc - mb;
+            carry += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+          }
       if (lane == 0) ws[w] = carry;
       __syncthreads();
       uint32_t wv0 = 0;
@@ -718,6 +760,14 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
                 }
               v = En | 0x80000000u;
             }
+#ifdef DMH_RS_PROFILE
+          else
+            { // hits in the clusters left to the chain kernels, by cluster size (<= 16, 32, 64, 128, 256, more)
+              const uint32_t sz = ce - cs;
+              const int bk = sz <= 16 ? 0 : (sz <= 32 ? 1 : (sz <= 64 ? 2 : (sz <= 128 ? 3 : (sz <= 256 ? 4 : 5))));
+              atomicAdd(&g_rsprof[10 + bk], (unsigned long long) sz);
+            }
+#endif
           A.lcnt[s0 + c] = v;
         }
 #ifdef DMH_RS_PROFILE
