@@ -56,6 +56,13 @@ WORKLOADS = {
     "ecoli": (4_600_000, 1, "random", 1),
 }
 
+# --flags: the mapper's options on both sides (BASELINE configs[3] = default, configs[4] = n95p: near-optimal chains and
+# the -p repeat profile)
+FLAG_SETS = {
+    "default": {"ref": [], "mapper": {}, "profile": False, "text": ""},
+    "n95p": {"ref": ["-n.95", "-p"], "mapper": {"best_tie": 0.95, "profile": 1}, "profile": True, "text": " -n.95 -p"},
+}
+
 # kernels whose time is HBM streaming: algorithmic bytes are meaningful as a bandwidth
 STAGE_KERNEL = {
     "k_radix_scatter": "k_radix_scatter", "k_radix_hist": "k_radix_hist", "radix_scan": "k_scan_*",
@@ -134,10 +141,23 @@ def parity_and_cpu_baseline(G, ranges, args, sort_path, threads, cores, world):
     if not run_ref.have_ref():
         return None, None
     import hashlib
+
+    def file_sha(path):
+        try:
+            return hashlib.sha1(open(path, "rb").read()).hexdigest()
+        except OSError:
+            return "-"
+    # everything the reference's files and its wall time depend on: the workload, the flags, -T (the per-thread file
+    # split and the time), the reference binary and the simulator that makes the inputs
+    ref_flags = ["-k20", "-e.85", "-M%d" % args.mem_gb] + FLAG_SETS[args.flags]["ref"]
     key = hashlib.sha1(repr((args.workload, args.genome_mbp, args.families, args.block_reads, args.mem_gb, args.read_lengths,
-                             [int(x) for x in G.lens])).encode()).hexdigest()[:16]
+                             [int(x) for x in G.lens], ref_flags, threads, args.ref_fasta,
+                             file_sha(os.path.join(run_ref.REF_DIR, "damapper")),
+                             file_sha(os.path.join(ROOT, "damapper_amd", "libdmh_sim.so")))).encode()).hexdigest()[:16]
     cache = os.path.join(tempfile.gettempdir(), "dmh_bench_refcache_%s" % key)
     cpu = None
+    if args.refresh_ref_cache:
+        shutil.rmtree(cache, ignore_errors=True)
     if not os.path.exists(os.path.join(cache, "cpu.json")):
         d = tempfile.mkdtemp(prefix="dmh_bench_cpu_")
         try:
@@ -146,10 +166,10 @@ def parity_and_cpu_baseline(G, ranges, args, sort_path, threads, cores, world):
             dazzdb.write_db_block(d, "READS", sample)
             bases = float(sample.db.totlen)
             del sample
-            dt, _ = run_ref.run_reference(d, "REF", ["READS.1"], flags=["-k20", "-e.85", "-M%d" % args.mem_gb], threads=threads)
+            dt, _ = run_ref.run_reference(d, "REF", ["READS.1"], flags=ref_flags, threads=threads)
             cpu = {"value": bases / dt / 1e9, "unit": "Gbp/s", "cores": threads, "kind": "reference",
-                   "host_cores_available": cores,
-                   "sample": "oracle/_ref/damapper -k20 -e.85 -T%d -M%d REF READS.1: read block 1 of the timed batch (%d reads, "
+                   "host_cores_available": cores, "cached": False,
+                   "sample": "oracle/_ref/damapper " + " ".join(ref_flags[3:]) + " -k20 -e.85 -T%d -M%d REF READS.1: read block 1 of the timed batch (%d reads, "
                              "%.0f Mbp) through the reference's whole loop damapper.c:825-880 -- Sort_Kmers + Match_Filter "
                              "against all %d REF blocks (%.0f Mbp) in both orientations, Reporter -- in %.1f s wall, DB "
                              "loading included, measured (no extrapolation); -T is the largest power of two <= the host "
@@ -158,11 +178,16 @@ def parity_and_cpu_baseline(G, ranges, args, sort_path, threads, cores, world):
             os.makedirs(cache, exist_ok=True)
             for f in os.listdir(os.path.join(d, "las_ref")):
                 shutil.copy(os.path.join(d, "las_ref", f), os.path.join(cache, f))
+            for x in ("anno", "data"):                      # (-p: the reference leaves the track next to the DBs)
+                f = os.path.join(d, ".READS.1.prof.%s" % x)
+                if os.path.exists(f):
+                    shutil.copy(f, os.path.join(cache, "ref.prof.%s" % x))
             json.dump(cpu, open(os.path.join(cache, "cpu.json"), "w"))
         finally:
             shutil.rmtree(d, ignore_errors=True)
     else:
         cpu = json.load(open(os.path.join(cache, "cpu.json")))
+        cpu["cached"] = True                                # (not measured in THIS run: --refresh-ref-cache measures again)
         cpu["sample"] += " [cached from an earlier run on this box]"
     ts_r, want = las.read_las_set(cache, "READS.1.REF.M@.las")
     ts_h, got = las.read_las_set(sort_path, "READS.1.REF.M@.las")
@@ -172,6 +197,27 @@ def parity_and_cpu_baseline(G, ranges, args, sort_path, threads, cores, world):
                       "(report mode %d, REF indices %s, %d ranks) against the reference's files for the same block; record "
                       "streams compared record for record, bytes 36-39 (struct padding) masked"
                       % (len(ranges), args.report_mode, "rebuilt" if args.rebuild_ref else "resident", world)}
+    if FLAG_SETS[args.flags]["profile"]:
+        # the -p track of the same block.  With more than one report thread the reference's special_log() (map.c:2270-2302)
+        # may read its lazily filled table while another thread fills it (entries not yet written read as 0: a value that
+        # is too LARGE, only during the first calls of a run), and a -T1 run of this size takes half an hour: equal, except
+        # for at most 32 bytes in which the reference's value is the larger one (tests/test_gpu_scale.py pins the track
+        # exactly against -T1 at test size)
+        import numpy as np
+        try:
+            anno_r = open(os.path.join(cache, "ref.prof.anno"), "rb").read()
+            want = np.frombuffer(open(os.path.join(cache, "ref.prof.data"), "rb").read(), dtype=np.uint8)
+            anno_h = open(".READS.1.prof.anno", "rb").read()
+            got = np.frombuffer(open(".READS.1.prof.data", "rb").read(), dtype=np.uint8)
+            diff = np.nonzero(got != want)[0] if len(got) == len(want) else None
+            ok = anno_r == anno_h and diff is not None and len(diff) <= 32 and bool(np.all(want[diff] > got[diff]))
+            parity["prof_track"] = {"bytes": int(len(want)), "differing": int(len(diff)) if diff is not None else -1, "ok": ok,
+                                    "rule": "identical but for <= 32 bytes in which the -T%d reference's racy special_log() value is the larger" % threads}
+            if not ok:
+                parity["differing"] += 1
+        except OSError as e:
+            parity["prof_track"] = {"ok": False, "error": str(e)}
+            parity["differing"] += 1
     return (cpu if world == 1 else None), parity
 
 
@@ -195,6 +241,13 @@ def main():
     ap.add_argument("--read-lengths", choices=["fixed", "lognormal"], default="fixed",
                     help="template lengths: fixed 10 kb (BASELINE north_star) or CLR-like log-normal with mean 10 kb "
                          "(sigma 0.4, clipped to 1-40 kb; SURVEY 8d for configs[3]/[4])")
+    ap.add_argument("--flags", choices=sorted(FLAG_SETS), default="default",
+                    help="n95p = BASELINE configs[4]: -n.95 (near-optimal chains) and -p (repeat profile track, compared too)")
+    ap.add_argument("--ref-fasta", default=None,
+                    help="map against this FASTA (a real genome on the box's disk: contigs as fasta2DAM cuts them, REF blocks of "
+                         "whole contigs <= 375 Mbp) instead of the synthetic reference; reads are still simulated from it")
+    ap.add_argument("--refresh-ref-cache", action="store_true",
+                    help="run the CPU reference again even if this box has its files for the same inputs cached")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference run (then there is no parity check either)")
     ap.add_argument("--mem-gb", type=int, default=64, help="-M of both sides (the limit rule of map.c:2992-3055 depends on it)")
     ap.add_argument("--roofline-only", action="store_true",
@@ -248,12 +301,20 @@ def main():
         fam = max(1, int(round(max(sum(lens[a:b]) for a, b in ranges) / 750_000)))
     if args.families is not None:
         fam = args.families
-    G = dazzdb.native_genome(20, lens, kind, families=fam)
+    if args.ref_fasta:
+        G = dazzdb.genome_from_fasta(args.ref_fasta, min_len=4 * READ_LEN if args.read_lengths == "lognormal" else READ_LEN)
+        lens = [int(x) for x in G.lens]
+        ncontig, kind, fam = len(lens), "fasta", 0
+        ranges = ref_block_ranges(lens)
+    else:
+        G = dazzdb.native_genome(20, lens, kind, families=fam)
     ref_whole = dazzdb.genome_block(G, path=b"./.REF")
     freq = [ref_whole.db.freq[j] for j in range(4)]
 
     sort_path = tempfile.mkdtemp(prefix="dmh_bench_%d_" % rank)
-    mapper_kw = dict(kmer=20, ave_corr=0.85, spacing=100, threads=4)
+    mapper_kw = dict(kmer=20, ave_corr=0.85, spacing=100, threads=4, **FLAG_SETS[args.flags]["mapper"])
+    if FLAG_SETS[args.flags]["profile"]:
+        os.chdir(sort_path)               # (the -p track goes to the working directory, map.c:3301-3302)
     m = driver.Mapper(sort_path=sort_path, mem_limit=args.mem_gb << 30, retain_ref=not args.rebuild_ref, **mapper_kw)
     m.make_spec(freq)
     L.dmh_preload_block(ref_whole.ptr())          # Reporter's copy of the whole reference: resident
@@ -321,6 +382,7 @@ def main():
         torch.cuda.synchronize()
     L.dmh_sync()
     t0 = time.time()
+    cpu0 = time.process_time()            # (CPU time of this rank's process, all its threads: the node's core budget at N ranks)
     bases = 0
     host = {"index_reads": 0.0, "filter": 0.0, "report": 0.0, "between_blocks": 0.0}
     step_t = []
@@ -350,6 +412,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
     dt = time.time() - t0
+    cpu_s = time.process_time() - cpu0
     if os.environ.get("DMH_BENCH_STEP_TIMES") and rank == 0:
         step_t.append(time.time())
         sys.stderr.write("step times (ms): %s\n" % " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(step_t, step_t[1:])))
@@ -364,6 +427,11 @@ def main():
         tb = torch.tensor([tot_bases], dtype=torch.float64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         tot_bases = float(tb.item())
+        tc = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tc, torch.tensor([cpu_s], dtype=torch.float64, device=dev))
+        cpu_per_rank = [round(float(x.item()), 3) for x in tc]
+    else:
+        cpu_per_rank = [round(cpu_s, 3)]
 
     timings = capi.timings()
     L.dmh_timing_enable(0)
@@ -474,14 +542,14 @@ def main():
                       "Gbp reads mapped/sec (whole node), -k20 -e.85; .las parity-checked vs CPU reference",
             "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u64/u8 integer", "data": "synthetic" if not args.ref_fasta else "real reference (FASTA), simulated reads",
             "config": {"workload": "%s: %.0f Mbp %s reference (%d contigs, %d REF blocks <= 375 Mbp, %s) + simulated PacBio "
                                    "reads (10 kb, 15%% err) in blocks of %d reads; a step = a fixed batch of %d read blocks "
                                    "dealt to the ranks b mod N, each through %d Match_Filter passes + Reporter; -k20 -e.85 "
-                                   "-s100 -M%d; REF index %s; read blocks %s" %
+                                   "-s100 -M%d%s; REF index %s; read blocks %s" %
                                    (args.workload, G.total / 1e6, kind, ncontig, len(ranges),
-                                    ("%d repeat families" % fam) if kind == "repeat" else "uniform ACGT",
-                                    args.block_reads, nbatch, 2 * len(ranges), args.mem_gb,
+                                    ("%d repeat families" % fam) if kind == "repeat" else ("FASTA " + os.path.basename(args.ref_fasta) if kind == "fasta" else "uniform ACGT"),
+                                    args.block_reads, nbatch, 2 * len(ranges), args.mem_gb, FLAG_SETS[args.flags]["text"],
                                     "rebuilt per read block" if args.rebuild_ref else "built once per GPU, resident",
                                     "resident in HBM" if args.resident_reads else
                                     "uploaded as 2-bit .bps bytes from page-locked memory and decoded on the device inside the timed region"),
@@ -503,6 +571,9 @@ def main():
                                     for k, v in side.items()},
             "cpu_baseline": cpu, "parity": parity,
             "host_seconds": {k: round(v, 3) for k, v in host.items()},
+            # CPU seconds of every rank's process over the timed region (all threads): cores busy per rank = this / wall
+            "host_cpu_seconds_per_rank": cpu_per_rank,
+            "host_cores_busy_per_rank": [round(c / dt, 2) for c in cpu_per_rank],
             "device_stage_ms": stages,
             # the same stages with the GPU to themselves (the extra untimed visit of ONE read block with nothing on the tail
             # stream): what a read block costs in machine time when nothing overlaps
@@ -515,6 +586,12 @@ def main():
         sys.stdout.flush()
         if parity is not None and parity["differing"] != 0:
             raise SystemExit("bench.py: HIP .las differs from the reference's on the parity sample")
+    keep = os.environ.get("DMH_BENCH_KEEP")       # (tests: every rank's per-thread files of its blocks' last visit)
+    if keep:
+        os.makedirs(keep, exist_ok=True)
+        for f in os.listdir(sort_path):
+            if f.endswith(".las"):
+                shutil.copy(os.path.join(sort_path, f), os.path.join(keep, f))
     shutil.rmtree(sort_path, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -14,8 +14,10 @@
 // is sequential per read and touches a handful of records per read.
 
 #include "dmh_state.h"
+#include "dmh_device.h"
 #include "dmh_chain.h"
 #include <algorithm>
+#include <sched.h>
 
 namespace dmh {
 
@@ -1452,59 +1454,84 @@ __global__ __launch_bounds__(256) void k_dominate(DomArgs D)
 // the records added by this pass that survived it: their Jump lists are stored next.  (One thread per read
 // walks the read's list: the slack behind a list -- a read may need fewer records than were reserved -- is
 // uninitialised memory.)
-__global__ void k_fresh_list(const DCand *__restrict__ pool, const uint32_t *__restrict__ noff,
-                             const uint32_t *__restrict__ nlen, int nreads,
-                             uint32_t *__restrict__ fresh, unsigned int *__restrict__ nfresh)
-{ const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nreads) return;
-  const uint32_t b = noff[r], n = nlen[r];
+__global__ __launch_bounds__(64) void k_fresh_list(const DCand *__restrict__ pool, const uint32_t *__restrict__ noff,
+                                                   const uint32_t *__restrict__ nlen, int nreads,
+                                                   uint32_t *__restrict__ fresh, unsigned int *__restrict__ nfresh)
+{ const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  const uint32_t b = (r < nreads) ? noff[r] : 0u, n = (r < nreads) ? nlen[r] : 0u;
+  uint32_t cnt = 0;
   for (uint32_t i = 0; i < n; i++)
     { const uint32_t fl = pool[b + i].flags;
-      if ((fl & DC_FRESH) && !(fl & DC_TOMB)) fresh[atomicAdd(nfresh, 1u)] = b + i;
+      cnt += ((fl & DC_FRESH) && !(fl & DC_TOMB)) ? 1u : 0u;
+    }
+  // one atomic per wavefront (they are served one after the other at the memory side, a few ns apiece: one per
+  // candidate was most of this kernel's time); the order of the list is of no consequence
+  const uint32_t incl = wave_incl_scan_dpp(cnt);
+  const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+  uint32_t base = 0;
+  if (lane == 0 && total > 0) base = atomicAdd(nfresh, total);
+  base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+  uint32_t at = base + incl - cnt;
+  for (uint32_t i = 0; i < n && cnt > 0; i++)
+    { const uint32_t fl = pool[b + i].flags;
+      if ((fl & DC_FRESH) && !(fl & DC_TOMB)) fresh[at++] = b + i;
     }
 }
 
 // Compressed Jump displacements of a kept chain (chain_length, map.c:1243-1260, and the encoding
 // loop map.c:1741-1759): links on one diagonal closer than 100 bp to the last kept point are
-// skipped.  One thread per surviving fresh candidate; pass 0 counts (jlen[c], 0 beyond the list), pass 1
-// writes the pairs at jbase + joff[c] of the jump pool and completes the candidate's record.
-__global__ void k_cand_jumps(const uint64_t *__restrict__ ab, const uint32_t *__restrict__ from, DCand *__restrict__ pool,
-                             const uint32_t *__restrict__ fresh, const unsigned int *__restrict__ nfresh, uint32_t cap,
-                             uint32_t *__restrict__ jlen, const uint32_t *__restrict__ joff, uint16_t *__restrict__ jout,
-                             uint32_t jbase, int write)
-{ const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cap) return;
-  if (c >= *nfresh)
-    { if (!write) jlen[c] = 0;
-      return;
-    }
-  const uint32_t slot = fresh[c];
-  uint32_t x  = pool[slot].end;
-  int      ax = (int) (uint32_t) ab[x], bx = (int) (ab[x] >> 32);
-  uint32_t y  = from[x];
-  uint32_t cnt = 0;
-  uint16_t *o = write ? jout + 2 * ((size_t) jbase + joff[c]) : nullptr;
-  while (y != NIL)
-    { // the three loads of a step depend on y only: request them together (one round trip per link)
-      const uint64_t ky = ab[y];
-      const uint32_t fy = from[y];
-      int ay = (int) (uint32_t) ky, by = (int) (ky >> 32);
-      int da = ax - ay, db = bx - by;
-      if (!(da == db && da < 100))
-        { if (write)
-            { o[2 * cnt]     = (uint16_t) da;
-              o[2 * cnt + 1] = (uint16_t) db;
+// skipped.  Pass 0 counts (jlen[c], 0 beyond the list), pass 1 writes the pairs at jbase + joff[c] of the jump pool
+// and completes the candidate's record.
+// One WAVEFRONT per surviving fresh candidate (round 4; a thread per candidate chased the links one memory round trip at
+// a time: 0.5 ms per launch for the 400 links of a read's true locus).  A chain's links point a few hits back -- the hit
+// before, in a plain chain --, so the wavefront keeps a WINDOW of 64 consecutive hits (words and links, two coalesced
+// loads) in its lanes, follows the links inside it with lane reads, and fetches a new window only when a link leaves it.
+constexpr int CJ_BLOCK = 256;
+__global__ __launch_bounds__(CJ_BLOCK) void k_cand_jumps(const uint64_t *__restrict__ ab, const uint32_t *__restrict__ from,
+                                                         DCand *__restrict__ pool, const uint32_t *__restrict__ fresh,
+                                                         const unsigned int *__restrict__ nfresh, uint32_t cap,
+                                                         uint32_t *__restrict__ jlen, const uint32_t *__restrict__ joff,
+                                                         uint16_t *__restrict__ jout, uint32_t jbase, int write)
+{ const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = (gridDim.x * CJ_BLOCK) >> 6, wave = (blockIdx.x * CJ_BLOCK + threadIdx.x) >> 6;
+  const uint32_t nf = min(*nfresh, cap);
+  if (!write)
+    for (uint32_t c = nf + blockIdx.x * CJ_BLOCK + threadIdx.x; c < cap; c += gridDim.x * CJ_BLOCK) jlen[c] = 0;
+  for (uint32_t c = wave; c < nf; c += nwaves)
+    { const uint32_t slot = fresh[c];
+      uint32_t x = pool[slot].end;
+      uint32_t base = (x >= 63u) ? x - 63u : 0u;                 // the window: hits base .. base + 63 (x is always inside)
+      uint64_t wv = ab[base + lane];
+      uint32_t fv = from[base + lane];
+      int ax = (int) (uint32_t) wave_lane_u64(wv, (int) (x - base)), bx = (int) (wave_lane_u64(wv, (int) (x - base)) >> 32);
+      uint32_t y = (uint32_t) __builtin_amdgcn_readlane((int) fv, (int) (x - base));
+      uint32_t cnt = 0;
+      uint32_t *o = write ? (uint32_t *) (jout + 2 * ((size_t) jbase + joff[c])) : nullptr;      // (a pair is one 32-bit word)
+      while (y != NIL)
+        { if (y < base)                                          // (links point backwards)
+            { base = (y >= 63u) ? y - 63u : 0u;
+              wv = ab[base + lane];
+              fv = from[base + lane];
             }
-          cnt += 1;
-          x = y; ax = ay; bx = by;
+          const uint64_t ky = wave_lane_u64(wv, (int) (y - base));
+          const uint32_t fy = (uint32_t) __builtin_amdgcn_readlane((int) fv, (int) (y - base));
+          const int ay = (int) (uint32_t) ky, by = (int) (ky >> 32);
+          const int da = ax - ay, db = bx - by;
+          if (!(da == db && da < 100))
+            { if (write && lane == 0) o[cnt] = (uint32_t) (uint16_t) da | ((uint32_t) (uint16_t) db << 16);
+              cnt += 1;
+              x = y; ax = ay; bx = by;
+            }
+          y = fy;
         }
-      y = fy;
-    }
-  if (!write) jlen[c] = cnt;
-  else
-    { pool[slot].joff  = jbase + joff[c];
-      pool[slot].jlen  = cnt;
-      pool[slot].flags &= ~DC_FRESH;
+      if (lane == 0)
+        { if (!write) jlen[c] = cnt;
+          else
+            { pool[slot].joff  = jbase + joff[c];
+              pool[slot].jlen  = cnt;
+              pool[slot].flags &= ~DC_FRESH;
+            }
+        }
     }
 }
 
@@ -1729,8 +1756,10 @@ static void finish_wait_tag(FinishState &F, int tag_at)
 { static const bool use_event = getenv("DMH_FINISH_EVENT_WAIT") != nullptr;
   if (use_event) { HIP_CHECK(hipEventSynchronize(F.ev)); return; }
   uint64_t spins = 0;
+  const bool yield = host_crowded();
   while (__atomic_load_n(&F.h_pin[tag_at], __ATOMIC_ACQUIRE) != F.seq)
     { __builtin_ia32_pause();
+      if (yield && (spins & 0xffu) == 0xffu) sched_yield();
       if ((++spins & 0xfffffu) == 0)
         { const hipError_t e = hipEventQuery(F.ev);             // (a fault on the device must not leave the host spinning)
           if (e == hipErrorNotReady) (void) hipGetLastError();
@@ -2199,8 +2228,8 @@ static void finish_step_b(MergeResult &R)
   { StageTimer tm("chain_jumps", 0.0);
     hipLaunchKernelGGL(k_fresh_list, dim3(ceil_div(nreads, 64)), dim3(64), 0, stream(), (const DCand *) cs.pool[nx].p,
                        (const uint32_t *) cs.seg_off[nx].p, (const uint32_t *) cs.seg_len[nx].p, nreads, fresh.p, cs.ctl.p + 2);
-    hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.sab,
-                       (const uint32_t *) from.p, cs.pool[nx].p,
+    hipLaunchKernelGGL(k_cand_jumps, dim3(std::min<uint32_t>(ceil_div((int64_t) nsum * 64, CJ_BLOCK), 2048u)), dim3(CJ_BLOCK), 0, stream(),
+                       (const uint64_t *) R.sab, (const uint32_t *) from.p, cs.pool[nx].p,
                        (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,
                        (const uint32_t *) nullptr, (uint16_t *) nullptr, 0u, 0);
     exclusive_scan_u32((const uint32_t *) jl.p, jl.p + nsum + 1, nsum, st.sort_fin.bsum, cs.ctl.p + 3);
@@ -2241,8 +2270,8 @@ static void finish_step_c(MergeResult &R)
         cs.jumps = nj;
       }
     if (h[2] > 0)
-      hipLaunchKernelGGL(k_cand_jumps, dim3(ceil_div(nsum, 64)), dim3(64), 0, stream(), (const uint64_t *) R.sab,
-                         (const uint32_t *) C.from.p, cs.pool[nx].p,
+      hipLaunchKernelGGL(k_cand_jumps, dim3(std::min<uint32_t>(ceil_div((int64_t) h[2] * 64, CJ_BLOCK), 2048u)), dim3(CJ_BLOCK), 0, stream(),
+                         (const uint64_t *) R.sab, (const uint32_t *) C.from.p, cs.pool[nx].p,
                          (const uint32_t *) C.fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, C.jl.p,
                          (const uint32_t *) (C.jl.p + nsum + 1), cs.jumps.p, (uint32_t) cs.jtop, 1);
     HIP_CHECK(hipGetLastError());

@@ -36,6 +36,7 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
                  hipGetErrorString(_e));                                                 \
   } while (0)
 
+bool        host_crowded();        // more ranks on this node than half its cores: host waits yield instead of spinning (dmh_core.hip)
 hipStream_t stream();              // the stream this thread's launches go to: the main stream unless a StreamScope is open
 hipStream_t main_stream();
 void        join_side_streams();   // the main stream waits for everything queued on the finish stream so far

@@ -2,6 +2,8 @@
 // and the small stage-level helpers of the C-ABI (see include/damapper_hip.h).
 
 #include "dmh_state.h"
+#include <sched.h>
+#include <unistd.h>
 #include "dmh_merge.h"
 #include <deque>
 #include "dmh_device.h"
@@ -58,6 +60,40 @@ void fatal(const char *fmt, ...)
 extern "C" void dmh_timing_enable(int on);
 static void timing_dump_at_exit();
 
+// Cores this process may use: the affinity mask, capped by the cgroup's CPU quota (a GPU box of this pool shows 256 CPUs
+// in the mask and a quota of 16).
+static int host_cores()
+{ int n = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (int) sysconf(_SC_NPROCESSORS_ONLN);
+  FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f != nullptr)
+    { char q[64];
+      long long per = 0;
+      if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0)
+        { const long long c = atoll(q) / per;
+          if (c >= 1 && c < n) n = (int) c;
+        }
+      fclose(f);
+    }
+  return n > 0 ? n : 1;
+}
+
+// One process per GPU keeps two threads busy at the peak (the block loop, which spins on the device's answers, and the
+// report worker).  When the ranks of a node outnumber half its cores -- eight ranks on a 16-core quota -- the waits give
+// the core up instead (blocking synchronisation, a yield in the finish's tag wait): a spinning rank would then only take
+// the time of another rank's worker.  DMH_YIELD=0 / 1 forces either.
+bool host_crowded()
+{ static int v = -1;
+  if (v < 0)
+    { const char *e = getenv("DMH_YIELD"), *ws = getenv("WORLD_SIZE");
+      if (e != nullptr) v = atoi(e) != 0;
+      else v = (ws != nullptr && 2 * atoi(ws) > host_cores()) ? 1 : 0;
+    }
+  return v == 1;
+}
+
 static void init_device()
 { if (g_init) return;
   int n = 0;
@@ -73,6 +109,8 @@ static void init_device()
   if (dv != nullptr) dev = atoi(dv) % n;
   HIP_CHECK(hipSetDevice(dev));
   if (getenv("DMH_SPIN") != nullptr) (void) hipSetDeviceFlags(hipDeviceScheduleSpin);
+  else if (host_crowded())
+    { if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void) hipGetLastError(); }
   HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&g_upstream, hipStreamNonBlocking));
   g_init = true;

@@ -1144,6 +1144,12 @@ static bool lds_atomics_ordered()
   return known == 1;
 }
 
+// the per-read route's coarse buckets: 2^RS_CB bases (DMH_RS_CB: experiments)
+static int rs_coarse_bits()
+{ static const int v = getenv("DMH_RS_CB") ? std::max(8, std::min(24, atoi(getenv("DMH_RS_CB")))) : RS_CB;
+  return v;
+}
+
 // per-read route: segment starts of the pass being collected (main stream only; a dense pass is closed at once)
 static DevBuf<uint64_t> g_rows;          // fused route: the row table of the pass being collected (read by its per-read kernel,
                                          //   which is queued before the next pass lists its rows)
@@ -1451,7 +1457,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // --- the per-read route (dmh_readsort.h): a dense pass in one-word mode writes its hits read by read
   static const int env_rs = getenv("DMH_READ_SORT") ? atoi(getenv("DMH_READ_SORT")) : 1;
   static const bool env_per_entry = getenv("DMH_EXPAND_PER_ENTRY") != nullptr;
-  const int  rs_cb = std::min(RS_CB, R.qbits);
+  const int  rs_cb = std::min(rs_coarse_bits(), R.qbits);
   const bool by_read = R.word && R.npass == 0 && !env_per_entry && st.opt_expand != 0 &&
                        (st.opt_read_sort >= 0 ? st.opt_read_sort != 0 : env_rs != 0) &&
                        R.pbits + R.qbits - rs_cb + R.bbits <= 32 &&        // (the sort key of k_read_sort is one 32-bit word)
@@ -1968,7 +1974,7 @@ static void close_batch(MergeResult &R, int phase)
           RA.in = k0; RA.out = k1; RA.rstart = R.rs_start.p;
           // the coarse buckets of this route (64 kb: a locus rarely lies across two) and its radix passes: the sort key
           // apos | coarse key << pbits cut into equal digits of at most RS_DB bits
-          const int rcb = std::min(RS_CB, qbits), kbits = qbits - rcb + R.bbits;
+          const int rcb = std::min(rs_coarse_bits(), qbits), kbits = qbits - rcb + R.bbits;
           RA.pbits = R.pbits; RA.qbits = qbits; RA.bbits = R.bbits; RA.cb = rcb;
           RA.kbits = kbits;
           RA.npass = 0;

@@ -644,6 +644,26 @@ def native_genome(seed: int, contig_lens: Sequence[int], kind: str = "repeat", f
     return Genome(layout=layout, lens=lens, offs=offs, kind=kind)
 
 
+def genome_from_contigs(seqs: Sequence[np.ndarray], kind: str = "fasta") -> Genome:
+    """Contigs (arrays of 0..3) in the whole-DB layout a Genome keeps."""
+    lens = np.asarray([len(x) for x in seqs], dtype=np.int64)
+    n = len(lens)
+    offs = 1 + np.concatenate(([0], np.cumsum(lens + 1)))[:n]
+    layout = np.full(int(lens.sum()) + n + 4, 4, dtype=np.uint8)
+    for o, x in zip(offs, seqs):
+        layout[int(o):int(o) + len(x)] = x
+    return Genome(layout=layout, lens=lens, offs=offs, kind=kind)
+
+
+def genome_from_fasta(path: str, min_len: int = 1) -> Genome:
+    """A FASTA on disk as a Genome: entries cut at runs of N into contigs as fasta2DAM does, contigs shorter than
+    `min_len` left out (a simulated read must fit its contig)."""
+    seqs, _ = read_fasta(path, split_n=True, min_len=min_len)
+    if not seqs:
+        raise ValueError("%s holds no contig of %d bases or more" % (path, min_len))
+    return genome_from_contigs(seqs)
+
+
 def genome_block(G: Genome, first: int = 0, last: Optional[int] = None, part: int = 0, path: bytes = b"./.REF",
                  copy: bool = False, freq: Optional[Sequence[float]] = None) -> Block:
     """Contigs [first, last) of a Genome as a DAZZ_DB block (tfirst = first).  Without `copy` the block's bases are
