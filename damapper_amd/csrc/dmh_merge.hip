@@ -109,46 +109,65 @@ constexpr int MG_TILE    = MG_THREADS * MG_ITEMS;
 struct MergeEntry { uint32_t a0, ma, b0, mb; };
 constexpr uint32_t PENDING = 0xffffffffu;     // mb of an entry whose REF run has still to be searched for
 
-template <int NK, bool LOW>
+// TWO: the same READ codes looked up in a second REF index in the same sweep -- the forward and the complement index of
+// one REF block, which the driver merges against one after the other (damapper.c:851, 861).  The launch has two
+// workgroups per tile, one per table, numbered so that the pair runs on the same XCD at the same time (workgroups b and
+// b + 8 share an L2): the READ index's keys, 2.1 of the 4.9 GB a pass reads, come from HBM once for the two passes and
+// from that L2 the second time.  (One workgroup probing both tables in turn holds the codes across the two rounds: 133
+// registers against 74, three wavefronts per SIMD against six, and was slower than two launches.)  Each table has its own
+// entry windows, counts and sums, so that everything behind the match stays per call (limit rule, candidate order,
+// domination: map.c:2992-3055).
+struct MatchOut
+{ MergeEntry         *tile_entries;
+  uint32_t           *tile_count;
+  unsigned long long *tile_hits;
+};
+
+template <int NK, bool LOW, bool TWO = false>
 __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__restrict__ akeys, int64_t na,
-                                                            BLookup B,
-                                                            MergeEntry *__restrict__ tile_entries,
-                                                            uint32_t *__restrict__ tile_count,
-                                                            unsigned long long *__restrict__ tile_hits)
+                                                            BLookup B0, MatchOut O0, BLookup B1, MatchOut O1)
 { __shared__ unsigned long long s_hits[2][4];
   __shared__ uint32_t s_count;
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) s_count = 0;
-  __syncthreads();
-
-  // hits of the tile: all of them, and those of the runs below MAXGRAM (what the limit rule can keep at most)
-  unsigned long long local = 0, below = 0;
-  MergeEntry *dst = tile_entries + (size_t) blockIdx.x * MG_TILE;        // the tile's own window of the entry list
+  const int      side = TWO ? (int) ((blockIdx.x >> 3) & 1u) : 0;
+  const uint32_t tile = TWO ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u)) : blockIdx.x;
+  if ((int64_t) tile * MG_TILE >= na) return;                  // (TWO: the grid is rounded up to whole groups of eight tiles)
 
   // The look-ups of a thread's MG_ITEMS codes are independent: issue them phase by phase (codes,
   // bucket bounds, the first two keys of the bucket) so that every thread has MG_ITEMS loads in
   // flight instead of one dependent chain after the other.  The bucket table is sized for ~0.15
   // entries per bucket, so two keys settle all but a few look-ups per thousand; only those run the
   // bisection (a wavefront pays its dependent loads if ANY of its lanes needs it).
-  const int64_t tile0 = (int64_t) blockIdx.x * MG_TILE + tid;
+  const int64_t tile0 = (int64_t) tile * MG_TILE + tid;
   uint64_t c[MG_ITEMS];
   bool     first[MG_ITEMS];
   uint32_t bs[MG_ITEMS], be[MG_ITEMS];
-  uint64_t pv[MG_ITEMS];
+  { uint64_t pv[MG_ITEMS];
 #pragma unroll
-  for (int j = 0; j < MG_ITEMS; j++)
-    { // unconditional loads from clamped addresses: a guarded load compiles to a branch with a wait at
-      // its join, which strings the 16 loads of this phase into 16 round trips
-      int64_t i  = tile0 + j * MG_THREADS;
-      int64_t ic = i < na ? i : na - 1;
-      c[j]  = akeys[ic];
-      pv[j] = akeys[ic > 0 ? ic - 1 : 0];
-    }
+    for (int j = 0; j < MG_ITEMS; j++)
+      { // unconditional loads from clamped addresses: a guarded load compiles to a branch with a wait at
+        // its join, which strings the 16 loads of this phase into 16 round trips
+        int64_t i  = tile0 + j * MG_THREADS;
+        int64_t ic = i < na ? i : na - 1;
+        c[j]  = akeys[ic];
+        pv[j] = akeys[ic > 0 ? ic - 1 : 0];
+      }
 #pragma unroll
-  for (int j = 0; j < MG_ITEMS; j++)
-    { int64_t i = tile0 + j * MG_THREADS;
-      first[j] = (i < na) && (i == 0 || pv[j] != c[j]);
-    }
+    for (int j = 0; j < MG_ITEMS; j++)
+      { int64_t i = tile0 + j * MG_THREADS;
+        first[j] = (i < na) && (i == 0 || pv[j] != c[j]);
+      }
+  }
+  const BLookup B = (TWO && side) ? B1 : B0;
+  MergeEntry *__restrict__ tile_entries = (TWO && side) ? O1.tile_entries : O0.tile_entries;
+  uint32_t *__restrict__ tile_count = (TWO && side) ? O1.tile_count : O0.tile_count;
+  unsigned long long *__restrict__ tile_hits = (TWO && side) ? O1.tile_hits : O0.tile_hits;
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+
+  // hits of the tile: all of them, and those of the runs below MAXGRAM (what the limit rule can keep at most)
+  unsigned long long local = 0, below = 0;
+  MergeEntry *dst = tile_entries + (size_t) tile * MG_TILE;              // the tile's own window of the entry list
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
     { bs[j] = be[j] = 0;
@@ -252,9 +271,9 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
   // map.c:881-934 is only needed when the hits do not fit the memory limit, and is then made from the
   // entry list (k_entry_hist).  k_merge_gather / k_merge_reduce put the pieces together.
   if (tid == 0)
-    { tile_hits[2 * (size_t) blockIdx.x]     = s_hits[0][0] + s_hits[0][1] + s_hits[0][2] + s_hits[0][3];
-      tile_hits[2 * (size_t) blockIdx.x + 1] = s_hits[1][0] + s_hits[1][1] + s_hits[1][2] + s_hits[1][3];
-      tile_count[blockIdx.x] = s_count;
+    { tile_hits[2 * (size_t) tile]     = s_hits[0][0] + s_hits[0][1] + s_hits[0][2] + s_hits[0][3];
+      tile_hits[2 * (size_t) tile + 1] = s_hits[1][0] + s_hits[1][1] + s_hits[1][2] + s_hits[1][3];
+      tile_count[tile] = s_count;
     }
 }
 
@@ -1192,15 +1211,87 @@ static bool local_cluster_sort(int pbits)
 // it early: merge_pass does at its start, or -- when the driver has said which pass comes next (dmh_next_pass) --
 // close_batch does for the FOLLOWING pass, in front of its wait for the cluster counters: the main stream then goes
 // straight on while the host queues the second half of the pass on the tail stream (0.5 ms).
-static DevBuf<unsigned long long> g_gram, g_thits;
-static DevBuf<MergeEntry> g_entries, g_tentries;
-static DevBuf<uint32_t>   g_tcount;
-static DevBuf<unsigned int> g_mctl;
-static const IndexDev *g_front_a = nullptr, *g_front_b = nullptr;       // the pass whose front is queued already
+// Two sets of the front's results: when the driver has said which pass comes next (dmh_next_pass) and that pass meets the
+// same READ index -- the complement of the REF block at hand --, ONE sweep of the READ keys probes both REF indices
+// (k_merge_match<.., TWO>), the second table's results wait in set 1 for the call that follows.
+struct FrontBufs
+{ DevBuf<unsigned long long> gram, thits;
+  DevBuf<MergeEntry> tentries;
+  DevBuf<uint32_t>   tcount;
+  DevBuf<unsigned int> mctl;
+  const IndexDev *a = nullptr, *b = nullptr;                            // the pass whose front is queued in this set
+};
+static FrontBufs g_fb[2];
+static DevBuf<MergeEntry> g_entries;
 static IndexDev *g_hint_a = nullptr, *g_hint_b = nullptr;               // the pass the driver says comes next
 static int g_hint_kshift = 0;
 
-static void match_front(IndexDev &A, IndexDev &Bx, int Kshift)
+static void ensure_bucket_table(IndexDev &Bx, int Kshift);
+
+static BLookup lookup_of(const IndexDev &Bx)
+{ return BLookup{Bx.keys, Bx.d_bstart, Bx.bshift, Bx.low_off ? (const uint16_t *) (Bx.d_bstart + Bx.low_off) : nullptr}; }
+
+// B2 != nullptr: the same sweep also probes B2 (results in set 1)
+static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nullptr)
+{ State &st = S();
+  ensure_bucket_table(Bx, Kshift);
+  if (B2 != nullptr)
+    { ensure_bucket_table(*B2, Kshift);
+      if (B2->bshift != Bx.bshift || B2->probe_keys != Bx.probe_keys || (B2->low_off != 0) != (Bx.low_off != 0)) B2 = nullptr;
+    }
+  const BLookup BL = lookup_of(Bx), BL2 = (B2 != nullptr) ? lookup_of(*B2) : BL;
+  const int64_t ntiles = ceil_div(A.n, MG_TILE);
+  MatchOut MO[2];
+  for (int q = 0; q < (B2 != nullptr ? 2 : 1); q++)
+    { FrontBufs &F = g_fb[q];
+      F.gram.ensure(MAXGRAM + 8, "hit histogram");
+      F.mctl.ensure(4, "merge counters");
+      F.tentries.ensure((size_t) ntiles * MG_TILE, "matched runs (per tile)");
+      F.tcount.ensure(ntiles + 1, "matched runs per tile");
+      F.thits.ensure(2 * (size_t) ntiles, "hits per tile");
+      HIP_CHECK(hipMemsetAsync(F.gram.p + MAXGRAM + 1, 0, sizeof(unsigned long long) * 3, stream()));     // [0] all hits, [1] hits of the runs below MAXGRAM
+      HIP_CHECK(hipMemsetAsync(F.mctl.p, 0, 4 * sizeof(unsigned int), stream()));
+      MO[q] = MatchOut{F.tentries.p, F.tcount.p, F.thits.p};
+    }
+  if (B2 == nullptr) MO[1] = MO[0];
+  { // bytes the kernel has to read in this layout: 8 per READ k-mer, 4 per bucket and 2 (the low bits) or 8 (the key) per
+    // REF k-mer -- SURVEY 8(d) prices the merge at the reference's 16-byte records, 16 (A.n + B.n), which is more than
+    // this kernel moves
+    const double per_table = 4.0 * ((double) ((int64_t) 1 << (Kshift - Bx.bshift)) + 2) + (BL.klow != nullptr ? 2.0 : 8.0) * Bx.n;
+    StageTimer tm(B2 != nullptr ? "merge_match2" : "merge_match", 8.0 * A.n + (B2 != nullptr ? 2.0 : 1.0) * per_table);
+    const dim3 grid(B2 != nullptr ? (uint32_t) (((ntiles + 7) / 8) * 16) : (uint32_t) ntiles), blk(MG_THREADS);
+    const uint64_t *ak = (const uint64_t *) A.keys;
+    const bool four = Bx.probe_keys == 4, low = BL.klow != nullptr;
+    if (B2 != nullptr)
+      { if (four && low)  hipLaunchKernelGGL((k_merge_match<4, true, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+        else if (four)    hipLaunchKernelGGL((k_merge_match<4, false, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+        else if (low)     hipLaunchKernelGGL((k_merge_match<2, true, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+        else              hipLaunchKernelGGL((k_merge_match<2, false, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+      }
+    else
+      { if (four && low)  hipLaunchKernelGGL((k_merge_match<4, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+        else if (four)    hipLaunchKernelGGL((k_merge_match<4, false>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+        else if (low)     hipLaunchKernelGGL((k_merge_match<2, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+        else              hipLaunchKernelGGL((k_merge_match<2, false>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+      }
+  }
+  { StageTimer tm("merge_fixup", 0.0);
+    for (int q = 0; q < (B2 != nullptr ? 2 : 1); q++)
+      { FrontBufs &F = g_fb[q];
+        hipLaunchKernelGGL(k_merge_fixup, dim3(ntiles), dim3(FX_THREADS), 0, stream(), (const uint64_t *) A.keys, A.n, q ? BL2 : BL,
+                           F.tentries.p, (const uint32_t *) F.tcount.p, F.thits.p);
+        hipLaunchKernelGGL(k_merge_reduce, dim3(64), dim3(256), 0, stream(), (const unsigned long long *) F.thits.p, ntiles,
+                           F.gram.p + MAXGRAM + 1);
+        exclusive_scan_u32(F.tcount.p, ntiles, st.sort.bsum, F.tcount.p + ntiles);
+      }
+    HIP_CHECK(hipGetLastError());
+  }
+  g_fb[0].a = &A; g_fb[0].b = &Bx;
+  if (B2 != nullptr) { g_fb[1].a = &A; g_fb[1].b = B2; }
+  else               { g_fb[1].a = nullptr; g_fb[1].b = nullptr; }
+}
+
+static void ensure_bucket_table(IndexDev &Bx, int Kshift)
 { State &st = S();
   // --- bucket table over the REF index: part of the index, built the first time it is merged against
   //     (a retained REF index meets every READS block)
@@ -1238,49 +1329,6 @@ static void match_front(IndexDev &A, IndexDev &Bx, int Kshift)
         hipLaunchKernelGGL(k_low16, dim3(ceil_div(Bx.n, 256)), dim3(256), 0, stream(), (const uint64_t *) Bx.keys, Bx.n,
                            (uint32_t) (((uint64_t) 1 << Bx.bshift) - 1), (uint16_t *) (Bx.d_bstart + Bx.low_off));
     }
-  BLookup BL{Bx.keys, Bx.d_bstart, Bx.bshift, Bx.low_off ? (const uint16_t *) (Bx.d_bstart + Bx.low_off) : nullptr};
-
-  // --- match + count (map.c:2984-2988)
-  DevBuf<unsigned long long> &gram = g_gram, &thits = g_thits;
-  DevBuf<MergeEntry> &tentries = g_tentries;
-  DevBuf<uint32_t>   &tcount = g_tcount;
-  DevBuf<unsigned int> &mctl = g_mctl;
-  const int64_t ntiles = ceil_div(A.n, MG_TILE);
-  gram.ensure(MAXGRAM + 8, "hit histogram");
-  mctl.ensure(4, "merge counters");
-  tentries.ensure((size_t) ntiles * MG_TILE, "matched runs (per tile)");
-  tcount.ensure(ntiles + 1, "matched runs per tile");
-  thits.ensure(2 * (size_t) ntiles, "hits per tile");
-  unsigned long long *sums = gram.p + MAXGRAM + 1;         // [0] all hits, [1] hits of the runs below MAXGRAM
-  HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(unsigned long long) * 3, stream()));
-  HIP_CHECK(hipMemsetAsync(mctl.p, 0, 4 * sizeof(unsigned int), stream()));
-  { // bytes the kernel has to read in this layout: 8 per READ k-mer, 4 per bucket and 2 (the low bits) or 8 (the key) per
-    // REF k-mer -- SURVEY 8(d) prices the merge at the reference's 16-byte records, 16 (A.n + B.n), which is more than
-    // this kernel moves
-    StageTimer tm("merge_match", 8.0 * A.n + 4.0 * ((double) ((int64_t) 1 << (Kshift - Bx.bshift)) + 2) +
-                                 (BL.klow != nullptr ? 2.0 : 8.0) * Bx.n);
-    if (Bx.probe_keys == 4 && BL.klow != nullptr)
-      hipLaunchKernelGGL((k_merge_match<4, true>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                         (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
-    else if (Bx.probe_keys == 4)
-      hipLaunchKernelGGL((k_merge_match<4, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                         (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
-    else if (BL.klow != nullptr)
-      hipLaunchKernelGGL((k_merge_match<2, true>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                         (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
-    else
-      hipLaunchKernelGGL((k_merge_match<2, false>), dim3(ntiles), dim3(MG_THREADS), 0, stream(),
-                         (const uint64_t *) A.keys, A.n, BL, tentries.p, tcount.p, thits.p);
-  }
-  { StageTimer tm("merge_fixup", 0.0);
-    hipLaunchKernelGGL(k_merge_fixup, dim3(ntiles), dim3(FX_THREADS), 0, stream(), (const uint64_t *) A.keys, A.n, BL,
-                       tentries.p, (const uint32_t *) tcount.p, thits.p);
-    hipLaunchKernelGGL(k_merge_reduce, dim3(64), dim3(256), 0, stream(), (const unsigned long long *) thits.p, ntiles, sums);
-    exclusive_scan_u32(tcount.p, ntiles, st.sort.bsum, tcount.p + ntiles);
-    HIP_CHECK(hipGetLastError());
-  }
-  g_front_a = &A;
-  g_front_b = &Bx;
 }
 
 void filter_hint_next_pass(IndexDev *A, IndexDev *B, int Kshift)
@@ -1288,7 +1336,8 @@ void filter_hint_next_pass(IndexDev *A, IndexDev *B, int Kshift)
 
 void filter_forget_index(const IndexDev *ix)
 { if (g_hint_a == ix || g_hint_b == ix) { g_hint_a = nullptr; g_hint_b = nullptr; }
-  if (g_front_a == ix || g_front_b == ix) { g_front_a = nullptr; g_front_b = nullptr; }
+  for (int q = 0; q < 2; q++)
+    if (g_fb[q].a == ix || g_fb[q].b == ix) { g_fb[q].a = nullptr; g_fb[q].b = nullptr; }
 }
 
 int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &Bx,
@@ -1300,13 +1349,27 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   static const bool hooked = (set_reclaim_hook(filter_reclaim), true);
   (void) hooked;
 
-  // --- the front of the pass (match_front above), unless the previous pass has queued it already
-  if (!(g_front_a == &A && g_front_b == &Bx)) match_front(A, Bx, Kshift);
-  g_front_a = nullptr; g_front_b = nullptr;
-  DevBuf<MergeEntry> &entries = g_entries, &tentries = g_tentries;
-  DevBuf<uint32_t>   &tcount = g_tcount;
-  DevBuf<unsigned long long> &gram = g_gram;
-  DevBuf<unsigned int> &mctl = g_mctl;
+  // --- the front of the pass (match_front above), unless the sweep of the pass before has made it already.  When the
+  //     driver has named the pass that follows (dmh_next_pass) and it meets the same READ index -- the complement of this
+  //     REF block, resident and complete --, this sweep probes both indices ("front_early" test option = 0: never)
+  int fs = -1;
+  for (int q = 0; q < 2; q++)
+    if (g_fb[q].a == &A && g_fb[q].b == &Bx) fs = q;
+  if (fs < 0)
+    { static const bool env_two = getenv("DMH_MATCH_TWO") == nullptr || atoi(getenv("DMH_MATCH_TWO")) != 0;
+      IndexDev *B2 = nullptr;
+      if (env_two && st.opt_front_early != 0 && g_hint_a == &A && g_hint_b != nullptr && g_hint_b != &Bx && g_hint_b->keys != nullptr &&
+          !g_hint_b->pending && g_hint_b->built == nullptr && g_hint_b->n > 0 && g_hint_kshift == Kshift)
+        B2 = g_hint_b;
+      match_front(A, Bx, Kshift, B2);
+      fs = 0;
+    }
+  g_fb[fs].a = nullptr; g_fb[fs].b = nullptr;
+  g_hint_a = nullptr; g_hint_b = nullptr;
+  DevBuf<MergeEntry> &entries = g_entries, &tentries = g_fb[fs].tentries;
+  DevBuf<uint32_t>   &tcount = g_fb[fs].tcount;
+  DevBuf<unsigned long long> &gram = g_fb[fs].gram;
+  DevBuf<unsigned int> &mctl = g_fb[fs].mctl;
   const int64_t ntiles = ceil_div(A.n, MG_TILE);
   unsigned long long *sums = gram.p + MAXGRAM + 1;         // [0] all hits, [1] hits of the runs below MAXGRAM
   // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
@@ -2147,24 +2210,6 @@ static void close_batch(MergeResult &R, int phase)
               for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
             else if (phase == 2)
               { HIP_CHECK(hipEventSynchronize(R.ev_known));
-                for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
-              }
-            else if (g_hint_a != nullptr && g_hint_b != nullptr && g_hint_a->keys != nullptr && g_hint_b->keys != nullptr &&
-                     !g_hint_a->pending && !g_hint_b->pending && g_hint_a->built == nullptr && g_hint_b->built == nullptr &&
-                     stream() == main_stream() &&
-                     st.opt_front_early != 0)
-              { // the counters set off for page-locked memory, the FOLLOWING pass's front is queued behind them, and
-                // only then does the host wait for the counters
-                if (R.h_known == nullptr)
-                  { HIP_CHECK(hipHostMalloc((void **) &R.h_known, 8 * sizeof(uint32_t), hipHostMallocDefault));
-                    HIP_CHECK(hipEventCreateWithFlags(&R.ev_known, hipEventDisableTiming));
-                  }
-                HIP_CHECK(hipMemcpyAsync(R.h_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
-                HIP_CHECK(hipEventRecord(R.ev_known, stream()));
-                IndexDev *ha = g_hint_a, *hb = g_hint_b;
-                g_hint_a = nullptr; g_hint_b = nullptr;
-                match_front(*ha, *hb, g_hint_kshift);
-                HIP_CHECK(hipEventSynchronize(R.ev_known));
                 for (int q = 0; q < 5; q++) g_known[q] = R.h_known[q];
               }
             else

@@ -164,8 +164,10 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   uint64_t *flagw = (uint64_t *) (wh + (size_t) W * D);       // cluster-start bits, one word per 64 hits (+ sentinel)
   uint32_t *mbits = (uint32_t *) (flagw + (T * E / 64 + 2));  // per cluster: spans buckets (T * E / 32 + 2 words)
   uint16_t *wpref = (uint16_t *) (mbits + (T * E / 32 + 2));  // starts before each flag word
-  // (fused route, step 5) per cluster: not a sequence of plain chains / not to be tried
+  // (fused route, step 5) per cluster: not a sequence of plain chains / not to be tried; (step 3) per position: a run starts
+  // here -- a cluster, or the next coarse bucket inside one
   uint32_t *cbad  = (uint32_t *) (rs_lds + read_sort_lds_words<T>());
+  uint64_t *runw  = (uint64_t *) (cbad + (T * E / 32 + 2));
   __shared__ uint32_t ws[W];
   __shared__ uint32_t ws2[W];
 
@@ -455,9 +457,13 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
           f = true;                                            // sentinel: the end of the last cluster
         const uint64_t m = __ballot(f);
         if (lane == 0 && (wbase + 64u * j) / 64 < nw) flagw[(wbase + 64u * j) / 64] = m;
+        if (FUSE)
+          { const uint64_t mr = __ballot(f || ((chg >> j) & 1u));
+            if (lane == 0 && (wbase + 64u * j) / 64 < nw) runw[(wbase + 64u * j) / 64] = mr;
+          }
       }
   // (the sentinel lies in the word after the last wavefront's last round when n is a multiple of 64 W)
-  if (tid == 0 && n == rounds * 64 * W) flagw[n / 64] = 1ull;
+  if (tid == 0 && n == rounds * 64 * W) { flagw[n / 64] = 1ull; if (FUSE) runw[n / 64] = 1ull; }
   __syncthreads();
   uint32_t ncl;
   { uint32_t c = 0;
@@ -510,22 +516,64 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
             { const uint32_t c = cid[j];
               multi = (mbits[c >> 5] >> (c & 31u)) & 1u;
               if ((flagw[wi] >> bi) & 1ull)
-                { A.lcl[s0 + c] = ((uint64_t) multi << 63) | (((key[j] >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
+                { // (fused route: every cluster leaves this kernel in chain order -- nothing for k_csort_wide)
+                  A.lcl[s0 + c] = ((uint64_t) (multi && !FUSE) << 63) | (((key[j] >> (A.pbits + A.qbits)) & bm) << 32) | (uint64_t) (s0 + i);
                   // the cluster's size: up to the next start (the sentinel ends the search)
                   uint64_t m = (bi == 63) ? 0ull : (flagw[wi] & (~0ull << (bi + 1)));
                   uint32_t ww = wi;
                   while (m == 0) { ww += 1; m = flagw[ww]; }
                   const uint32_t size = ww * 64 + (uint32_t) __ffsll((long long) m) - 1 - i;
-                  // (step 5 leaves alone: a cluster that is not in chain order when this kernel is done with it, or too large)
-                  if (FUSE && ((multi && size > (uint32_t) RS_IN) || size > A.simple_max)) atomicOr(&cbad[c >> 5], 1u << (c & 31u));
+                  // (step 5 leaves alone: a cluster that is too large)
+                  if (FUSE && size > A.simple_max) atomicOr(&cbad[c >> 5], 1u << (c & 31u));
                   if (size >= A.big_min)
                     { if (size >= A.pile_min) { atomicAdd(A.counts + 5, 1u); atomicAdd(A.counts + 6, size); }
                       else atomicAdd(A.counts + 4, 1u);
                     }
-                  if (multi && size > A.medium) atomicAdd(A.counts + 3, 1u);
+                  if (multi && !FUSE && size > A.medium) atomicAdd(A.counts + 3, 1u);
                 }
             }
-          if (__any(multi))                                    // (one locus in fifteen: most rounds skip this)
+          if (FUSE)
+            { // A cluster that spans coarse buckets is a sequence of RUNS -- one per bucket, each in (apos, bpos) order
+              // (the passes are stable and the words started out that way) --, so its order is a MERGE: the place of a hit
+              // is its place in its own run plus, for every other run of its cluster, the number of that run's hits that
+              // come before it (a binary search).  Any size; nothing is left to k_csort_wide.
+              se[j] = i;
+              if (__any(multi))
+                { if (multi)
+                    { const uint64_t x = key[j];
+                      const uint64_t kk = ((x & pm) << 32) | ((x >> A.pbits) & qm);
+                      auto at_or_below = [&](const uint64_t *mw, uint32_t p) -> uint32_t
+                      { uint32_t ww = p >> 6;
+                        uint64_t y = mw[ww] & (~0ull >> (63u - (p & 63u)));
+                        while (y == 0) { ww -= 1; y = mw[ww]; }
+                        return ww * 64 + 63u - (uint32_t) __clzll((long long) y);
+                      };
+                      auto above = [&](const uint64_t *mw, uint32_t p) -> uint32_t          // (the sentinel n ends every search)
+                      { uint32_t ww = p >> 6;
+                        uint64_t y = ((p & 63u) == 63u) ? 0ull : (mw[ww] & (~0ull << ((p & 63u) + 1)));
+                        while (y == 0) { ww += 1; y = mw[ww]; }
+                        return ww * 64 + (uint32_t) __ffsll((long long) y) - 1;
+                      };
+                      const uint32_t cs = at_or_below(flagw, i), ce = above(flagw, i), rs = at_or_below(runw, i);
+                      uint32_t place = cs + (i - rs);
+                      for (uint32_t a = cs; a < ce; )
+                        { const uint32_t b = above(runw, a);                 // the run [a, b)
+                          if (a != rs)
+                            { uint32_t lo = a, hi = b;                       // first word of the run that does not come before mine
+                              while (lo < hi)
+                                { const uint32_t md = (lo + hi) >> 1;
+                                  const uint64_t y = buf[md];
+                                  if ((((y & pm) << 32) | ((y >> A.pbits) & qm)) < kk) lo = md + 1; else hi = md;
+                                }
+                              place += lo - a;
+                            }
+                          a = b;
+                        }
+                      se[j] = place;
+                    }
+                }
+            }
+          else if (__any(multi))                               // (one locus in fifteen: most rounds skip this)
             { const uint64_t f0 = flagw[wi > 0 ? wi - 1 : 0], f1 = flagw[wi < nw ? wi : 0], f2 = flagw[wi + 1 < nw ? wi + 1 : 0];
               if (multi)
                 { const uint64_t x = key[j];
@@ -556,7 +604,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
       { const uint32_t i = wbase + 64u * j + lane;
         const uint64_t x = key[j];
         key[j] = (x & pm) | (((x >> A.pbits) & qm) << 32);     // the chain kernels' word: apos | bpos << 32
-        if (se[j] != 0)                                        // (only the words of clusters that are ranked are read back)
+        if (!FUSE && se[j] != 0)                               // (only the words of clusters that are ranked are read back)
           { if (K32) b32[i] = k32[j];
             else     buf[i] = (key[j] << 32) | (key[j] >> 32);
           }
@@ -569,8 +617,8 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   for (int j = 0; j < E; j++)
     if ((uint32_t) j < rounds)
       { const uint32_t i = wbase + 64u * j + lane;
-        uint32_t dst = i;
-        if ((anym >> j) & 1u)                                  // (uniform)
+        uint32_t dst = FUSE ? se[j] : i;
+        if (!FUSE && ((anym >> j) & 1u))                       // (uniform)
           { const uint32_t s = se[j] & 0xffffu, m = se[j] >> 16;
             uint32_t rank = 0;
             if (K32)
@@ -782,7 +830,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
 }
 
 // dynamic LDS of k_read_sort<T>: the unfused kernel's arrays, in 8-byte words (read_sort_lds_words, declared ahead of the
-// kernel), and behind them the bit map of the fused route's step 5
+// kernel), and behind them the two bit maps of the fused route's steps 3 and 5
 template <int T> constexpr size_t read_sort_lds()
 { return sizeof(uint64_t) * read_sort_lds_words<T>()
          + sizeof(uint64_t) * (T * RS_E / 64 + 2) + sizeof(uint32_t) * (T * RS_E / 32 + 2);

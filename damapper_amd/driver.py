@@ -45,10 +45,10 @@ class Mapper:
         self._pending = None
         self.overlap_passes = int(os.environ.get("DMH_OVERLAP_PASSES", "10"))
         self.prefetch_overlap = os.environ.get("DMH_PREFETCH_OVERLAP", "1") != "0"
-        # (dmh_next_pass: the following pass's match kernels queued ahead of a pass's last wait.  Measured on the bench
-        #  workload: 148.5 against 144.9 ms per read block -- the main stream no longer waits 0.5 ms per pass, but the second
-        #  half of the pass then runs next to the expansion and the per-read sort instead of next to the match kernels.  Opt-in.)
-        self.hint_passes = os.environ.get("DMH_HINT_PASSES", "0") != "0"
+        # dmh_next_pass: the library is told which (READS index, REF index) pair the NEXT Match_Filter call will bring, and
+        # -- when that is the complement of the REF block at hand, as in damapper.c:851,861 -- probes both orientations'
+        # indices in ONE sweep of the READ keys (results unchanged; DMH_HINT_PASSES=0: every pass sweeps for itself)
+        self.hint_passes = os.environ.get("DMH_HINT_PASSES", "1") != "0"
 
     def release_ref(self) -> None:
         self.finish()
@@ -183,7 +183,7 @@ class Mapper:
         if self.retain_ref:
             refs = self._ref_indices(ref_blocks)
             for j, (h, n, comp, k) in enumerate(refs):
-                # (the pass after this one: the library queues its match kernels ahead of this pass's last wait)
+                # (the pass after this one: when it is this REF block's complement, one sweep of the READ keys serves both)
                 if self.hint_passes:
                     self.L.dmh_next_pass(rh, refs[j + 1][0]) if j + 1 < len(refs) else self.L.dmh_next_pass(None, None)
                 capi.match_filter(reads, ref_blocks[k], rh, rn, h, n, comp, 1 if (k == 0 and comp == 0) else 0)

@@ -415,8 +415,9 @@ def test_resident_driver_recipe_matches_reference(tmp_path):
 
 
 def test_next_pass_hint_gives_identical_files(tmp_path, monkeypatch):
-    """dmh_next_pass (the following pass's match kernels queued ahead of a pass's last wait; driver: DMH_HINT_PASSES=1):
-    the same files as without -- through the bench's call sequence on a three-block reference, two read blocks."""
+    """dmh_next_pass (the driver names the pass that follows; the library then probes the forward and the complement
+    index of a REF block in ONE sweep of the READ keys -- the driver's default; DMH_HINT_PASSES=0: every pass for itself):
+    the same files either way -- through the bench's call sequence on a three-block reference, two read blocks."""
     import test_gpu_scale as scale
     run_ref = _run_ref()
     g, reads = make_dataset("repeat", 346, [200000, 150000, 120000], 75, dropouts=1)
@@ -426,13 +427,14 @@ def test_next_pass_hint_gives_identical_files(tmp_path, monkeypatch):
     nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
     blocks = ["READS.%d" % (k + 1) for k in range(nb)]
     run_ref.run_reference(d, "REF", blocks, flags=[], threads=4, keep="las_ref")
-    monkeypatch.setenv("DMH_HINT_PASSES", "1")
-    out = os.path.join(d, "las_hint")
-    scale._map_blocks_like_bench(d, "REF", "READS", out, report_mode=2, overlap=True)
-    for b in blocks:
-        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
-        _, hr = las.read_las_set(out, b + ".REF.M@.las")
-        assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
+    for hint in ("1", "0"):
+        monkeypatch.setenv("DMH_HINT_PASSES", hint)
+        out = os.path.join(d, "las_hint" + hint)
+        scale._map_blocks_like_bench(d, "REF", "READS", out, report_mode=2, overlap=True)
+        for b in blocks:
+            _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+            _, hr = las.read_las_set(out, b + ".REF.M@.las")
+            assert len(rr) > 0 and rr == hr, "hints %s, block %s: %d vs %d records" % (hint, b, len(rr), len(hr))
 
 
 def test_dispatcher_maps_every_read_block(tmp_path):
