@@ -109,7 +109,7 @@ def exported_symbols() -> List[str]:
             "dmh_last_seed_count", "dmh_last_seeds", "dmh_last_limit", "dmh_read_candidates",
             "dmh_candidate_jumps", "dmh_read_cover", "dmh_sort_pairs", "dmh_exclusive_scan", "dmh_local_alignment",
             "dmh_timing_enable", "dmh_timing_reset", "dmh_timing_count", "dmh_timing_get", "dmh_sync",
-            "dmh_async_report", "dmh_report_wait", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free", "dmh_test_option", "dmh_next_pass", "dmh_ref_cache",
+            "dmh_async_report", "dmh_report_wait", "dmh_reports_done", "dmh_sort_kmers_async", "dmh_host_alloc", "dmh_host_free", "dmh_test_option", "dmh_next_pass", "dmh_ref_cache",
             "dmh_preload_block_2bit", "dmh_download_block", "dmh_prepare_block", "dmh_device_memory"]
 
 

@@ -338,6 +338,9 @@ void *dev_alloc(size_t bytes, const char *what)
   { HostTimer ht("pool_hipMalloc");
     e = hipMalloc(&p, bytes);
   }
+  { static const bool log_miss = getenv("DMH_POOL_LOG") != nullptr;        // (which buffers the pool does not hold)
+    if (log_miss) fprintf(stderr, "dmh: pool miss %10.1f MB  [%s]  pooled %.1f GB in %zu blocks\n", bytes / 1048576.0, what, g_pooled / 1e9, g_free.size());
+  }
   if (e != hipSuccess)
     { // give the pool back and retry once
       (void) hipGetLastError();            // (the failure must not surface at some later launch check)

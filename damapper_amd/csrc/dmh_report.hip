@@ -1145,6 +1145,7 @@ static int                       g_rbusy = 0;
 static int                       g_async = 0;      // 0 synchronous, 1 report stage on a worker, 2 also the alignment kernel deferred
 static bool                      g_stop  = false;
 static std::vector<ReportCtx *>  g_rdone;
+static int                       g_reports_done = 0;   // Reporter calls whose files are complete (dmh_reports_done)
 
 static void dispose_done()
 { std::vector<ReportCtx *> d;
@@ -1173,6 +1174,7 @@ static void worker_main()
         std::unique_lock<std::mutex> lk(g_rmu);
         g_rdone.push_back(C);
         g_rbusy -= 1;
+        g_reports_done += 1;
       }
       g_rcv.notify_all();
     }
@@ -1189,6 +1191,9 @@ static void report_submit(ReportCtx *C)
 { if (!g_async)
     { select_and_write(*C);
       delete C;
+      { std::unique_lock<std::mutex> lk(g_rmu);
+        g_reports_done += 1;
+      }
       return;
     }
   { std::unique_lock<std::mutex> lk(g_rmu);
@@ -1806,6 +1811,11 @@ void dmh_async_report(int on)
 void dmh_report_wait(void)
 { report_finish_pending();
   report_wait();
+}
+
+int dmh_reports_done(void)
+{ std::unique_lock<std::mutex> lk(g_rmu);
+  return g_reports_done;
 }
 
 int dmh_local_alignment(Align_Spec *spec, const uint8_t *abases, int64_t abytes, const uint8_t *bbases,

@@ -272,6 +272,10 @@ int dmh_local_alignment(Align_Spec *spec,
  * been written; a driver that uses mode 1 or 2 must call it before it reads the files or exits. */
 void dmh_async_report(int mode);
 void dmh_report_wait(void);
+/* Reporter calls, since the library was loaded, whose files are completely written: with mode 1 or 2 a driver runs its
+ * post-processing of READS block i (damapper.c:894-910: LAsort, LAcat) once this exceeds i, without waiting for the
+ * blocks behind it.  (Calls complete in the order they were made.)                                                   */
+int  dmh_reports_done(void);
 
 /* Kernel timing (HIP events on the library's stream).  Stages are named; dmh_timing_get
  * returns accumulated milliseconds and launch count since the last dmh_timing_reset.

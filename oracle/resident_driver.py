@@ -20,6 +20,12 @@ DECLS = r'''  DAZZ_DB    *rblock = NULL;      //  resident reference: block k-1 
 '''
 
 EXTERN = r'''extern void dmh_retain_ref_index(int on);     //  libdamapper_hip.so (include/damapper_hip.h)
+extern void dmh_free_index(void *table);
+'''
+
+# with the reference indices retained Reporter leaves the READS index to the driver: a plain free() of the handle (as in
+# damapper.c:879) would leak its 3.4 GB of HBM per READS block
+FREE = r'''        dmh_free_index(bindex);
 '''
 
 LOOP = r'''        if (rblock == NULL)
@@ -73,6 +79,7 @@ RECIPE = [
     (51, 50, EXTERN),          # behind #include "map.h"
     (559, 558, DECLS),         # behind the declaration of ablock / bblock
     (835, 877, LOOP),          # the loop over the REF blocks, the whole-REF load, Reporter, Close_DB(ablock)
+    (879, 879, FREE),          # free(bindex)
 ]
 
 

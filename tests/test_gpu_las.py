@@ -414,6 +414,47 @@ def test_resident_driver_recipe_matches_reference(tmp_path):
         assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
 
 
+@pytest.mark.parametrize("flags", [["-p"], ["-v", "-C"]], ids=["p", "v_C"])
+def test_fast_driver_recipe_matches_reference(flags, tmp_path):
+    """The C host side that "stays", driving the library the way driver.py does (oracle/fast_driver.py applied to the
+    reference's damapper.c, oracle/_ref/damapper_hip_fast): REF resident, READS blocks opened by DB.c but decoded on the
+    device from page-locked .bps bytes, dmh_async_report(2) with two READS blocks open, dmh_next_pass, the LAsort / LAcat
+    commands on a thread once dmh_reports_done() allows -- three READS blocks (one shorter than ten passes' worth)
+    against a three-block REF: the same per-thread files (and -p track) as the all-CPU reference."""
+    run_ref = _run_ref()
+    if not os.path.exists(os.path.join(run_ref.REF_DIR, "damapper_hip_fast")):
+        pytest.skip("oracle/_ref/damapper_hip_fast not built")
+    g, reads = make_dataset("repeat", 446, [200000, 150000, 120000, 90000, 80000, 70000], 75, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=130000)             # six REF blocks: twelve passes, Reporter ten passes late
+    dazzdb.write_db(d, "READS", reads, block_size=260000)
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    nrb, _ = dazzdb.read_stub(os.path.join(d, "REF.db"))
+    assert nb >= 3 and nrb >= 5
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    run_ref.run_reference(d, "REF", blocks, flags=flags, threads=4, keep="las_ref")
+    prof = {}
+    if "-p" in flags:
+        for b in blocks:
+            for x in ("anno", "data"):
+                f = os.path.join(d, ".%s.prof.%s" % (b, x))
+                prof[f] = open(f, "rb").read()
+                os.remove(f)
+    run_ref.run_reference(d, "REF", blocks, flags=flags, threads=4, keep="las_fast", binary="damapper_hip_fast")
+    pats = [".REF.M@.las"] + ([] if "-C" not in flags else [None])
+    for b in blocks:
+        _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+        _, hr = las.read_las_set(os.path.join(d, "las_fast"), b + ".REF.M@.las")
+        assert len(rr) > 0 and rr == hr, "block %s: %d vs %d records" % (b, len(rr), len(hr))
+        if "-C" in flags:
+            _, rr = las.read_las_set(os.path.join(d, "las_ref"), "REF." + b + ".R@.las")
+            _, hr = las.read_las_set(os.path.join(d, "las_fast"), "REF." + b + ".R@.las")
+            assert len(rr) > 0 and rr == hr, "block %s (R files): %d vs %d records" % (b, len(rr), len(hr))
+    for f, want in prof.items():
+        assert open(f, "rb").read() == want, f
+    del pats
+
+
 def test_next_pass_hint_gives_identical_files(tmp_path, monkeypatch):
     """dmh_next_pass (the driver names the pass that follows; the library then probes the forward and the complement
     index of a REF block in ONE sweep of the READ keys -- the driver's default; DMH_HINT_PASSES=0: every pass for itself):
