@@ -601,12 +601,14 @@ __global__ void k_row_place(const MergeEntry *__restrict__ entries, uint32_t n, 
 // from an atomic count of the read's rows, and rcount[r] sums the read's hits as k_row_place does.  One wavefront per
 // tile of k_merge_match, straight from the tiles' own windows of the entry list (toff = the scanned tile counts), so
 // neither the compact entry list nor the entries' offsets are needed: k_merge_gather, k_entry_sizes, the scan over the
-// entries, k_tile_first and k_merge_expand_tiled of round 3's route do not run.
+// entries, k_tile_first and k_merge_expand_tiled of round 3's route do not run.  [r0, r1): the reads whose rows are
+// wanted (a pass of more hits than 32-bit slots is made range by range).
 __global__ __launch_bounds__(256) void k_row_list(const MergeEntry *__restrict__ tile_entries,
                                                   const uint32_t *__restrict__ toff, int64_t ntiles, uint32_t total,
                                                   int64_t limit, const uint32_t *__restrict__ avals, int aposbits,
                                                   const int64_t *__restrict__ boff, uint32_t *__restrict__ rcount,
-                                                  uint32_t *__restrict__ nrow, uint64_t *__restrict__ rows)
+                                                  uint32_t *__restrict__ nrow, uint64_t *__restrict__ rows,
+                                                  uint32_t r0, uint32_t r1)
 { const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= ntiles) return;
@@ -621,9 +623,11 @@ __global__ __launch_bounds__(256) void k_row_list(const MergeEntry *__restrict__
       for (uint32_t a = 0; a < en.ma; a++)
         { const uint32_t q  = avals[en.a0 + a];
           const uint32_t ar = q >> aposbits, ap = q & apm;
+          if (ar < r0 || ar >= r1) continue;                  // (a pass split into ranges of reads: this range's rows only)
           const uint32_t at = atomicAdd(&nrow[ar], 1u);
           atomicAdd(&rcount[ar], en.mb);
-          rows[boff[ar] + at] = ((uint64_t) en.b0 << 32) | ((uint64_t) ap << RW_MB) | (uint64_t) en.mb;
+          if (rows != nullptr)                                // (nullptr: the hits per read are only counted)
+            rows[boff[ar] + at] = ((uint64_t) en.b0 << 32) | ((uint64_t) ap << RW_MB) | (uint64_t) en.mb;
         }
     }
 }
@@ -1460,14 +1464,13 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     { printf("   Hit count = %lld\n", (long long) nhits);
       fflush(stdout);
     }
-  // hits are numbered in 32 bits from here on (group starts, links, chain ends): a pass of 2^32 hits and more is
-  // refused -- the reference's -M rule keeps a pass under (M - DBs) / 32 hits, i.e. below 2^32 for -M up to 137 GB,
-  // and a 375 Mbp block pair reaches 10^9 only against a one-family reference ("hit_limit" test option: the refusal
-  // at a smaller number)
-  if (nhits >= (st.opt_hit_limit > 0 ? (int64_t) st.opt_hit_limit : (int64_t) 0xfffffff0ll))
-    fatal("Match_Filter: %lld seed hits in one block pair exceed the 32-bit slot range; use smaller blocks or -M",
-          (long long) nhits);
   if (nhits == 0) return 0;
+  const int64_t pass_hits = nhits;
+
+  // Everything behind the limit rule, for the hits of the reads [r0, r1) -- the whole pass, or (below) one range of a
+  // pass that has more hits than 32-bit slots
+  auto submit = [&](const int r0, const int r1, const int64_t nhits) -> int64_t
+  { const bool ranged = (r0 > 0 || r1 < ablock->nreads);
 
   // --- which batch the pass goes to.  Cluster mode (dmh_merge.h): when a read meets thousands of hits per pass
   //     (repeat families), the hits of an (aread, bread) pair are cut into B-clusters, which chain independently -- a
@@ -1481,6 +1484,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   const int abits = ceil_log2(ablock->nreads), bbits = ceil_log2(bblock->nreads);
   const int qbits = ceil_log2(bblock->maxlen > 1 ? (int64_t) bblock->maxlen + 1 : 2);
   bool cluster = (optcl >= 0) ? (optcl != 0) : (nhits >= (int64_t) 1024 * ablock->nreads);
+  if (ranged) cluster = true;                 // (a range of an oversize pass: dense by definition, and only the per-read route takes ranges)
   if (qbits + bbits + abits > 64 || nhits >= (int64_t) 0x7fffffff) cluster = false;
   const bool batching = !cluster && !VERBOSE && !st.capture_seeds && (st.opt_batch >= 0 ? st.opt_batch != 0 : env_batch != 0);
   if (R.open && (cluster || !batching || R.ablock != ablock || R.npass >= MAXPASS || R.nhits + nhits > BATCH_CAP ||
@@ -1540,6 +1544,9 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   const bool fuse = by_read && (st.opt_fuse >= 0 ? st.opt_fuse != 0 : env_fuse != 0) && limit <= (int64_t) MAXGRAM &&
                     R.pbits <= RW_AP && A.posbits > 0 && Bx.posbits > 0 && !(env_dc0 || st.opt_defer_close > 0) &&
                     A.L + 1 < ((int64_t) 1 << 32);
+  if (ranged && !fuse)
+    fatal("Match_Filter: %lld seed hits in one block pair exceed the 32-bit slot range and the pass cannot be split (it takes "
+          "the -M limit rule, reads of up to 2^18 bases and a seed word of 64 bits); use smaller blocks or -M", (long long) pass_hits);
   if (fuse)
     { StageTimer tm("merge_rows", 16.0 * nhits);
       const int nr = ablock->nreads;
@@ -1551,7 +1558,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
       HIP_CHECK(hipMemsetAsync(R.rs_stats.p, 0, sizeof(uint32_t) * 8, stream()));
       hipLaunchKernelGGL(k_row_list, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(), (const MergeEntry *) tentries.p,
                          (const uint32_t *) tcount.p, ntiles, nent, limit, (const uint32_t *) A.vals, A.posbits,
-                         (const int64_t *) A.d_boff, R.rs_start.p, nrow, g_rows.p);
+                         (const int64_t *) A.d_boff, R.rs_start.p, nrow, g_rows.p, (uint32_t) r0, (uint32_t) r1);
       exclusive_scan_u32(R.rs_start.p, nr, st.sort.bsum, R.rs_start.p + nr);
       R.rs_lists.ensure(4 * (size_t) nr + 16, "reads by segment size");
       g_rs_small = report_in_flight() || st.opt_read_sort == 6 || st.opt_read_sort == 7;      // (see the unfused route below)
@@ -1727,6 +1734,48 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
       g_cur = warm;
     }
   return nhits;
+  };        // submit
+
+  // Hits are numbered in 32 bits behind the merge (group starts, links, chain ends); the reference counts them in 64
+  // (map.c:876, 2899).  Its -M rule keeps a pass under (M - DBs) / 32 hits -- below 2^32 for -M up to 137 GB --, and a
+  // 375 Mbp block pair reaches 10^9 only against a one-family reference; a pass beyond the range is made in RANGES OF
+  // READS, each a batch of its own: the hits of different reads never meet before the domination rule, which is per read
+  // (map.c:1668-1766), so the candidate lists come out as from one pass ("hit_limit" test option: the split at a smaller
+  // number).
+  const int64_t hlim = st.opt_hit_limit > 0 ? (int64_t) st.opt_hit_limit : (int64_t) 0xfffffff0ll;
+  if (pass_hits < hlim) return submit(0, ablock->nreads, pass_hits);
+  { const int nr = ablock->nreads;
+    if (!(A.posbits > 0 && limit <= (int64_t) MAXGRAM))
+      fatal("Match_Filter: %lld seed hits in one block pair exceed the 32-bit slot range; use smaller blocks or -M", (long long) pass_hits);
+    // hits per read: the rows counted, not listed
+    static DevBuf<uint32_t> cnt_all;
+    cnt_all.ensure(2 * ((size_t) nr + 2), "hits per read of an oversize pass");
+    HIP_CHECK(hipMemsetAsync(cnt_all.p, 0, sizeof(uint32_t) * 2 * ((size_t) nr + 2), stream()));
+    hipLaunchKernelGGL(k_row_list, dim3(ceil_div(ntiles * 64, 256)), dim3(256), 0, stream(), (const MergeEntry *) tentries.p,
+                       (const uint32_t *) tcount.p, ntiles, nent, limit, (const uint32_t *) A.vals, A.posbits,
+                       (const int64_t *) A.d_boff, cnt_all.p, cnt_all.p + nr + 2, (uint64_t *) nullptr, 0u, (uint32_t) nr);
+    std::vector<uint32_t> hc((size_t) nr);
+    copy_d2h(hc.data(), cnt_all.p, sizeof(uint32_t) * (size_t) nr);
+    const int64_t lim = std::max<int64_t>(1, std::min<int64_t>(hlim - 1, (int64_t) 0x7ffffff0ll));
+    int64_t total = 0, acc = 0;
+    int     first = 0, nranges = 0;
+    for (int r = 0; r < nr; r++)
+      { if ((int64_t) hc[r] > lim)
+          fatal("Match_Filter: read %d alone meets %u seed hits in one block pair, more than a batch takes (%lld)", r, hc[r], (long long) lim);
+        if (acc + (int64_t) hc[r] > lim)
+          { st.capture_append = nranges > 0;
+            total += submit(first, r, acc);
+            nranges += 1;
+            first = r; acc = 0;
+          }
+        acc += hc[r];
+      }
+    if (acc > 0) { st.capture_append = nranges > 0; total += submit(first, nr, acc); nranges += 1; }
+    st.capture_append = false;
+    if (total != pass_hits) fatal("Match_Filter: the ranges of an oversize pass hold %lld hits, the pass %lld", (long long) total, (long long) pass_hits);
+    if (getenv("DMH_STATS")) fprintf(stderr, "dmh: a pass of %lld hits made in %d ranges of reads\n", (long long) pass_hits, nranges);
+    return total;
+  }
 #undef R
 }
 
@@ -2434,12 +2483,13 @@ static void close_batch(MergeResult &R, int phase)
                     if (x.apos != y.apos) return x.apos < y.apos;
                     return x.bpos < y.bpos;
                   });
-      st.last_seeds.resize((size_t) nhits * 4);
+      const size_t sbase = st.capture_append ? st.last_seeds.size() : 0;      // (a later range of a split pass: behind the earlier ones)
+      st.last_seeds.resize(sbase + (size_t) nhits * 4);
       for (int64_t i = 0; i < nhits; i++)
-        { st.last_seeds[4 * i + 0] = (int) hs[i].apos - (int) hs[i].bpos;
-          st.last_seeds[4 * i + 1] = (int) hs[i].apos;
-          st.last_seeds[4 * i + 2] = (int) (hs[i].pair & bm);
-          st.last_seeds[4 * i + 3] = (int) (hs[i].pair >> R.bbits);
+        { st.last_seeds[sbase + 4 * i + 0] = (int) hs[i].apos - (int) hs[i].bpos;
+          st.last_seeds[sbase + 4 * i + 1] = (int) hs[i].apos;
+          st.last_seeds[sbase + 4 * i + 2] = (int) (hs[i].pair & bm);
+          st.last_seeds[sbase + 4 * i + 3] = (int) (hs[i].pair >> R.bbits);
         }
     }
   { HostTimer hs("chain_submit_host");

@@ -146,6 +146,7 @@ struct State
   int  next_index_id = 1;
   bool retain_ref    = false;
   bool capture_seeds = false;
+  bool capture_append = false;    // ... of a later range of a pass made in ranges of reads: appended to the earlier ranges' 
   int  last_limit    = 0;
   std::vector<int32_t> last_seeds;     // SeedPair records (4 ints each)
 
