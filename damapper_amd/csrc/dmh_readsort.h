@@ -812,8 +812,32 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
           else
             { // hits in the clusters left to the chain kernels, by cluster size (<= 16, 32, 64, 128, 256, more)
               const uint32_t sz = ce - cs;
-              const int bk = sz <= 16 ? 0 : (sz <= 32 ? 1 : (sz <= 64 ? 2 : (sz <= 128 ? 3 : (sz <= 256 ? 4 : 5))));
+              const int bk = sz <= 16 ? 0 : (sz <= 32 ? 1 : (sz <= 64 ? 2 : 3));            // ([13]: everything above 64)
               atomicAdd(&g_rsprof[10 + bk], (unsigned long long) sz);
+              // ... and how many of them lie in clusters that fall apart by DIAGONAL (bins of 1024, classes = runs of
+              // occupied bins with an empty bin between them): [14] hits in clusters of two classes and more, [15] of one
+              if (sz <= 1023)
+                { int dmin = 0x7fffffff, dmax = (int) 0x80000000;
+                  for (uint32_t t = cs; t < ce; t++)
+                    { const uint64_t y = buf[t]; const int dg = (int) (uint32_t) y - (int) (y >> 32);
+                      dmin = min(dmin, dg); dmax = max(dmax, dg);
+                    }
+                  unsigned long long bm[4] = {0, 0, 0, 0};
+                  if (((dmax - dmin) >> 10) < 256)
+                    { for (uint32_t t = cs; t < ce; t++)
+                        { const uint64_t y = buf[t]; const int b = (((int) (uint32_t) y - (int) (y >> 32)) - dmin) >> 10;
+                          bm[b >> 6] |= 1ull << (b & 63);
+                        }
+                      int classes = 0, prev = 0, gap = 2;
+                      for (int b = 0; b < 256; b++)
+                        { const int on = (int) ((bm[b >> 6] >> (b & 63)) & 1ull);
+                          if (on) { if (gap >= 2) classes += 1; gap = 0; } else gap += 1;
+                          prev = on;
+                        }
+                      (void) prev;
+                      atomicAdd(&g_rsprof[classes >= 2 ? 14 : 15], (unsigned long long) sz);
+                    }
+                }
             }
 #endif
           A.lcnt[s0 + c] = v;

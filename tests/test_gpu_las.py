@@ -435,13 +435,14 @@ def test_fast_driver_recipe_matches_reference(flags, tmp_path):
     run_ref.run_reference(d, "REF", blocks, flags=flags, threads=4, keep="las_ref")
     prof = {}
     if "-p" in flags:
+        # (the track from a single-threaded run: special_log() races with more than one report thread)
+        run_ref.run_reference(d, "REF", blocks, flags=flags, threads=1, keep="las_ref_T1")
         for b in blocks:
             for x in ("anno", "data"):
                 f = os.path.join(d, ".%s.prof.%s" % (b, x))
                 prof[f] = open(f, "rb").read()
                 os.remove(f)
     run_ref.run_reference(d, "REF", blocks, flags=flags, threads=4, keep="las_fast", binary="damapper_hip_fast")
-    pats = [".REF.M@.las"] + ([] if "-C" not in flags else [None])
     for b in blocks:
         _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
         _, hr = las.read_las_set(os.path.join(d, "las_fast"), b + ".REF.M@.las")
@@ -452,7 +453,6 @@ def test_fast_driver_recipe_matches_reference(flags, tmp_path):
             assert len(rr) > 0 and rr == hr, "block %s (R files): %d vs %d records" % (b, len(rr), len(hr))
     for f, want in prof.items():
         assert open(f, "rb").read() == want, f
-    del pats
 
 
 def test_next_pass_hint_gives_identical_files(tmp_path, monkeypatch):
