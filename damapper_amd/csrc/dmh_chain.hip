@@ -643,6 +643,200 @@ __global__ __launch_bounds__(256) void k_chain_simple(ChainArgs A, uint32_t size
 }
 
 // ---------------------------------------------------------------------------------------
+//  Groups that fall apart BY DIAGONAL (round 4).  What k_chain_simple (or the per-read kernel, dmh_readsort.h) leaves
+//  is, on a repeat-rich reference, almost always a cluster that holds TWO OR MORE loci side by side -- a stretch of the
+//  read opposite two copies of a repeat a few kb apart in the contig: 99.7 % of the hits left in groups of up to 1,023
+//  (DMH_RS_PROFILE counters).  Their hits alternate between the copies in (apos, bpos) order, so no hit's predecessor is
+//  its only candidate, yet the copies never meet: a hit N and a live hit X (X.apos within MAX_GAP behind N.apos) whose
+//  DIAGONALS differ by more than MAX_GAP are no candidates for each other -- on a larger diagonal X would need
+//  X.bpos >= N.bpos - MAX_GAP, i.e. a diagonal at most MAX_GAP + (X.apos - N.apos) <= MAX_GAP above N's; on a smaller one
+//  X.bpos <= N.bpos, i.e. at most N.apos - X.apos <= MAX_GAP below (map.c:1262-1318).  So the diagonal CLASSES of a group --
+//  runs of occupied 1024-wide diagonal bins with a free bin between -- chain independently, exactly as the B-clusters
+//  of a pair do, and each class is usually a sequence of plain chains.  One wavefront per group left (up to 1,024 hits in
+//  its registers, up to eight classes): per class the plain-chain test and the segmented prefix sum of k_chain_simple over
+//  the class's hits alone (the others are transparent), links to the previous hit OF THE CLASS, chain ends reported when
+//  the next hit of the class breaks (or the class ends).  A group all of whose classes pass is done; the others
+//  (one in 350) stay for k_chain_lane.  No hit moves: the classes stay interleaved, only the links know them.
+// ---------------------------------------------------------------------------------------
+constexpr int CLS_MAX    = 8;         // classes of a group
+
+// CLS_ROUNDS x 64 hits of a group at most: 2 for the bulk (two copies of a repeat: 80 hits; few registers, many groups in
+// flight -- what bounds the kernel is the chain of memory round trips per group), 16 for the rest; a launch takes the groups
+// of size_min .. size_max hits
+template <int CLS_ROUNDS>
+__global__ __launch_bounds__(256) void k_chain_classes(ChainArgs A, uint32_t size_min, uint32_t size_max)
+{ __shared__ unsigned long long s_occ[4][4];                  // per wavefront: the occupied diagonal bins (256)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t nwaves = gridDim.x * 4u, wave = blockIdx.x * 4u + (uint32_t) wv;
+  const int K = A.K;
+  for (uint64_t gb = (uint64_t) wave * 64u; gb < A.ngroups; gb += (uint64_t) nwaves * 64u)
+    { // 64 groups at a time: which of them are left, and of a size for this kernel?
+      const uint64_t gl = gb + (uint32_t) lane;
+      uint32_t q0 = 0, q1 = 0;
+      bool todo = false;
+      if (gl < A.ngroups)
+        { q0 = A.gstart[gl]; q1 = A.gstart[gl + 1];
+          todo = A.gdone[gl] == 0u && q1 - q0 <= size_max && q1 - q0 >= size_min;
+        }
+      for (uint64_t tm = __ballot(todo); tm != 0; tm &= tm - 1)
+        { const int      src = __ffsll((long long) tm) - 1;
+          const uint32_t g   = (uint32_t) gb + (uint32_t) src;
+          const uint32_t g0  = (uint32_t) __builtin_amdgcn_readlane((int) q0, src);
+          const uint32_t n   = (uint32_t) __builtin_amdgcn_readlane((int) q1, src) - g0;
+          const uint32_t rounds = (n + 63u) / 64u;            // <= CLS_ROUNDS
+          // the group's hits, and the range of their diagonals
+          uint64_t wq[CLS_ROUNDS];
+          int dmin = 0x7fffffff, dmax = (int) 0x80000000;
+#pragma unroll
+          for (int j = 0; j < CLS_ROUNDS; j++)
+            { wq[j] = 0;
+              if ((uint32_t) j < rounds)
+                { const uint32_t i = 64u * j + lane;
+                  wq[j] = A.ab[g0 + (i < n ? i : n - 1)];
+                  const int dg = (int) (uint32_t) wq[j] - (int) (wq[j] >> 32);
+                  dmin = min(dmin, dg); dmax = max(dmax, dg);
+                }
+            }
+          dmin = (int) (group_reduce_u32<64, false>((uint32_t) dmin + 0x80000000u) - 0x80000000u);
+          dmax = (int) (group_reduce_u32<64, true>((uint32_t) dmax + 0x80000000u) - 0x80000000u);
+          if (((dmax - dmin) >> 10) >= 256) continue;         // (uniform)
+          // occupied bins -> class starts (a bin whose lower neighbour is free) -> the class of every hit
+          if (lane < 4) s_occ[wv][lane] = 0ull;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < CLS_ROUNDS; j++)
+            if ((uint32_t) j < rounds)
+              { const uint32_t i = 64u * j + lane;
+                const int b = (((int) (uint32_t) wq[j] - (int) (wq[j] >> 32)) - dmin) >> 10;
+                if (i < n) atomicOr(&s_occ[wv][b >> 6], 1ull << (b & 63));
+              }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          unsigned long long cst[4];
+          uint32_t ncls = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            { const unsigned long long oc = s_occ[wv][q], lowc = (q > 0) ? (s_occ[wv][q - 1] >> 63) : 0ull;
+              cst[q] = oc & ~((oc << 1) | lowc);
+              ncls += (uint32_t) __popcll(cst[q]);
+            }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier();                    // (s_occ is the next group's from here on)
+          if (ncls < 2u || ncls > (uint32_t) CLS_MAX) continue;           // one class: a walk; more than eight: rare
+          uint32_t clsv[CLS_ROUNDS];
+#pragma unroll
+          for (int j = 0; j < CLS_ROUNDS; j++)
+            { const int b = (((int) (uint32_t) wq[j] - (int) (wq[j] >> 32)) - dmin) >> 10;
+              uint32_t c = 0;
+#pragma unroll
+              for (int q = 0; q < 4; q++)
+                { if (q < (b >> 6)) c += (uint32_t) __popcll(cst[q]);
+                  else if (q == (b >> 6)) c += (uint32_t) __popcll(cst[q] & (~0ull >> (63 - (b & 63))));
+                }
+              clsv[j] = c - 1u;
+            }
+          const uint32_t obase = (g0 + HITMIN - 1) / HITMIN;
+          const int lastv = (int) (A.glast ? A.glast[g] : (uint32_t) A.ab[g0 + n - 1] + 1u);
+          uint32_t E = 0;
+          bool bad = false;
+          auto report = [&](bool who, int cost, int oa, int ob, int ea, int eb, uint32_t ex)
+          { const uint64_t em = __ballot(who);
+            if (who)
+              { const bool live = ea >= lastv - MAX_GAP;      // (a chain's end is its last hit: never removed by the slope rule)
+                const int  d = ea - eb;
+                ChainSummary sm;
+                sm.group = g;
+                sm.live  = live ? 1u : 0u;
+                sm.okey  = live ? (((uint64_t) ((uint32_t) d + 0x80000000u) << 32) | (uint32_t) ea) : (((uint64_t) (uint32_t) ea << 32) | (uint32_t) eb);
+                sm.cost  = cost;
+                sm.ab    = oa - K;
+                sm.bb    = ob - K;
+                sm.ae    = ea;
+                sm.be    = eb;
+                sm.end   = g0 + ex;
+                A.out[obase + E + (uint32_t) __popcll(em & lt)] = sm;
+              }
+            E += (uint32_t) __popcll(em);
+          };
+          for (uint32_t k = 0; k < ncls; k++)
+            { bool     have_prev = false;                         // the class's last hit so far, and the chain running at it:
+              uint64_t prevw = 0, corig = 0;                      //   its score up to there, its first hit
+              uint32_t prev_i = 0;
+              int      ccost = 0;
+#pragma unroll
+              for (int j = 0; j < CLS_ROUNDS; j++)
+                { if ((uint32_t) j >= rounds) continue;
+                  const uint32_t i = 64u * j + lane;
+                  const bool member = i < n && clsv[j] == k;
+                  const uint64_t M = __ballot(member);
+                  if (M == 0) continue;                           // (uniform)
+                  // the hit of the class before this one: a lane below, or the last of an earlier round
+                  const uint64_t w = wq[j];
+                  const uint64_t below = M & lt;
+                  const int  sl = below ? 63 - __clzll((long long) below) : 0;
+                  uint64_t pw = ((uint64_t) (uint32_t) __shfl((int) (uint32_t) (w >> 32), sl) << 32) | (uint64_t) (uint32_t) __shfl((int) (uint32_t) w, sl);
+                  uint32_t pi = 64u * j + (uint32_t) sl;
+                  bool havep = true;
+                  if (!below) { pw = prevw; pi = prev_i; havep = have_prev; }
+                  const int a = (int) (uint32_t) w + 1, b = (int) (w >> 32) + 1, pa = (int) (uint32_t) pw + 1, pb = (int) (pw >> 32) + 1;
+                  const int d = a - b, pd = pa - pb;
+                  const bool brk = member && (!havep || pa < a - MAX_GAP);
+                  { const bool cand = (pd > d) ? (pb >= b - MAX_GAP) : (pb <= b);
+                    int dd = pd - d;
+                    if (dd < 0) dd = -dd;
+                    if (member && !brk && !(cand && 5 * dd <= a - pa)) bad = true;
+                  }
+                  const int adv = (pd > d) ? a - pa : b - pb;
+                  const int inc = !member ? 0 : (brk ? K : (adv >= K ? K : adv));
+                  // The running score of a chain = a prefix sum over the lanes (the hits of other classes add nothing) minus the
+                  // sum below the chain's first hit -- the last break at or below the lane, from the ballot -- or, with no
+                  // break in this round so far, plus the score carried in.  No scan through LDS: a DPP sum and lane reads.
+                  const uint64_t BR = __ballot(brk);
+                  const int P = (int) wave_incl_scan_dpp((uint32_t) inc);
+                  // a hit that breaks ends the chain of the hit before it (lane sl of this round, or the carried one)
+                  { const uint64_t brp = below ? (BR & ((1ull << sl) | ((1ull << sl) - 1ull))) : 0ull;      // breaks at or below the predecessor
+                    const int stp = brp ? 63 - __clzll((long long) brp) : 0;
+                    const int Pp  = __shfl(P, sl), Pb = __shfl(P, stp > 0 ? stp - 1 : 0);
+                    const uint64_t ow = ((uint64_t) (uint32_t) __shfl((int) (uint32_t) (w >> 32), stp) << 32) | (uint64_t) (uint32_t) __shfl((int) (uint32_t) w, stp);
+                    int px; uint64_t po;
+                    if (!below)   { px = ccost; po = corig; }
+                    else if (brp) { px = Pp - (stp > 0 ? Pb : 0); po = ow; }
+                    else          { px = Pp + ccost; po = corig; }
+                    report(member && brk && havep && px >= A.hithr, px, (int) (uint32_t) po + 1, (int) (po >> 32) + 1, pa, pb, pi);
+                  }
+                  if (member) A.from[g0 + i] = brk ? NIL : g0 + pi;
+                  // carry: the class's last hit of this round and the chain running at it
+                  { const int ll = 63 - __clzll((long long) M);
+                    const uint64_t brl = BR & ((ll == 63) ? ~0ull : ((1ull << (ll + 1)) - 1ull));
+                    const int Pl = __builtin_amdgcn_readlane(P, ll);
+                    if (brl)
+                      { const int stl = 63 - __clzll((long long) brl);
+                        ccost = Pl - (stl > 0 ? __builtin_amdgcn_readlane(P, stl > 0 ? stl - 1 : 0) : 0);
+                        corig = wave_lane_u64(w, stl);
+                      }
+                    else
+                      ccost += Pl;
+                    prevw = wave_lane_u64(w, ll);
+                    prev_i = 64u * j + (uint32_t) ll;
+                    have_prev = true;
+                  }
+                }
+              // the class's last chain
+              report(lane == 0 && have_prev && ccost >= A.hithr, ccost, (int) (uint32_t) corig + 1, (int) (corig >> 32) + 1,
+                     (int) (uint32_t) prevw + 1, (int) (prevw >> 32) + 1, prev_i);
+            }
+          if (__ballot(bad) == 0 && lane == 0)
+            { A.gcount[g] = E;
+              A.gbase[g]  = obase;
+              A.gdone[g]  = 1u;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 //  One LANE per group.  A lane group per chain group keeps 15 of its 16 lanes idle through the sequential part of
 //  every hit, and the 10^6-10^7 groups of a pass on a repeat-rich genome (B-clusters of some twenty hits) offer all
 //  the parallelism a GPU wants without any inside a group.  Here every lane walks groups of its own: the live
@@ -1996,6 +2190,9 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
                 const int nbs = (int) std::min<int64_t>((R.ngroups + 15) / 16, 256 * 8);
                 hipLaunchKernelGGL(k_chain_simple, dim3(nbs), dim3(256), 0, stream(), A, R.lane_max);
               }
+            // groups that fall apart by diagonal (k_chain_classes above; "chain_classes" test option / DMH_CHAIN_CLASSES = 0: off)
+            static const int env_classes = getenv("DMH_CHAIN_CLASSES") ? atoi(getenv("DMH_CHAIN_CLASSES")) : 1;
+            const bool classes_on = A.gdone != nullptr && (st.opt_chain_classes >= 0 ? st.opt_chain_classes : env_classes) != 0;
             // the tail: from here on the launches walk what k_chain_simple has left (7 % of the hits of a dense pass,
             // the time of each launch the LENGTH of its longest walk) -- on the tail stream, next to the following
             // pass's match kernels
@@ -2010,6 +2207,12 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
                 HIP_CHECK(hipStreamWaitEvent(tail_stream(), C.lane_done, 0));
               }
             StreamScope on_tail(tail_from_lane ? tail_stream() : stream());
+            if (classes_on)
+              { StageTimer t0("chain_class_groups", 12.0 * nhits);
+                hipLaunchKernelGGL(k_chain_classes<2>, dim3(4096), dim3(256), 0, stream(), A, 2u, std::min<uint32_t>(R.lane_max, 128u));
+                if (R.lane_max > 128u)
+                  hipLaunchKernelGGL(k_chain_classes<16>, dim3(2048), dim3(256), 0, stream(), A, 129u, std::min<uint32_t>(R.lane_max, 1024u));
+              }
             // one lane per group: every group below the wavefront-per-group size tries this first; the ones whose
             // window or tree table overflows are appended to the medium list
             ChainArgs Q = A;

@@ -165,7 +165,7 @@ def test_ragged_and_degenerate_reads(tmp_path):
                                   dict(cluster=1, read_sort=7), dict(cluster=1, defer_close=1), dict(cluster=1, tails=0),
                                   dict(chain_simple=0), dict(cluster=1, chain_simple=0),
                                   dict(cluster=1, fuse=0), dict(cluster=1, fuse=0, read_sort=3), dict(cluster=1, fuse=0, read_sort=5),
-                                  dict(cluster=1, fuse=0, chain_simple=0)],
+                                  dict(cluster=1, fuse=0, chain_simple=0), dict(cluster=1, chain_classes=0), dict(chain_classes=0)],
                          ids=["four_per_wavefront", "wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
                               "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table", "merge_low16_probes",
                               "clusters", "clusters_piles", "clusters_chain64",
@@ -179,7 +179,8 @@ def test_ragged_and_degenerate_reads(tmp_path):
                               "clusters_nothing_on_the_tail_stream",
                               "no_simple_groups", "clusters_no_simple_groups",
                               "clusters_unfused_round3_route", "clusters_unfused_oversize_through_global_memory",
-                              "clusters_unfused_ballot_ranks", "clusters_unfused_no_simple_groups"])
+                              "clusters_unfused_ballot_ranks", "clusters_unfused_no_simple_groups",
+                              "clusters_no_diagonal_classes", "no_diagonal_classes"])
 def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes
     to the same bytes: force each one and compare with the default route on data that has repeats, dropouts and
@@ -204,7 +205,7 @@ def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
 VARIANT_DEFAULTS = dict(align_level=-1, align_g=-1, chain_g=0, pool_div=1, chain_pile=-1, pile_cap=0, merge_dense=-1,
                         cluster=-1, chain_small=-1, chain_lane=-1, batch=-1, cluster_sort=-1, expand=-1, in_flight=-1,
                         seed_word=-1, alloc_fail=0, fin_stream=-1, read_sort=-1, oom_finish=0, chain_simple=-1,
-                        defer_close=-1, tails=-1, fuse=-1)
+                        defer_close=-1, tails=-1, fuse=-1, chain_classes=-1)
 _VARIANT = {}
 
 
