@@ -1552,6 +1552,8 @@ struct DomArgs
   const uint32_t *cov_off;
   int             spacing;
   unsigned int   *ctl;              // [0] += candidates added, [1] += removed
+  uint32_t       *fresh;            // the records added by this pass that survived it (positions in newp) ...
+  unsigned int   *nfresh;           // ... and their number
 };
 
 // map.c:1654-1730 for all reads at once: a 16-lane group per read walks the read's chain ends of this pass in the
@@ -1560,7 +1562,13 @@ struct DomArgs
 // leaves the deletions made so far in place); a chain that survives the scan is appended.  The list (oldest
 // first, tombstones squeezed out) is first copied from the other pool.
 constexpr int DOM_G = 16;
+constexpr int DOM_CAP = 96;        // records of a read's list whose scan fields are kept in LDS
 
+// Round 4: (1) a read's chain ends are fetched SIXTEEN at a time (score and A interval, a lane each) and handed round the
+// group with lane reads -- one end after the other cost a memory round trip each, 116 per read and pass, which was the
+// kernel's time (0.5 ms); (2) what the scan of the list looks at -- score, A interval, flags of its first DOM_CAP records --
+// lives in LDS (records beyond are read where they are; the records themselves stay in the pool); (3) the records this
+// pass added that survived it are listed here (k_fresh_list walked every read's list again for them).
 __global__ __launch_bounds__(256) void k_dominate(DomArgs D)
 { const int      lane  = threadIdx.x & (DOM_G - 1);
   const int      sbase = (threadIdx.x & 63) & ~(DOM_G - 1);
@@ -1568,10 +1576,17 @@ __global__ __launch_bounds__(256) void k_dominate(DomArgs D)
   auto gballot = [&](bool p) -> uint32_t { return (uint32_t) ((__ballot(p) >> sbase) & 0xffffull); };
   const uint64_t bmask = (D.bbits >= 64) ? ~0ull : ((1ull << D.bbits) - 1ull);
   const uint64_t qmask = (1ull << D.passbits) - 1ull;
-
-  for (int ar = blockIdx.x * (256 / DOM_G) + threadIdx.x / DOM_G; ar < D.nreads; ar += gridDim.x * (256 / DOM_G))
-    { const uint32_t ooff = D.ooff[ar], olen = D.olen[ar], nb = D.noff[ar];
-      const uint32_t s0 = D.goff[D.rgfirst[ar]], s1 = D.goff[D.rgfirst[ar + 1]];
+  __shared__ int32_t  l_sc[256 / DOM_G][DOM_CAP], l_af[256 / DOM_G][DOM_CAP], l_al[256 / DOM_G][DOM_CAP];
+  __shared__ uint32_t l_fl[256 / DOM_G][DOM_CAP];
+  const int gi = threadIdx.x / DOM_G;
+  const int stride = gridDim.x * (256 / DOM_G);
+  // (the four groups of a wavefront make the same number of turns: the fresh records of a turn take ONE atomic)
+  const int wfirst = blockIdx.x * (256 / DOM_G) + (threadIdx.x >> 6) * (64 / DOM_G);
+  for (int ar0 = wfirst; ar0 < D.nreads; ar0 += stride)
+    { const int  ar = ar0 + (gi & (64 / DOM_G - 1));
+      const bool mine = ar < D.nreads;
+      const uint32_t ooff = mine ? D.ooff[ar] : 0u, olen = mine ? D.olen[ar] : 0u, nb = mine ? D.noff[ar] : 0u;
+      const uint32_t s0 = mine ? D.goff[D.rgfirst[ar]] : 0u, s1 = mine ? D.goff[D.rgfirst[ar + 1]] : 0u;
       uint32_t n = 0;
       for (uint32_t base = 0; base < olen; base += DOM_G)
         { const uint32_t i = base + lane;
@@ -1582,93 +1597,117 @@ __global__ __launch_bounds__(256) void k_dominate(DomArgs D)
               keep = !(e.flags & DC_TOMB);
             }
           const uint32_t m = gballot(keep);
-          if (keep) D.newp[nb + n + (uint32_t) __popc(m & (uint32_t) lt)] = e;
+          if (keep)
+            { const uint32_t at = n + (uint32_t) __popc(m & (uint32_t) lt);
+              D.newp[nb + at] = e;
+              if (at < (uint32_t) DOM_CAP) { l_sc[gi][at] = e.score; l_af[gi][at] = e.afirst; l_al[gi][at] = e.alast; l_fl[gi][at] = e.flags; }
+            }
           n += (uint32_t) __popc(m);
         }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const uint32_t n0 = n;                                    // what this pass adds lies behind
       uint32_t added = 0, removed = 0;
-      int16_t *cov = D.cover ? D.cover + D.cov_off[ar] : nullptr;
-      for (uint32_t c = s0; c < s1; c++)
-        { const OrdChain S = D.ord[c];
-          if (cov != nullptr && lane == 0)                           // map.c:1654-1666
-            { const int tb = S.ab / D.spacing, te = (S.ae - 1) / D.spacing + 1;
-              const int cb = cov[tb], ce = cov[te];
-              if (cb < 0x7fff && ce > -0xffff)
-                { cov[tb] = (int16_t) (cb + 1);
-                  cov[te] = (int16_t) (ce - 1);
+      int16_t *cov = (D.cover && mine) ? D.cover + D.cov_off[ar] : nullptr;
+      for (uint32_t c0 = s0; c0 < s1; c0 += DOM_G)
+        { // sixteen ends: score and A interval, a lane each
+          OrdChain Se;                                           // (the whole record: the lane that holds it appends it)
+          Se.cost = 0; Se.ab = 0; Se.ae = 0; Se.bb = 0; Se.be = 0; Se.end = 0; Se.gkey = 0;
+          if (c0 + lane < s1) Se = D.ord[c0 + lane];
+          const int e_cost = Se.cost, e_ab = Se.ab, e_ae = Se.ae;
+          const uint32_t nc = min((uint32_t) DOM_G, s1 - c0);
+          for (uint32_t k = 0; k < nc; k++)
+            { const int S_cost = __shfl(e_cost, (int) k, DOM_G), S_ab = __shfl(e_ab, (int) k, DOM_G), S_ae = __shfl(e_ae, (int) k, DOM_G);
+              if (cov != nullptr && lane == 0)                           // map.c:1654-1666
+                { const int tb = S_ab / D.spacing, te = (S_ae - 1) / D.spacing + 1;
+                  const int cb = cov[tb], ce = cov[te];
+                  if (cb < 0x7fff && ce > -0xffff)
+                    { cov[tb] = (int16_t) (cb + 1);
+                      cov[te] = (int16_t) (ce - 1);
+                    }
                 }
+              bool dropped = false;
+              for (int hi = (int) n; hi > 0; hi -= DOM_G)
+                { const int i = hi - 1 - lane;             // lane 0 looks at the newest record of the chunk
+                  int      sc = 0, af = 0, al = 0;
+                  uint32_t fl = DC_TOMB;
+                  if (i >= 0)
+                    { if (i < DOM_CAP) { sc = l_sc[gi][i]; af = l_af[gi][i]; al = l_al[gi][i]; fl = l_fl[gi][i]; }
+                      else
+                        { const DCand *e = D.newp + nb + i;
+                          sc = e->score; af = e->afirst; al = e->alast; fl = e->flags;
+                        }
+                    }
+                  const bool live = !(fl & DC_TOMB);
+                  const bool dhc  = live && af < S_ab + MIN_PIECE && al > S_ae - MIN_PIECE;
+                  const bool chd  = live && S_ab < af + MIN_PIECE && S_ae > al - MIN_PIECE;
+                  const bool dom  = dhc && (.9 * (double) sc >= (double) S_cost);
+                  bool       del  = chd && !dom && ((double) sc <= .9 * (double) S_cost);
+                  const uint32_t md = gballot(dom);
+                  if (md != 0)
+                    { del = del && lane < (__ffs((int) md) - 1);
+                      dropped = true;
+                    }
+                  if (del)
+                    { D.newp[nb + i].flags = fl | DC_TOMB;
+                      if (i < DOM_CAP) l_fl[gi][i] = fl | DC_TOMB;
+                    }
+                  removed += (uint32_t) __popc(gballot(del));
+                  if (dropped) break;
+                }
+              if (!dropped)
+                { if ((uint32_t) lane == k)
+                    { const OrdChain &S = Se;
+                      const uint32_t q = (uint32_t) ((S.gkey >> D.bbits) & qmask);
+                      DCand e;
+                      e.score = S.cost; e.afirst = S.ab; e.alast = S.ae; e.bfirst = S.bb; e.blast = S.be;
+                      e.bread = (int32_t) (S.gkey & bmask) + D.pass[q].bbase;
+                      e.end   = S.end;
+                      e.joff  = 0; e.jlen = 0;
+                      e.flags = DC_FRESH | (D.pass[q].comp ? DC_COMP : 0u);
+                      D.newp[nb + n] = e;
+                      if (n < (uint32_t) DOM_CAP) { l_sc[gi][n] = e.score; l_af[gi][n] = e.afirst; l_al[gi][n] = e.alast; l_fl[gi][n] = e.flags; }
+                    }
+                  n += 1;
+                  added += 1;
+                }
+              // the next end reads what the lanes stored: LDS is served in order within the wavefront; the records beyond
+              // DOM_CAP are read from the pool, behind a fence
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (n > (uint32_t) DOM_CAP) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
-          bool dropped = false;
-          for (int hi = (int) n; hi > 0; hi -= DOM_G)
-            { const int i = hi - 1 - lane;             // lane 0 looks at the newest record of the chunk
-              int      sc = 0, af = 0, al = 0;
-              uint32_t fl = DC_TOMB;
-              if (i >= 0)
-                { const DCand *e = D.newp + nb + i;
-                  sc = e->score; af = e->afirst; al = e->alast; fl = e->flags;
-                }
-              const bool live = !(fl & DC_TOMB);
-              const bool dhc  = live && af < S.ab + MIN_PIECE && al > S.ae - MIN_PIECE;
-              const bool chd  = live && S.ab < af + MIN_PIECE && S.ae > al - MIN_PIECE;
-              const bool dom  = dhc && (.9 * (double) sc >= (double) S.cost);
-              bool       del  = chd && !dom && ((double) sc <= .9 * (double) S.cost);
-              const uint32_t md = gballot(dom);
-              if (md != 0)
-                { del = del && lane < (__ffs((int) md) - 1);
-                  dropped = true;
-                }
-              if (del) D.newp[nb + i].flags = fl | DC_TOMB;
-              removed += (uint32_t) __popc(gballot(del));
-              if (dropped) break;
-            }
-          if (!dropped)
-            { if (lane == 0)
-                { const uint32_t q = (uint32_t) ((S.gkey >> D.bbits) & qmask);
-                  DCand e;
-                  e.score = S.cost; e.afirst = S.ab; e.alast = S.ae; e.bfirst = S.bb; e.blast = S.be;
-                  e.bread = (int32_t) (S.gkey & bmask) + D.pass[q].bbase;
-                  e.end   = S.end;
-                  e.joff  = 0; e.jlen = 0;
-                  e.flags = DC_FRESH | (D.pass[q].comp ? DC_COMP : 0u);
-                  D.newp[nb + n] = e;
-                }
-              n += 1;
-              added += 1;
-            }
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // the next chain reads what the lanes stored
         }
-      if (lane == 0)
+      // the records this pass added that are still there: listed for the Jump lists (one atomic per wavefront and turn)
+      { uint32_t mycnt = 0;
+        for (uint32_t base = n0; base < n; base += DOM_G)
+          { const uint32_t i = base + lane;
+            uint32_t fl = DC_TOMB;
+            if (i < n) fl = (i < (uint32_t) DOM_CAP) ? l_fl[gi][i] : D.newp[nb + i].flags;
+            mycnt += (uint32_t) __popc(gballot((fl & DC_FRESH) && !(fl & DC_TOMB)));
+          }
+        // (mycnt is the group's count in every lane of the group)
+        const uint32_t g0c = (uint32_t) __builtin_amdgcn_readlane((int) mycnt, 0), g1c = (uint32_t) __builtin_amdgcn_readlane((int) mycnt, 16),
+                       g2c = (uint32_t) __builtin_amdgcn_readlane((int) mycnt, 32), g3c = (uint32_t) __builtin_amdgcn_readlane((int) mycnt, 48);
+        uint32_t wbase = 0;
+        if ((threadIdx.x & 63) == 0 && g0c + g1c + g2c + g3c > 0) wbase = atomicAdd(D.nfresh, g0c + g1c + g2c + g3c);
+        wbase = (uint32_t) __builtin_amdgcn_readfirstlane((int) wbase);
+        const int gw = (threadIdx.x & 63) / DOM_G;
+        uint32_t at = wbase + (gw > 0 ? g0c : 0u) + (gw > 1 ? g1c : 0u) + (gw > 2 ? g2c : 0u);
+        for (uint32_t base = n0; base < n; base += DOM_G)
+          { const uint32_t i = base + lane;
+            uint32_t fl = DC_TOMB;
+            if (i < n) fl = (i < (uint32_t) DOM_CAP) ? l_fl[gi][i] : D.newp[nb + i].flags;
+            const bool f = (fl & DC_FRESH) && !(fl & DC_TOMB);
+            const uint32_t m = gballot(f);
+            if (f) D.fresh[at + (uint32_t) __popc(m & (uint32_t) lt)] = nb + i;
+            at += (uint32_t) __popc(m);
+          }
+      }
+      if (lane == 0 && mine)
         { D.nlen[ar] = n;
           if (added)   atomicAdd(D.ctl, added);
           if (removed) atomicAdd(D.ctl + 1, removed);
         }
-    }
-}
-
-// the records added by this pass that survived it: their Jump lists are stored next.  (One thread per read
-// walks the read's list: the slack behind a list -- a read may need fewer records than were reserved -- is
-// uninitialised memory.)
-__global__ __launch_bounds__(64) void k_fresh_list(const DCand *__restrict__ pool, const uint32_t *__restrict__ noff,
-                                                   const uint32_t *__restrict__ nlen, int nreads,
-                                                   uint32_t *__restrict__ fresh, unsigned int *__restrict__ nfresh)
-{ const int r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-  const uint32_t b = (r < nreads) ? noff[r] : 0u, n = (r < nreads) ? nlen[r] : 0u;
-  uint32_t cnt = 0;
-  for (uint32_t i = 0; i < n; i++)
-    { const uint32_t fl = pool[b + i].flags;
-      cnt += ((fl & DC_FRESH) && !(fl & DC_TOMB)) ? 1u : 0u;
-    }
-  // one atomic per wavefront (they are served one after the other at the memory side, a few ns apiece: one per
-  // candidate was most of this kernel's time); the order of the list is of no consequence
-  const uint32_t incl = wave_incl_scan_dpp(cnt);
-  const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
-  uint32_t base = 0;
-  if (lane == 0 && total > 0) base = atomicAdd(nfresh, total);
-  base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
-  uint32_t at = base + incl - cnt;
-  for (uint32_t i = 0; i < n && cnt > 0; i++)
-    { const uint32_t fl = pool[b + i].flags;
-      if ((fl & DC_FRESH) && !(fl & DC_TOMB)) fresh[at++] = b + i;
     }
 }
 
@@ -2425,12 +2464,11 @@ static void finish_step_b(MergeResult &R)
     D.cov_off = cs.cov_off.p;
     D.spacing = SPACING;
     D.ctl = cs.ctl.p;
+    D.fresh = fresh.p; D.nfresh = cs.ctl.p + 2;
     hipLaunchKernelGGL(k_dominate, dim3(std::min(ceil_div(nreads, 256 / DOM_G), 256 * 8)), dim3(256), 0, stream(), D);
     HIP_CHECK(hipGetLastError());
   }
   { StageTimer tm("chain_jumps", 0.0);
-    hipLaunchKernelGGL(k_fresh_list, dim3(ceil_div(nreads, 64)), dim3(64), 0, stream(), (const DCand *) cs.pool[nx].p,
-                       (const uint32_t *) cs.seg_off[nx].p, (const uint32_t *) cs.seg_len[nx].p, nreads, fresh.p, cs.ctl.p + 2);
     hipLaunchKernelGGL(k_cand_jumps, dim3(std::min<uint32_t>(ceil_div((int64_t) nsum * 64, CJ_BLOCK), 2048u)), dim3(CJ_BLOCK), 0, stream(),
                        (const uint64_t *) R.sab, (const uint32_t *) from.p, cs.pool[nx].p,
                        (const uint32_t *) fresh.p, (const unsigned int *) (cs.ctl.p + 2), nsum, jl.p,

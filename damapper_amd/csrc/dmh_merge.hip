@@ -1199,6 +1199,7 @@ static bool    finish_tick(int64_t *nfilt);
 static int     flight_keep();
 static void    finish_pipeline(int64_t *nfilt);
 static bool    filter_reclaim();
+static bool    g_finish_in_close = false;    // this pass's share of finishing is done behind its per-read kernels (close_batch)
 static int     g_flight_cap = IN_FLIGHT;     // batches that may be in flight: fewer after every time memory ran out, one more
                                              //   again after every READS block that went through without (filter_flush_block)
 static bool    g_reclaimed_in_block = false; // memory ran out since the last READS block was flushed
@@ -1359,6 +1360,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   int fs = -1;
   for (int q = 0; q < 2; q++)
     if (g_fb[q].a == &A && g_fb[q].b == &Bx) fs = q;
+  const bool front_was_made = fs >= 0;
   if (fs < 0)
     { static const bool env_two = getenv("DMH_MATCH_TWO") == nullptr || atoi(getenv("DMH_MATCH_TWO")) != 0;
       IndexDev *B2 = nullptr;
@@ -1379,6 +1381,11 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
   // main stream has the match kernels (and the previous pass's chain kernels) to run meanwhile
   close_pending();       // (the previous pass's second half: behind this pass's match kernels)
+  // (When the sweep of the pass before has made this pass's front already, the main stream has NOTHING queued here: the
+  //  host's wait for the finish stream -- a millisecond -- would be the main stream's too, on every second pass.  The
+  //  oldest batch is then finished a little later, behind this pass's per-read kernels: close_batch.)
+  g_finish_in_close = front_was_made && flight_keep() > 0;
+  if (!g_finish_in_close)
   { static const bool nosteps = getenv("DMH_FINISH_STEPS") == nullptr;
     static const bool pipe = getenv("DMH_FINISH_PIPE") != nullptr;      // (opt-in: measured 178.5 against 173.1 ms per read block)
     const int keep2 = flight_keep();
@@ -2251,6 +2258,13 @@ static void close_batch(MergeResult &R, int phase)
             }
           { int64_t nf = 0;                   // (the per-read sort is queued: the third step of the oldest batch's finish)
             finish_tick_if_due(&nf);
+            if (g_finish_in_close && phase == 0)
+              { // the oldest batch's finish that merge_pass has left for here (its front was made by the pass before: the
+                // per-read kernels just queued are what the main stream runs while the host waits for the finish stream)
+                g_finish_in_close = false;
+                const int keep2 = flight_keep();
+                while ((int) g_inflight.size() > keep2) nf += finish_oldest();
+              }
             st.tfilt += nf;
           }
           // one round trip: clusters, clusters the radix sort has to finish, the chain kernels' big groups and piles
