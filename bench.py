@@ -66,11 +66,11 @@ FLAG_SETS = {
 # kernels whose time is HBM streaming: algorithmic bytes are meaningful as a bandwidth
 STAGE_KERNEL = {
     "k_radix_scatter": "k_radix_scatter", "k_radix_hist": "k_radix_hist", "radix_scan": "k_scan_*",
-    "kmer_emit": "k_kmer_emit", "merge_match": "k_merge_match", "merge_fixup": "k_merge_fixup (+reduce, scan)",
+    "kmer_emit": "k_kmer_emit", "merge_match": "k_merge_match", "merge_match2": "k_merge_match (both orientations of a REF block in one sweep)", "merge_fixup": "k_merge_fixup (+reduce, scan)",
     "merge_emit": "k_merge_expand (+sizes, scan)", "merge_rows": "k_row_list (+scan, classes)",
     "seed_groups": "k_group_flag/write (+scan)", "chain_small_groups": "k_chain<16>", "chain_listed_groups": "k_chain<64>",
  "chain_lane_groups": "k_chain_lane", "chain_simple_groups": "k_chain_simple", "chain_lds_groups": "k_chain_small",
-    "chain_piles": "k_chain_pile", "chain_dominate": "k_order_summaries + k_dominate (+ scans)", "seed_clusters": "k_cluster_flag/rekey (+scan)",
+    "chain_class_groups": "k_chain_classes", "chain_piles": "k_chain_pile", "chain_dominate": "k_order_summaries + k_dominate (+ scans)", "seed_clusters": "k_cluster_flag/rekey (+scan)",
     "seed_pairs": "k_pair_flag/write (+scan)", "chain_spilled_piles": "k_chain<64> (spilled piles)", "chain_jumps": "k_chain_jumps",
     "align": "k_align_cands32", "align_wave64": "k_align_cands<128>", "align_global_band": "k_align_cands<8192>",
     "read_sort": "k_read_sort (fused: rows -> ordered hits -> plain chains)", "unpack_2bit": "k_unpack_2bit", "pack_bases": "k_pack_fwd", "pack_revcomp": "k_pack_rc", "merge_buckets": "k_bucket_bounds",
@@ -80,12 +80,12 @@ ENCLOSING = {"kmer_sort", "seed_sort", "cluster_sort", "chain", "sort_pairs"}
 SIDE_STREAM = {"chain_piles"}
 # stages that are ONE kernel on the main stream: the candidates for "the dominant kernel" (the finish stream's stages --
 # chain_jumps, chain_dominate -- and the alignment stream's run next to these, a dozen small kernels each)
-SINGLE_MAIN = {"merge_match", "chain_simple_groups", "chain_lane_groups", "chain_small_groups", "chain_listed_groups",
+SINGLE_MAIN = {"merge_match", "merge_match2", "chain_simple_groups", "chain_lane_groups", "chain_small_groups", "chain_listed_groups",
                "chain_lds_groups", "k_radix_scatter", "k_radix_hist", "kmer_emit", "merge_buckets"}
 # kernel symbols as rocprofv3 names them, for the PMC traffic summary under profiles/
 PMC_SYMBOL = {"k_radix_scatter": "dmh::k_radix_scatter", "k_radix_hist": "dmh::k_radix_hist", "chain_lane_groups": "dmh::k_chain_lane",
               "kmer_emit": "dmh::k_kmer_emit", "chain_piles": "dmh::k_chain_pile", "read_sort": "dmh::k_read_sort",
-              "merge_match": "dmh::k_merge_match", "align": "dmh::k_align_cands32", "chain_simple_groups": "dmh::k_chain_simple"}
+              "merge_match": "dmh::k_merge_match", "merge_match2": "dmh::k_merge_match", "align": "dmh::k_align_cands32", "chain_simple_groups": "dmh::k_chain_simple"}
 
 
 def ref_block_ranges(lens):
