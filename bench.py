@@ -36,6 +36,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")      # (before anything touches the GPU: damapper_amd/__init__.py)
+
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -2185,13 +2185,22 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             P.pile_cap = (st.opt_pile_cap >= 128 && st.opt_pile_cap < PILE_CAP) ? (uint32_t) st.opt_pile_cap : (uint32_t) PILE_CAP;
             // on a stream of their own, next to the other two launches; piles whose window outgrows LDS are
             // listed for a last 64-lane launch behind everything
-            static hipStream_t pstream = nullptr;
+            // (round 4: FOUR such streams taken in turn -- a pass's piles are a handful of workgroups that run for 12 ms
+            //  alone and 30 next to the other streams' kernels, four passes of a read block have them, and on one stream
+            //  those launches stood in a queue that was as long as the read block itself: 126 ms per read block with one
+            //  stream, 117 with two or four, 120 with three; DMH_PILE_STREAMS)
+            constexpr int MAXPS = 4;
+            static hipStream_t pstreams[MAXPS] = {nullptr, nullptr, nullptr, nullptr};
             static hipEvent_t  ev_go = nullptr;
+            static int         turn = 0;
+            static const int   nps = std::max(1, std::min(MAXPS, getenv("DMH_PILE_STREAMS") ? atoi(getenv("DMH_PILE_STREAMS")) : 4));
             hipEvent_t &ev_done = C.piles_done;
-            if (pstream == nullptr)
-              { HIP_CHECK(hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking));
+            if (pstreams[0] == nullptr)
+              { for (int q = 0; q < nps; q++) HIP_CHECK(hipStreamCreateWithFlags(&pstreams[q], hipStreamNonBlocking));
                 HIP_CHECK(hipEventCreateWithFlags(&ev_go, hipEventDisableTiming));
               }
+            hipStream_t pstream = pstreams[turn];
+            turn = (turn + 1) % nps;
             if (ev_done == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
             HIP_CHECK(hipEventRecord(ev_go, stream()));
             HIP_CHECK(hipStreamWaitEvent(pstream, ev_go, 0));

@@ -97,6 +97,12 @@ bool host_crowded()
 static void init_device()
 { if (g_init) return;
   int n = 0;
+  // The filter keeps six streams busy next to each other (main, tail, finish, piles, alignment, upload) and the HIP runtime
+  // maps streams onto FOUR hardware queues by default, in creation order: two streams on one queue run one behind the
+  // other -- with the tail stream behind the pile stream's 30 ms kernels a read block took 141 ms instead of 124, and which
+  // streams meet depends on the order the code happens to create them in.  Twelve queues: every stream its own (main, upload, tail, finish, alignment, four for the piles, the caller's) (read when the
+  // runtime starts: no effect when the process has used HIP before this library, see damapper_amd/__init__.py)
+  setenv("GPU_MAX_HW_QUEUES", "12", 0);
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
     fatal("no HIP device available (%s): libdamapper_hip has no CPU fallback",

@@ -1193,6 +1193,7 @@ static void    close_batch(MergeResult &R, int phase = 0);
 static void    close_pending();
 static int     g_pending_close = -1;       // ring slot whose close stopped at the cluster-count copy (close_batch phase 1)
 static bool    g_closing = false;          // inside the second half of such a close
+static int     g_closing_slot = -1;        // ... and the ring slot it works on (busy for filter_reclaim: it is in no list meanwhile)
 static int64_t finish_oldest();
 static void    finish_tick_if_due(int64_t *nfilt);
 static bool    finish_tick(int64_t *nfilt);
@@ -1225,6 +1226,8 @@ struct FrontBufs
   DevBuf<uint32_t>   tcount;
   DevBuf<unsigned int> mctl;
   const IndexDev *a = nullptr, *b = nullptr;                            // the pass whose front is queued in this set
+  unsigned long long hsum[3] = {0, 0, 0};                               // its hit sums and run count, when the round trip of the
+  bool have_sums = false;                                               //   sweep's own pass has fetched them along
 };
 static FrontBufs g_fb[2];
 static DevBuf<MergeEntry> g_entries;
@@ -1235,6 +1238,18 @@ static void ensure_bucket_table(IndexDev &Bx, int Kshift);
 
 static BLookup lookup_of(const IndexDev &Bx)
 { return BLookup{Bx.keys, Bx.d_bstart, Bx.bshift, Bx.low_off ? (const uint16_t *) (Bx.d_bstart + Bx.low_off) : nullptr}; }
+
+// Fused per-read route: a pass returns with its per-read kernels queued on the main stream and their counters on the way
+// to page-locked memory; its second half (cluster numbering, pairs, chain stage: the tail stream's) is queued by the NEXT
+// pass once that has given the main stream its own work -- the host then waits for the counters of kernels that have
+// long finished instead of standing between the main stream and its next launch twice per pass (round 4: 26 % of the
+// main stream's time were such gaps).  "defer_close" test option = 0 / DMH_DEFER_CLOSE=0: every pass closed before
+// Match_Filter returns.
+static bool defer_fused_close()
+{ static const int env = getenv("DMH_DEFER_CLOSE") ? atoi(getenv("DMH_DEFER_CLOSE")) : 4;
+  const int o = S().opt_defer_close;
+  return (o >= 0 ? o : env) == 4;
+}
 
 // B2 != nullptr: the same sweep also probes B2 (results in set 1)
 static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nullptr)
@@ -1257,6 +1272,7 @@ static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nu
       HIP_CHECK(hipMemsetAsync(F.gram.p + MAXGRAM + 1, 0, sizeof(unsigned long long) * 3, stream()));     // [0] all hits, [1] hits of the runs below MAXGRAM
       HIP_CHECK(hipMemsetAsync(F.mctl.p, 0, 4 * sizeof(unsigned int), stream()));
       MO[q] = MatchOut{F.tentries.p, F.tcount.p, F.thits.p};
+      F.have_sums = false;
     }
   if (B2 == nullptr) MO[1] = MO[0];
   { // bytes the kernel has to read in this layout: 8 per READ k-mer, 4 per bucket and 2 (the low bits) or 8 (the key) per
@@ -1380,7 +1396,9 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   unsigned long long *sums = gram.p + MAXGRAM + 1;         // [0] all hits, [1] hits of the runs below MAXGRAM
   // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
   // main stream has the match kernels (and the previous pass's chain kernels) to run meanwhile
-  close_pending();       // (the previous pass's second half: behind this pass's match kernels)
+  // (... unless this pass's front was made by the sweep before: the main stream has nothing of this pass yet -- the close
+  //  that is pending is then taken up behind this pass's per-read kernels, close_batch phase 4, or by whatever closes next)
+  if (!(front_was_made && defer_fused_close())) close_pending();
   // (When the sweep of the pass before has made this pass's front already, the main stream has NOTHING queued here: the
   //  host's wait for the finish stream -- a millisecond -- would be the main stream's too, on every second pass.  The
   //  oldest batch is then finished a little later, behind this pass's per-read kernels: close_batch.)
@@ -1396,10 +1414,27 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // one round trip for the pass: the number of matched runs and the two hit sums (the count is parked behind the sums)
   unsigned int nent = 0;
   unsigned long long hsum[3] = {0, 0, 0};
-  HIP_CHECK(hipMemcpyAsync(sums + 2, tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
-  { HostTimer hw("wait_hit_sums");
-    copy_d2h(hsum, sums, sizeof(unsigned long long) * 3, 1);                       // the limit rule next
-  }
+  if (front_was_made && g_fb[fs].have_sums)
+    { for (int q = 0; q < 3; q++) hsum[q] = g_fb[fs].hsum[q]; }         // (fetched with the sweep's own pass: no round trip)
+  else
+    { FrontBufs *F2 = nullptr;               // the other set, when this sweep has filled it for the pass that follows
+      static const bool env_sc = getenv("DMH_SUMS_CACHE") == nullptr || atoi(getenv("DMH_SUMS_CACHE")) != 0;
+      if (env_sc && !front_was_made && g_fb[1].a != nullptr && g_fb[1].b != nullptr) F2 = &g_fb[1];
+      HIP_CHECK(hipMemcpyAsync(sums + 2, tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
+      if (F2 != nullptr)
+        { HIP_CHECK(hipMemcpyAsync(F2->gram.p + MAXGRAM + 1 + 2, F2->tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
+          HIP_CHECK(hipMemcpyAsync(sums + 3, F2->gram.p + MAXGRAM + 1, sizeof(unsigned long long) * 3, hipMemcpyDeviceToDevice, stream()));
+        }
+      HostTimer hw("wait_hit_sums");
+      unsigned long long both[6] = {0, 0, 0, 0, 0, 0};
+      copy_d2h(both, sums, sizeof(unsigned long long) * (F2 != nullptr ? 6 : 3), 1);                       // the limit rule next
+      for (int q = 0; q < 3; q++) hsum[q] = both[q];
+      if (F2 != nullptr)
+        { for (int q = 0; q < 3; q++) F2->hsum[q] = both[3 + q];
+          F2->have_sums = true;
+        }
+    }
+  g_fb[fs].have_sums = false;
   nent = (unsigned int) (hsum[2] & 0xffffffffull);
   // the compact entry list, made when somebody needs it (the fused per-read route reads the tiles' own windows)
   bool gathered = false;
@@ -1549,7 +1584,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   static const int env_fuse = getenv("DMH_FUSE") ? atoi(getenv("DMH_FUSE")) : 1;
   static const bool env_dc0 = getenv("DMH_DEFER_CLOSE") != nullptr && atoi(getenv("DMH_DEFER_CLOSE")) == 1;
   const bool fuse = by_read && (st.opt_fuse >= 0 ? st.opt_fuse != 0 : env_fuse != 0) && limit <= (int64_t) MAXGRAM &&
-                    R.pbits <= RW_AP && A.posbits > 0 && Bx.posbits > 0 && !(env_dc0 || st.opt_defer_close > 0) &&
+                    R.pbits <= RW_AP && A.posbits > 0 && Bx.posbits > 0 && !(env_dc0 || (st.opt_defer_close > 0 && st.opt_defer_close != 4)) &&
                     A.L + 1 < ((int64_t) 1 << 32);
   if (ranged && !fuse)
     fatal("Match_Filter: %lld seed hits in one block pair exceed the 32-bit slot range and the pass cannot be split (it takes "
@@ -1723,9 +1758,13 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
       static const bool env_dl = getenv("DMH_DEFER_CLOSE") != nullptr && atoi(getenv("DMH_DEFER_CLOSE")) == 2;
       const bool defer_light = !defer_close && env_dl && st.opt_defer_close != 0 && R.word && R.read_sorted &&
                                !st.capture_seeds && !VERBOSE && flight_keep() > 0 && tail_stream() != main_stream() && R.nhits > 0;
-      close_batch(R, defer_close ? 1 : (defer_light ? 3 : 0));
+      const bool defer_fused = !defer_close && !defer_light && R.fused && R.word && R.read_sorted && !st.capture_seeds && !VERBOSE &&
+                               flight_keep() > 0 && tail_stream() != main_stream() && R.nhits > 0 && defer_fused_close();
+      close_batch(R, defer_close ? 1 : (defer_light ? 3 : (defer_fused ? 4 : 0)));
       if (R.word) bg_pump_tail(1);      // (a stage of the next read block's index, behind this pass's second half)
     }
+  else
+    close_pending();                    // (a pass that is collected, not closed: nothing would take the pending close up)
   // batches in flight: under -v every call reports its own candidate counts, and the stage-level API looks at the
   // lists after every call -- then nothing stays in flight
   static const int env_fl = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;
@@ -1890,7 +1929,7 @@ static void finish_retire(int x)
 // per hit; three such batches in flight next to 120 GB of indices do not fit 288 GB, one at a time does.
 static void release_idle_slots(bool &got)
 { for (int i = 0; i < NRING; i++)
-    { bool busy = (i == g_cur) || (i == g_finishing_slot) || (i == g_pending_close);       // (chain_finish still reads the slot it is finishing)
+    { bool busy = (i == g_cur) || (i == g_finishing_slot) || (i == g_pending_close) || (i == g_closing_slot);       // (chain_finish still reads the slot it is finishing)
       for (int y : g_inflight) busy = busy || (y == i);
       if (busy) continue;
       MergeResult &R = g_ring[i];
@@ -1932,7 +1971,7 @@ static bool filter_reclaim()
   if (stats)
     { int nbusy = 0;
       for (int i = 0; i < NRING; i++)
-        { bool busy = (i == g_cur) || (i == g_finishing_slot) || (i == g_pending_close);
+        { bool busy = (i == g_cur) || (i == g_finishing_slot) || (i == g_pending_close) || (i == g_closing_slot);
           for (int y : g_inflight) busy = busy || (y == i);
           nbusy += busy ? 1 : 0;
         }
@@ -2010,8 +2049,10 @@ static void close_pending()
   const int x = g_pending_close;
   g_pending_close = -1;
   g_closing = true;
+  g_closing_slot = x;
   close_batch(g_ring[x], 2);
   g_closing = false;
+  g_closing_slot = -1;
 }
 
 // phase 0: everything.  Per-read route only: phase 1 = up to the per-read sort and the copy of its counters (queued on
@@ -2020,7 +2061,7 @@ static void close_batch(MergeResult &R, int phase)
 { State &st = S();
   std::unique_ptr<StreamScope> tail_scope;       // set where the pass moves to the tail stream (per-read route)
   std::unique_ptr<HostTimer> post_sync;          // host time from the counter round trip to the end of the close
-  if (phase != 2) close_pending();               // (one close at a time)
+  if (phase != 2 && phase != 4) close_pending(); // (one close at a time; phase 4 takes the pending one up behind its own per-read kernels)
   const int64_t nhits = R.nhits;
   const DAZZ_DB *ablock = R.ablock;
   R.open = false;
@@ -2081,7 +2122,7 @@ static void close_batch(MergeResult &R, int phase)
               tail_scope.reset(new StreamScope(tail_stream()));
             }
           else if (phase == 2)
-            { if (R.h_known[7] == 1u) HIP_CHECK(hipStreamWaitEvent(tail_stream(), R.ev_known, 0));      // (the light version)
+            { if (R.h_known[7] != 0u) HIP_CHECK(hipStreamWaitEvent(tail_stream(), R.ev_known, 0));      // (the light version, phase 4)
               tail_scope.reset(new StreamScope(tail_stream()));       // (else: where phase 1 left off)
             }
           if (phase != 2)
@@ -2258,7 +2299,7 @@ static void close_batch(MergeResult &R, int phase)
             }
           { int64_t nf = 0;                   // (the per-read sort is queued: the third step of the oldest batch's finish)
             finish_tick_if_due(&nf);
-            if (g_finish_in_close && phase == 0)
+            if (g_finish_in_close && (phase == 0 || phase == 4))
               { // the oldest batch's finish that merge_pass has left for here (its front was made by the pass before: the
                 // per-read kernels just queued are what the main stream runs while the host waits for the finish stream)
                 g_finish_in_close = false;
@@ -2267,6 +2308,29 @@ static void close_batch(MergeResult &R, int phase)
               }
             st.tfilt += nf;
           }
+          if (phase == 4)
+            { // the counters travel to page-locked memory behind the per-read kernels (main stream); the pass before is
+              // closed now -- its counters have long arrived --, this one by the pass that follows (close_pending)
+              if (R.h_known == nullptr)
+                { HIP_CHECK(hipHostMalloc((void **) &R.h_known, 8 * sizeof(uint32_t), hipHostMallocDefault));
+                  HIP_CHECK(hipEventCreateWithFlags(&R.ev_known, hipEventDisableTiming));
+                }
+              R.h_known[7] = 2u;
+              HIP_CHECK(hipMemcpyAsync(R.h_known, R.rs_wcnt.p + 2, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()));
+              HIP_CHECK(hipEventRecord(R.ev_known, stream()));
+              int slot = -1;
+              for (int i = 0; i < NRING; i++)
+                if (&g_ring[i] == &R) slot = i;
+              // (this batch's slot is in no list while the pending close runs: it stays g_cur until then)
+              close_pending();
+              g_pending_close = slot;
+              for (int i = 0; i < NRING; i++)
+                { bool busy = (i == slot);
+                  for (int y : g_inflight) busy = busy || (y == i);
+                  if (!busy) { g_cur = i; break; }
+                }
+              return;
+            }
           // one round trip: clusters, clusters the radix sort has to finish, the chain kernels' big groups and piles
           { HostTimer hw("wait_cluster_counts");
             if (phase == 2 && R.h_known[7] == 1u)

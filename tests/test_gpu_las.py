@@ -165,7 +165,8 @@ def test_ragged_and_degenerate_reads(tmp_path):
                                   dict(cluster=1, read_sort=7), dict(cluster=1, defer_close=1), dict(cluster=1, tails=0),
                                   dict(chain_simple=0), dict(cluster=1, chain_simple=0),
                                   dict(cluster=1, fuse=0), dict(cluster=1, fuse=0, read_sort=3), dict(cluster=1, fuse=0, read_sort=5),
-                                  dict(cluster=1, fuse=0, chain_simple=0), dict(cluster=1, chain_classes=0), dict(chain_classes=0)],
+                                  dict(cluster=1, fuse=0, chain_simple=0), dict(cluster=1, chain_classes=0), dict(chain_classes=0),
+                                  dict(cluster=1, defer_close=0), dict(defer_close=0)],
                          ids=["four_per_wavefront", "wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
                               "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table", "merge_low16_probes",
                               "clusters", "clusters_piles", "clusters_chain64",
@@ -180,7 +181,8 @@ def test_ragged_and_degenerate_reads(tmp_path):
                               "no_simple_groups", "clusters_no_simple_groups",
                               "clusters_unfused_round3_route", "clusters_unfused_oversize_through_global_memory",
                               "clusters_unfused_ballot_ranks", "clusters_unfused_no_simple_groups",
-                              "clusters_no_diagonal_classes", "no_diagonal_classes"])
+                              "clusters_no_diagonal_classes", "no_diagonal_classes",
+                              "clusters_every_pass_closed_before_it_returns", "every_pass_closed_before_it_returns"])
 def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes
     to the same bytes: force each one and compare with the default route on data that has repeats, dropouts and
