@@ -4,6 +4,9 @@
 set -u
 cd "${GRAFT_REPO_ROOT:?not on a gpurun box}" || exit 1
 export TMPDIR=/tmp
+# the library asks for twelve hardware queues when it is the first to use HIP in the process (dmh_core.hip init_device);
+# under rocprofv3 the profiler is first, so the setting comes from here
+export GPU_MAX_HW_QUEUES=12
 T="${1:-r04a}"
 O="gpurun_out/ev_$T"
 rm -rf "$O"; mkdir -p "$O"

@@ -47,3 +47,11 @@ v = list(lp)
 tot = max(1, sum(v[:9]))
 print("k_chain_lane: hits by live window entries before the hit:", " ".join("%d:%.2f%%" % (i, 100.0 * v[i] / tot) for i in range(9)))
 print("k_chain_lane: hits by live trees:", " ".join("%d:%.2f%%" % (i, 100.0 * v[12 + i] / tot) for i in range(6)))
+
+cp = (C.c_ulonglong * 16)()
+L.dmh_chain_profile.argtypes = [C.c_void_p, C.c_int]
+L.dmh_chain_profile(cp, 0)
+v = list(cp)
+h = max(1, v[6])
+print("k_chain_pile: hits %d, mean list %d, compactions %d, spills %d; cycles per hit: scan %.0f reduce %.0f barrier1 %.0f serial %.0f barrier2 %.0f compaction %.0f" %
+      (v[6], v[7] / h, v[8], v[9], v[0] / h, v[1] / h, v[2] / h, v[3] / h, v[4] / h, v[5] / h))
