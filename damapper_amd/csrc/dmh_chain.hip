@@ -2193,7 +2193,10 @@ void chain_submit(MergeResult &R, const DAZZ_DB *ablock)
             static hipStream_t pstreams[MAXPS] = {nullptr, nullptr, nullptr, nullptr};
             static hipEvent_t  ev_go = nullptr;
             static int         turn = 0;
-            static const int   nps = std::max(1, std::min(MAXPS, getenv("DMH_PILE_STREAMS") ? atoi(getenv("DMH_PILE_STREAMS")) : 4));
+            // (on a runtime that runs only four streams side by side four pile streams would sit on every queue the other
+            //  streams have: one then)
+            static const int   nps = std::max(1, std::min(MAXPS, getenv("DMH_PILE_STREAMS") ? atoi(getenv("DMH_PILE_STREAMS"))
+                                                                                             : (hw_queues_seen() >= 8 ? 4 : 1)));
             hipEvent_t &ev_done = C.piles_done;
             if (pstreams[0] == nullptr)
               { for (int q = 0; q < nps; q++) HIP_CHECK(hipStreamCreateWithFlags(&pstreams[q], hipStreamNonBlocking));

@@ -10,6 +10,7 @@
 #include <stdarg.h>
 #include <time.h>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -94,6 +95,44 @@ bool host_crowded()
   return v == 1;
 }
 
+// How many of the library's streams run side by side?  (dmh_core.hip init_device asks the runtime for twelve hardware
+// queues, which only works when the process has not used HIP before.)  Eight streams get a kernel each that spins for
+// 1 ms of the constant-rate clock: side by side they are done in 1.2 ms, on the runtime's default of four queues in 2.2,
+// on one in 8.  Once per process; the answer sizes the pile streams (dmh_chain.hip) and a
+// host that gets the default is told so.
+__global__ void k_queue_probe(unsigned long long ticks)
+{ const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+static int g_hw_queues_seen = 0;       // 0: not probed; else the streams found to run side by side (1..8)
+int hw_queues_seen() { return g_hw_queues_seen; }
+
+static void probe_hw_queues()
+{ static const bool off = getenv("DMH_QUEUE_PROBE") != nullptr && atoi(getenv("DMH_QUEUE_PROBE")) == 0;
+  if (off) { g_hw_queues_seen = 8; return; }
+  constexpr int NP = 8;
+  hipStream_t ps[NP];
+  for (int i = 0; i < NP; i++) HIP_CHECK(hipStreamCreateWithFlags(&ps[i], hipStreamNonBlocking));
+  // (the first launch of a kernel loads its code object, the first on a stream makes its queue: once untimed)
+  for (int i = 0; i < NP; i++) hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, ps[i], 100ull);
+  HIP_CHECK(hipDeviceSynchronize());
+  const unsigned long long ticks = 100000ull;           // 1 ms at 100 MHz
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < NP; i++) hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, ps[i], ticks);
+  HIP_CHECK(hipDeviceSynchronize());
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  for (int i = 0; i < NP; i++) HIP_CHECK(hipStreamDestroy(ps[i]));
+  const int rounds = std::max(1, (int) ((us + 400.0) / 1000.0));       // kernels that ran one behind the other (+ 0.2 ms of launches)
+  g_hw_queues_seen = std::max(1, std::min(NP, (NP + rounds - 1) / rounds));
+  if (getenv("DMH_STATS") != nullptr)
+    fprintf(stderr, "dmh: eight probe kernels on eight streams took %.0f us: about %d run side by side\n", us, g_hw_queues_seen);
+  if (g_hw_queues_seen < NP)
+    fprintf(stderr, "libdamapper_hip: the HIP runtime of this process runs only about %d streams side by side (its default is four "
+            "hardware queues); the library keeps nine busy.  Export GPU_MAX_HW_QUEUES=12 before the process starts (INTEGRATION.md 3): "
+            "a read block takes a quarter longer without.\n", g_hw_queues_seen);
+}
+
 static void init_device()
 { if (g_init) return;
   int n = 0;
@@ -117,6 +156,7 @@ static void init_device()
   if (getenv("DMH_SPIN") != nullptr) (void) hipSetDeviceFlags(hipDeviceScheduleSpin);
   else if (host_crowded())
     { if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void) hipGetLastError(); }
+  probe_hw_queues();
   HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&g_upstream, hipStreamNonBlocking));
   g_init = true;

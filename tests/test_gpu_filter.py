@@ -120,3 +120,22 @@ def test_pass_beyond_the_hit_range_is_made_in_ranges_of_reads(limit):
             assert np.array_equal(a1, a2) and np.array_equal(b1, b2), "read %d cand %d jumps" % (ar, k)
         nc += len(ca)
     assert nc > 0
+
+
+@pytest.mark.gpu
+def test_library_says_so_when_the_runtime_has_too_few_hardware_queues():
+    """The library keeps nine streams busy and asks the HIP runtime for twelve hardware queues (dmh_core.hip init_device);
+    a process whose runtime was started with the default of four gets one pile stream instead of four and a line on stderr
+    (probe_hw_queues: eight kernels of 1 ms on eight streams, timed)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "profiles", "scripts", "x_qprobe.py")
+    for queues, want in (("4", 4), ("12", 8)):
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=queues, DMH_STATS="1")
+        r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "sorted True" in r.stdout
+        assert ("about %d run side by side" % want) in r.stderr, r.stderr
+        assert ("only about" in r.stderr) == (want < 8), r.stderr
