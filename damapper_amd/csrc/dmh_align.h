@@ -63,12 +63,36 @@ template <int W> struct WaveWork
 { int      *band;        // ring: (F_COUNT*2 + 2) * W ints  (LDS or global)
   int4     *cells;       // pebble arena {ptr, diag, diff, mark}
   int       cellcap;
+  int4     *cells_hi  = nullptr;       // lane-group kernels: the pebbles from number `cellsplit` on live here (global
+  int       cellsplit = 0x7fffffff;    //   memory) -- the first ones in the group's LDS; cellcap counts both parts
   uint16_t *atrace;      // origin (element 0 of the forward part); room for tcap values either side
   uint16_t *btrace;
   int       tcap;
   int      *mbox;        // 16 ints of LDS: lane 0 hands the trace-back results to the wavefront
   const int2 *trimtab;   // 32 x {sum, max proper-prefix sum} of 5-column chunks (LDS, per workgroup)
 };
+
+// Pebble number i of a pass (see cells_hi)
+template <class WK> __device__ __forceinline__ void cell_put(const WK &wk, int i, const int4 &v)
+{ if (i < wk.cellsplit) wk.cells[i] = v;
+  else                  wk.cells_hi[i - wk.cellsplit] = v;
+}
+
+struct CellsView
+{ int4 *lo, *hi;
+  int   split;
+  __device__ __forceinline__ int4 at(int i) const
+  { if (i < split) return lo[i];
+    return hi[i - split];
+  }
+  __device__ __forceinline__ void setx(int i, int x) const
+  { if (i < split) lo[i].x = x;
+    else           hi[i - split].x = x;
+  }
+};
+
+template <class WK> __device__ __forceinline__ CellsView cells_of(const WK &wk)
+{ return CellsView{wk.cells, wk.cells_hi, wk.cellsplit}; }
 
 // 32 bases starting at block position q (q may be as low as -64: the packed arrays carry two pad
 // words in front and two behind)
@@ -237,8 +261,8 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
       { na = (((y + k) + (TS - aoff)) / TS - 1) * TS + aoff;
         nb = ((y + (TS - boff)) / TS - 1) * TS + boff;
         if (lane == 0)
-          { wk.cells[0] = make_int4(-1, k, 0, na);
-            wk.cells[1] = make_int4(-1, k, 0, nb);
+          { cell_put(wk, 0, make_int4(-1, k, 0, na));
+            cell_put(wk, 1, make_int4(-1, k, 0, nb));
           }
         ham = na; hbm = nb;
         na += TS; nb += TS;
@@ -247,8 +271,8 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
       { na = (((y + k) + (TS - aoff) - 1) / TS - 1) * TS + aoff;
         nb = ((y + (TS - boff) - 1) / TS - 1) * TS + boff;
         if (lane == 0)
-          { wk.cells[0] = make_int4(-1, k, 0, y + k);
-            wk.cells[1] = make_int4(-1, k, 0, y);
+          { cell_put(wk, 0, make_int4(-1, k, 0, y + k));
+            cell_put(wk, 1, make_int4(-1, k, 0, y));
           }
         ham = y + k; hbm = y;
       }
@@ -268,12 +292,12 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
     if (DIR > 0)
       { while (y + k >= na)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            if (lane == 0) cell_put(wk, ncell, make_int4(ha, k, 0, na));
             ha = ncell++; ham = na; na += TS;
           }
         while (y >= nb)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(hb, k, 0, nb);
+            if (lane == 0) cell_put(wk, ncell, make_int4(hb, k, 0, nb));
             hb = ncell++; hbm = nb; nb += TS;
           }
         if (c > besta)
@@ -282,12 +306,12 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
     else
       { while (y + k <= na)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            if (lane == 0) cell_put(wk, ncell, make_int4(ha, k, 0, na));
             ha = ncell++; ham = na; na -= TS;
           }
         while (y <= nb)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(hb, k, 0, nb);
+            if (lane == 0) cell_put(wk, ncell, make_int4(hb, k, 0, nb));
             hb = ncell++; hbm = nb; nb -= TS;
           }
         if (c < besta)
@@ -461,21 +485,21 @@ __device__ int wave_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Se
             { int idx = ncell + off;
               if (DIR > 0)
                 { while (y + k >= na)
-                    { if (ham < na) { wk.cells[idx] = make_int4(ha, k, dif, na); ha = idx++; ham = na; }
+                    { if (ham < na) { cell_put(wk, idx, make_int4(ha, k, dif, na)); ha = idx++; ham = na; }
                       na += TS;
                     }
                   while (y >= nb)
-                    { if (hbm < nb) { wk.cells[idx] = make_int4(hb, k, dif, nb); hb = idx++; hbm = nb; }
+                    { if (hbm < nb) { cell_put(wk, idx, make_int4(hb, k, dif, nb)); hb = idx++; hbm = nb; }
                       nb += TS;
                     }
                 }
               else
                 { while (y + k <= na)
-                    { if (ham > na) { wk.cells[idx] = make_int4(ha, k, dif, na); ha = idx++; ham = na; }
+                    { if (ham > na) { cell_put(wk, idx, make_int4(ha, k, dif, na)); ha = idx++; ham = na; }
                       na -= TS;
                     }
                   while (y <= nb)
-                    { if (hbm > nb) { wk.cells[idx] = make_int4(hb, k, dif, nb); hb = idx++; hbm = nb; }
+                    { if (hbm > nb) { cell_put(wk, idx, make_int4(hb, k, dif, nb)); hb = idx++; hbm = nb; }
                       nb -= TS;
                     }
                 }
@@ -779,8 +803,8 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
       { na = (((y + k) + (TS - aoff)) / TS - 1) * TS + aoff;
         nb = ((y + (TS - boff)) / TS - 1) * TS + boff;
         if (lane == 0)
-          { wk.cells[0] = make_int4(-1, k, 0, na);
-            if (WANT_B) wk.cells[1] = make_int4(-1, k, 0, nb);
+          { cell_put(wk, 0, make_int4(-1, k, 0, na));
+            if (WANT_B) cell_put(wk, 1, make_int4(-1, k, 0, nb));
           }
         ham = na; hbm = nb;
         na += TS; nb += TS;
@@ -789,8 +813,8 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
       { na = (((y + k) + (TS - aoff) - 1) / TS - 1) * TS + aoff;
         nb = ((y + (TS - boff) - 1) / TS - 1) * TS + boff;
         if (lane == 0)
-          { wk.cells[0] = make_int4(-1, k, 0, y + k);
-            if (WANT_B) wk.cells[1] = make_int4(-1, k, 0, y);
+          { cell_put(wk, 0, make_int4(-1, k, 0, y + k));
+            if (WANT_B) cell_put(wk, 1, make_int4(-1, k, 0, y));
           }
         ham = y + k; hbm = y;
       }
@@ -809,12 +833,12 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
     if (DIR > 0)
       { while (y + k >= na)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            if (lane == 0) cell_put(wk, ncell, make_int4(ha, k, 0, na));
             ha = ncell++; ham = na; na += TS;
           }
         while (WANT_B && y >= nb)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(hb, k, 0, nb);
+            if (lane == 0) cell_put(wk, ncell, make_int4(hb, k, 0, nb));
             hb = ncell++; hbm = nb; nb += TS;
           }
         if (c > besta)
@@ -823,12 +847,12 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
     else
       { while (y + k <= na)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            if (lane == 0) cell_put(wk, ncell, make_int4(ha, k, 0, na));
             ha = ncell++; ham = na; na -= TS;
           }
         while (WANT_B && y <= nb)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(hb, k, 0, nb);
+            if (lane == 0) cell_put(wk, ncell, make_int4(hb, k, 0, nb));
             hb = ncell++; hbm = nb; nb -= TS;
           }
         if (c < besta)
@@ -1012,21 +1036,21 @@ __device__ int wave_pass_reg(const WK &wk, const AlignSpecDev &sp, const SeqView
         { int idx = ncell + off;
           if (DIR > 0)
             { while (y + k >= na)
-                { if (ham < na) { wk.cells[idx] = make_int4(ha, k, dif, na); ha = idx++; ham = na; }
+                { if (ham < na) { cell_put(wk, idx, make_int4(ha, k, dif, na)); ha = idx++; ham = na; }
                   na += TS;
                 }
               while (WANT_B && y >= nb)
-                { if (hbm < nb) { wk.cells[idx] = make_int4(hb, k, dif, nb); hb = idx++; hbm = nb; }
+                { if (hbm < nb) { cell_put(wk, idx, make_int4(hb, k, dif, nb)); hb = idx++; hbm = nb; }
                   nb += TS;
                 }
             }
           else
             { while (y + k <= na)
-                { if (ham > na) { wk.cells[idx] = make_int4(ha, k, dif, na); ha = idx++; ham = na; }
+                { if (ham > na) { cell_put(wk, idx, make_int4(ha, k, dif, na)); ha = idx++; ham = na; }
                   na -= TS;
                 }
               while (WANT_B && y <= nb)
-                { if (hbm > nb) { wk.cells[idx] = make_int4(hb, k, dif, nb); hb = idx++; hbm = nb; }
+                { if (hbm > nb) { cell_put(wk, idx, make_int4(hb, k, dif, nb)); hb = idx++; hbm = nb; }
                   nb -= TS;
                 }
             }
@@ -1194,13 +1218,13 @@ __device__ int wave_pass_reg16(const WK &wk, const AlignSpecDev &sp, const SeqVi
     if (wk.cellcap < 8) return AL_ERR_PEBBLES;
     if (DIR > 0)
       { na = (((y + k) + (TS - aoff)) / TS - 1) * TS + aoff;
-        if (lane == 0) wk.cells[0] = make_int4(-1, k, 0, na);
+        if (lane == 0) cell_put(wk, 0, make_int4(-1, k, 0, na));
         ham = na;
         na += TS;
       }
     else
       { na = (((y + k) + (TS - aoff) - 1) / TS - 1) * TS + aoff;
-        if (lane == 0) wk.cells[0] = make_int4(-1, k, 0, y + k);
+        if (lane == 0) cell_put(wk, 0, make_int4(-1, k, 0, y + k));
         ham = y + k;
       }
     ha = 0;
@@ -1218,7 +1242,7 @@ __device__ int wave_pass_reg16(const WK &wk, const AlignSpecDev &sp, const SeqVi
     if (DIR > 0)
       { while (y + k >= na)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            if (lane == 0) cell_put(wk, ncell, make_int4(ha, k, 0, na));
             ha = ncell++; ham = na; na += TS;
           }
         if (c > besta)
@@ -1227,7 +1251,7 @@ __device__ int wave_pass_reg16(const WK &wk, const AlignSpecDev &sp, const SeqVi
     else
       { while (y + k <= na)
           { if (ncell >= wk.cellcap) return AL_ERR_PEBBLES;
-            if (lane == 0) wk.cells[ncell] = make_int4(ha, k, 0, na);
+            if (lane == 0) cell_put(wk, ncell, make_int4(ha, k, 0, na));
             ha = ncell++; ham = na; na -= TS;
           }
         if (c < besta)
@@ -1442,13 +1466,13 @@ __device__ int wave_pass_reg16(const WK &wk, const AlignSpecDev &sp, const SeqVi
             int idx = ncell + off + (s ? cntA[0] : 0);
             if (DIR > 0)
               { while (y[s] + k >= na[s])
-                  { if (ham[s] < na[s]) { wk.cells[idx] = make_int4(ha[s], k, dif, na[s]); ha[s] = idx++; ham[s] = na[s]; }
+                  { if (ham[s] < na[s]) { cell_put(wk, idx, make_int4(ha[s], k, dif, na[s])); ha[s] = idx++; ham[s] = na[s]; }
                     na[s] += TS;
                   }
               }
             else
               { while (y[s] + k <= na[s])
-                  { if (ham[s] > na[s]) { wk.cells[idx] = make_int4(ha[s], k, dif, na[s]); ha[s] = idx++; ham[s] = na[s]; }
+                  { if (ham[s] > na[s]) { cell_put(wk, idx, make_int4(ha[s], k, dif, na[s])); ha[s] = idx++; ham[s] = na[s]; }
                     na[s] -= TS;
                   }
               }
@@ -1546,11 +1570,11 @@ __device__ int wave_pass_reg16(const WK &wk, const AlignSpecDev &sp, const SeqVi
 }
 
 // Reverse a pebble chain in place and return its first pebble (align.c:900-906)
-__device__ __forceinline__ int reverse_chain(int4 *cells, int head)
+__device__ __forceinline__ int reverse_chain(const CellsView &cells, int head)
 { int a = -1, h = head;
   while (h >= 0)
-    { int nx = cells[h].x;
-      cells[h].x = a;
+    { int nx = cells.at(h).x;
+      cells.setx(h, a);
       a = h;
       h = nx;
     }
@@ -1561,7 +1585,7 @@ __device__ __forceinline__ int reverse_chain(int4 *cells, int head)
 template <int W, bool WANT_B>
 __device__ int forward_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, const WaveEnd &E, int mida,
                              PathRes &P, int &klow)
-{ int4 *cells = wk.cells;
+{ const CellsView cells = cells_of(wk);
   uint16_t *atrace = wk.atrace + P.aorg, *btrace = wk.btrace + P.borg;
   int trimx, trimy = E.trimy, trimd = E.trimd, trimha = E.trimha, trimhb = E.trimhb;
   int atlen = 0, btlen = 0;
@@ -1574,11 +1598,11 @@ __device__ int forward_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
     trimx = E.trima - trimy;
 
   h = reverse_chain(cells, trimha);
-  k = cells[h].y;
+  k = cells.at(h).y;
   b = (mida - k) / 2;
   e = 0;
-  for (h = cells[h].x; h >= 0; h = cells[h].x)
-    { int4 p = cells[h];
+  for (h = cells.at(h).x; h >= 0; h = cells.at(h).x)
+    { int4 p = cells.at(h);
       k = p.y;
       a = p.w - k;
       d = p.z;
@@ -1602,12 +1626,12 @@ __device__ int forward_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
       return AL_OK;
     }
   h = reverse_chain(cells, trimhb);
-  k = cells[h].y;
+  k = cells.at(h).y;
   b = (mida + k) / 2;
   e = 0;
   klow = k;
-  for (h = cells[h].x; h >= 0; h = cells[h].x)
-    { int4 p = cells[h];
+  for (h = cells.at(h).x; h >= 0; h = cells.at(h).x)
+    { int4 p = cells.at(h);
       k = p.y;
       a = p.w + k;
       d = p.z;
@@ -1638,7 +1662,7 @@ __device__ int forward_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
 template <int W, bool WANT_B>
 __device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, const WaveEnd &E,
                              int aoff, int boff, PathRes &P)
-{ int4 *cells = wk.cells;
+{ const CellsView cells = cells_of(wk);
   const int TS = sp.TS;
   uint16_t *atrace = wk.atrace + P.aorg, *btrace = wk.btrace + P.borg;
   int trimx, trimy = E.trimy, trimd = E.trimd, trimha = E.trimha, trimhb = E.trimhb;
@@ -1653,15 +1677,15 @@ __device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
 
   // A view
   h = reverse_chain(cells, trimha);
-  k = cells[h].y;
-  b = cells[h].w - k;
+  k = cells.at(h).y;
+  b = cells.at(h).w - k;
   e = 0;
   if ((b + k) % TS != aoff)
-    { h = cells[h].x;
+    { h = cells.at(h).x;
       if (h < 0)
         { a = trimy; d = trimd; }
       else
-        { int4 p = cells[h];
+        { int4 p = cells.at(h);
           k = p.y; a = p.w - k; d = p.z;
         }
       if (P.atlen == 0)
@@ -1675,8 +1699,8 @@ __device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
       b = a; e = d;
     }
   if (h >= 0)
-    { for (h = cells[h].x; h >= 0; h = cells[h].x)
-        { int4 p = cells[h];
+    { for (h = cells.at(h).x; h >= 0; h = cells.at(h).x)
+        { int4 p = cells.at(h);
           k = p.y;
           a = p.w - k;
           d = p.z;
@@ -1703,15 +1727,15 @@ __device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
       return AL_OK;
     }
   h = reverse_chain(cells, trimhb);
-  k = cells[h].y;
-  b = cells[h].w + k;
+  k = cells.at(h).y;
+  b = cells.at(h).w + k;
   e = 0;
   if ((b - k) % TS != boff)
-    { h = cells[h].x;
+    { h = cells.at(h).x;
       if (h < 0)
         { a = trimx; d = trimd; }
       else
-        { int4 p = cells[h];
+        { int4 p = cells.at(h);
           k = p.y; a = p.w + k; d = p.z;
         }
       if (P.btlen == 0)
@@ -1725,8 +1749,8 @@ __device__ int reverse_trace(const WaveWork<W> &wk, const AlignSpecDev &sp, cons
       b = a; e = d;
     }
   if (h >= 0)
-    { for (h = cells[h].x; h >= 0; h = cells[h].x)
-        { int4 p = cells[h];
+    { for (h = cells.at(h).x; h >= 0; h = cells.at(h).x)
+        { int4 p = cells.at(h);
           k = p.y;
           a = p.w + k;
           d = p.z;
@@ -1791,6 +1815,7 @@ __device__ int run_pass(const WaveWork<W> &wk, const AlignSpecDev &sp, const Seq
   if (!WANT_B && G == 64)
     { wf.cells   = (int4 *) wk.band;
       wf.cellcap = ((F_COUNT * 2 + 2) * W) / 4;
+      wf.cells_hi = nullptr; wf.cellsplit = 0x7fffffff;
     }
   APROF_T0();
   if constexpr (G == 16)

@@ -1810,6 +1810,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "read_sort") == 0)   st.opt_read_sort = value;
   else if (strcmp(key, "fuse") == 0)        st.opt_fuse = value;
   else if (strcmp(key, "chain_classes") == 0) st.opt_chain_classes = value;
+  else if (strcmp(key, "pebble_spill") == 0) st.opt_pebble_spill = value;
   else return -1;
   return 0;
 }

@@ -286,7 +286,7 @@ __device__ __forceinline__ void align_cands_groups(const uint64_t *apk, const ui
                                                    const uint16_t *jumps, int hithr, const AlignSpecDev &sp,
                                                    uint16_t *traces, int tcap, unsigned int *ticket, int *status,
                                                    int *pool, unsigned int *pool_used,
-                                                   unsigned int pool_cap, const int *only)
+                                                   unsigned int pool_cap, const int *only, int4 *spill, int spillcap)
 { constexpr int NG = 256 / G;
   __shared__ int4 peb[NG * PEB];
   __shared__ int  mbox[NG * 16];
@@ -299,6 +299,13 @@ __device__ __forceinline__ void align_cands_groups(const uint64_t *apk, const ui
   wk.band    = nullptr;
   wk.cells   = peb + gid * PEB;
   wk.cellcap = PEB;
+  if (spill != nullptr)
+    { // a pass of more than PEB pebbles (a read beyond ~100 PEB bases) puts the rest into the group's arena in global
+      // memory instead of ending the job for the one-per-wavefront kernel (align.c:771-817 has one arena)
+      wk.cells_hi  = spill + (size_t) gg * (size_t) spillcap;
+      wk.cellsplit = PEB;
+      wk.cellcap   = PEB + spillcap;
+    }
   wk.tcap    = tcap;
   wk.atrace  = traces + (size_t) gg * (4 * (size_t) tcap) + tcap;
   wk.btrace  = wk.atrace + 2 * (size_t) tcap;
@@ -363,9 +370,9 @@ __global__ __launch_bounds__(256, 4) void k_align_cands32(const uint64_t *apk, c
                                                         const uint16_t *jumps, int hithr, AlignSpecDev sp,
                                                         uint16_t *traces, int tcap, unsigned int *ticket, int *status,
                                                         int *pool, unsigned int *pool_used,
-                                                        unsigned int pool_cap, const int *only)
+                                                        unsigned int pool_cap, const int *only, int4 *spill, int spillcap)
 { align_cands_groups<32, PEB32>(apk, arc, bpk, jobs, njobs, jumps, hithr, sp, traces, tcap, ticket, status, pool, pool_used,
-                                pool_cap, only);
+                                pool_cap, only, spill, spillcap);
 }
 
 __global__ __launch_bounds__(256, 3) void k_align_cands16(const uint64_t *apk, const uint64_t *arc, const uint64_t *bpk,
@@ -373,9 +380,9 @@ __global__ __launch_bounds__(256, 3) void k_align_cands16(const uint64_t *apk, c
                                                         const uint16_t *jumps, int hithr, AlignSpecDev sp,
                                                         uint16_t *traces, int tcap, unsigned int *ticket, int *status,
                                                         int *pool, unsigned int *pool_used,
-                                                        unsigned int pool_cap, const int *only)
+                                                        unsigned int pool_cap, const int *only, int4 *spill, int spillcap)
 { align_cands_groups<16, PEB16>(apk, arc, bpk, jobs, njobs, jumps, hithr, sp, traces, tcap, ticket, status, pool, pool_used,
-                                pool_cap, only);
+                                pool_cap, only, spill, spillcap);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -395,10 +402,14 @@ static AlignScratch &ascr()
   return s;
 }
 
+// Pebbles a lane group keeps in global memory behind the ones in its LDS (k_align_cands32 / 16): 288 + 1,760 cover a
+// pass over 200 kb of read
+constexpr int SPILLCAP = 1760;
+
 static Scratch prepare_scratch(int nblocks, int tcap, bool global_band, int groups_per_block = 4, bool arenas = true)
 { AlignScratch &a = ascr();
   int nw = nblocks * groups_per_block;
-  if (arenas) a.cells.ensure((size_t) nw * CELLCAP, "pebble arenas");
+  a.cells.ensure((size_t) nw * (arenas ? CELLCAP : SPILLCAP), "pebble arenas");
   a.traces.ensure((size_t) nw * 4 * tcap, "trace buffers");
   if (global_band)
     a.band.ensure((size_t) nw * (F_COUNT * 2 + 2) * GLB_W, "global d-wave bands");
@@ -1353,17 +1364,20 @@ static void launch_round(PendingReport &P)
     }
   HIP_CHECK(hipMemsetAsync(ascr().ctl.p, 0, 8 * sizeof(unsigned int), ks));
   HIP_CHECK(hipMemsetAsync(d_pool.p, 0xff, sizeof(int) * P.pool_cap, ks));   // cand = -1 ends the parse
+  // "pebble_spill" test option / DMH_PEBBLE_SPILL = 0: a lane group's pass ends at the pebbles its LDS holds (round 3)
+  static const int env_spill = getenv("DMH_PEBBLE_SPILL") ? atoi(getenv("DMH_PEBBLE_SPILL")) : 1;
+  int4 *spill = (S().opt_pebble_spill >= 0 ? S().opt_pebble_spill : env_spill) != 0 ? sc.cells : nullptr;
   { StageTimer tm(level == 2 ? "align_global_band" : (level == 1 ? "align_wave64" : "align"), 0.0, ks);
     if (level == 0 && g16)
       hipLaunchKernelGGL(k_align_cands16, dim3(nblocks), dim3(256), 0, ks,
                          P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
                          (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
-                         d_pool.p, ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
+                         d_pool.p, ascr().ctl.p + 1, (unsigned int) P.pool_cap, only, spill, SPILLCAP);
     else if (level == 0)
       hipLaunchKernelGGL(k_align_cands32, dim3(nblocks), dim3(256), 0, ks,
                          P.apk, P.arc, P.bpk, (const CandJob *) d_jobs.p, nrun,
                          (const uint16_t *) P.jumps.p, P.hithr, P.spd, sc.traces, sc.tcap, ascr().ctl.p, d_status.p,
-                         d_pool.p, ascr().ctl.p + 1, (unsigned int) P.pool_cap, only);
+                         d_pool.p, ascr().ctl.p + 1, (unsigned int) P.pool_cap, only, spill, SPILLCAP);
     else if (level == 2)
       { if (doB)
           hipLaunchKernelGGL((k_align_cands<GLB_W, false, true>), dim3(nblocks), dim3(256), 0, ks,

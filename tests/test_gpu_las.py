@@ -166,7 +166,8 @@ def test_ragged_and_degenerate_reads(tmp_path):
                                   dict(chain_simple=0), dict(cluster=1, chain_simple=0),
                                   dict(cluster=1, fuse=0), dict(cluster=1, fuse=0, read_sort=3), dict(cluster=1, fuse=0, read_sort=5),
                                   dict(cluster=1, fuse=0, chain_simple=0), dict(cluster=1, chain_classes=0), dict(chain_classes=0),
-                                  dict(cluster=1, defer_close=0), dict(defer_close=0)],
+                                  dict(cluster=1, defer_close=0), dict(defer_close=0),
+                                  dict(cluster=1, chain_pile=0)],
                          ids=["four_per_wavefront", "wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
                               "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table", "merge_low16_probes",
                               "clusters", "clusters_piles", "clusters_chain64",
@@ -182,7 +183,8 @@ def test_ragged_and_degenerate_reads(tmp_path):
                               "clusters_unfused_round3_route", "clusters_unfused_oversize_through_global_memory",
                               "clusters_unfused_ballot_ranks", "clusters_unfused_no_simple_groups",
                               "clusters_no_diagonal_classes", "no_diagonal_classes",
-                              "clusters_every_pass_closed_before_it_returns", "every_pass_closed_before_it_returns"])
+                              "clusters_every_pass_closed_before_it_returns", "every_pass_closed_before_it_returns",
+                              "clusters_no_piles"])
 def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes
     to the same bytes: force each one and compare with the default route on data that has repeats, dropouts and
@@ -204,10 +206,45 @@ def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     assert base == alt
 
 
+def test_long_reads_identical_to_reference(tmp_path):
+    """Reads of 38 kb (a log-normal library's tail): a pass of the d-wave drops more pebbles than a lane group's LDS
+    holds (288: reads beyond ~29 kb) -- they spill into the group's arena in global memory instead of sending the
+    candidate one rung up.  Files against the reference's; the switch off gives the same files, and the ladder's
+    counters say which route ran."""
+    from damapper_amd import capi
+    run_ref = _run_ref()
+    g, reads = make_dataset("repeat", 61, [500000, 400000], 16, read_len=38000, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=1000000)
+    dazzdb.write_db(d, "READS", reads)
+    run_ref.run_reference(d, "REF", ["READS"], flags=["-M8"], threads=4)
+    _, want = las.read_las_set(os.path.join(d, "las_ref"), "READS.REF.M@.las")
+    assert len(want) >= 16
+    L = capi.lib()
+    counts = {}
+    try:
+        for name, opts in (("default", {}), ("off", dict(pebble_spill=0))):
+            for k, v in opts.items():
+                assert L.dmh_test_option(k.encode(), v) == 0
+            L.dmh_timing_reset()
+            L.dmh_timing_enable(1)
+            driver.map_db(d, "REF", "READS", threads=4, mem_limit=8 << 30, sort_path=os.path.join(d, "las_" + name))
+            L.dmh_sync()
+            counts[name] = {k: v["launches"] for k, v in capi.timings().items()}
+            L.dmh_timing_enable(0)
+            _, got = las.read_las_set(os.path.join(d, "las_" + name), "READS.REF.M@.las")
+            assert got == want, name
+    finally:
+        L.dmh_timing_enable(0)
+        L.dmh_test_option(b"pebble_spill", -1)
+    assert counts["off"].get("count:align32_pebbles_over_288", 0) > 0, counts["off"]
+    assert counts["default"].get("count:align32_pebbles_over_288", 0) == 0, counts["default"]
+
+
 VARIANT_DEFAULTS = dict(align_level=-1, align_g=-1, chain_g=0, pool_div=1, chain_pile=-1, pile_cap=0, merge_dense=-1,
                         cluster=-1, chain_small=-1, chain_lane=-1, batch=-1, cluster_sort=-1, expand=-1, in_flight=-1,
                         seed_word=-1, alloc_fail=0, fin_stream=-1, read_sort=-1, oom_finish=0, chain_simple=-1,
-                        defer_close=-1, tails=-1, fuse=-1, chain_classes=-1)
+                        defer_close=-1, tails=-1, fuse=-1, chain_classes=-1, pebble_spill=-1)
 _VARIANT = {}
 
 
