@@ -43,6 +43,7 @@ void        join_side_streams();   // the main stream waits for everything queue
 void        bg_pump_tail(int nstages);   // stages of a deferred index build on the tail stream (dmh_core.hip)
 int         hw_queues_seen();      // streams the runtime was found to run side by side (1..8; probed once, dmh_core.hip)
 hipStream_t tail_stream();         // where the chain stage's last, latency-bound launches of a batch run (dmh_core.hip)
+hipStream_t front_stream();        // where the match kernels of the REF block AFTER the one at hand run (dmh_merge.hip); the main stream when off
 hipStream_t finish_stream();       // where the filter finishes its batches (chain_finish); the main stream when switched off
 struct StreamScope                 // stream() = s for the calling thread while the scope lives
 { explicit StreamScope(hipStream_t s);

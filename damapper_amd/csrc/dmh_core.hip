@@ -214,9 +214,34 @@ hipStream_t tail_stream()
   return g_tstream;
 }
 
+// The front of the NEXT REF block (its match kernels, fix-ups, hit sums) next to the per-read kernels of the block at hand:
+// "front_ahead" test option / DMH_FRONT_AHEAD = 0: everything on the main stream, one REF block after the other.
+static hipStream_t g_frstream = nullptr;
+hipStream_t front_stream()
+{ init_device();
+  static const int env_fa = getenv("DMH_FRONT_AHEAD") ? atoi(getenv("DMH_FRONT_AHEAD")) : 1;
+  const int on = S().opt_front_ahead >= 0 ? S().opt_front_ahead : env_fa;
+  if (on == 0 || S().opt_tails == 0 || hw_queues_seen() < 8) return g_stream;
+  if (g_frstream == nullptr)
+    { static const int prio = getenv("DMH_FRONT_PRIO") ? atoi(getenv("DMH_FRONT_PRIO")) : 0;
+      if (prio != 0)
+        { int least = 0, greatest = 0;
+          HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+          HIP_CHECK(hipStreamCreateWithPriority(&g_frstream, hipStreamNonBlocking, prio > 0 ? greatest : least));
+        }
+      else
+        HIP_CHECK(hipStreamCreateWithFlags(&g_frstream, hipStreamNonBlocking));
+    }
+  return g_frstream;
+}
+
 void join_side_streams()
 { static hipEvent_t ev = nullptr;
   if (ev == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (g_frstream != nullptr)
+    { HIP_CHECK(hipEventRecord(ev, g_frstream));
+      HIP_CHECK(hipStreamWaitEvent(g_stream, ev, 0));
+    }
   if (g_tstream != nullptr)
     { HIP_CHECK(hipEventRecord(ev, g_tstream));
       HIP_CHECK(hipStreamWaitEvent(g_stream, ev, 0));
@@ -234,6 +259,7 @@ static void sync_all_streams()
 { init_device();
   HIP_CHECK(hipStreamSynchronize(g_upstream));
   if (g_tstream != nullptr) HIP_CHECK(hipStreamSynchronize(g_tstream));
+  if (g_frstream != nullptr) HIP_CHECK(hipStreamSynchronize(g_frstream));
   if (g_fstream != nullptr) HIP_CHECK(hipStreamSynchronize(g_fstream));
   HIP_CHECK(hipStreamSynchronize(g_stream));
 }
@@ -1811,6 +1837,7 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "fuse") == 0)        st.opt_fuse = value;
   else if (strcmp(key, "chain_classes") == 0) st.opt_chain_classes = value;
   else if (strcmp(key, "pebble_spill") == 0) st.opt_pebble_spill = value;
+  else if (strcmp(key, "front_ahead") == 0) st.opt_front_ahead = value;
   else return -1;
   return 0;
 }

@@ -15,6 +15,7 @@
 #include "dmh_chain.h"
 #include <algorithm>
 #include <deque>
+#include <unordered_map>
 #include <type_traits>
 
 namespace dmh {
@@ -1228,8 +1229,17 @@ struct FrontBufs
   const IndexDev *a = nullptr, *b = nullptr;                            // the pass whose front is queued in this set
   unsigned long long hsum[3] = {0, 0, 0};                               // its hit sums and run count, when the round trip of the
   bool have_sums = false;                                               //   sweep's own pass has fetched them along
+  // a front made AHEAD, on the front stream (round 4): `made` is recorded there behind the front and the copy of its sums
+  // to h_sums; the main stream and the host wait for it when the pass comes.  `consumed` is recorded on the main stream
+  // behind the last kernel of a pass that reads the set: whoever fills the set again waits for it.
+  hipEvent_t made = nullptr, consumed = nullptr;
+  bool ahead = false, posted = false, was_made = false, was_used = false;
+  unsigned long long *h_sums = nullptr;                                 // page-locked: {all hits, hits below MAXGRAM, runs}
 };
-static FrontBufs g_fb[2];
+// Two banks of two sets: the passes of a REF block (forward, complement) use the sets of one bank, the front of the REF
+// block that follows is made in the other
+static FrontBufs g_fb[4];
+static std::unordered_map<const IndexDev *, IndexDev *> g_next_of;       // REF index -> the REF index the driver named after it last time
 static DevBuf<MergeEntry> g_entries;
 static IndexDev *g_hint_a = nullptr, *g_hint_b = nullptr;               // the pass the driver says comes next
 static int g_hint_kshift = 0;
@@ -1252,8 +1262,24 @@ static bool defer_fused_close()
 }
 
 // B2 != nullptr: the same sweep also probes B2 (results in set 1)
-static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nullptr)
+static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nullptr, int bank = 0, hipStream_t on = nullptr)
 { State &st = S();
+  if (on == nullptr) on = main_stream();
+  StreamScope on_stream(on);
+  const bool ahead = (on != main_stream());
+  FrontBufs *const fb = g_fb + 2 * bank;
+  for (int q = 0; q < 2; q++)
+    { // whoever used the set last -- the stream that filled it, the main stream that read it -- is done before it is filled again
+      FrontBufs &F = fb[q];
+      if (F.made == nullptr)
+        { HIP_CHECK(hipEventCreateWithFlags(&F.made, hipEventDisableTiming));
+          HIP_CHECK(hipEventCreateWithFlags(&F.consumed, hipEventDisableTiming));
+          HIP_CHECK(hipHostMalloc((void **) &F.h_sums, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        }
+      if (F.was_made) HIP_CHECK(hipStreamWaitEvent(on, F.made, 0));
+      if (F.was_used) HIP_CHECK(hipStreamWaitEvent(on, F.consumed, 0));
+      F.ahead = false; F.posted = false;
+    }
   ensure_bucket_table(Bx, Kshift);
   if (B2 != nullptr)
     { ensure_bucket_table(*B2, Kshift);
@@ -1263,7 +1289,7 @@ static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nu
   const int64_t ntiles = ceil_div(A.n, MG_TILE);
   MatchOut MO[2];
   for (int q = 0; q < (B2 != nullptr ? 2 : 1); q++)
-    { FrontBufs &F = g_fb[q];
+    { FrontBufs &F = fb[q];
       F.gram.ensure(MAXGRAM + 8, "hit histogram");
       F.mctl.ensure(4, "merge counters");
       F.tentries.ensure((size_t) ntiles * MG_TILE, "matched runs (per tile)");
@@ -1298,18 +1324,34 @@ static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nu
   }
   { StageTimer tm("merge_fixup", 0.0);
     for (int q = 0; q < (B2 != nullptr ? 2 : 1); q++)
-      { FrontBufs &F = g_fb[q];
+      { FrontBufs &F = fb[q];
         hipLaunchKernelGGL(k_merge_fixup, dim3(ntiles), dim3(FX_THREADS), 0, stream(), (const uint64_t *) A.keys, A.n, q ? BL2 : BL,
                            F.tentries.p, (const uint32_t *) F.tcount.p, F.thits.p);
         hipLaunchKernelGGL(k_merge_reduce, dim3(64), dim3(256), 0, stream(), (const unsigned long long *) F.thits.p, ntiles,
                            F.gram.p + MAXGRAM + 1);
-        exclusive_scan_u32(F.tcount.p, ntiles, st.sort.bsum, F.tcount.p + ntiles);
+        exclusive_scan_u32(F.tcount.p, ntiles, (ahead ? st.sort_front : st.sort).bsum, F.tcount.p + ntiles);
       }
     HIP_CHECK(hipGetLastError());
   }
-  g_fb[0].a = &A; g_fb[0].b = &Bx;
-  if (B2 != nullptr) { g_fb[1].a = &A; g_fb[1].b = B2; }
-  else               { g_fb[1].a = nullptr; g_fb[1].b = nullptr; }
+  fb[0].a = &A; fb[0].b = &Bx;
+  if (B2 != nullptr) { fb[1].a = &A; fb[1].b = B2; }
+  else               { fb[1].a = nullptr; fb[1].b = nullptr; }
+  if (ahead)
+    { // the sums of the front travel to page-locked memory behind it: no round trip when the pass comes
+      for (int q = 0; q < (B2 != nullptr ? 2 : 1); q++)
+        { FrontBufs &F = fb[q];
+          unsigned long long *sums = F.gram.p + MAXGRAM + 1;
+          HIP_CHECK(hipMemcpyAsync(sums + 2, F.tcount.p + ntiles, sizeof(unsigned int), hipMemcpyDeviceToDevice, stream()));
+          HIP_CHECK(hipMemcpyAsync(F.h_sums, sums, sizeof(unsigned long long) * 3, hipMemcpyDeviceToHost, stream()));
+          F.posted = true;
+        }
+    }
+  for (int q = 0; q < (B2 != nullptr ? 2 : 1); q++)
+    { FrontBufs &F = fb[q];
+      HIP_CHECK(hipEventRecord(F.made, stream()));
+      F.was_made = true;
+      F.ahead = ahead;
+    }
 }
 
 static void ensure_bucket_table(IndexDev &Bx, int Kshift)
@@ -1357,8 +1399,15 @@ void filter_hint_next_pass(IndexDev *A, IndexDev *B, int Kshift)
 
 void filter_forget_index(const IndexDev *ix)
 { if (g_hint_a == ix || g_hint_b == ix) { g_hint_a = nullptr; g_hint_b = nullptr; }
-  for (int q = 0; q < 2; q++)
-    if (g_fb[q].a == ix || g_fb[q].b == ix) { g_fb[q].a = nullptr; g_fb[q].b = nullptr; }
+  for (int q = 0; q < 4; q++)
+    if (g_fb[q].a == ix || g_fb[q].b == ix)
+      { // (a front made ahead for a pass that did not come may still be reading the index: whatever frees it comes after)
+        if (g_fb[q].ahead && g_fb[q].was_made) (void) hipStreamWaitEvent(main_stream(), g_fb[q].made, 0);
+        g_fb[q].a = nullptr; g_fb[q].b = nullptr;
+      }
+  g_next_of.erase(ix);
+  for (auto it = g_next_of.begin(); it != g_next_of.end(); )
+    if (it->second == ix) it = g_next_of.erase(it); else ++it;
 }
 
 int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, IndexDev &Bx,
@@ -1374,20 +1423,56 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   //     driver has named the pass that follows (dmh_next_pass) and it meets the same READ index -- the complement of this
   //     REF block, resident and complete --, this sweep probes both indices ("front_early" test option = 0: never)
   int fs = -1;
-  for (int q = 0; q < 2; q++)
+  for (int q = 0; q < 4; q++)
     if (g_fb[q].a == &A && g_fb[q].b == &Bx) fs = q;
   const bool front_was_made = fs >= 0;
+  static const bool env_two = getenv("DMH_MATCH_TWO") == nullptr || atoi(getenv("DMH_MATCH_TWO")) != 0;
+  auto usable = [&](const IndexDev *x) -> bool
+  { return x != nullptr && x->keys != nullptr && !x->pending && x->built == nullptr && x->n > 0; };
+  if (g_hint_a == &A && g_hint_b != nullptr && g_hint_b != &Bx) g_next_of[&Bx] = g_hint_b;       // (the order of the REF indices, learnt)
   if (fs < 0)
-    { static const bool env_two = getenv("DMH_MATCH_TWO") == nullptr || atoi(getenv("DMH_MATCH_TWO")) != 0;
-      IndexDev *B2 = nullptr;
-      if (env_two && st.opt_front_early != 0 && g_hint_a == &A && g_hint_b != nullptr && g_hint_b != &Bx && g_hint_b->keys != nullptr &&
-          !g_hint_b->pending && g_hint_b->built == nullptr && g_hint_b->n > 0 && g_hint_kshift == Kshift)
+    { IndexDev *B2 = nullptr;
+      if (env_two && st.opt_front_early != 0 && g_hint_a == &A && g_hint_b != &Bx && usable(g_hint_b) && g_hint_kshift == Kshift)
         B2 = g_hint_b;
-      match_front(A, Bx, Kshift, B2);
-      fs = 0;
+      // into a bank that holds nobody's front (one that was made ahead for a pass that did not come is given up)
+      int bank = 0;
+      if (g_fb[0].a != nullptr || g_fb[1].a != nullptr) bank = 1;
+      for (int q = 0; q < 2; q++) { g_fb[2 * bank + q].a = nullptr; g_fb[2 * bank + q].b = nullptr; }
+      match_front(A, Bx, Kshift, B2, bank);
+      fs = 2 * bank;
+    }
+  FrontBufs &FS = g_fb[fs];
+  if (FS.ahead) HIP_CHECK(hipStreamWaitEvent(main_stream(), FS.made, 0));      // (a front made on the front stream)
+  // ... and the front of the REF block that FOLLOWS, on the front stream, next to this pass's per-read kernels: the driver has
+  // named the next pass (dmh_next_pass), and the pass after that is the one that followed it for the READS block before
+  if (front_stream() != main_stream() && st.opt_front_early != 0 && env_two && g_hint_a == &A && g_hint_b != &Bx && usable(g_hint_b) &&
+      g_hint_kshift == Kshift && stream() == main_stream() && !st.capture_seeds && !VERBOSE)
+    { bool have = false;
+      for (int q = 0; q < 4; q++) have = have || (g_fb[q].a == &A && g_fb[q].b == g_hint_b);
+      const int other = (fs >> 1) ^ 1;
+      if (!have && g_fb[2 * other].a == nullptr && g_fb[2 * other + 1].a == nullptr)
+        { IndexDev *B2 = nullptr;
+          auto it = g_next_of.find(g_hint_b);
+          if (it != g_next_of.end() && it->second != g_hint_b && it->second != &Bx && usable(it->second)) B2 = it->second;
+          // (once per READS index: the front stream starts behind what the main stream had queued when the index was
+          //  first met -- the index's own build, the REF indices')
+          static const IndexDev *seen_a = nullptr;
+          static hipEvent_t ev_a = nullptr;
+          if (seen_a != &A)
+            { if (ev_a == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+              HIP_CHECK(hipEventRecord(ev_a, main_stream()));
+              HIP_CHECK(hipStreamWaitEvent(front_stream(), ev_a, 0));
+              seen_a = &A;
+            }
+          match_front(A, *g_hint_b, Kshift, B2, other, front_stream());
+        }
     }
   g_fb[fs].a = nullptr; g_fb[fs].b = nullptr;
   g_hint_a = nullptr; g_hint_b = nullptr;
+  struct ConsumedMark        // (every way out of this call: the set may be filled again behind what has been queued here)
+  { FrontBufs &F;
+    ~ConsumedMark() { if (F.consumed != nullptr) { (void) hipEventRecord(F.consumed, main_stream()); F.was_used = true; } }
+  } consumed_mark{FS};
   DevBuf<MergeEntry> &entries = g_entries, &tentries = g_fb[fs].tentries;
   DevBuf<uint32_t>   &tcount = g_fb[fs].tcount;
   DevBuf<unsigned long long> &gram = g_fb[fs].gram;
@@ -1401,13 +1486,21 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // stream standing still for 1.4 ms per REF block between the front's last kernel and these copies
   unsigned int nent = 0;
   unsigned long long hsum[3] = {0, 0, 0};
+  if (front_was_made && FS.posted)
+    { // made ahead: its sums have been on their way since (the event is long done when the GPU is the bottleneck)
+      HostTimer hw("wait_front_ahead");
+      HIP_CHECK(hipEventSynchronize(FS.made));
+      for (int q = 0; q < 3; q++) FS.hsum[q] = FS.h_sums[q];
+      FS.have_sums = true;
+      FS.posted = false;
+    }
   const bool cached_sums = front_was_made && g_fb[fs].have_sums;
   FrontBufs *F2 = nullptr;                 // the other set, when this sweep has filled it for the pass that follows
   static unsigned long long *h_sums = nullptr;           // page-locked
   static hipEvent_t ev_sums = nullptr;
   if (!cached_sums)
     { static const bool env_sc = getenv("DMH_SUMS_CACHE") == nullptr || atoi(getenv("DMH_SUMS_CACHE")) != 0;
-      if (env_sc && !front_was_made && g_fb[1].a != nullptr && g_fb[1].b != nullptr) F2 = &g_fb[1];
+      if (env_sc && !front_was_made && (fs & 1) == 0 && g_fb[fs + 1].a != nullptr && g_fb[fs + 1].b != nullptr) F2 = &g_fb[fs + 1];
       if (h_sums == nullptr)
         { HIP_CHECK(hipHostMalloc((void **) &h_sums, 8 * sizeof(unsigned long long), hipHostMallocDefault));
           HIP_CHECK(hipEventCreateWithFlags(&ev_sums, hipEventDisableTiming));

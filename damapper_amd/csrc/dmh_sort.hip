@@ -160,7 +160,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const uint32_t *
 // of scans so far and of tiles.
 constexpr size_t LB_WORDS = 8 + 2 * (size_t) (LB_MAX / LB_TILE) + 8;
 struct LookbackState { const void *buf; unsigned gen; uint32_t epoch, tiles; };
-static LookbackState g_lb[4] = {{nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}};
+static LookbackState g_lb[6] = {{nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0}};
 
 void exclusive_scan_u32(const uint32_t *d_src, uint32_t *d_data, int64_t n, DevBuf<uint32_t> &bsum, uint32_t *d_total)
 { if (n <= 0)

@@ -193,6 +193,7 @@ struct State
   int  opt_chain_simple = -1;   // 0: no group is chained without a walk (k_chain_simple off)
   int  opt_oom_finish  = 0;     // n > 0: the n-th chain_finish from now meets a (simulated) out-of-memory in its middle
   int  opt_read_sort   = -1;    // cluster mode: 0 = hits ordered by the global radix sort instead of per read in LDS; 2 = the 1024-thread workgroups from 129 hits; 3 = reads of more than 512 hits go through global memory (k_read_sort_big); 5 = ranks from ballots; 6 = no 1024-thread workgroups (as while an alignment kernel is deferred); 7 = 3 and 6
+  int  opt_front_ahead = -1;    // 0: the match kernels of a REF block are queued when its own pass comes (no front stream)
   int  opt_pebble_spill = -1;   // 0: k_align_cands32's pebbles end with its LDS (longer passes are re-run one rung up)
   int  opt_chain_classes = -1;  // 0: groups that fall apart by diagonal are walked like any other (k_chain_classes off)
   int  opt_fuse        = -1;    // 0: dense passes take round 3's route (hits expanded to HBM, k_read_sort, k_chain_simple) instead of the fused per-read kernel
@@ -208,6 +209,7 @@ struct State
   SortScratch sort;
   SortScratch sort_aux;         // scratch of the deferred index build (lives across Match_Filter calls)
   SortScratch sort_fin;         // scratch of the scans of chain_finish (its own stream)
+  SortScratch sort_front;       // ... of the scans of a front made ahead (the front stream)
   SortScratch sort_tail;        // ... and of the scans behind the per-read seed order (the tail stream)
 };
 

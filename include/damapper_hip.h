@@ -173,6 +173,9 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  *   "tails" 0            nothing runs on the tail stream: every kernel of a pass has the GPU to itself
  *   "defer_close" 1      the close of a dense pass is taken up by the next Match_Filter call (experiment)
  *   "hit_limit" n        a pass of n hits or more is refused (the refusal at 2^32 hits, at a testable size)
+ *   "front_ahead" 0      the match kernels of a REF block are queued when its own pass comes, on the main stream (default:
+ *                        those of the REF block that follows run on a stream of their own next to the block at hand's
+ *                        per-read kernels, when the driver names the passes with dmh_next_pass)
  *   "pebble_spill" 0     a lane group's d-wave pass ends at the 288 pebbles its LDS holds (the candidate is re-run one
  *                        rung up) instead of spilling the rest into global memory
  * Returns 0, or -1 for an unknown key.                                                                       */

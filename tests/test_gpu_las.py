@@ -244,7 +244,7 @@ def test_long_reads_identical_to_reference(tmp_path):
 VARIANT_DEFAULTS = dict(align_level=-1, align_g=-1, chain_g=0, pool_div=1, chain_pile=-1, pile_cap=0, merge_dense=-1,
                         cluster=-1, chain_small=-1, chain_lane=-1, batch=-1, cluster_sort=-1, expand=-1, in_flight=-1,
                         seed_word=-1, alloc_fail=0, fin_stream=-1, read_sort=-1, oom_finish=0, chain_simple=-1,
-                        defer_close=-1, tails=-1, fuse=-1, chain_classes=-1, pebble_spill=-1)
+                        defer_close=-1, tails=-1, fuse=-1, chain_classes=-1, pebble_spill=-1, front_ahead=-1)
 _VARIANT = {}
 
 
@@ -508,14 +508,29 @@ def test_next_pass_hint_gives_identical_files(tmp_path, monkeypatch):
     nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
     blocks = ["READS.%d" % (k + 1) for k in range(nb)]
     run_ref.run_reference(d, "REF", blocks, flags=[], threads=4, keep="las_ref")
-    for hint in ("1", "0"):
-        monkeypatch.setenv("DMH_HINT_PASSES", hint)
-        out = os.path.join(d, "las_hint" + hint)
-        scale._map_blocks_like_bench(d, "REF", "READS", out, report_mode=2, overlap=True)
-        for b in blocks:
-            _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
-            _, hr = las.read_las_set(out, b + ".REF.M@.las")
-            assert len(rr) > 0 and rr == hr, "hints %s, block %s: %d vs %d records" % (hint, b, len(rr), len(hr))
+    from damapper_amd import capi
+    L = capi.lib()
+    # (with the hints the front of the REF block that FOLLOWS is made on a stream of its own, next to the per-read kernels
+    #  of the block at hand -- "front_ahead" test option = 0: every front on the main stream when its pass comes)
+    try:
+        for hint, ahead in (("1", -1), ("1", 0), ("0", -1)):
+            monkeypatch.setenv("DMH_HINT_PASSES", hint)
+            assert L.dmh_test_option(b"front_ahead", ahead) == 0
+            out = os.path.join(d, "las_hint%s_%d" % (hint, ahead))
+            L.dmh_timing_reset()
+            L.dmh_timing_enable(1)
+            scale._map_blocks_like_bench(d, "REF", "READS", out, report_mode=2, overlap=True)
+            L.dmh_sync()
+            waits = capi.timings().get("host:wait_front_ahead", {}).get("launches", 0)
+            L.dmh_timing_enable(0)
+            assert (waits > 0) == (hint == "1" and ahead != 0), (hint, ahead, waits)
+            for b in blocks:
+                _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+                _, hr = las.read_las_set(out, b + ".REF.M@.las")
+                assert len(rr) > 0 and rr == hr, "hints %s, ahead %d, block %s: %d vs %d records" % (hint, ahead, b, len(rr), len(hr))
+    finally:
+        L.dmh_timing_enable(0)
+        L.dmh_test_option(b"front_ahead", -1)
 
 
 def test_dispatcher_maps_every_read_block(tmp_path):
