@@ -510,8 +510,10 @@ def main():
             roof["alone"] = {"achieved": round(ach, 1), "frac": float("%.3g" % (ach / HBM_PEAK_GBS)), "launches": int(v["launches"]),
                              "avg_ms": round(v["ms"] / v["launches"], 4),
                              "note": "the same kernel on the same inputs with the GPU to itself: one more read block mapped outside "
-                                     "the clock with nothing on the tail stream (in the timed pipeline it runs next to the "
-                                     "previous pass's ordering and chain kernels, which is what `achieved` measures)"}
+                                     "the clock with nothing on the side streams (in the timed pipeline it runs on the front stream "
+                                     "next to the per-read kernels of the REF block before -- which fill the vector ALUs -- and the "
+                                     "previous passes' ordering and chain kernels, which is what `achieved` measures; "
+                                     "DMH_FRONT_AHEAD=0 puts it back on the main stream: shorter launches, longer read blocks)"}
         hbm_stage = roof_of("k_radix_scatter") if dominant != "k_radix_scatter" else None
         stages = {k: round(v["ms"], 2) for k, v in sorted(timings.items(), key=lambda kv: -kv[1]["ms"]) if not k.startswith("count:")}
 

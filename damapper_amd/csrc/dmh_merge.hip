@@ -2264,7 +2264,8 @@ static void close_batch(MergeResult &R, int phase)
               }
           }
           // ("read_sort" test option = 5: ranks from ballots, as on a device whose LDS does not serve atomics in lane order)
-          RA.ordered = (lds_atomics_ordered() && st.opt_read_sort != 5) ? 1 : 0;
+          static const bool env_ballot = getenv("DMH_RS_BALLOT") != nullptr && atoi(getenv("DMH_RS_BALLOT")) != 0;      // (experiments)
+          RA.ordered = (lds_atomics_ordered() && st.opt_read_sort != 5 && !env_ballot) ? 1 : 0;
           RA.lcl = lcl.p; RA.rncl = rncl.p;
           // the clusters are counted by size while they are found, in the chain kernels' classes and the cluster sorts'
           chain_group_limits(R);

@@ -755,6 +755,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
             pe[(uint32_t) bkpref[wi] + (uint32_t) __popcll(bkw[wi] & (~0ull >> (63u - bi))) - 1u] = wv0 + P[j];
           }
       __syncthreads();
+      RSPROF_LAP(7);
       // A thread per CLUSTER (a read has some 150): its first hit is the c-th start bit -- the word by a search in the
       // prefix counts, the bit by clearing c' lower ones --, its chains are the breaks inside it, the score of each the
       // difference of two neighbouring prefix sums; the chains that score are reported (in any order: k_order_summaries
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
                 }
               v = En | 0x80000000u;
             }
-#ifdef DMH_RS_PROFILE
+#ifdef DMH_RS_PROFILE_STATS                                     // (not with the phase clock: these loops are a third of the phase they sit in)
           else
             { // hits in the clusters left to the chain kernels, by cluster size (<= 16, 32, 64, 128, 256, more)
               const uint32_t sz = ce - cs;
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
                           prev = on;
                         }
                       (void) prev;
-                      atomicAdd(&g_rsprof[classes >= 2 ? 14 : 15], (unsigned long long) sz);
+                      atomicAdd(&g_rsprof[14], (unsigned long long) (classes >= 2 ? sz : 0));
                     }
                 }
             }
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
 #ifdef DMH_RS_PROFILE
       __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
 #endif
-      RSPROF_LAP(7);
+      RSPROF_LAP(15);                                            // (the thread-per-cluster part of step 5)
     }
   if (!LOOP) break;
   __syncthreads();                                             // (the next read of this workgroup starts with empty LDS)

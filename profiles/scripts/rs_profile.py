@@ -31,13 +31,14 @@ for b in range(3):
 L.dmh_rs_profile(out, 0)
 v = list(out)
 names = ["load / rows -> words", "rank (ballots)", "digit scan", "scatter + reload", "flags + scan", "convert + records", "cluster ranks + store",
-         "plain chains (fused)"]
-tot = sum(v[:8])
+         "plain chains: the sweep"]
+tot = sum(v[:8]) + v[15]
 print("workgroups %d, hits %d (%.0f per workgroup)" % (v[8], v[9], v[9] / max(1, v[8])))
 for i, nm in enumerate(names):
     print("%-24s %6.1f %%  %8.0f cycles per workgroup" % (nm, 100.0 * v[i] / max(1, tot), v[i] / max(1, v[8])))
+print("%-24s %6.1f %%  %8.0f cycles per workgroup" % ("plain chains: per cluster", 100.0 * v[15] / max(1, tot), v[15] / max(1, v[8])))
 print("hits in clusters left to the chain kernels, by cluster size <=16 <=32 <=64 more:", v[10:14], "of", v[9])
-print("... of clusters up to 1023 hits: in clusters of two and more diagonal classes (1024-wide bins, a free bin between):", v[14], "of one class:", v[15])
+print("... of clusters up to 1023 hits: in clusters of two and more diagonal classes (1024-wide bins, a free bin between):", v[14])
 print({k: round(x["ms"], 1) for k, x in sorted(capi.timings().items(), key=lambda kv: -kv[1]["ms"])[:10]})
 
 lp = (C.c_ulonglong * 24)()
