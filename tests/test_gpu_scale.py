@@ -106,10 +106,16 @@ def test_configs2_chr1_sized_repeat_rich_reference(tmp_path):
     d = str(tmp_path)
     G = dazzdb.native_genome(21, [125_000_000, 125_000_000], "repeat", families=333)
     dazzdb.write_db_block(d, "REF", dazzdb.genome_block(G))
-    dazzdb.write_db_block(d, "READS", dazzdb.simulate_block_genome(2000, G, 25000))
-    run_ref.run_reference(d, "REF", ["READS.1"], flags=["-k20", "-e.85", "-M64"], threads=_threads())
-    _map_blocks_like_bench(d, "REF", "READS", "las_hip", mem_limit=64 << 30)
-    _compare(d, "las_ref", "las_hip", ["READS.1"], 25000)
+    # two READS blocks that differ in the number of reads AND in the longest read (log-normal lengths in the second): the
+    # byte counts of the seed key (map.c:2920-2936) and every per-block size change at the block boundary, at this size
+    blocks = [dazzdb.simulate_block_genome(2000, G, 19000, tfirst=0, part=1),
+              dazzdb.simulate_block_genome(2001, G, 6000, tfirst=19000, part=2, lengths="lognormal")]
+    dazzdb.write_db_blocks(d, "READS", blocks)
+    del blocks
+    names = ["READS.1", "READS.2"]
+    run_ref.run_reference(d, "REF", names, flags=["-k20", "-e.85", "-M64"], threads=_threads())
+    assert _map_blocks_like_bench(d, "REF", "READS", "las_hip", mem_limit=64 << 30) == 2
+    _compare(d, "las_ref", "las_hip", names, 25000)
 
 
 def test_configs4_resident_multi_block_reference_n95_p(tmp_path):
