@@ -533,6 +533,35 @@ def test_next_pass_hint_gives_identical_files(tmp_path, monkeypatch):
         L.dmh_test_option(b"front_ahead", -1)
 
 
+def test_memory_runs_out_while_a_front_is_made_ahead(tmp_path):
+    """The n-th device allocation "runs out of memory" (alloc_fail: the batches in flight are finished, idle buffers go
+    back, the allocation is made again) while the block loop runs with the front of the following REF block on its own
+    stream -- three REF blocks, two read blocks, the bench's call sequence: the files stay the reference's for every n."""
+    import test_gpu_scale as scale
+    from damapper_amd import capi
+    run_ref = _run_ref()
+    g, reads = make_dataset("repeat", 347, [200000, 150000, 120000], 60, dropouts=1)
+    d = str(tmp_path)
+    dazzdb.write_db(d, "REF", g, block_size=260000)
+    dazzdb.write_db(d, "READS", reads, block_size=320000)
+    nb, _ = dazzdb.read_stub(os.path.join(d, "READS.db"))
+    blocks = ["READS.%d" % (k + 1) for k in range(nb)]
+    assert nb >= 2
+    run_ref.run_reference(d, "REF", blocks, flags=[], threads=4, keep="las_ref")
+    L = capi.lib()
+    try:
+        for n in range(4, 160, 6):
+            assert L.dmh_test_option(b"alloc_fail", n) == 0
+            out = os.path.join(d, "las_fail%d" % n)
+            scale._map_blocks_like_bench(d, "REF", "READS", out, report_mode=2, overlap=True)
+            for b in blocks:
+                _, rr = las.read_las_set(os.path.join(d, "las_ref"), b + ".REF.M@.las")
+                _, hr = las.read_las_set(out, b + ".REF.M@.las")
+                assert len(rr) > 0 and rr == hr, "alloc_fail %d, block %s: %d vs %d records" % (n, b, len(rr), len(hr))
+    finally:
+        L.dmh_test_option(b"alloc_fail", 0)
+
+
 def test_dispatcher_maps_every_read_block(tmp_path):
     """damapper_amd.dispatch (read blocks -> GPUs, resume by output file) against the reference run on
     the same blocks."""
