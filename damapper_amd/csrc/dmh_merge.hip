@@ -144,21 +144,41 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
   bool     first[MG_ITEMS];
   uint32_t bs[MG_ITEMS], be[MG_ITEMS];
   { uint64_t pv[MG_ITEMS];
+    // (positions in 32 bits: an index has fewer than 2^32 k-mers, checked by the host -- the 64-bit clamps and compares of
+    //  these sixteen loads were a tenth of the kernel's vector instructions; a tile in the middle needs no clamp at all)
+    const uint32_t t0 = (uint32_t) tile * MG_TILE + (uint32_t) tid, n32 = (uint32_t) na;
+    if (tile > 0 && (uint64_t) (tile + 1) * MG_TILE <= (uint64_t) na)         // (uniform)
+      {
 #pragma unroll
-    for (int j = 0; j < MG_ITEMS; j++)
-      { // unconditional loads from clamped addresses: a guarded load compiles to a branch with a wait at
-        // its join, which strings the 16 loads of this phase into 16 round trips
-        int64_t i  = tile0 + j * MG_THREADS;
-        int64_t ic = i < na ? i : na - 1;
-        c[j]  = akeys[ic];
-        pv[j] = akeys[ic > 0 ? ic - 1 : 0];
+        for (int j = 0; j < MG_ITEMS; j++)
+          { const uint32_t i = t0 + (uint32_t) (j * MG_THREADS);
+            c[j]  = akeys[i];
+            pv[j] = akeys[i - 1];
+          }
+#pragma unroll
+        for (int j = 0; j < MG_ITEMS; j++) first[j] = pv[j] != c[j];
       }
+    else
+      {
 #pragma unroll
-    for (int j = 0; j < MG_ITEMS; j++)
-      { int64_t i = tile0 + j * MG_THREADS;
-        first[j] = (i < na) && (i == 0 || pv[j] != c[j]);
+        for (int j = 0; j < MG_ITEMS; j++)
+          { // unconditional loads from clamped addresses: a guarded load compiles to a branch with a wait at
+            // its join, which strings the 16 loads of this phase into 16 round trips
+            const uint32_t i  = t0 + (uint32_t) (j * MG_THREADS);
+            const uint32_t ic = i < n32 ? i : n32 - 1u;
+            c[j]  = akeys[ic];
+            pv[j] = akeys[ic > 0 ? ic - 1u : 0u];
+          }
+#pragma unroll
+        for (int j = 0; j < MG_ITEMS; j++)
+          { const uint32_t i = t0 + (uint32_t) (j * MG_THREADS);
+            first[j] = (i < n32) && (i == 0 || pv[j] != c[j]);
+          }
       }
   }
+  uint64_t firstm[MG_ITEMS];                 // (wave-uniform: scalar registers)
+#pragma unroll
+  for (int j = 0; j < MG_ITEMS; j++) firstm[j] = __ballot(first[j]);
   const BLookup B = (TWO && side) ? B1 : B0;
   MergeEntry *__restrict__ tile_entries = (TWO && side) ? O1.tile_entries : O0.tile_entries;
   uint32_t *__restrict__ tile_count = (TWO && side) ? O1.tile_count : O0.tile_count;
@@ -235,7 +255,12 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
           if (mb == PENDING)
             { e = i; hit = true; }                 // (entry {i, 0, 0, PENDING}: no hits counted yet)
           else if (mb != 0)
-            { e   = (i + 1 < na && akeys[i + 1] == cc) ? run_end(akeys, na, i) : i + 1;
+            { // does the code go on at i + 1?  That k-mer is the next lane's (same item): it is no `first` then -- a bit of
+              // the ballot instead of a dependent load in front of every entry (only the wavefront's last lane has to look)
+              bool same;
+              if (lane < 63) same = (i + 1 < na) && ((firstm[j] >> (lane + 1)) & 1ull) == 0;
+              else           same = (i + 1 < na) && akeys[i + 1] == cc;
+              e   = same ? run_end(akeys, na, i) : i + 1;
               ct  = (unsigned long long) (e - i) * mb;
               hit = true;
             }
@@ -1286,6 +1311,7 @@ static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nu
       if (B2->bshift != Bx.bshift || B2->probe_keys != Bx.probe_keys || (B2->low_off != 0) != (Bx.low_off != 0)) B2 = nullptr;
     }
   const BLookup BL = lookup_of(Bx), BL2 = (B2 != nullptr) ? lookup_of(*B2) : BL;
+  if (A.n >= ((int64_t) 1 << 32)) fatal("Match_Filter: a READS index of %lld k-mers (positions are kept in 32 bits)", (long long) A.n);
   const int64_t ntiles = ceil_div(A.n, MG_TILE);
   MatchOut MO[2];
   for (int q = 0; q < (B2 != nullptr ? 2 : 1); q++)
