@@ -155,6 +155,12 @@ template <int T> constexpr size_t read_sort_lds_words()
            + sizeof(uint16_t) * (T * RS_E / 64 + 2) + 64) + 7) / 8;
 }
 
+// The kernel tests `position < n` and `slot < rounds` some four hundred times; left alone the compiler computes the sixteen
+// lane masks of each once and keeps them -- 64 scalar registers of masks, most of them spilled to lanes of a vector register
+// and read back with two v_readlane each (a tenth of the kernel's vector instructions, round 4).  Behind every barrier the
+// two numbers are made opaque, so that each phase computes the masks it needs (one v_cmp each) and lets them go.
+#define RS_FORGET() asm volatile("" : "+s"(n), "+s"(rounds))
+
 template <int T, bool K32, bool FUSE = false>
 __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
 { constexpr int W = T / 64, D = 1 << RS_DB, E = RS_E;
@@ -180,12 +186,12 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   {
   const uint32_t r  = A.list[rb];
   const uint32_t s0 = A.rstart[r];
-  const uint32_t n  = A.rstart[r + 1] - s0;                   // 0 < n <= T * E (k_read_classes)
+  uint32_t n  = (uint32_t) __builtin_amdgcn_readfirstlane((int) (A.rstart[r + 1] - s0));      // 0 < n <= T * E (k_read_classes); a scalar (RS_FORGET)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   RSPROF_T0();
   RSPROF_ADD(8, 1); RSPROF_ADD(9, n);
-  const uint32_t rounds = (n + 64 * W - 1) / (64 * W);        // <= E
+  uint32_t rounds = (n + 64 * W - 1) / (64 * W);        // <= E
   const uint32_t wbase  = (uint32_t) w * rounds * 64;         // the wavefront's words: [wbase, wbase + 64 rounds)
   const uint64_t lt = (1ull << lane) - 1ull;
 
@@ -228,28 +234,28 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
           const uint32_t aw = ((1u << A.pbits) + 63u) / 64u;
           uint16_t *apf = (uint16_t *) (abm + aw);
           for (uint32_t x = tid; x < aw; x += T) abm[x] = 0;
-          __syncthreads();
+          __syncthreads(); RS_FORGET();
 #pragma unroll
           for (int j = 0; j < E; j++)
             if ((uint32_t) j < rrounds)
               { const uint32_t x = rbase + 64u * j + lane, ap = (uint32_t) ((rec[j] >> RW_MB) & RW_APMASK);
                 if (x < nr) atomicOr((unsigned long long *) &abm[ap >> 6], 1ull << (ap & 63u));
               }
-          __syncthreads();
+          __syncthreads(); RS_FORGET();
           { const uint32_t per = (aw + T - 1) / T, lo = min(aw, (uint32_t) tid * per), hi = min(aw, lo + per);
             uint32_t c = 0, all;
             for (uint32_t x = lo; x < hi; x++) c += (uint32_t) __popcll(abm[x]);
             uint32_t e = block_excl_scan_t<T>(c, ws, &all);
             for (uint32_t x = lo; x < hi; x++) { apf[x] = (uint16_t) e; e += (uint32_t) __popcll(abm[x]); }
           }
-          __syncthreads();
+          __syncthreads(); RS_FORGET();
 #pragma unroll
           for (int j = 0; j < E; j++)
             if ((uint32_t) j < rrounds)
               { const uint32_t x = rbase + 64u * j + lane, ap = (uint32_t) ((rec[j] >> RW_MB) & RW_APMASK);
                 if (x < nr) buf[(uint32_t) apf[ap >> 6] + (uint32_t) __popcll(abm[ap >> 6] & ((1ull << (ap & 63u)) - 1ull))] = rec[j];
               }
-          __syncthreads();
+          __syncthreads(); RS_FORGET();
 #pragma unroll
           for (int j = 0; j < E; j++)
             if ((uint32_t) j < rrounds)
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
             carry += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
           }
       if (lane == 0) ws[w] = carry;
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       uint32_t wv0 = 0;
 #pragma unroll
       for (int v = 0; v < W; v++)
@@ -281,12 +287,12 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
                 atomicOr((unsigned long long *) &rflag[o >> 6], 1ull << (o & 63u));
               }
           }
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       { uint32_t c = ((uint32_t) tid < nfw) ? (uint32_t) __popcll(rflag[tid]) : 0u, all;
         const uint32_t e = block_excl_scan_t<T>(c, ws, &all);
         if ((uint32_t) tid < nfw) rpref[tid] = (uint16_t) e;
       }
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       uint32_t q[E];
 #pragma unroll
       for (int j = 0; j < E; j++)
@@ -309,10 +315,10 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
           const uint64_t v = ((uint64_t) (q[j] >> A.bposbits) << top) | ((uint64_t) (q[j] & bpm) << A.pbits) | key[j];
           key[j] = (i < n) ? v : ~0ull;
         }
-      __syncthreads();                                           // (the rows have been read: buf and the flag words are free)
+      __syncthreads(); RS_FORGET();                                           // (the rows have been read: buf and the flag words are free)
     }
 #ifdef DMH_RS_PROFILE
-  __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); RS_FORGET();
 #endif
   RSPROF_LAP(0);
 
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
     { const int sh = A.sh[p], wd = A.wd[p];
       const uint32_t dmask = (1u << wd) - 1u;
       for (int x = tid; x < W * D / 2; x += T) ((uint32_t *) wh)[x] = 0;
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       uint32_t rk[E];
       if (A.ordered)
         { // the counter before the add = words of this wavefront with the digit in earlier rounds and lower lanes
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
               __builtin_amdgcn_sched_barrier(0);               // (one item at a time: interleaved, their ballots spill)
             }
         }
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       RSPROF_LAP(1);
       // digit d: counts per wavefront -> first slot of (d, wavefront) in the order digit, wavefront, position
       { constexpr int PER = (D + T - 1) / T;                   // digits per thread (consecutive)
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
               }
           }
       }
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       RSPROF_LAP(2);
 #pragma unroll
       for (int j = 0; j < E; j++)
@@ -411,14 +417,14 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
                 buf[rk[j] + (uint32_t) mywh[d]] = key[j];
               }
           }
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
 #pragma unroll
       for (int j = 0; j < E; j++)
         if ((uint32_t) j < rounds)
           { const uint32_t i = wbase + 64u * j + lane;
             key[j] = (i < n) ? buf[i] : ~0ull;
           }
-      __syncthreads();                                         // (everybody has its words: buf and wh are free again)
+      __syncthreads(); RS_FORGET();                                         // (everybody has its words: buf and wh are free again)
       RSPROF_LAP(3);
     }
   if (A.npass == 0)
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
           { const uint32_t i = wbase + 64u * j + lane;
             if (i < n) buf[i] = key[j];
           }
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
     }
 
   // ---- 2. cluster starts: bit i of the flag words (the words of a round are consecutive, so a ballot is a flag word),
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
       }
   // (the sentinel lies in the word after the last wavefront's last round when n is a multiple of 64 W)
   if (tid == 0 && n == rounds * 64 * W) { flagw[n / 64] = 1ull; if (FUSE) runw[n / 64] = 1ull; }
-  __syncthreads();
+  __syncthreads(); RS_FORGET();
   uint32_t ncl;
   { uint32_t c = 0;
     if ((uint32_t) tid < nw)
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
     const uint32_t e = block_excl_scan_t<T>(c, ws, &ncl);
     if ((uint32_t) tid < nw) wpref[tid] = (uint16_t) e;
   }
-  __syncthreads();
+  __syncthreads(); RS_FORGET();
   // the cluster of every word (starts at or below it, minus one); a bucket change marks its cluster
   uint16_t cid[E];
 #pragma unroll
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
         }
     }
   if (tid == 0) A.rncl[r] = ncl;
-  __syncthreads();
+  __syncthreads(); RS_FORGET();
   RSPROF_LAP(4);
 
   // ---- 3. every start leaves its cluster's record; the words of clusters that span buckets look for their cluster's
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
             }
         }
     }
-  __syncthreads();                                             // (nobody reads the sorted words any more)
+  __syncthreads(); RS_FORGET();                                             // (nobody reads the sorted words any more)
   uint32_t *b32 = (uint32_t *) buf;
 #pragma unroll
   for (int j = 0; j < E; j++)
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
             else     buf[i] = (key[j] << 32) | (key[j] >> 32);
           }
       }
-  __syncthreads();
+  __syncthreads(); RS_FORGET();
   RSPROF_LAP(5);
 
   // ---- 4. clusters across buckets of up to RS_IN hits: rank by counting; everything else keeps its position
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
         if (FUSE) se[j] = dst;
       }
 #ifdef DMH_RS_PROFILE
-  __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); RS_FORGET();
 #endif
   RSPROF_LAP(6);
 
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   // two prefix sums of the per-hit increments (one scan over the read; the sums at the chain ends are kept, by chain number
   // = breaks at or below the position), and the ends that score are counted per cluster in a bit map.
   if (FUSE && A.simple_max > 0)
-    { __syncthreads();                                           // (the ranking above has read buf for the last time)
+    { __syncthreads(); RS_FORGET();                                           // (the ranking above has read buf for the last time)
 #pragma unroll
       for (int j = 0; j < E; j++)
         if ((uint32_t) j < rounds)
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
       uint16_t *bkpref = wh;                                     // breaks before each word of them
       uint32_t *pe     = (uint32_t *) (wh + (T * E / 64 + 2));   // prefix sum at every chain's end, by chain number
       constexpr uint32_t PECAP = (uint32_t) ((W * D * 2 - 2 * (T * E / 64 + 2)) / 4);
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       const int K = A.K;
       uint32_t P[E];
       uint32_t endm = 0, carry = 0;
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
         }
       if (tid == 0 && n == rounds * 64 * W) bkw[n / 64] = 1ull;
       if (lane == 0) ws2[w] = carry;
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       uint32_t wv0 = 0;
 #pragma unroll
       for (int v = 0; v < W; v++)
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
         const uint32_t e = block_excl_scan_t<T>(c, ws, &nchain);
         if ((uint32_t) tid < nw) bkpref[tid] = (uint16_t) e;
       }
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       const bool fits = nchain <= PECAP;                         // (else: a read of singletons -- all of it left to the chain kernels)
 #pragma unroll
       for (int j = 0; j < E; j++)
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
           { const uint32_t i = wbase + 64u * j + lane, wi = i >> 6, bi = i & 63u;
             pe[(uint32_t) bkpref[wi] + (uint32_t) __popcll(bkw[wi] & (~0ull >> (63u - bi))) - 1u] = wv0 + P[j];
           }
-      __syncthreads();
+      __syncthreads(); RS_FORGET();
       RSPROF_LAP(7);
       // A thread per CLUSTER (a read has some 150): its first hit is the c-th start bit -- the word by a search in the
       // prefix counts, the bit by clearing c' lower ones --, its chains are the breaks inside it, the score of each the
@@ -844,12 +850,12 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
           A.lcnt[s0 + c] = v;
         }
 #ifdef DMH_RS_PROFILE
-      __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads();
+      __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); RS_FORGET();
 #endif
       RSPROF_LAP(15);                                            // (the thread-per-cluster part of step 5)
     }
   if (!LOOP) break;
-  __syncthreads();                                             // (the next read of this workgroup starts with empty LDS)
+  __syncthreads(); RS_FORGET();                                             // (the next read of this workgroup starts with empty LDS)
   rb += gridDim.x;
   } while (rb < *A.count);
 }
