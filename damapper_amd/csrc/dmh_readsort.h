@@ -87,7 +87,7 @@ struct ReadSortArgs
 template <int T>
 __device__ __forceinline__ uint32_t block_excl_scan_t(uint32_t v, uint32_t *ws, uint32_t *total)
 { constexpr int W = T / 64;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // (a scalar: tests against it are no lane masks)
   const uint32_t x = wave_incl_scan_dpp(v);
   if (lane == 63) ws[w] = x;
   __syncthreads();
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(T, 4) void k_read_sort(ReadSortArgs A)
   const uint32_t s0 = A.rstart[r];
   uint32_t n  = (uint32_t) __builtin_amdgcn_readfirstlane((int) (A.rstart[r + 1] - s0));      // 0 < n <= T * E (k_read_classes); a scalar (RS_FORGET)
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: `v < w` is a scalar test, not a lane mask kept in two registers)
   RSPROF_T0();
   RSPROF_ADD(8, 1); RSPROF_ADD(9, n);
   uint32_t rounds = (n + 64 * W - 1) / (64 * W);        // <= E
