@@ -153,6 +153,7 @@ void radix_pass_scatter(const uint64_t *keys, const uint32_t *vals, uint64_t *ok
 // Exclusive scan of n uint32 values in place; returns nothing, total is written to *d_total
 // (device pointer to one uint32) if not null.  n < 2^32, sum < 2^32.
 void exclusive_scan_u32(uint32_t *d_data, int64_t n, DevBuf<uint32_t> &bsum, uint32_t *d_total);
+bool lds_atomics_ordered();       // LDS atomic adds of a wavefront are served in lane order (checked on the device once, dmh_merge.hip)
 void scan_state_reset();           // call when a scan scratch buffer (SortScratch::bsum) has been released
 // ... of d_src into d_data (the two may be the same array)
 void exclusive_scan_u32(const uint32_t *d_src, uint32_t *d_data, int64_t n, DevBuf<uint32_t> &bsum, uint32_t *d_total);

@@ -259,7 +259,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
 // through LDS into digit order, so that consecutive threads write consecutive slots of each
 // digit's output run (coalesced 8-byte / 4-byte stores), the run's global start coming from the
 // scanned histogram.
-template <bool VALS>
+// ORD: the rank of a pair among its wavefront's pairs with the same digit is what an LDS atomic add on the digit's counter
+// returns -- the adds of a wavefront are served in lane order on gfx950 (lds_atomics_ordered(): checked on the device) and
+// one instruction after the other, so the ranks are stable; else eight ballots per pair (round 1).  The kernel moves its
+// bytes at 0.7 of the HBM peak alone, but runs next to kernels that are bound by vector issue: the ballots were two thirds
+// of its vector instructions.
+template <bool VALS, bool ORD>
 __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_t *__restrict__ kin,
                                                                  const uint32_t *__restrict__ vin,
                                                                  uint64_t *__restrict__ kout,
@@ -299,6 +304,10 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_
   for (int j = 0; j < SORT_ITEMS; j++)
     { bool     ok = (base + j * 64) < n;
       uint32_t d  = (uint32_t) (key[j] >> shift) & mask;
+      if (ORD)
+        { rk[j] = ok ? atomicAdd(&wh[w][d], 1u) : 0u;
+          continue;
+        }
       uint64_t peers = __ballot(ok);
 #pragma unroll
       for (int b = 0; b < 8; b++)
@@ -366,6 +375,12 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_
     }
 }
 
+// "DMH_SORT_BALLOT=1": the ranks from ballots whatever the device does
+static bool scatter_ordered()
+{ static const bool env_ballot = getenv("DMH_SORT_BALLOT") != nullptr && atoi(getenv("DMH_SORT_BALLOT")) != 0;
+  return !env_ballot && lds_atomics_ordered();
+}
+
 void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32_t **ovals,
                       int64_t n, int lo_bit, int nbits, SortScratch &scr, const char *stage)
 { if (n <= 1 || nbits <= 0) return;
@@ -389,12 +404,21 @@ void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32
       { // one LSD pass over 16-byte records in the reference: read 16 B + write 16 B per record; a keys-only pass
         // (the one-word hits of cluster mode) is charged what it moves, 8 B + 8 B
         StageTimer tc("k_radix_scatter", (vals != nullptr ? 32.0 : 16.0) * (double) n);
-        if (vals != nullptr)
-          hipLaunchKernelGGL(k_radix_scatter<true>, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+        const bool ord = scatter_ordered();
+        if (vals != nullptr && ord)
+          hipLaunchKernelGGL((k_radix_scatter<true, true>), dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
                              (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,
                              shift, mask, (const uint32_t *) scr.hist.p, ntiles, 0);
+        else if (vals != nullptr)
+          hipLaunchKernelGGL((k_radix_scatter<true, false>), dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+                             (const uint64_t *) *keys, (const uint32_t *) *vals, *okeys, *ovals, n,
+                             shift, mask, (const uint32_t *) scr.hist.p, ntiles, 0);
+        else if (ord)
+          hipLaunchKernelGGL((k_radix_scatter<false, true>), dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+                             (const uint64_t *) *keys, (const uint32_t *) nullptr, *okeys, (uint32_t *) nullptr, n,
+                             shift, mask, (const uint32_t *) scr.hist.p, ntiles, 0);
         else
-          hipLaunchKernelGGL(k_radix_scatter<false>, dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
+          hipLaunchKernelGGL((k_radix_scatter<false, false>), dim3(ntiles), dim3(SORT_THREADS), 0, stream(),
                              (const uint64_t *) *keys, (const uint32_t *) nullptr, *okeys, (uint32_t *) nullptr, n,
                              shift, mask, (const uint32_t *) scr.hist.p, ntiles, 0);
       }
@@ -440,8 +464,12 @@ void radix_pass_scatter(const uint64_t *keys, const uint32_t *vals, uint64_t *ok
   if (t1 <= t0) return;
   int64_t recs = std::min<int64_t>(n, (int64_t) t1 * SORT_TILE) - (int64_t) t0 * SORT_TILE;
   StageTimer tc("k_radix_scatter", 32.0 * (double) recs);
-  hipLaunchKernelGGL(k_radix_scatter<true>, dim3(t1 - t0), dim3(SORT_THREADS), 0, stream(), keys, vals, okeys, ovals, n,
-                     shift, mask, (const uint32_t *) scr.hist.p, ntiles, t0);
+  if (scatter_ordered())
+    hipLaunchKernelGGL((k_radix_scatter<true, true>), dim3(t1 - t0), dim3(SORT_THREADS), 0, stream(), keys, vals, okeys, ovals, n,
+                       shift, mask, (const uint32_t *) scr.hist.p, ntiles, t0);
+  else
+    hipLaunchKernelGGL((k_radix_scatter<true, false>), dim3(t1 - t0), dim3(SORT_THREADS), 0, stream(), keys, vals, okeys, ovals, n,
+                       shift, mask, (const uint32_t *) scr.hist.p, ntiles, t0);
   HIP_CHECK(hipGetLastError());
 }
 
