@@ -1473,13 +1473,23 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
   // named the next pass (dmh_next_pass), and the pass after that is the one that followed it for the READS block before
   if (front_stream() != main_stream() && st.opt_front_early != 0 && env_two && g_hint_a == &A && g_hint_b != &Bx && usable(g_hint_b) &&
       g_hint_kshift == Kshift && stream() == main_stream() && !st.capture_seeds && !VERBOSE)
-    { bool have = false;
-      for (int q = 0; q < 4; q++) have = have || (g_fb[q].a == &A && g_fb[q].b == g_hint_b);
+    { auto has_front = [&](const IndexDev *x) -> bool
+      { for (int q = 0; q < 4; q++) if (g_fb[q].a == &A && g_fb[q].b == x) return true;
+        return false;
+      };
+      auto after = [&](IndexDev *x) -> IndexDev *
+      { auto it = g_next_of.find(x);
+        return (it != g_next_of.end() && it->second != x && it->second != &Bx && usable(it->second)) ? it->second : nullptr;
+      };
+      // the first REF index to come that has no front yet: the next pass's, or -- when the sweep of this REF block has made
+      // that one -- the first of the REF block that follows: queued at a REF block's FIRST pass, its front has two passes'
+      // time (queued at the second pass it was late one time in three: 0.4 ms of main stream waiting per REF block)
+      IndexDev *t = g_hint_b;
+      for (int hop = 0; hop < 2 && t != nullptr && has_front(t); hop++) t = after(t);
       const int other = (fs >> 1) ^ 1;
-      if (!have && g_fb[2 * other].a == nullptr && g_fb[2 * other + 1].a == nullptr)
-        { IndexDev *B2 = nullptr;
-          auto it = g_next_of.find(g_hint_b);
-          if (it != g_next_of.end() && it->second != g_hint_b && it->second != &Bx && usable(it->second)) B2 = it->second;
+      if (t != nullptr && !has_front(t) && g_fb[2 * other].a == nullptr && g_fb[2 * other + 1].a == nullptr)
+        { IndexDev *B2 = after(t);
+          if (B2 != nullptr && has_front(B2)) B2 = nullptr;
           // (once per READS index: the front stream starts behind what the main stream had queued when the index was
           //  first met -- the index's own build, the REF indices')
           static const IndexDev *seen_a = nullptr;
@@ -1490,7 +1500,7 @@ int64_t merge_pass(const DAZZ_DB *ablock, const DAZZ_DB *bblock, IndexDev &A, In
               HIP_CHECK(hipStreamWaitEvent(front_stream(), ev_a, 0));
               seen_a = &A;
             }
-          match_front(A, *g_hint_b, Kshift, B2, other, front_stream());
+          match_front(A, *t, Kshift, B2, other, front_stream());
         }
     }
   g_fb[fs].a = nullptr; g_fb[fs].b = nullptr;
