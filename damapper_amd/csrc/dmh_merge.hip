@@ -124,11 +124,18 @@ struct MatchOut
   unsigned long long *tile_hits;
 };
 
-template <int NK, bool LOW, bool TWO = false>
+// COMPACT (round 4, last): the look-ups that pass the cheap tests -- a `first`, a bucket that is not empty, a first key
+// that does not exceed the code: one in four -- are LISTED per wavefront (LDS), and the expensive part (the four probes,
+// the open look-ups, the run test, the entry and its place in the tile's window) runs over the list with every lane busy:
+// two or three rounds per wavefront instead of eight, in each of which one lane in fifty had something to do while the
+// wavefront paid for all of it (the kernel is the largest consumer of vector instructions of a read block).
+constexpr int MG_CAND = 192;        // candidates a wavefront may have listed: 63 waiting + two items' worth
+template <int NK, bool LOW, bool TWO = false, bool COMPACT = true>
 __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__restrict__ akeys, int64_t na,
                                                             BLookup B0, MatchOut O0, BLookup B1, MatchOut O1)
 { __shared__ unsigned long long s_hits[2][4];
   __shared__ uint32_t s_count;
+  __shared__ uint32_t s_f0[4];       // per wavefront: the `first` flags of its lane 0 (bit j: item j)
   const int tid = threadIdx.x, lane = tid & 63;
   const int      side = TWO ? (int) ((blockIdx.x >> 3) & 1u) : 0;
   const uint32_t tile = TWO ? (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u)) : blockIdx.x;
@@ -179,6 +186,12 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
   uint64_t firstm[MG_ITEMS];                 // (wave-uniform: scalar registers)
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++) firstm[j] = __ballot(first[j]);
+  if (COMPACT && lane == 0)
+    { uint32_t f0 = 0;
+#pragma unroll
+      for (int j = 0; j < MG_ITEMS; j++) f0 |= (uint32_t) (firstm[j] & 1ull) << j;
+      s_f0[tid >> 6] = f0;
+    }
   const BLookup B = (TWO && side) ? B1 : B0;
   MergeEntry *__restrict__ tile_entries = (TWO && side) ? O1.tile_entries : O0.tile_entries;
   uint32_t *__restrict__ tile_count = (TWO && side) ? O1.tile_count : O0.tile_count;
@@ -230,6 +243,123 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
     return kk[PACK4 ? 0 : t][j];
   };
 
+  if constexpr (COMPACT)
+    { __shared__ uint64_t s_cc[4][MG_CAND];
+      __shared__ uint32_t s_bs[4][MG_CAND], s_sz[4][MG_CAND], s_id[4][MG_CAND];
+      __shared__ uint64_t s_kq[PACK4 ? 4 : 1][PACK4 ? MG_CAND : 1];
+      __shared__ KT       s_kk[PACK4 ? 1 : 4][PACK4 ? 1 : NK][PACK4 ? 1 : MG_CAND];
+      const int      wv = tid >> 6;
+      const uint64_t lt = (1ull << lane) - 1ull;
+      uint32_t ncand = 0;                                   // (wave-uniform)
+      // the code at i + 1 is the next lane's (same item), the next wavefront's lane 0 (lane 63), or the first thread's of
+      // the item that follows (the tile's last thread): a `first` flag says whether it differs
+      const uint32_t f0next = s_f0[wv < 3 ? wv + 1 : 0];     // (the barrier above stands between the writes and this)
+#pragma unroll
+      for (int j = 0; j < MG_ITEMS; j++)
+        { const int64_t i = tile0 + j * MG_THREADS;
+          const KT cq = (KT) (c[j] & lowmask);             // what the fetched keys are compared with
+          bool pass;
+          if (PACK4)
+            { // the four probes here already, without a branch: what is listed is what becomes an entry (one look-up in
+              // fifty; an empty bucket or a lane that is no `first` has size 0, its keys are never looked at)
+              const uint32_t sz = be[j] - bs[j], q = (uint32_t) cq;
+              const uint32_t k0 = (uint32_t) key_at(0, j), k1 = (uint32_t) key_at(1, j), k2 = (uint32_t) key_at(2, j), k3 = (uint32_t) key_at(3, j);
+              pass = (sz > 0 && k0 == q) || (sz > 1 && k1 == q) || (sz > 2 && k2 == q) || (sz > 3 && k3 == q) || (sz > 4 && k3 <= q);
+            }
+          else
+            pass = first[j] && bs[j] < be[j] && key_at(0, j) <= cq;
+          const uint64_t m = __ballot(pass);
+          if (m)
+            { if (pass)
+                { bool nfirst;                              // the k-mer at i + 1 is a `first` (or there is none)
+                  if (lane < 63)   nfirst = ((firstm[j] >> (lane + 1)) & 1ull) != 0;
+                  else if (wv < 3) nfirst = ((f0next >> j) & 1u) != 0;
+                  else if (j < MG_ITEMS - 1) nfirst = ((f0next >> (j + 1)) & 1u) != 0;
+                  else             nfirst = !(i + 1 < na && akeys[i + 1] == c[j]);       // (the next tile's)
+                  const bool same = (i + 1 < na) && !nfirst;
+                  const uint32_t pos = ncand + (uint32_t) __popcll(m & lt);
+                  s_cc[wv][pos] = c[j];
+                  s_bs[wv][pos] = bs[j];
+                  s_sz[wv][pos] = be[j] - bs[j];
+                  s_id[wv][pos] = (uint32_t) (j * MG_THREADS + tid) | (same ? 0x10000u : 0u);
+                  if (PACK4) s_kq[PACK4 ? wv : 0][PACK4 ? pos : 0] = kq[PACK4 ? j : 0];
+                  else
+                    {
+#pragma unroll
+                      for (int t = 0; t < NK; t++) s_kk[PACK4 ? 0 : wv][PACK4 ? 0 : t][PACK4 ? 0 : pos] = kk[PACK4 ? 0 : t][j];
+                    }
+                }
+              ncand += (uint32_t) __popcll(m);
+            }
+          if ((j & 1) == 1)
+            { // every second item: rounds of 64 candidates off the top of the list (all of it behind the last item)
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              while (ncand >= 64u || (j == MG_ITEMS - 1 && ncand > 0u))
+                { const uint32_t take = ncand < 64u ? ncand : 64u, x = ncand - take + (uint32_t) lane;
+                  const bool act = (uint32_t) lane < take;
+                  const uint32_t xs = act ? x : 0u;
+                  const uint64_t cc = s_cc[wv][xs];
+                  const uint32_t bsv = s_bs[wv][xs], sz = s_sz[wv][xs], idw = s_id[wv][xs];
+                  const uint64_t kqv = PACK4 ? s_kq[PACK4 ? wv : 0][PACK4 ? xs : 0] : 0ull;
+                  KT kv[NK];
+#pragma unroll
+                  for (int t = 0; t < NK; t++)
+                    kv[t] = PACK4 ? (KT) ((kqv >> (16 * t)) & 0xffffull) : s_kk[PACK4 ? 0 : wv][PACK4 ? 0 : t][PACK4 ? 0 : xs];
+                  const KT      cq2 = (KT) (cc & lowmask);
+                  const int64_t i2  = (int64_t) tile * MG_TILE + (int64_t) (idw & 0xffffu);
+                  unsigned long long ct = 0;
+                  uint32_t lo = 0, mb = 0;
+                  int64_t  e = 0;
+                  bool     hit = false;
+                  if (act)
+                    { if (sz > (uint32_t) NK && kv[NK - 1] <= cq2)
+                        mb = PENDING;        // a long bucket: searched by k_merge_fixup, where every lane has such a look-up
+                      else
+                        {
+#pragma unroll
+                          for (int t = 0; t < NK; t++)
+                            if ((uint32_t) t < sz && kv[t] == cq2)
+                              { if (mb == 0) lo = bsv + (uint32_t) t;
+                                mb += 1;
+                              }
+                        }
+                      if (mb == PENDING)
+                        { e = i2; hit = true; }             // (entry {i, 0, 0, PENDING}: no hits counted yet)
+                      else if (mb != 0)
+                        { e   = (idw & 0x10000u) ? run_end(akeys, na, i2) : i2 + 1;
+                          ct  = (unsigned long long) (e - i2) * mb;
+                          hit = true;
+                        }
+                    }
+                  if (hit)
+                    { local += ct;
+                      if (ct < MAXGRAM) below += ct;
+                    }
+                  const uint64_t hm = __ballot(hit);
+                  if (hm)
+                    { uint32_t base = 0;
+                      const int leader = __ffsll((long long) hm) - 1;
+                      if (lane == leader) base = atomicAdd(&s_count, (uint32_t) __popcll(hm));
+                      base = __shfl(base, leader);
+                      if (hit)
+                        { MergeEntry en;
+                          en.a0 = (uint32_t) i2;
+                          en.ma = (uint32_t) (e - i2);
+                          en.b0 = lo;
+                          en.mb = mb;
+                          dst[base + __popcll(hm & lt)] = en;
+                        }
+                    }
+                  ncand -= take;
+                }
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+  else
+  {
 #pragma unroll
   for (int j = 0; j < MG_ITEMS; j++)
     { int64_t i = tile0 + j * MG_THREADS;
@@ -285,6 +415,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_match(const uint64_t *__re
             }
         }
     }
+  }
   for (int o = 32; o > 0; o >>= 1)
     { local += __shfl_down(local, o);
       below += __shfl_down(below, o);
@@ -1335,18 +1466,24 @@ static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nu
     const dim3 grid(B2 != nullptr ? (uint32_t) (((ntiles + 7) / 8) * 16) : (uint32_t) ntiles), blk(MG_THREADS);
     const uint64_t *ak = (const uint64_t *) A.keys;
     const bool four = Bx.probe_keys == 4, low = BL.klow != nullptr;
+    // "DMH_MATCH_COMPACT=0": the look-ups item by item, as until round 4 (comparisons)
+    static const bool compact = getenv("DMH_MATCH_COMPACT") == nullptr || atoi(getenv("DMH_MATCH_COMPACT")) != 0;
+#define MM_LAUNCH(NK_, LOW_, TWO_) \
+    do { if (compact) hipLaunchKernelGGL((k_merge_match<NK_, LOW_, TWO_, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]); \
+         else         hipLaunchKernelGGL((k_merge_match<NK_, LOW_, TWO_, false>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]); } while (0)
     if (B2 != nullptr)
-      { if (four && low)  hipLaunchKernelGGL((k_merge_match<4, true, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
-        else if (four)    hipLaunchKernelGGL((k_merge_match<4, false, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
-        else if (low)     hipLaunchKernelGGL((k_merge_match<2, true, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
-        else              hipLaunchKernelGGL((k_merge_match<2, false, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+      { if (four && low)  MM_LAUNCH(4, true, true);
+        else if (four)    MM_LAUNCH(4, false, true);
+        else if (low)     MM_LAUNCH(2, true, true);
+        else              MM_LAUNCH(2, false, true);
       }
     else
-      { if (four && low)  hipLaunchKernelGGL((k_merge_match<4, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
-        else if (four)    hipLaunchKernelGGL((k_merge_match<4, false>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
-        else if (low)     hipLaunchKernelGGL((k_merge_match<2, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
-        else              hipLaunchKernelGGL((k_merge_match<2, false>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]);
+      { if (four && low)  MM_LAUNCH(4, true, false);
+        else if (four)    MM_LAUNCH(4, false, false);
+        else if (low)     MM_LAUNCH(2, true, false);
+        else              MM_LAUNCH(2, false, false);
       }
+#undef MM_LAUNCH
   }
   { StageTimer tm("merge_fixup", 0.0);
     for (int q = 0; q < (B2 != nullptr ? 2 : 1); q++)
