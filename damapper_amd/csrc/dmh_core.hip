@@ -1838,6 +1838,8 @@ int dmh_test_option(const char *key, int value)
   else if (strcmp(key, "chain_classes") == 0) st.opt_chain_classes = value;
   else if (strcmp(key, "pebble_spill") == 0) st.opt_pebble_spill = value;
   else if (strcmp(key, "front_ahead") == 0) st.opt_front_ahead = value;
+  else if (strcmp(key, "match_compact") == 0) st.opt_match_compact = value;
+  else if (strcmp(key, "sort_ballot") == 0) st.opt_sort_ballot = value;
   else return -1;
   return 0;
 }

@@ -1467,7 +1467,8 @@ static void match_front(IndexDev &A, IndexDev &Bx, int Kshift, IndexDev *B2 = nu
     const uint64_t *ak = (const uint64_t *) A.keys;
     const bool four = Bx.probe_keys == 4, low = BL.klow != nullptr;
     // "DMH_MATCH_COMPACT=0": the look-ups item by item, as until round 4 (comparisons)
-    static const bool compact = getenv("DMH_MATCH_COMPACT") == nullptr || atoi(getenv("DMH_MATCH_COMPACT")) != 0;
+    static const bool env_compact = getenv("DMH_MATCH_COMPACT") == nullptr || atoi(getenv("DMH_MATCH_COMPACT")) != 0;
+    const bool compact = st.opt_match_compact >= 0 ? st.opt_match_compact != 0 : env_compact;      // ("match_compact" test option)
 #define MM_LAUNCH(NK_, LOW_, TWO_) \
     do { if (compact) hipLaunchKernelGGL((k_merge_match<NK_, LOW_, TWO_, true>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]); \
          else         hipLaunchKernelGGL((k_merge_match<NK_, LOW_, TWO_, false>), grid, blk, 0, stream(), ak, A.n, BL, MO[0], BL2, MO[1]); } while (0)

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include "dmh_common.h"
+#include "dmh_state.h"
 #include "dmh_device.h"
 
 namespace dmh {
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_radix_scatter(const uint64_
 // "DMH_SORT_BALLOT=1": the ranks from ballots whatever the device does
 static bool scatter_ordered()
 { static const bool env_ballot = getenv("DMH_SORT_BALLOT") != nullptr && atoi(getenv("DMH_SORT_BALLOT")) != 0;
-  return !env_ballot && lds_atomics_ordered();
+  const int o = S().opt_sort_ballot;                 // ("sort_ballot" test option)
+  return !(o >= 0 ? o != 0 : env_ballot) && lds_atomics_ordered();
 }
 
 void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **okeys, uint32_t **ovals,

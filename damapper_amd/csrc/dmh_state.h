@@ -193,6 +193,8 @@ struct State
   int  opt_chain_simple = -1;   // 0: no group is chained without a walk (k_chain_simple off)
   int  opt_oom_finish  = 0;     // n > 0: the n-th chain_finish from now meets a (simulated) out-of-memory in its middle
   int  opt_read_sort   = -1;    // cluster mode: 0 = hits ordered by the global radix sort instead of per read in LDS; 2 = the 1024-thread workgroups from 129 hits; 3 = reads of more than 512 hits go through global memory (k_read_sort_big); 5 = ranks from ballots; 6 = no 1024-thread workgroups (as while an alignment kernel is deferred); 7 = 3 and 6
+  int  opt_match_compact = -1;  // 0: k_merge_match finishes its look-ups item by item (no candidate list in LDS)
+  int  opt_sort_ballot = -1;    // 1: k_radix_scatter ranks by ballots whatever the device does (no ordered LDS atomics)
   int  opt_front_ahead = -1;    // 0: the match kernels of a REF block are queued when its own pass comes (no front stream)
   int  opt_pebble_spill = -1;   // 0: k_align_cands32's pebbles end with its LDS (longer passes are re-run one rung up)
   int  opt_chain_classes = -1;  // 0: groups that fall apart by diagonal are walked like any other (k_chain_classes off)

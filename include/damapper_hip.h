@@ -173,6 +173,8 @@ void *dmh_sort_kmers_async(DAZZ_DB *block, int *len);
  *   "tails" 0            nothing runs on the tail stream: every kernel of a pass has the GPU to itself
  *   "defer_close" 1      the close of a dense pass is taken up by the next Match_Filter call (experiment)
  *   "hit_limit" n        a pass of n hits or more is refused (the refusal at 2^32 hits, at a testable size)
+ *   "match_compact" 0    k_merge_match finishes its look-ups item by item (no list of the look-ups that become entries)
+ *   "sort_ballot" 1      k_radix_scatter ranks by ballots (not by the values ordered LDS atomic adds return)
  *   "front_ahead" 0      the match kernels of a REF block are queued when its own pass comes, on the main stream (default:
  *                        those of the REF block that follows run on a stream of their own next to the block at hand's
  *                        per-read kernels, when the driver names the passes with dmh_next_pass)

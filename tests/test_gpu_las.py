@@ -167,7 +167,8 @@ def test_ragged_and_degenerate_reads(tmp_path):
                                   dict(cluster=1, fuse=0), dict(cluster=1, fuse=0, read_sort=3), dict(cluster=1, fuse=0, read_sort=5),
                                   dict(cluster=1, fuse=0, chain_simple=0), dict(cluster=1, chain_classes=0), dict(chain_classes=0),
                                   dict(cluster=1, defer_close=0), dict(defer_close=0),
-                                  dict(cluster=1, chain_pile=0)],
+                                  dict(cluster=1, chain_pile=0), dict(match_compact=0), dict(cluster=1, match_compact=0),
+                                  dict(sort_ballot=1)],
                          ids=["four_per_wavefront", "wave64", "global_band", "pool_grows", "chain64", "chain32", "chain16",
                               "chain_piles", "chain_piles_spill", "chain_no_piles", "merge_dense_table", "merge_low16_probes",
                               "clusters", "clusters_piles", "clusters_chain64",
@@ -184,7 +185,7 @@ def test_ragged_and_degenerate_reads(tmp_path):
                               "clusters_unfused_ballot_ranks", "clusters_unfused_no_simple_groups",
                               "clusters_no_diagonal_classes", "no_diagonal_classes",
                               "clusters_every_pass_closed_before_it_returns", "every_pass_closed_before_it_returns",
-                              "clusters_no_piles"])
+                              "clusters_no_piles", "match_item_by_item", "clusters_match_item_by_item", "sort_ranks_from_ballots"])
 def test_every_kernel_variant_gives_the_same_files(opts, tmp_path):
     """The alignment kernel ladder, the chain group sizes and the pool-overflow retry are alternative routes
     to the same bytes: force each one and compare with the default route on data that has repeats, dropouts and
@@ -244,7 +245,7 @@ def test_long_reads_identical_to_reference(tmp_path):
 VARIANT_DEFAULTS = dict(align_level=-1, align_g=-1, chain_g=0, pool_div=1, chain_pile=-1, pile_cap=0, merge_dense=-1,
                         cluster=-1, chain_small=-1, chain_lane=-1, batch=-1, cluster_sort=-1, expand=-1, in_flight=-1,
                         seed_word=-1, alloc_fail=0, fin_stream=-1, read_sort=-1, oom_finish=0, chain_simple=-1,
-                        defer_close=-1, tails=-1, fuse=-1, chain_classes=-1, pebble_spill=-1, front_ahead=-1)
+                        defer_close=-1, tails=-1, fuse=-1, chain_classes=-1, pebble_spill=-1, front_ahead=-1, match_compact=-1, sort_ballot=-1)
 _VARIANT = {}
 
 
