@@ -1253,6 +1253,7 @@ void release_ref_index(IndexDev &ix)
   index_pack_positions(ix);                  // it will be merged against again
   st.ref_cached.push_front(ix);
   st.ref_cache_bytes += bytes;
+  filter_forget_index(&ix);                  // (the handle's record goes away: nothing of the filter may keep its address)
   ix.keys = nullptr; ix.vals = nullptr; ix.d_boff = nullptr; ix.d_chunk = nullptr; ix.d_bstart = nullptr;
 }
 
